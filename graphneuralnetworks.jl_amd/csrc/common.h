@@ -1,0 +1,158 @@
+// common.h — shared host/device helpers of libgnnmp (MI355X / gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "gnnmp.h"
+
+namespace gnnmp {
+
+// ---- error plumbing (thread-local message, negative status codes; nothing throws) -------------
+int fail(int status, const char *fmt, ...);
+int hip_fail(hipError_t e, const char *what);
+
+#define GNNMP_HIP(expr)                                         \
+    do {                                                        \
+        hipError_t e__ = (expr);                                \
+        if (e__ != hipSuccess) return ::gnnmp::hip_fail(e__, #expr); \
+    } while (0)
+
+#define GNNMP_LAUNCH_CHECK(what)                                \
+    do {                                                        \
+        hipError_t e__ = hipGetLastError();                     \
+        if (e__ != hipSuccess) return ::gnnmp::hip_fail(e__, what); \
+    } while (0)
+
+// ---- tuning knobs (perf experiments; not part of the drop-in surface) -------------------------
+enum Knob {
+    KNOB_FORCE_VEC = 0,    // 0 = auto, else 1|2|4
+    KNOB_FORCE_LOG2G = 1,  // -1 = auto, else 0..6
+    KNOB_UNROLL = 2,       // 0 = auto (4), else 2|4|8
+    KNOB_XCD_REMAP = 3,    // 1 = on (default), 0 = off
+    KNOB_LONG_ROW = 4,     // long-row threshold (default GNNMP_LONG_ROW)
+    KNOB_BLOCK_WAVES = 5,  // waves per block in the row kernels (default 4)
+    KNOB_COUNT = 8
+};
+int knob(int k);
+
+// ---- device helpers ---------------------------------------------------------------------------
+// index element load: idx_bytes in {4, 8}; returns 0-based int64
+__device__ __forceinline__ int64_t load_index(const void *p, int64_t k, int idx_bytes, int base) {
+    return idx_bytes == 8 ? (reinterpret_cast<const int64_t *>(p)[k] - base)
+                          : (static_cast<int64_t>(reinterpret_cast<const int32_t *>(p)[k]) - base);
+}
+__device__ __forceinline__ void store_index(void *p, int64_t k, int idx_bytes, int64_t v) {
+    if (idx_bytes == 8)
+        reinterpret_cast<int64_t *>(p)[k] = v;
+    else
+        reinterpret_cast<int32_t *>(p)[k] = static_cast<int32_t>(v);
+}
+
+// Julia Base.max / Base.min on floats: NaN-propagating, max(-0.0, +0.0) = +0.0, min(+0.0,-0.0) = -0.0.
+// (NNlib.scatter!(max, ...) applies Base.max element by element.)
+__device__ __forceinline__ float jl_max(float x, float y) {
+    if (x != x) return x;
+    if (y != y) return y;
+    if (y > x) return y;
+    if (x > y) return x;
+    return __builtin_signbitf(x) ? y : x;
+}
+__device__ __forceinline__ float jl_min(float x, float y) {
+    if (x != x) return x;
+    if (y != y) return y;
+    if (y < x) return y;
+    if (x < y) return x;
+    return __builtin_signbitf(x) ? x : y;
+}
+
+enum { OP_SUM = 0, OP_MAX = 1, OP_MIN = 2 };
+
+template <int OP>
+__device__ __forceinline__ float op_identity() {
+    return OP == OP_SUM ? 0.0f : (OP == OP_MAX ? -__builtin_inff() : __builtin_inff());
+}
+template <int OP>
+__device__ __forceinline__ float op_apply(float a, float b) {
+    if (OP == OP_SUM) return a + b;
+    if (OP == OP_MAX) return jl_max(a, b);
+    return jl_min(a, b);
+}
+
+// vector-of-VEC-floats load/store (16/8/4-byte global accesses)
+template <int VEC>
+struct Vec;
+template <>
+struct Vec<4> {
+    using T = float4;
+    static __device__ __forceinline__ void load(const float *p, float v[4]) {
+        float4 t = *reinterpret_cast<const float4 *>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+    static __device__ __forceinline__ void store(float *p, const float v[4]) {
+        *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+};
+template <>
+struct Vec<2> {
+    using T = float2;
+    static __device__ __forceinline__ void load(const float *p, float v[2]) {
+        float2 t = *reinterpret_cast<const float2 *>(p);
+        v[0] = t.x; v[1] = t.y;
+    }
+    static __device__ __forceinline__ void store(float *p, const float v[2]) {
+        *reinterpret_cast<float2 *>(p) = make_float2(v[0], v[1]);
+    }
+};
+template <>
+struct Vec<1> {
+    using T = float;
+    static __device__ __forceinline__ void load(const float *p, float v[1]) { v[0] = *p; }
+    static __device__ __forceinline__ void store(float *p, const float v[1]) { *p = v[0]; }
+};
+
+// block -> logical chunk remap so that each XCD (block b runs on XCD b % 8) walks a contiguous range of
+// destination rows; grid must be launched with 8 * cpx blocks.
+__device__ __forceinline__ int xcd_remap(int b, int cpx, int enabled) {
+    return enabled ? (b & 7) * cpx + (b >> 3) : b;
+}
+
+}  // namespace gnnmp
+
+// ---- the opaque plan ---------------------------------------------------------------------------
+struct gnnmp_graph {
+    int64_t n_src = 0, n_dst = 0, n_edges = 0, n_total = 0;
+    int self_loops = 0;
+    int32_t *rowptr = nullptr;  // [n_dst + 1]
+    int32_t *col = nullptr;     // [n_total] 0-based source of each slot
+    int32_t *eid = nullptr;     // [n_total] 0-based original edge position of each slot
+    // rows longer than the long-row threshold (sorted ascending), handled one workgroup per row
+    int32_t *long_rows = nullptr;
+    int n_long = 0;
+    int long_thresh = GNNMP_LONG_ROW;
+    int64_t max_degree = 0;
+    int64_t bytes = 0;
+};
+
+namespace gnnmp {
+// vector width usable for rows of D floats at these base pointers
+inline int pick_vec(int64_t D, const void *a, const void *b) {
+    uintptr_t m = reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b);
+    int forced = knob(KNOB_FORCE_VEC);
+    int v = 1;
+    if (D % 4 == 0 && (m & 15) == 0)
+        v = 4;
+    else if (D % 2 == 0 && (m & 7) == 0)
+        v = 2;
+    if (forced == 1 || forced == 2 || forced == 4) {
+        if (forced <= v) v = forced;
+    }
+    return v;
+}
+// lanes per row group: smallest power of two >= D / vec, clamped to [1, 64]
+inline int pick_log2g(int64_t lanes_needed) {
+    int forced = knob(KNOB_FORCE_LOG2G);
+    if (forced >= 0 && forced <= 6) return forced;
+    int l = 0;
+    while ((1 << l) < lanes_needed && l < 6) ++l;
+    return l;
+}
+}  // namespace gnnmp

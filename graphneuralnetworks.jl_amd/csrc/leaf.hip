@@ -1,0 +1,208 @@
+// leaf.hip — the leaf ops of GNNGraphs/src/gatherscatter.jl (NNlib.gather :4, NNlib.scatter :12-18) for callers
+// that go through the generic (closure) path of propagate, the NNlib-style atomic scatter kept as the measured
+// comparator, and reduce_nodes over a sorted graph_indicator (GNNlib/src/utils.jl:12-16).
+#include "common.h"
+
+namespace gnnmp {
+
+// out[k][:] = x[idx[k]][:]; one group of G lanes per gathered row, VEC floats per lane per step.
+template <int VEC>
+__global__ void __launch_bounds__(256) gather_kernel(const float *x, const void *idx, int idx_bytes,
+                                                     int base, int64_t K, float *out, int D,
+                                                     int log2g) {
+    const int G = 1 << log2g;
+    const int lig = threadIdx.x & (G - 1);
+    const int64_t k = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> log2g;
+    if (k >= K) return;
+    const int64_t r = load_index(idx, k, idx_bytes, base);
+    const float *srow = x + r * D;
+    float *drow = out + k * D;
+    for (int f = lig * VEC; f < D; f += G * VEC) {
+        float v[VEC];
+        Vec<VEC>::load(srow + f, v);
+        Vec<VEC>::store(drow + f, v);
+    }
+}
+
+__device__ __forceinline__ void atomic_max_f32(float *addr, float v) {
+    // CAS loop with Julia max semantics (comparator path only)
+    unsigned int *ua = reinterpret_cast<unsigned int *>(addr);
+    unsigned int old = *ua, assumed;
+    do {
+        assumed = old;
+        float cur = __uint_as_float(assumed);
+        float nv = jl_max(cur, v);
+        if (__float_as_uint(nv) == assumed) break;
+        old = atomicCAS(ua, assumed, __float_as_uint(nv));
+    } while (old != assumed);
+}
+__device__ __forceinline__ void atomic_min_f32(float *addr, float v) {
+    unsigned int *ua = reinterpret_cast<unsigned int *>(addr);
+    unsigned int old = *ua, assumed;
+    do {
+        assumed = old;
+        float cur = __uint_as_float(assumed);
+        float nv = jl_min(cur, v);
+        if (__float_as_uint(nv) == assumed) break;
+        old = atomicCAS(ua, assumed, __float_as_uint(nv));
+    } while (old != assumed);
+}
+
+// NNlib's GPU scatter: one thread per (feature, edge) element, one atomic each.
+template <int OP>
+__global__ void __launch_bounds__(256) scatter_atomic_kernel(const float *m, const void *idx,
+                                                             int idx_bytes, int base, int64_t K,
+                                                             float *out, int D) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= K * D) return;
+    const int64_t k = t / D;
+    const int f = (int)(t - k * D);
+    const int64_t r = load_index(idx, k, idx_bytes, base);
+    float *dst = out + r * D + f;
+    const float v = m[t];
+    if (OP == OP_SUM)
+        atomicAdd(dst, v);
+    else if (OP == OP_MAX)
+        atomic_max_f32(dst, v);
+    else
+        atomic_min_f32(dst, v);
+}
+
+// reduce_nodes over a sorted indicator: group of G lanes per graph, boundaries by binary search,
+// node rows are contiguous => coalesced streaming reads, sum in node order.
+template <int VEC, int OP>
+__global__ void __launch_bounds__(256) segment_pool_kernel(const float *x, const void *seg,
+                                                           int idx_bytes, int base, float *out,
+                                                           int D, int64_t N, int64_t Gn, int log2g,
+                                                           int mean) {
+    const int G = 1 << log2g;
+    const int lig = threadIdx.x & (G - 1);
+    const int64_t g = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> log2g;
+    if (g >= Gn) return;
+    // first node with seg >= g, first node with seg >= g+1
+    int64_t lo = 0, hi = N;
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if (load_index(seg, mid, idx_bytes, base) < g) lo = mid + 1; else hi = mid;
+    }
+    const int64_t beg = lo;
+    hi = N;
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if (load_index(seg, mid, idx_bytes, base) < g + 1) lo = mid + 1; else hi = mid;
+    }
+    const int64_t end = lo;
+    const float cnt = (float)(end - beg);
+    for (int f = lig * VEC; f < D; f += G * VEC) {
+        float acc[VEC];
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) acc[q] = op_identity<OP>();
+        int64_t n = beg;
+        for (; n + 4 <= end; n += 4) {
+            float v[4][VEC];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) Vec<VEC>::load(x + (n + u) * D + f, v[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) acc[q] = op_apply<OP>(acc[q], v[u][q]);
+        }
+        for (; n < end; ++n) {
+            float v[VEC];
+            Vec<VEC>::load(x + n * D + f, v);
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) acc[q] = op_apply<OP>(acc[q], v[q]);
+        }
+        if (OP == OP_SUM && mean) {
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) acc[q] = 0.0f + (end == beg ? acc[q] : acc[q] / cnt);
+        }
+        Vec<VEC>::store(out + g * D + f, acc);
+    }
+}
+
+}  // namespace gnnmp
+
+using namespace gnnmp;
+
+extern "C" {
+
+int gnnmp_gather_f32(const float *x, const void *idx, int idx_bytes, int index_base, int64_t K,
+                     float *out, int64_t D, gnnmp_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (idx_bytes != 4 && idx_bytes != 8) return fail(GNNMP_EINVAL, "gather: idx_bytes %d", idx_bytes);
+    if (index_base != 0 && index_base != 1) return fail(GNNMP_EINVAL, "gather: index_base %d", index_base);
+    if (K < 0 || D < 0 || D > (1 << 20)) return fail(GNNMP_EINVAL, "gather: bad size");
+    if (K == 0 || D == 0) return GNNMP_OK;
+    if (!x || !idx || !out) return fail(GNNMP_EINVAL, "gather: null pointer");
+    const int vec = pick_vec(D, x, out);
+    const int log2g = pick_log2g((D + vec - 1) / vec);
+    const int64_t threads = K << log2g;
+    const unsigned nb = (unsigned)((threads + 255) / 256);
+    switch (vec) {
+        case 4: gather_kernel<4><<<nb, 256, 0, stream>>>(x, idx, idx_bytes, index_base, K, out, (int)D, log2g); break;
+        case 2: gather_kernel<2><<<nb, 256, 0, stream>>>(x, idx, idx_bytes, index_base, K, out, (int)D, log2g); break;
+        default: gather_kernel<1><<<nb, 256, 0, stream>>>(x, idx, idx_bytes, index_base, K, out, (int)D, log2g); break;
+    }
+    GNNMP_LAUNCH_CHECK("gather_kernel");
+    return GNNMP_OK;
+}
+
+int gnnmp_scatter_atomic_f32(int aggr, const float *m, const void *idx, int idx_bytes,
+                             int index_base, int64_t K, float *out, int64_t D,
+                             gnnmp_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (idx_bytes != 4 && idx_bytes != 8) return fail(GNNMP_EINVAL, "scatter_atomic: idx_bytes %d", idx_bytes);
+    if (index_base != 0 && index_base != 1) return fail(GNNMP_EINVAL, "scatter_atomic: index_base %d", index_base);
+    if (aggr != GNNMP_SUM && aggr != GNNMP_MAX && aggr != GNNMP_MIN)
+        return fail(GNNMP_EINVAL, "scatter_atomic: aggr must be SUM, MAX or MIN (got %d)", aggr);
+    if (K < 0 || D < 0) return fail(GNNMP_EINVAL, "scatter_atomic: bad size");
+    if (K == 0 || D == 0) return GNNMP_OK;
+    if (!m || !idx || !out) return fail(GNNMP_EINVAL, "scatter_atomic: null pointer");
+    const int64_t total = K * D;
+    const unsigned nb = (unsigned)((total + 255) / 256);
+    if (aggr == GNNMP_SUM)
+        scatter_atomic_kernel<OP_SUM><<<nb, 256, 0, stream>>>(m, idx, idx_bytes, index_base, K, out, (int)D);
+    else if (aggr == GNNMP_MAX)
+        scatter_atomic_kernel<OP_MAX><<<nb, 256, 0, stream>>>(m, idx, idx_bytes, index_base, K, out, (int)D);
+    else
+        scatter_atomic_kernel<OP_MIN><<<nb, 256, 0, stream>>>(m, idx, idx_bytes, index_base, K, out, (int)D);
+    GNNMP_LAUNCH_CHECK("scatter_atomic_kernel");
+    return GNNMP_OK;
+}
+
+int gnnmp_segment_pool_f32(int aggr, const float *x, const void *seg_ids, int idx_bytes,
+                           int index_base, float *out, int64_t D, int64_t N, int64_t G,
+                           gnnmp_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (idx_bytes != 4 && idx_bytes != 8) return fail(GNNMP_EINVAL, "segment_pool: idx_bytes %d", idx_bytes);
+    if (index_base != 0 && index_base != 1) return fail(GNNMP_EINVAL, "segment_pool: index_base %d", index_base);
+    if (aggr < GNNMP_SUM || aggr > GNNMP_MIN) return fail(GNNMP_EINVAL, "segment_pool: bad aggr %d", aggr);
+    if (N < 0 || G < 0 || D < 0 || D > (1 << 20)) return fail(GNNMP_EINVAL, "segment_pool: bad size");
+    if (G == 0 || D == 0) return GNNMP_OK;
+    if (!out || (N > 0 && (!x || !seg_ids))) return fail(GNNMP_EINVAL, "segment_pool: null pointer");
+    const int vec = pick_vec(D, x, out);
+    const int log2g = pick_log2g((D + vec - 1) / vec);
+    const int64_t threads = G << log2g;
+    const unsigned nb = (unsigned)((threads + 255) / 256);
+    const int mean = aggr == GNNMP_MEAN;
+#define POOL_LAUNCH(V, O) \
+    segment_pool_kernel<V, O><<<nb, 256, 0, stream>>>(x, seg_ids, idx_bytes, index_base, out, (int)D, N, G, log2g, mean)
+#define POOL_OP(V)                                             \
+    do {                                                       \
+        if (aggr == GNNMP_MAX) POOL_LAUNCH(V, OP_MAX);         \
+        else if (aggr == GNNMP_MIN) POOL_LAUNCH(V, OP_MIN);    \
+        else POOL_LAUNCH(V, OP_SUM);                           \
+    } while (0)
+    switch (vec) {
+        case 4: POOL_OP(4); break;
+        case 2: POOL_OP(2); break;
+        default: POOL_OP(1); break;
+    }
+#undef POOL_OP
+#undef POOL_LAUNCH
+    GNNMP_LAUNCH_CHECK("segment_pool_kernel");
+    return GNNMP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,375 @@
+// plan.hip — graph-side prep: dst-sorted CSR plan of a COO edge index, plus the bit-exact index ops
+// (add_self_loops, batch).  Reference: GNNGraphs/src/gnngraph.jl:108-117 (COO container),
+// GNNGraphs/src/convert.jl:221-237 (to_sparse, rebuilt per call by the reference fast path),
+// GNNGraphs/src/transform.jl:12-28 (add_self_loops), :682-709 (batch).
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <algorithm>
+#include <vector>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "common.h"
+
+namespace gnnmp {
+
+static thread_local char g_err[512] = "";
+static int g_knobs[KNOB_COUNT] = {0, -1, 0, 1, GNNMP_LONG_ROW, 4, 0, 0};
+
+int fail(int status, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return status;
+}
+int hip_fail(hipError_t e, const char *what) {
+    snprintf(g_err, sizeof(g_err), "HIP error %d (%s) at %s", (int)e, hipGetErrorString(e), what);
+    return e == hipErrorOutOfMemory ? GNNMP_EALLOC : GNNMP_ELAUNCH;
+}
+int knob(int k) { return (k >= 0 && k < KNOB_COUNT) ? g_knobs[k] : 0; }
+
+// ---- kernels -----------------------------------------------------------------------------------
+
+// keys[k] = 0-based destination of edge k (self loops k >= E: k - E); vals[k] = k.
+// bad[0] is set if any index is outside its range.
+__global__ void plan_fill_keys(const void *src, const void *dst, int idx_bytes, int base, int64_t E,
+                               int64_t Etot, int64_t n_src, int64_t n_dst, uint32_t *keys,
+                               uint32_t *vals, int *bad) {
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= Etot) return;
+    int64_t d;
+    if (k < E) {
+        d = load_index(dst, k, idx_bytes, base);
+        int64_t s = load_index(src, k, idx_bytes, base);
+        if (d < 0 || d >= n_dst || s < 0 || s >= n_src) {
+            *bad = 1;
+            d = 0;
+        }
+    } else {
+        d = k - E;
+    }
+    keys[k] = (uint32_t)d;
+    vals[k] = (uint32_t)k;
+}
+
+// rowptr[i] = first slot whose key >= i  (binary search in the sorted keys); rowptr[n_dst] = Etot
+__global__ void plan_rowptr(const uint32_t *keys, int64_t Etot, int64_t n_dst, int32_t *rowptr) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n_dst) return;
+    int64_t lo = 0, hi = Etot;
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)keys[mid] < i)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    rowptr[i] = (int32_t)lo;
+}
+
+// col[p] = 0-based source of the edge in slot p
+__global__ void plan_col(const void *src, int idx_bytes, int base, int64_t E, int64_t Etot,
+                         const uint32_t *eid, int32_t *col) {
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= Etot) return;
+    int64_t e = eid[p];
+    int64_t s = e < E ? load_index(src, e, idx_bytes, base) : e - E;
+    col[p] = (int32_t)s;
+}
+
+// collect rows longer than `thresh`; meta[0] = count (atomic), meta[1] = max degree
+__global__ void plan_long_rows(const int32_t *rowptr, int64_t n_dst, int thresh, int32_t *list,
+                               int cap, int *meta) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_dst) return;
+    int len = rowptr[i + 1] - rowptr[i];
+    atomicMax(&meta[1], len);
+    if (len > thresh) {
+        int pos = atomicAdd(&meta[0], 1);
+        if (pos < cap) list[pos] = (int32_t)i;
+    }
+}
+
+__global__ void self_loops_kernel(const void *src, const void *dst, int idx_bytes, int base,
+                                  int64_t E, int64_t n, void *out_src, void *out_dst,
+                                  const float *w, float *out_w) {
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= E + n) return;
+    if (k < E) {
+        store_index(out_src, k, idx_bytes, load_index(src, k, idx_bytes, 0));
+        store_index(out_dst, k, idx_bytes, load_index(dst, k, idx_bytes, 0));
+        if (out_w) out_w[k] = w[k];
+    } else {
+        int64_t v = (k - E) + base;
+        store_index(out_src, k, idx_bytes, v);
+        store_index(out_dst, k, idx_bytes, v);
+        if (out_w) out_w[k] = 1.0f;
+    }
+}
+
+// one thread per edge: find its graph by binary search in edge_ptr, add the node offset.
+__global__ void batch_edges_kernel(const void *src, const void *dst, int idx_bytes,
+                                   const int64_t *edge_ptr, const int64_t *node_ptr, int64_t G,
+                                   int64_t Etot, void *out_src, void *out_dst) {
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= Etot) return;
+    int64_t lo = 0, hi = G;  // largest g with edge_ptr[g] <= k
+    while (hi - lo > 1) {
+        int64_t mid = (lo + hi) >> 1;
+        if (edge_ptr[mid] <= k)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    int64_t off = node_ptr[lo];
+    store_index(out_src, k, idx_bytes, load_index(src, k, idx_bytes, 0) + off);
+    store_index(out_dst, k, idx_bytes, load_index(dst, k, idx_bytes, 0) + off);
+}
+__global__ void batch_indicator_kernel(const int64_t *node_ptr, int64_t G, int64_t Ntot,
+                                       int idx_bytes, int base, void *gi) {
+    int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= Ntot) return;
+    int64_t lo = 0, hi = G;
+    while (hi - lo > 1) {
+        int64_t mid = (lo + hi) >> 1;
+        if (node_ptr[mid] <= v)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    store_index(gi, v, idx_bytes, lo + base);
+}
+
+static inline unsigned nblocks(int64_t n, int bs) { return (unsigned)((n + bs - 1) / bs); }
+
+}  // namespace gnnmp
+
+using namespace gnnmp;
+
+extern "C" {
+
+int gnnmp_version(void) { return GNNMP_VERSION; }
+const char *gnnmp_last_error(void) { return g_err; }
+
+// perf-experiment hook, see common.h Knob (not part of the drop-in surface)
+int gnnmp_tune(int k, int value) {
+    if (k < 0 || k >= KNOB_COUNT) return fail(GNNMP_EINVAL, "gnnmp_tune: bad knob %d", k);
+    g_knobs[k] = value;
+    return GNNMP_OK;
+}
+
+int gnnmp_plan_destroy(gnnmp_graph_t *p) {
+    if (!p) return GNNMP_OK;
+    if (p->rowptr) (void)hipFree(p->rowptr);
+    if (p->col) (void)hipFree(p->col);
+    if (p->eid) (void)hipFree(p->eid);
+    if (p->long_rows) (void)hipFree(p->long_rows);
+    delete p;
+    return GNNMP_OK;
+}
+
+int gnnmp_plan_create(gnnmp_graph_t **out, const void *src, const void *dst, int idx_bytes,
+                      int index_base, int64_t n_src, int64_t n_dst, int64_t n_edges,
+                      int add_self_loops, int validate, gnnmp_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!out) return fail(GNNMP_EINVAL, "plan_create: out is NULL");
+    *out = nullptr;
+    if (idx_bytes != 4 && idx_bytes != 8)
+        return fail(GNNMP_EINVAL, "plan_create: idx_bytes must be 4 or 8 (got %d)", idx_bytes);
+    if (index_base != 0 && index_base != 1)
+        return fail(GNNMP_EINVAL, "plan_create: index_base must be 0 or 1 (got %d)", index_base);
+    if (n_src < 0 || n_dst < 0 || n_edges < 0)
+        return fail(GNNMP_EINVAL, "plan_create: negative size");
+    if (n_edges > 0 && (!src || !dst)) return fail(GNNMP_EINVAL, "plan_create: null edge index");
+    if (add_self_loops && n_src != n_dst)
+        return fail(GNNMP_EINVAL, "plan_create: add_self_loops needs n_src == n_dst (%lld vs %lld)",
+                    (long long)n_src, (long long)n_dst);
+    const int64_t Etot = n_edges + (add_self_loops ? n_dst : 0);
+    if (Etot >= (int64_t)INT32_MAX || n_src >= (int64_t)INT32_MAX || n_dst >= (int64_t)INT32_MAX)
+        return fail(GNNMP_EUNSUPPORTED, "plan_create: E' = %lld / N = %lld exceed the int32 plan format",
+                    (long long)Etot, (long long)std::max(n_src, n_dst));
+
+    gnnmp_graph_t *p = new gnnmp_graph_t();
+    p->n_src = n_src;
+    p->n_dst = n_dst;
+    p->n_edges = n_edges;
+    p->n_total = Etot;
+    p->self_loops = add_self_loops ? 1 : 0;
+    p->long_thresh = knob(KNOB_LONG_ROW) > 0 ? knob(KNOB_LONG_ROW) : GNNMP_LONG_ROW;
+
+    uint32_t *keys_in = nullptr, *keys_out = nullptr, *vals_in = nullptr;
+    void *tmp = nullptr;
+    int *flags = nullptr;  // [0] bad index, [1] long count, [2] max degree
+    int32_t *long_tmp = nullptr;
+    int rc = GNNMP_OK;
+    const int BS = 256;
+    const size_t epad = (size_t)std::max<int64_t>(Etot, 1);
+
+#define PLAN_HIP(expr)                                  \
+    do {                                                \
+        hipError_t e__ = (expr);                        \
+        if (e__ != hipSuccess) {                        \
+            rc = hip_fail(e__, #expr);                  \
+            goto done;                                  \
+        }                                               \
+    } while (0)
+
+    PLAN_HIP(hipMalloc((void **)&p->rowptr, sizeof(int32_t) * (size_t)(n_dst + 1)));
+    PLAN_HIP(hipMalloc((void **)&p->col, sizeof(int32_t) * epad));
+    PLAN_HIP(hipMalloc((void **)&p->eid, sizeof(int32_t) * epad));
+    PLAN_HIP(hipMalloc((void **)&flags, sizeof(int) * 4));
+    PLAN_HIP(hipMemsetAsync(flags, 0, sizeof(int) * 4, stream));
+    p->bytes = (int64_t)(sizeof(int32_t) * ((size_t)(n_dst + 1) + 2 * epad));
+
+    if (Etot > 0) {
+        PLAN_HIP(hipMalloc((void **)&keys_in, sizeof(uint32_t) * epad));
+        PLAN_HIP(hipMalloc((void **)&keys_out, sizeof(uint32_t) * epad));
+        PLAN_HIP(hipMalloc((void **)&vals_in, sizeof(uint32_t) * epad));
+        plan_fill_keys<<<nblocks(Etot, BS), BS, 0, stream>>>(src, dst, idx_bytes, index_base,
+                                                             n_edges, Etot, n_src, n_dst, keys_in,
+                                                             vals_in, flags);
+        PLAN_HIP(hipGetLastError());
+        if (validate) {
+            int bad = 0;
+            PLAN_HIP(hipMemcpyAsync(&bad, flags, sizeof(int), hipMemcpyDeviceToHost, stream));
+            PLAN_HIP(hipStreamSynchronize(stream));
+            if (bad) {
+                rc = fail(GNNMP_EBOUNDS, "plan_create: edge index outside 1..N (n_src=%lld n_dst=%lld)",
+                          (long long)n_src, (long long)n_dst);
+                goto done;
+            }
+        }
+        // stable LSD radix sort of (dst, edge position) on the bits that can be set
+        unsigned bits = 1;
+        while (bits < 32 && ((int64_t)1 << bits) < n_dst) ++bits;
+        size_t tmp_bytes = 0;
+        PLAN_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_in, keys_out, vals_in,
+                                           reinterpret_cast<uint32_t *>(p->eid), (size_t)Etot, 0,
+                                           bits, stream));
+        PLAN_HIP(hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 16)));
+        PLAN_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, vals_in,
+                                           reinterpret_cast<uint32_t *>(p->eid), (size_t)Etot, 0,
+                                           bits, stream));
+        plan_col<<<nblocks(Etot, BS), BS, 0, stream>>>(src, idx_bytes, index_base, n_edges, Etot,
+                                                       reinterpret_cast<uint32_t *>(p->eid), p->col);
+        PLAN_HIP(hipGetLastError());
+    }
+    plan_rowptr<<<nblocks(n_dst + 1, BS), BS, 0, stream>>>(keys_out, Etot, n_dst, p->rowptr);
+    PLAN_HIP(hipGetLastError());
+
+    {
+        // long rows: at most Etot / thresh of them
+        int cap = (int)std::min<int64_t>(Etot / std::max(1, p->long_thresh) + 1, n_dst + 1);
+        PLAN_HIP(hipMalloc((void **)&long_tmp, sizeof(int32_t) * (size_t)std::max(cap, 1)));
+        if (n_dst > 0) {
+            plan_long_rows<<<nblocks(n_dst, BS), BS, 0, stream>>>(p->rowptr, n_dst, p->long_thresh,
+                                                                  long_tmp, cap, flags + 1);
+            PLAN_HIP(hipGetLastError());
+        }
+        int meta[2] = {0, 0};
+        PLAN_HIP(hipMemcpyAsync(meta, flags + 1, sizeof(int) * 2, hipMemcpyDeviceToHost, stream));
+        PLAN_HIP(hipStreamSynchronize(stream));
+        p->max_degree = meta[1];
+        p->n_long = std::min(meta[0], cap);
+        if (p->n_long > 0) {
+            std::vector<int32_t> h((size_t)p->n_long);
+            PLAN_HIP(hipMemcpy(h.data(), long_tmp, sizeof(int32_t) * h.size(), hipMemcpyDeviceToHost));
+            std::sort(h.begin(), h.end());  // atomics filled it in arbitrary order: make it canonical
+            PLAN_HIP(hipMalloc((void **)&p->long_rows, sizeof(int32_t) * h.size()));
+            PLAN_HIP(hipMemcpy(p->long_rows, h.data(), sizeof(int32_t) * h.size(), hipMemcpyHostToDevice));
+            p->bytes += (int64_t)(sizeof(int32_t) * h.size());
+        }
+    }
+
+done:
+    if (keys_in) (void)hipFree(keys_in);
+    if (keys_out) (void)hipFree(keys_out);
+    if (vals_in) (void)hipFree(vals_in);
+    if (tmp) (void)hipFree(tmp);
+    if (flags) (void)hipFree(flags);
+    if (long_tmp) (void)hipFree(long_tmp);
+#undef PLAN_HIP
+    if (rc != GNNMP_OK) {
+        gnnmp_plan_destroy(p);
+        return rc;
+    }
+    *out = p;
+    return GNNMP_OK;
+}
+
+int gnnmp_plan_info(const gnnmp_graph_t *p, int64_t info[8]) {
+    if (!p || !info) return fail(GNNMP_EINVAL, "plan_info: null argument");
+    info[0] = p->n_src;
+    info[1] = p->n_dst;
+    info[2] = p->n_edges;
+    info[3] = p->n_total;
+    info[4] = p->max_degree;
+    info[5] = p->n_long;
+    info[6] = p->bytes;
+    info[7] = p->long_thresh;
+    return GNNMP_OK;
+}
+
+int gnnmp_plan_export(const gnnmp_graph_t *p, int32_t *rowptr, int32_t *col, int32_t *eid,
+                      gnnmp_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!p) return fail(GNNMP_EINVAL, "plan_export: null plan");
+    if (rowptr)
+        GNNMP_HIP(hipMemcpyAsync(rowptr, p->rowptr, sizeof(int32_t) * (size_t)(p->n_dst + 1),
+                                 hipMemcpyDeviceToDevice, stream));
+    if (col && p->n_total > 0)
+        GNNMP_HIP(hipMemcpyAsync(col, p->col, sizeof(int32_t) * (size_t)p->n_total,
+                                 hipMemcpyDeviceToDevice, stream));
+    if (eid && p->n_total > 0)
+        GNNMP_HIP(hipMemcpyAsync(eid, p->eid, sizeof(int32_t) * (size_t)p->n_total,
+                                 hipMemcpyDeviceToDevice, stream));
+    return GNNMP_OK;
+}
+
+int gnnmp_add_self_loops(const void *src, const void *dst, int idx_bytes, int index_base,
+                         int64_t n_edges, int64_t n, void *out_src, void *out_dst, const float *w,
+                         float *out_w, gnnmp_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (idx_bytes != 4 && idx_bytes != 8) return fail(GNNMP_EINVAL, "add_self_loops: idx_bytes %d", idx_bytes);
+    if (index_base != 0 && index_base != 1) return fail(GNNMP_EINVAL, "add_self_loops: index_base %d", index_base);
+    if (n_edges < 0 || n < 0) return fail(GNNMP_EINVAL, "add_self_loops: negative size");
+    if ((w == nullptr) != (out_w == nullptr))
+        return fail(GNNMP_EINVAL, "add_self_loops: w and out_w must both be NULL or both non-NULL");
+    if (n_edges + n == 0) return GNNMP_OK;
+    if (!out_src || !out_dst || (n_edges > 0 && (!src || !dst)))
+        return fail(GNNMP_EINVAL, "add_self_loops: null pointer");
+    self_loops_kernel<<<nblocks(n_edges + n, 256), 256, 0, stream>>>(
+        src, dst, idx_bytes, index_base, n_edges, n, out_src, out_dst, w, out_w);
+    GNNMP_LAUNCH_CHECK("self_loops_kernel");
+    return GNNMP_OK;
+}
+
+int gnnmp_batch_coo(const void *src, const void *dst, int idx_bytes, int index_base,
+                    const int64_t *edge_ptr, const int64_t *node_ptr, int64_t n_graphs,
+                    void *out_src, void *out_dst, void *graph_indicator, gnnmp_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (idx_bytes != 4 && idx_bytes != 8) return fail(GNNMP_EINVAL, "batch_coo: idx_bytes %d", idx_bytes);
+    if (index_base != 0 && index_base != 1) return fail(GNNMP_EINVAL, "batch_coo: index_base %d", index_base);
+    if (n_graphs <= 0 || !edge_ptr || !node_ptr) return fail(GNNMP_EINVAL, "batch_coo: bad graph table");
+    // totals live on the device; read them back (graph prep, not on the timed path)
+    int64_t tot[2] = {0, 0};
+    GNNMP_HIP(hipMemcpyAsync(&tot[0], edge_ptr + n_graphs, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+    GNNMP_HIP(hipMemcpyAsync(&tot[1], node_ptr + n_graphs, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+    GNNMP_HIP(hipStreamSynchronize(stream));
+    if (tot[0] > 0) {
+        if (!src || !dst || !out_src || !out_dst) return fail(GNNMP_EINVAL, "batch_coo: null edge arrays");
+        batch_edges_kernel<<<nblocks(tot[0], 256), 256, 0, stream>>>(
+            src, dst, idx_bytes, edge_ptr, node_ptr, n_graphs, tot[0], out_src, out_dst);
+        GNNMP_LAUNCH_CHECK("batch_edges_kernel");
+    }
+    if (tot[1] > 0 && graph_indicator) {
+        batch_indicator_kernel<<<nblocks(tot[1], 256), 256, 0, stream>>>(
+            node_ptr, n_graphs, tot[1], idx_bytes, index_base, graph_indicator);
+        GNNMP_LAUNCH_CHECK("batch_indicator_kernel");
+    }
+    return GNNMP_OK;
+}
+
+}  // extern "C"

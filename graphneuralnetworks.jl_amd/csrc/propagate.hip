@@ -1,0 +1,360 @@
+// propagate.hip — the fused gather -> message -> per-destination reduce of GNNlib's propagate
+// (GNNlib/src/msgpass.jl:71-79), i.e. apply_edges (:121-129: _gather(xj, s), message fn) followed by
+// aggregate_neighbors (:145-149: _scatter(aggr, m, t, n)), without ever materialising the (D, E') message
+// array.  Also the reference's SpMM fast path `xj * adjacency_matrix(g)` (:215-238): same kernel.
+//
+// HBM-bound (0.33-0.48 flop/B): the design goal is to keep every lane's 16-byte row loads in flight.
+//   - one GROUP of G = 2^k lanes owns one destination row; lane l of the group owns VEC consecutive features
+//     (G*VEC >= D; D=128 -> 32 lanes x float4, two rows per wave; D=100 -> 25 of 32 lanes active).
+//   - the row's source ids are loaded coalesced, G at a time, one per lane, and broadcast inside the group with
+//     ds_bpermute (__shfl) — the CDNA cross-lane path, no LDS allocation, no barrier.
+//   - U row loads are issued back to back before the first add; the adds then run in ORIGINAL edge order,
+//     one fp32 accumulator chain per feature => bit-identical to NNlib's CPU scatter loop, no atomics.
+//   - rows longer than the plan's threshold are skipped here and reduced by one 1024-thread workgroup each
+//     (fixed partition, fixed combine order through LDS).
+//   - block -> row-chunk mapping is XCD-aware (contiguous destination ranges per XCD / L2).
+#include "common.h"
+
+namespace gnnmp {
+
+struct ReduceArgs {
+    const int32_t *rowptr;
+    const int32_t *idx;   // per slot: source row of x to read (plan->col, or plan->eid for scatter)
+    const int32_t *eid;   // per slot: original edge position (weights lookup); may be null if !w
+    const float *x;       // [n_src][D]
+    const float *w;       // [n_edges] original order, nullable
+    const float *ss;      // [n_src] nullable
+    const float *sd;      // [n_dst] nullable
+    float *out;           // [n_dst][D]
+    const int32_t *long_rows;
+    int n_long;
+    int D;
+    int n_rows;
+    int n_edges;          // weights exist for eid < n_edges; others are 1
+    int log2g;
+    int mean;
+    int long_thresh;
+    int cpx;              // chunks per XCD (grid.x = 8*cpx) ; 0 = no remap
+    int waves;            // waves per block
+};
+
+// reduce slots [beg, end) of one destination into acc[VEC]; all lanes of the group call this together.
+template <int VEC, int OP, bool SCALED, int U>
+__device__ __forceinline__ void reduce_range(const ReduceArgs &a, int beg, int end, int lig,
+                                             int gbase, int G, int f0, bool active,
+                                             float acc[VEC]) {
+    for (int base = beg; base < end; base += G) {
+        const int p = base + lig;
+        int c = 0;
+        float wv = 1.0f, sv = 1.0f;
+        if (p < end) {
+            c = a.idx[p];
+            if (SCALED) {
+                if (a.w) {
+                    const int e = a.eid[p];
+                    if (e < a.n_edges) wv = a.w[e];
+                }
+                if (a.ss) sv = a.ss[c];
+            }
+        }
+        const int n = min(G, end - base);
+        for (int j = 0; j < n; j += U) {
+            float v[U][VEC];
+            float wj[U], sj[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int jj = min(j + u, n - 1);
+                const int cj = __shfl(c, gbase + jj, 64);
+                if (SCALED) {
+                    wj[u] = __shfl(wv, gbase + jj, 64);
+                    sj[u] = __shfl(sv, gbase + jj, 64);
+                }
+                if (active && (j + u < n)) {
+                    Vec<VEC>::load(a.x + (int64_t)cj * a.D + f0, v[u]);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) v[u][q] = 0.0f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (j + u < n) {
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) {
+                        float t = v[u][q];
+                        if (SCALED) {
+                            t = t * sj[u];  // xj .* cout'   (GNNlib/src/layers/conv.jl:59), rounded
+                            t = wj[u] * t;  // w .* xj        (GNNlib/src/msgpass.jl:203-208), rounded
+                        }
+                        acc[q] = op_apply<OP>(acc[q], t);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int VEC, int OP>
+__device__ __forceinline__ void finalize_store(const ReduceArgs &a, int row, int len, int f0,
+                                               bool active, float acc[VEC]) {
+    if (OP == OP_SUM && a.mean) {
+        // NNlib scatter(mean): dst = 0 .+ safe_div.(sum, count); count == 0 keeps the sum (0)
+        const float cnt = (float)len;
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) acc[q] = 0.0f + (len == 0 ? acc[q] : acc[q] / cnt);
+    }
+    if (a.sd) {
+        const float s = a.sd[row];  // x .* cin'  (GNNlib/src/layers/conv.jl:67)
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) acc[q] = acc[q] * s;
+    }
+    if (active) Vec<VEC>::store(a.out + (int64_t)row * a.D + f0, acc);
+}
+
+template <int VEC, int OP, bool SCALED, int U>
+__global__ void __launch_bounds__(256) csr_rows_kernel(const ReduceArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int G = 1 << a.log2g;
+    const int lig = lane & (G - 1);
+    const int grp = lane >> a.log2g;
+    const int gbase = lane - lig;
+    const int rpw = 64 >> a.log2g;
+    const int chunk = a.cpx ? xcd_remap(blockIdx.x, a.cpx, 1) : (int)blockIdx.x;
+    const int64_t row64 = ((int64_t)chunk * a.waves + wave) * rpw + grp;
+    if (row64 >= a.n_rows) return;
+    const int row = (int)row64;
+    const int f0 = ((int)blockIdx.y * G + lig) * VEC;
+    const bool active = f0 < a.D;
+    const int beg = a.rowptr[row];
+    const int end = a.rowptr[row + 1];
+    if (end - beg > a.long_thresh) return;  // handled by csr_long_rows_kernel
+    float acc[VEC];
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) acc[q] = op_identity<OP>();
+    reduce_range<VEC, OP, SCALED, U>(a, beg, end, lig, gbase, G, f0, active, acc);
+    finalize_store<VEC, OP>(a, row, end - beg, f0, active, acc);
+}
+
+// one 1024-thread workgroup per long row: group q of NG = 1024/G reduces the q-th contiguous part of the
+// row in edge order; the NG partial vectors are combined in q order through LDS.
+template <int VEC, int OP, bool SCALED, int U>
+__global__ void __launch_bounds__(1024) csr_long_rows_kernel(const ReduceArgs a) {
+    extern __shared__ float lds[];  // [NG][G*VEC]
+    const int lane = threadIdx.x & 63;
+    const int G = 1 << a.log2g;
+    const int lig = lane & (G - 1);
+    const int gbase = lane - lig;
+    const int q = threadIdx.x >> a.log2g;
+    const int NG = 1024 >> a.log2g;
+    const int row = a.long_rows[blockIdx.x];
+    const int f0 = ((int)blockIdx.y * G + lig) * VEC;
+    const bool active = f0 < a.D;
+    const int beg = a.rowptr[row];
+    const int end = a.rowptr[row + 1];
+    const int len = end - beg;
+    const int part = (len + NG - 1) / NG;
+    const int pb = min(beg + q * part, end);
+    const int pe = min(pb + part, end);
+    float acc[VEC];
+#pragma unroll
+    for (int t = 0; t < VEC; ++t) acc[t] = op_identity<OP>();
+    reduce_range<VEC, OP, SCALED, U>(a, pb, pe, lig, gbase, G, f0, active, acc);
+#pragma unroll
+    for (int t = 0; t < VEC; ++t) lds[(q * G + lig) * VEC + t] = acc[t];
+    __syncthreads();
+    if (q == 0) {
+#pragma unroll
+        for (int t = 0; t < VEC; ++t) acc[t] = op_identity<OP>();
+        for (int k = 0; k < NG; ++k) {
+#pragma unroll
+            for (int t = 0; t < VEC; ++t)
+                acc[t] = op_apply<OP>(acc[t], lds[(k * G + lig) * VEC + t]);
+        }
+        finalize_store<VEC, OP>(a, row, len, f0, active, acc);
+    }
+}
+
+template <int VEC, int OP, bool SCALED, int U>
+static int launch_reduce(const ReduceArgs &a0, hipStream_t stream) {
+    ReduceArgs a = a0;
+    const int G = 1 << a.log2g;
+    const int rpw = 64 / G;
+    int waves = knob(KNOB_BLOCK_WAVES);
+    if (waves < 1 || waves > 4) waves = 4;
+    a.waves = waves;
+    const int rows_per_block = rpw * waves;
+    const int64_t chunks = ((int64_t)a.n_rows + rows_per_block - 1) / rows_per_block;
+    const int lanes_needed = (a.D + VEC - 1) / VEC;
+    const int tiles = (lanes_needed + G - 1) / G;
+    if (chunks > 0) {
+        int64_t gx = chunks;
+        a.cpx = 0;
+        if (knob(KNOB_XCD_REMAP) && chunks >= 64) {
+            a.cpx = (int)((chunks + 7) / 8);
+            gx = (int64_t)a.cpx * 8;
+        }
+        dim3 grid((unsigned)gx, (unsigned)tiles);
+        csr_rows_kernel<VEC, OP, SCALED, U><<<grid, 64 * waves, 0, stream>>>(a);
+        GNNMP_LAUNCH_CHECK("csr_rows_kernel");
+    }
+    if (a.n_long > 0) {
+        dim3 grid((unsigned)a.n_long, (unsigned)tiles);
+        const size_t lds = sizeof(float) * 1024 * VEC;
+        csr_long_rows_kernel<VEC, OP, SCALED, U><<<grid, 1024, lds, stream>>>(a);
+        GNNMP_LAUNCH_CHECK("csr_long_rows_kernel");
+    }
+    return GNNMP_OK;
+}
+
+template <int VEC, int OP, bool SCALED>
+static int dispatch_u(const ReduceArgs &a, hipStream_t s) {
+    switch (knob(KNOB_UNROLL)) {
+        case 2: return launch_reduce<VEC, OP, SCALED, 2>(a, s);
+        case 8: return launch_reduce<VEC, OP, SCALED, 8>(a, s);
+        default: return launch_reduce<VEC, OP, SCALED, 4>(a, s);
+    }
+}
+template <int VEC, int OP>
+static int dispatch_scaled(const ReduceArgs &a, bool scaled, hipStream_t s) {
+    return scaled ? dispatch_u<VEC, OP, true>(a, s) : dispatch_u<VEC, OP, false>(a, s);
+}
+template <int VEC>
+static int dispatch_op(const ReduceArgs &a, int op, bool scaled, hipStream_t s) {
+    switch (op) {
+        case OP_SUM: return dispatch_scaled<VEC, OP_SUM>(a, scaled, s);
+        case OP_MAX: return dispatch_scaled<VEC, OP_MAX>(a, scaled, s);
+        default: return dispatch_scaled<VEC, OP_MIN>(a, scaled, s);
+    }
+}
+
+// shared by propagate (idx = col) and scatter (idx = eid)
+int run_reduce(gnnmp_graph_t *p, const int32_t *idx, int aggr, const float *x, const float *w,
+               const float *ss, const float *sd, float *out, int64_t D, hipStream_t stream) {
+    if (p->n_dst == 0 || D == 0) return GNNMP_OK;
+    ReduceArgs a;
+    a.rowptr = p->rowptr;
+    a.idx = idx;
+    a.eid = p->eid;
+    a.x = x;
+    a.w = w;
+    a.ss = ss;
+    a.sd = sd;
+    a.out = out;
+    a.long_rows = p->long_rows;
+    a.n_long = p->n_long;
+    a.D = (int)D;
+    a.n_rows = (int)p->n_dst;
+    a.n_edges = (int)p->n_edges;
+    a.mean = (aggr == GNNMP_MEAN);
+    a.long_thresh = p->long_thresh;
+    a.cpx = 0;
+    a.waves = 4;
+    const int vec = pick_vec(D, x, out);
+    a.log2g = pick_log2g((D + vec - 1) / vec);
+    const int op = (aggr == GNNMP_MAX) ? OP_MAX : (aggr == GNNMP_MIN ? OP_MIN : OP_SUM);
+    const bool scaled = (w != nullptr) || (ss != nullptr);
+    switch (vec) {
+        case 4: return dispatch_op<4>(a, op, scaled, stream);
+        case 2: return dispatch_op<2>(a, op, scaled, stream);
+        default: return dispatch_op<1>(a, op, scaled, stream);
+    }
+}
+
+// ---- degree / norm ------------------------------------------------------------------------------
+__global__ void degree_count_kernel(const int32_t *rowptr, int64_t n, float *deg) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) deg[i] = 0.0f + (float)(rowptr[i + 1] - rowptr[i]);
+}
+// weighted in-degree: one thread per destination, weights added in original edge order
+// (zeros(T,N) .+ scatter(+, w, t) — GNNGraphs/src/query.jl:359-369)
+__global__ void degree_weighted_kernel(const int32_t *rowptr, const int32_t *eid, const float *w,
+                                       int64_t n, int n_edges, float *deg) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int beg = rowptr[i], end = rowptr[i + 1];
+    float acc = 0.0f;
+    int p = beg;
+    for (; p + 8 <= end; p += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = eid[p + u];
+            v[u] = e < n_edges ? w[e] : 1.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = acc + v[u];
+    }
+    for (; p < end; ++p) {
+        const int e = eid[p];
+        acc = acc + (e < n_edges ? w[e] : 1.0f);
+    }
+    deg[i] = 0.0f + acc;
+}
+__global__ void inv_sqrt_kernel(const float *deg, float *out, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = __fdiv_rn(1.0f, __fsqrt_rn(deg[i]));
+}
+
+}  // namespace gnnmp
+
+using namespace gnnmp;
+
+static int check_aggr(int aggr, const char *who) {
+    if (aggr < GNNMP_SUM || aggr > GNNMP_MIN) return fail(GNNMP_EINVAL, "%s: bad aggr %d", who, aggr);
+    return GNNMP_OK;
+}
+
+extern "C" {
+
+int gnnmp_propagate_f32(gnnmp_graph_t *plan, int msg, int aggr, const float *xj, const float *w,
+                        const float *scale_src, const float *scale_dst, float *out, int64_t D,
+                        gnnmp_stream_t stream) {
+    if (!plan) return fail(GNNMP_EINVAL, "propagate: null plan");
+    if (int rc = check_aggr(aggr, "propagate")) return rc;
+    if (msg != GNNMP_COPY_XJ && msg != GNNMP_W_MUL_XJ) return fail(GNNMP_EINVAL, "propagate: bad msg %d", msg);
+    if (D < 0 || D > (1 << 20)) return fail(GNNMP_EINVAL, "propagate: bad D %lld", (long long)D);
+    if (plan->n_dst > 0 && D > 0 && (!out || (!xj && plan->n_total > 0)))
+        return fail(GNNMP_EINVAL, "propagate: null xj/out");
+    if (msg == GNNMP_W_MUL_XJ && !w && plan->n_edges > 0)
+        return fail(GNNMP_EINVAL, "propagate: W_MUL_XJ needs w");
+    if (msg == GNNMP_COPY_XJ) w = nullptr;
+    return run_reduce(plan, plan->col, aggr, xj, w, scale_src, scale_dst, out, D, (hipStream_t)stream);
+}
+
+int gnnmp_scatter_f32(gnnmp_graph_t *plan, int aggr, const float *m, float *out, int64_t D,
+                      gnnmp_stream_t stream) {
+    if (!plan) return fail(GNNMP_EINVAL, "scatter: null plan");
+    if (int rc = check_aggr(aggr, "scatter")) return rc;
+    if (D < 0 || D > (1 << 20)) return fail(GNNMP_EINVAL, "scatter: bad D %lld", (long long)D);
+    if (plan->n_dst > 0 && D > 0 && (!out || (!m && plan->n_total > 0)))
+        return fail(GNNMP_EINVAL, "scatter: null m/out");
+    return run_reduce(plan, plan->eid, aggr, m, nullptr, nullptr, nullptr, out, D, (hipStream_t)stream);
+}
+
+int gnnmp_degree_f32(gnnmp_graph_t *plan, const float *w, float *deg, gnnmp_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!plan) return fail(GNNMP_EINVAL, "degree: null plan");
+    if (plan->n_dst == 0) return GNNMP_OK;
+    if (!deg) return fail(GNNMP_EINVAL, "degree: null output");
+    const unsigned nb = (unsigned)((plan->n_dst + 255) / 256);
+    if (w)
+        degree_weighted_kernel<<<nb, 256, 0, stream>>>(plan->rowptr, plan->eid, w, plan->n_dst,
+                                                        (int)plan->n_edges, deg);
+    else
+        degree_count_kernel<<<nb, 256, 0, stream>>>(plan->rowptr, plan->n_dst, deg);
+    GNNMP_LAUNCH_CHECK("degree kernel");
+    return GNNMP_OK;
+}
+
+int gnnmp_inv_sqrt_f32(const float *deg, float *out, int64_t n, gnnmp_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n < 0) return fail(GNNMP_EINVAL, "inv_sqrt: negative n");
+    if (n == 0) return GNNMP_OK;
+    if (!deg || !out) return fail(GNNMP_EINVAL, "inv_sqrt: null pointer");
+    inv_sqrt_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(deg, out, n);
+    GNNMP_LAUNCH_CHECK("inv_sqrt_kernel");
+    return GNNMP_OK;
+}
+
+}  // extern "C"

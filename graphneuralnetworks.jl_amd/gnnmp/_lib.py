@@ -1,0 +1,108 @@
+"""ctypes binding of libgnnmp.so (include/gnnmp.h) — the same symbols the Julia extension `@ccall`s.
+
+torch is used only as plumbing: it owns device memory and the HIP stream.  Every compute call goes through the
+C ABI; there is NO CPU fallback — if the library is missing or no GPU is visible, calls raise.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG, "lib", "libgnnmp.so")
+
+OK, EINVAL, EBOUNDS, EALLOC, ELAUNCH, EUNSUPPORTED = 0, -1, -2, -3, -4, -5
+SUM, MEAN, MAX, MIN = 0, 1, 2, 3
+COPY_XJ, W_MUL_XJ = 0, 1
+ACT_IDENTITY, ACT_RELU = 0, 1
+LONG_ROW = 512
+
+# every symbol include/gnnmp.h declares (tests check the library exports exactly these)
+SYMBOLS = (
+    "gnnmp_version", "gnnmp_last_error",
+    "gnnmp_plan_create", "gnnmp_plan_destroy", "gnnmp_plan_info", "gnnmp_plan_export",
+    "gnnmp_add_self_loops", "gnnmp_batch_coo",
+    "gnnmp_gather_f32", "gnnmp_scatter_f32", "gnnmp_scatter_atomic_f32",
+    "gnnmp_propagate_f32", "gnnmp_degree_f32", "gnnmp_inv_sqrt_f32",
+    "gnnmp_edge_softmax_f32", "gnnmp_gat_node_scores_f32", "gnnmp_gat_aggregate_f32", "gnnmp_bias_act_f32",
+    "gnnmp_segment_pool_f32", "gnnmp_dense_f32",
+)
+
+
+class GnnmpError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(f"libgnnmp status {status}: {msg}")
+        self.status = status
+
+
+_lib = None
+
+
+def load():
+    """Load libgnnmp.so; raises (loudly) if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  gnnmp has no CPU fallback.")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i, i64, f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+    L.gnnmp_version.restype = i
+    L.gnnmp_last_error.restype = ctypes.c_char_p
+    sig = {
+        "gnnmp_plan_create": [ctypes.POINTER(vp), vp, vp, i, i, i64, i64, i64, i, i, vp],
+        "gnnmp_plan_destroy": [vp],
+        "gnnmp_plan_info": [vp, ctypes.POINTER(i64)],
+        "gnnmp_plan_export": [vp, vp, vp, vp, vp],
+        "gnnmp_add_self_loops": [vp, vp, i, i, i64, i64, vp, vp, vp, vp, vp],
+        "gnnmp_batch_coo": [vp, vp, i, i, vp, vp, i64, vp, vp, vp, vp],
+        "gnnmp_gather_f32": [vp, vp, i, i, i64, vp, i64, vp],
+        "gnnmp_scatter_f32": [vp, i, vp, vp, i64, vp],
+        "gnnmp_scatter_atomic_f32": [i, vp, vp, i, i, i64, vp, i64, vp],
+        "gnnmp_propagate_f32": [vp, i, i, vp, vp, vp, vp, vp, i64, vp],
+        "gnnmp_degree_f32": [vp, vp, vp, vp],
+        "gnnmp_inv_sqrt_f32": [vp, vp, i64, vp],
+        "gnnmp_edge_softmax_f32": [vp, vp, vp, i64, vp],
+        "gnnmp_gat_node_scores_f32": [vp, vp, vp, vp, i64, i64, i64, vp],
+        "gnnmp_gat_aggregate_f32": [vp, vp, vp, vp, f, vp, i, vp, vp, i64, i64, vp],
+        "gnnmp_bias_act_f32": [vp, vp, i, vp, i64, i64, vp],
+        "gnnmp_segment_pool_f32": [i, vp, vp, i, i, vp, i64, i64, i64, vp],
+        "gnnmp_dense_f32": [vp, vp, i64, i64, vp, vp, i64, i64, i, vp, i, vp, i64, i64, vp],
+        "gnnmp_tune": [i, i],
+    }
+    for name, args in sig.items():
+        fn = getattr(L, name)
+        fn.argtypes = args
+        fn.restype = i
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != OK:
+        raise GnnmpError(rc, load().gnnmp_last_error().decode())
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("gnnmp needs an AMD GPU (gfx950); there is no CPU fallback on the product path")
+
+
+def stream_ptr():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """device pointer of a tensor (None -> NULL)"""
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def tune(knob: int, value: int):
+    """perf-experiment hook (csrc/common.h Knob); not part of the drop-in surface"""
+    check(load().gnnmp_tune(knob, value))

@@ -1,0 +1,292 @@
+"""GNNGraph{COO_T} and the graph queries / transforms that sit on the hot path.
+
+Mirror of the reference container and functions (same names, argument meaning and error behaviour):
+  GNNGraph            GNNGraphs/src/gnngraph.jl:108-117 (COO storage `graph = (s, t, w | nothing)`)
+  edge_index          GNNGraphs/src/query.jl:12
+  degree              GNNGraphs/src/query.jl:314-331, 355-369
+  graph_indicator     GNNGraphs/src/query.jl:500-512
+  add_self_loops      GNNGraphs/src/transform.jl:12-28
+  set_edge_weight     GNNGraphs/src/transform.jl:568-577
+  batch               GNNGraphs/src/transform.jl:682-709 (MLUtils.batch)
+  check_num_nodes / check_num_edges   GNNGraphs/src/utils.jl:1-28  (AssertionError, like Julia's @assert)
+
+Feature arrays are torch float32 tensors shaped [N, ...] (= Julia (..., N) column-major).  Index vectors are kept
+exactly as the reference holds them: 1-based Int64 (or Int32) device vectors; `index_base=0` is accepted for
+Python callers.  All arithmetic happens in libgnnmp (HIP); torch only owns the memory.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _lib as L
+
+
+def _as_index(v, device):
+    if isinstance(v, torch.Tensor):
+        t = v
+    else:
+        t = torch.as_tensor(v)
+    if t.dtype not in (torch.int64, torch.int32):
+        t = t.to(torch.int64)
+    return t.to(device).contiguous()
+
+
+def _as_f32(v, device):
+    if v is None:
+        return None
+    t = v if isinstance(v, torch.Tensor) else torch.as_tensor(v)
+    return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+class Plan:
+    """Owner of one gnnmp_graph_t (dst-sorted CSR of an edge index); freed with the Python object."""
+
+    def __init__(self, s, t, n_src, n_dst, index_base, add_self_loops, validate=True):
+        L.require_gpu()
+        lib = L.load()
+        self._h = ctypes.c_void_p()
+        self._lib = lib
+        idx_bytes = 8 if s.dtype == torch.int64 else 4
+        rc = lib.gnnmp_plan_create(ctypes.byref(self._h), L.ptr(s), L.ptr(t), idx_bytes, index_base,
+                                   n_src, n_dst, s.numel(), 1 if add_self_loops else 0,
+                                   1 if validate else 0, L.stream_ptr())
+        if rc == L.EBOUNDS:
+            # GNNGraphs/src/convert.jl:47-54 asserts the index range at construction
+            raise AssertionError(lib.gnnmp_last_error().decode())
+        L.check(rc)
+        info = (ctypes.c_int64 * 8)()
+        L.check(lib.gnnmp_plan_info(self._h, info))
+        self.n_src, self.n_dst, self.n_edges, self.n_total = info[0], info[1], info[2], info[3]
+        self.max_degree, self.n_long, self.bytes, self.long_thresh = info[4], info[5], info[6], info[7]
+        self.device = s.device
+
+    @property
+    def handle(self):
+        return self._h
+
+    def export(self):
+        """(rowptr, col, eid) int32 device tensors — the plan's bit-exact index outputs"""
+        rowptr = torch.empty(self.n_dst + 1, dtype=torch.int32, device=self.device)
+        col = torch.empty(self.n_total, dtype=torch.int32, device=self.device)
+        eid = torch.empty(self.n_total, dtype=torch.int32, device=self.device)
+        L.check(self._lib.gnnmp_plan_export(self._h, L.ptr(rowptr), L.ptr(col), L.ptr(eid), L.stream_ptr()))
+        return rowptr, col, eid
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._lib.gnnmp_plan_destroy(self._h)
+                self._h = ctypes.c_void_p()
+        except Exception:
+            pass
+
+
+class GNNGraph:
+    """COO graph: `GNNGraph(s, t)` / `GNNGraph((s, t, w))` — GNNGraphs/src/gnngraph.jl:108-117.
+
+    s, t       : source / target node of each edge (1-based by default, like Julia)
+    w          : optional edge weights (Float32[E])
+    num_nodes  : defaults to max(maximum(s), maximum(t))  (convert.jl:33-36)
+    ndata `x`  : optional node features [num_nodes, ...]
+    """
+
+    def __init__(self, s, t=None, w=None, num_nodes=None, graph_indicator=None, num_graphs=1, x=None,
+                 index_base=1, device=None, _validated=False):
+        L.require_gpu()
+        if t is None and isinstance(s, (tuple, list)) and len(s) in (2, 3) and not isinstance(s[0], (int, float)):
+            tup = s
+            s, t = tup[0], tup[1]
+            w = tup[2] if len(tup) == 3 else w
+        device = torch.device(device) if device is not None else (
+            s.device if isinstance(s, torch.Tensor) and s.is_cuda else torch.device("cuda", torch.cuda.current_device()))
+        self.index_base = int(index_base)
+        assert self.index_base in (0, 1)
+        s = _as_index(s, device)
+        t = _as_index(t, device)
+        if s.dtype != t.dtype:
+            t = t.to(s.dtype)
+        assert s.dim() == 1 and t.dim() == 1 and s.numel() == t.numel(), "length(s) == length(t)"
+        self.w = _as_f32(w, device)
+        assert self.w is None or self.w.numel() == s.numel(), "length(val) == length(s)"
+        if num_nodes is None:
+            num_nodes = 0 if s.numel() == 0 else int(max(int(s.max()), int(t.max()))) + (1 - self.index_base)
+        self.s, self.t = s, t
+        self.num_nodes = int(num_nodes)
+        self.num_edges = int(s.numel())
+        self.num_graphs = int(num_graphs)
+        self.graph_indicator = None if graph_indicator is None else _as_index(graph_indicator, device)
+        self.x = _as_f32(x, device)
+        if self.x is not None:
+            check_num_nodes(self, self.x)
+        self.device = device
+        self._plans = {}
+        if not _validated:
+            self.plan(False)  # builds the CSR plan and validates 1 <= s,t <= n (convert.jl:47-54)
+
+    # -- plans (cached; the reference rebuilds sparse(s,t,...) on every call, convert.jl:221-237) --
+    def plan(self, add_self_loops: bool = False) -> Plan:
+        key = bool(add_self_loops)
+        p = self._plans.get(key)
+        if p is None:
+            p = Plan(self.s, self.t, self.num_nodes, self.num_nodes, self.index_base, key, validate=not key)
+            self._plans[key] = p
+        return p
+
+    @property
+    def idx_bytes(self):
+        return 8 if self.s.dtype == torch.int64 else 4
+
+    def __repr__(self):
+        return f"GNNGraph(num_nodes={self.num_nodes}, num_edges={self.num_edges}, num_graphs={self.num_graphs})"
+
+
+# ---------------------------------------------------------------------------------------------------------
+# checks — GNNGraphs/src/utils.jl:1-28
+# ---------------------------------------------------------------------------------------------------------
+def check_num_nodes(g: GNNGraph, x):
+    if x is None:
+        return True
+    if isinstance(x, dict):
+        for v in x.values():
+            check_num_nodes(g, v)
+        return True
+    if isinstance(x, (tuple, list)):
+        for v in x:
+            check_num_nodes(g, v)
+        return True
+    assert g.num_nodes == x.shape[0], \
+        f"Got {x.shape[0]} as last dimension size instead of num_nodes={g.num_nodes}"
+    return True
+
+
+def check_num_edges(g: GNNGraph, e):
+    if e is None:
+        return True
+    if isinstance(e, dict):
+        for v in e.values():
+            check_num_edges(g, v)
+        return True
+    if isinstance(e, (tuple, list)):
+        for v in e:
+            check_num_edges(g, v)
+        return True
+    assert g.num_edges == e.shape[0], \
+        f"Got {e.shape[0]} as last dimension size instead of num_edges={g.num_edges}"
+    return True
+
+
+# ---------------------------------------------------------------------------------------------------------
+# queries
+# ---------------------------------------------------------------------------------------------------------
+def edge_index(g: GNNGraph):
+    """(s, t) — zero-copy for COO graphs (GNNGraphs/src/query.jl:12)"""
+    return g.s, g.t
+
+
+def get_edge_weight(g: GNNGraph):
+    return g.w
+
+
+def graph_indicator(g: GNNGraph, edges: bool = False):
+    """GNNGraphs/src/query.jl:500-512"""
+    gi = g.graph_indicator
+    if gi is None:
+        gi = torch.full((g.num_nodes,), g.index_base, dtype=g.s.dtype, device=g.device)
+    if edges:
+        raise NotImplementedError("graph_indicator(g, edges=true) feeds softmax_edges/reduce_edges only: out of scope")
+    return gi
+
+
+def degree(g: GNNGraph, T=torch.float32, dir: str = "in", edge_weight=True):
+    """degree(g, T; dir, edge_weight) — GNNGraphs/src/query.jl:314-331,355-369.
+
+    edge_weight: True (use the graph's weights if any), False/None (count edges) or a weight vector.
+    Computed in Float32 on the device (the element type gcn_conv asks for, conv.jl:43,53-55)."""
+    assert dir in ("in", "out", "both")
+    if isinstance(edge_weight, torch.Tensor) or isinstance(edge_weight, (list, tuple)):
+        w = _as_f32(edge_weight, g.device)
+        assert w.numel() == g.num_edges
+    elif edge_weight is True:
+        w = g.w
+    else:
+        w = None
+    out = None
+    lib = L.load()
+    for d in (("in", "out") if dir == "both" else (dir,)):
+        if d == "in":
+            plan = g.plan(False)
+        else:
+            plan = g._plans.get("T")
+            if plan is None:
+                plan = Plan(g.t, g.s, g.num_nodes, g.num_nodes, g.index_base, False, validate=False)
+                g._plans["T"] = plan
+        deg = torch.empty(g.num_nodes, dtype=torch.float32, device=g.device)
+        L.check(lib.gnnmp_degree_f32(plan.handle, L.ptr(w), L.ptr(deg), L.stream_ptr()))
+        out = deg if out is None else out + deg
+    if T is not None and T != torch.float32:
+        out = out.to(T)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# transforms
+# ---------------------------------------------------------------------------------------------------------
+def add_self_loops(g: GNNGraph) -> GNNGraph:
+    """add_self_loops(g::GNNGraph{COO}) — GNNGraphs/src/transform.jl:12-28: appends (i, i) for every node, after
+    the existing edges, never de-duplicating; appended weights are 1."""
+    n, E = g.num_nodes, g.num_edges
+    s2 = torch.empty(E + n, dtype=g.s.dtype, device=g.device)
+    t2 = torch.empty(E + n, dtype=g.s.dtype, device=g.device)
+    w2 = None if g.w is None else torch.empty(E + n, dtype=torch.float32, device=g.device)
+    L.check(L.load().gnnmp_add_self_loops(L.ptr(g.s), L.ptr(g.t), g.idx_bytes, g.index_base, E, n, L.ptr(s2),
+                                          L.ptr(t2), L.ptr(g.w), L.ptr(w2), L.stream_ptr()))
+    return GNNGraph(s2, t2, w2, num_nodes=n, graph_indicator=g.graph_indicator, num_graphs=g.num_graphs, x=g.x,
+                    index_base=g.index_base, device=g.device, _validated=True)
+
+
+def set_edge_weight(g: GNNGraph, w) -> GNNGraph:
+    """GNNGraphs/src/transform.jl:568-577"""
+    w = _as_f32(w, g.device)
+    assert w.numel() == g.num_edges
+    g2 = GNNGraph(g.s, g.t, w, num_nodes=g.num_nodes, graph_indicator=g.graph_indicator,
+                  num_graphs=g.num_graphs, x=g.x, index_base=g.index_base, device=g.device, _validated=True)
+    g2._plans = g._plans  # same (s, t): plans are shared, like the reference shares s, t across copies
+    return g2
+
+
+def batch(gs) -> GNNGraph:
+    """MLUtils.batch(::Vector{GNNGraph{COO}}) — GNNGraphs/src/transform.jl:682-709: concatenates the edge indices with
+    node offsets cumsum(num_nodes), builds graph_indicator, concatenates node features."""
+    gs = list(gs)
+    if len(gs) == 0:
+        raise ValueError("Cannot batch an empty vector of graphs")
+    g0 = gs[0]
+    dev, base, dt = g0.device, g0.index_base, g0.s.dtype
+    for g in gs:
+        if not isinstance(g, GNNGraph):
+            raise ValueError("Cannot batch a non-GNNGraph")  # ArgumentError, transform.jl:711-713
+        assert g.index_base == base and g.s.dtype == dt
+        assert g.num_graphs == 1 or g.graph_indicator is not None
+    if any(g.num_graphs != 1 for g in gs):
+        # nested batches: flatten through their own indicators (graphsum offsets, transform.jl:697-699)
+        raise NotImplementedError("batching already-batched graphs is outside the hot path")
+    import itertools
+    ne = torch.tensor([0] + list(itertools.accumulate(g.num_edges for g in gs)), dtype=torch.int64, device=dev)
+    nn = torch.tensor([0] + list(itertools.accumulate(g.num_nodes for g in gs)), dtype=torch.int64, device=dev)
+    Etot, Ntot = int(ne[-1]), int(nn[-1])
+    s_cat = torch.cat([g.s for g in gs])
+    t_cat = torch.cat([g.t for g in gs])
+    s2, t2 = torch.empty_like(s_cat), torch.empty_like(t_cat)
+    gi = torch.empty(Ntot, dtype=dt, device=dev)
+    L.check(L.load().gnnmp_batch_coo(L.ptr(s_cat), L.ptr(t_cat), g0.idx_bytes, base, L.ptr(ne), L.ptr(nn), len(gs),
+                                     L.ptr(s2), L.ptr(t2), L.ptr(gi), L.stream_ptr()))
+    ws = [g.w for g in gs]
+    w = torch.cat(ws) if all(x is not None for x in ws) else None
+    xs = [g.x for g in gs]
+    x = torch.cat(xs) if all(v is not None for v in xs) else None
+    out = GNNGraph(s2, t2, w, num_nodes=Ntot, graph_indicator=gi, num_graphs=len(gs), x=x, index_base=base,
+                   device=dev, _validated=True)
+    assert out.num_edges == Etot
+    return out

@@ -1,0 +1,307 @@
+"""Functional layer bodies and thin layer objects for the four convolutions on the hot path + GlobalPool.
+
+Mirror of GNNlib/src/layers/conv.jl (functional bodies taking a bag of fields `l`) and of the Flux front-end structs in
+GraphNeuralNetworks/src/layers/conv.jl (same constructor arguments, field names and defaults):
+  gcn_conv      GNNlib conv.jl:14-72     GCNConv     front-end conv.jl:77-104   (add_self_loops=true, use_edge_weight=false)
+  graph_conv    GNNlib conv.jl:102-108   GraphConv   front-end conv.jl:226-245  (aggr = +)
+  gat_conv      GNNlib conv.jl:112-167   GATConv     front-end conv.jl:309-346  (heads=1, concat=true, slope=0.2)
+  sage_conv     GNNlib conv.jl:277-283   SAGEConv    front-end conv.jl:770-787  (aggr = mean)
+  global_pool   GNNlib pool.jl:3-5       GlobalPool  front-end pool.jl:35-41
+
+Weights keep the Julia shapes: `weight (out, in)` etc., stored as row-major torch tensors [out, in].
+Every arithmetic step is a libgnnmp call (HIP); torch only allocates.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import _lib as L
+from .graph import GNNGraph, check_num_nodes, degree
+from .msgpass import _flat, _fused, aggr_code
+from .utils import expand_srcdst, reduce_nodes
+
+_ACT = {None: L.ACT_IDENTITY, "identity": L.ACT_IDENTITY, "relu": L.ACT_RELU, torch.relu: L.ACT_RELU,
+        torch.nn.functional.relu: L.ACT_RELU}
+
+
+def _act_code(sigma):
+    """(fused code or None, python callable or None)"""
+    if sigma in _ACT:
+        return _ACT[sigma], None
+    if callable(sigma):
+        return L.ACT_IDENTITY, sigma
+    raise ValueError(f"unsupported activation {sigma!r}")
+
+
+def dense(x, W, bias=None, sigma=None, x2=None, W2=None):
+    """act(W * x (+ W2 * x2) (+ bias)) on the MFMA kernel.  W: [Dout, Din] (Julia (out, in)); W/W2 may be column
+    slices of a wider matrix (sage_conv's `weight * vcat(xi, m)`): only the last stride must be 1."""
+    assert x.dtype == torch.float32 and W.dtype == torch.float32
+    x = x.contiguous()
+    N, D1 = x.shape
+    Dout = W.shape[0]
+    assert W.shape[1] == D1 and W.stride(1) == 1
+    D2 = 0
+    ld2 = 0
+    if x2 is not None:
+        x2 = x2.contiguous()
+        D2 = x2.shape[1]
+        assert W2.shape == (Dout, D2) and W2.stride(1) == 1 and x2.shape[0] == N
+        ld2 = W2.stride(0)
+    code, post = _act_code(sigma)
+    out = torch.empty((N, Dout), dtype=torch.float32, device=x.device)
+    b = None if bias is None or bias is False else bias.contiguous()
+    L.check(L.load().gnnmp_dense_f32(L.ptr(x), L.ptr(W), D1, W.stride(0), L.ptr(x2), L.ptr(W2), D2, ld2, 0,
+                                     L.ptr(b), code, L.ptr(out), N, Dout, L.stream_ptr()))
+    return post(out) if post is not None else out
+
+
+def bias_act(x, bias, sigma):
+    code, post = _act_code(sigma)
+    b = None if bias is None or bias is False else bias.contiguous()
+    if b is None and code == L.ACT_IDENTITY:
+        return post(x) if post is not None else x
+    xf = _flat(x)
+    out = torch.empty_like(xf)
+    L.check(L.load().gnnmp_bias_act_f32(L.ptr(xf), L.ptr(b), code, L.ptr(out), xf.shape[0], xf.shape[1], L.stream_ptr()))
+    out = out.view(x.shape)
+    return post(out) if post is not None else out
+
+
+def _inv_sqrt(d):
+    out = torch.empty_like(d)
+    L.check(L.load().gnnmp_inv_sqrt_f32(L.ptr(d), L.ptr(out), d.numel(), L.stream_ptr()))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# GCNConv
+# ---------------------------------------------------------------------------------------------------------
+def gcn_conv(l, g: GNNGraph, x, edge_weight=None, norm_fn=None, conv_weight=None):
+    """GNNlib/src/layers/conv.jl:14-72.  One fused propagate: the two normalisation passes (`xj .* cout'`,
+    `x .* cin'`), the self loops and the edge weights all live inside gnnmp_propagate_f32."""
+    if edge_weight is not None:
+        edge_weight = edge_weight.to(device=g.device, dtype=torch.float32).contiguous()
+        if edge_weight.numel() != g.num_edges:
+            raise ValueError(f"Wrong number of edge weights (expected {g.num_edges} but given {edge_weight.numel()})")
+    weight = l.weight
+    if conv_weight is not None:
+        if tuple(conv_weight.shape) != tuple(l.weight.shape):
+            raise ValueError(f"The weight matrix has the wrong size. Expected {tuple(l.weight.shape)} "
+                             f"but got {tuple(conv_weight.shape)}")
+        weight = conv_weight
+    check_num_nodes(g, x)
+    loops = bool(l.add_self_loops)
+    plan = g.plan(loops)
+    Dout, Din = weight.shape
+    if Dout < Din:
+        x = dense(x, weight)  # multiply before convolution if it is more convenient (conv.jl:36-40)
+    # degree(g, T; dir = :in, edge_weight) on the self-looped graph (conv.jl:52-56)
+    if edge_weight is not None:
+        w = edge_weight
+    elif l.use_edge_weight:
+        w = g.w
+    else:
+        w = None
+    d = torch.empty(g.num_nodes, dtype=torch.float32, device=g.device)
+    L.check(L.load().gnnmp_degree_f32(plan.handle, L.ptr(w), L.ptr(d), L.stream_ptr()))
+    c = _inv_sqrt(d) if norm_fn is None else norm_fn(d).to(torch.float32).contiguous()
+    msg = L.COPY_XJ if w is None else L.W_MUL_XJ
+    x = _fused(g, msg, "+", x, w, scale_src=c, scale_dst=c, add_self_loops=loops)
+    if Dout >= Din:
+        return dense(x, weight, l.bias, l.sigma)
+    return bias_act(x, l.bias, l.sigma)
+
+
+class GCNConv:
+    """GCNConv(in => out, σ=identity; bias=true, add_self_loops=true, use_edge_weight=false)
+    — GraphNeuralNetworks/src/layers/conv.jl:77-104"""
+
+    def __init__(self, ch, sigma=None, bias=True, add_self_loops=True, use_edge_weight=False, device="cuda", seed=None):
+        cin, cout = ch
+        self.weight = glorot_uniform(cout, cin, device=device, seed=seed)
+        self.bias = torch.zeros(cout, dtype=torch.float32, device=device) if bias else None
+        self.sigma = sigma
+        self.add_self_loops = add_self_loops
+        self.use_edge_weight = use_edge_weight
+
+    def __call__(self, g, x, edge_weight=None, norm_fn=None, conv_weight=None):
+        return gcn_conv(self, g, x, edge_weight, norm_fn, conv_weight)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# GraphConv
+# ---------------------------------------------------------------------------------------------------------
+def graph_conv(l, g: GNNGraph, x):
+    """GNNlib/src/layers/conv.jl:102-108: σ.(W1*xi .+ W2*propagate(copy_xj, g, aggr) .+ b)"""
+    check_num_nodes(g, x)
+    xj, xi = expand_srcdst(g, x)
+    m = _fused(g, L.COPY_XJ, l.aggr, xj, None)
+    return dense(xi, l.weight1, l.bias, l.sigma, x2=m, W2=l.weight2)
+
+
+class GraphConv:
+    """GraphConv(in => out, σ=identity; aggr=+, bias=true) — GraphNeuralNetworks/src/layers/conv.jl:226-245"""
+
+    def __init__(self, ch, sigma=None, aggr="+", bias=True, device="cuda", seed=None):
+        cin, cout = ch
+        self.weight1 = glorot_uniform(cout, cin, device=device, seed=seed)
+        self.weight2 = glorot_uniform(cout, cin, device=device, seed=None if seed is None else seed + 1)
+        self.bias = torch.zeros(cout, dtype=torch.float32, device=device) if bias else None
+        self.sigma = sigma
+        self.aggr = aggr
+
+    def __call__(self, g, x):
+        return graph_conv(self, g, x)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# SAGEConv
+# ---------------------------------------------------------------------------------------------------------
+def sage_conv(l, g: GNNGraph, x):
+    """GNNlib/src/layers/conv.jl:277-283: σ.(W * vcat(xi, propagate(copy_xj, g, aggr)) .+ b); the vcat is never built —
+    the first `in` columns of W multiply xi, the last `in` multiply the aggregate."""
+    check_num_nodes(g, x)
+    xj, xi = expand_srcdst(g, x)
+    m = _fused(g, L.COPY_XJ, l.aggr, xj, None)
+    Din = xi.shape[1]
+    W = l.weight
+    return dense(xi, W[:, :Din], l.bias, l.sigma, x2=m, W2=W[:, Din:])
+
+
+class SAGEConv:
+    """SAGEConv(in => out, σ=identity; aggr=mean, bias=true) — GraphNeuralNetworks/src/layers/conv.jl:770-787"""
+
+    def __init__(self, ch, sigma=None, aggr="mean", bias=True, device="cuda", seed=None):
+        cin, cout = ch
+        self.weight = glorot_uniform(cout, 2 * cin, device=device, seed=seed)
+        self.bias = torch.zeros(cout, dtype=torch.float32, device=device) if bias else None
+        self.sigma = sigma
+        self.aggr = aggr
+
+    def __call__(self, g, x):
+        return sage_conv(self, g, x)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# GATConv
+# ---------------------------------------------------------------------------------------------------------
+def gat_conv(l, g: GNNGraph, x, e=None, return_alpha=False):
+    """GNNlib/src/layers/conv.jl:112-167 (no edge features: dense_e === nothing).  dense_x GEMM -> node scores ->
+    one fused edge-softmax + weighted aggregate over the (self-looped) plan."""
+    check_num_nodes(g, x)
+    assert e is None, "edge features (dense_e) are outside the hot path"
+    loops = bool(l.add_self_loops)
+    plan = g.plan(loops)
+    H = l.heads
+    C = l.channel[1]
+    N = g.num_nodes
+    Wx = dense(x, l.dense_x_weight)                        # reshape(dense_x(x), C, H, N)
+    a_hc = l.a_hc                                          # [H][2C]
+    sd = torch.empty((N, H), dtype=torch.float32, device=x.device)
+    ss = torch.empty((N, H), dtype=torch.float32, device=x.device)
+    lib = L.load()
+    L.check(lib.gnnmp_gat_node_scores_f32(L.ptr(Wx), L.ptr(a_hc), L.ptr(sd), L.ptr(ss), N, H, C, L.stream_ptr()))
+    out = torch.empty((N, H * C), dtype=torch.float32, device=x.device)
+    alpha = torch.empty((plan.n_total, H), dtype=torch.float32, device=x.device) if return_alpha else None
+    code, post = _act_code(l.sigma)
+    fuse_tail = bool(l.concat)
+    b = l.bias if (fuse_tail and l.bias is not None) else None
+    L.check(lib.gnnmp_gat_aggregate_f32(plan.handle, L.ptr(Wx), L.ptr(sd), L.ptr(ss), float(l.negative_slope),
+                                        L.ptr(b), code if fuse_tail else L.ACT_IDENTITY, L.ptr(out), L.ptr(alpha),
+                                        H, C, L.stream_ptr()))
+    if fuse_tail:
+        y = post(out) if post is not None else out
+    else:
+        # mean(x, dims = 2) over heads (conv.jl:143-145): H is tiny; torch strided adds are plumbing-level elementwise
+        y3 = out.view(N, H, C)
+        acc = y3[:, 0, :].clone()
+        for h in range(1, H):
+            acc = acc + y3[:, h, :]
+        y = bias_act(acc / float(H), l.bias, l.sigma)
+    return (y, alpha) if return_alpha else y
+
+
+class GATConv:
+    """GATConv(in => out, σ=identity; heads=1, concat=true, negative_slope=0.2, bias=true, add_self_loops=true,
+    dropout=0.0) — GraphNeuralNetworks/src/layers/conv.jl:309-346.  `a` has the Julia shape (2*out, heads)."""
+
+    def __init__(self, ch, sigma=None, heads=1, concat=True, negative_slope=0.2, bias=True, add_self_loops=True,
+                 dropout=0.0, device="cuda", seed=None):
+        cin, cout = ch
+        assert dropout == 0.0, "dropout is identity in the forward/test mode this engine covers"
+        self.channel = (cin, cout)
+        self.heads = heads
+        self.concat = concat
+        self.negative_slope = float(negative_slope)
+        self.add_self_loops = add_self_loops
+        self.dense_x_weight = glorot_uniform(cout * heads, cin, device=device, seed=seed)
+        self.a = glorot_uniform(2 * cout, heads, device=device, seed=None if seed is None else seed + 1)
+        nb = cout * heads if concat else cout
+        self.bias = torch.zeros(nb, dtype=torch.float32, device=device) if bias else None
+        self.sigma = sigma
+
+    @property
+    def a_hc(self):
+        return self.a.t().contiguous()  # [H][2C]: a[h][0:C] targets, a[h][C:2C] sources
+
+    def __call__(self, g, x, e=None):
+        return gat_conv(self, g, x, e)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# GlobalPool, GNNChain, Dense
+# ---------------------------------------------------------------------------------------------------------
+def global_pool(l, g: GNNGraph, x):
+    """GNNlib/src/layers/pool.jl:3-5"""
+    return reduce_nodes(l.aggr, g, x)
+
+
+class GlobalPool:
+    """GlobalPool(aggr) — GraphNeuralNetworks/src/layers/pool.jl:35-41"""
+
+    def __init__(self, aggr):
+        self.aggr = aggr
+
+    def __call__(self, g, x):
+        return global_pool(self, g, x)
+
+
+class Dense:
+    """Flux.Dense(in => out, σ) acting on [N, in] features (used as the classifier head of the example models)."""
+
+    def __init__(self, ch, sigma=None, bias=True, device="cuda", seed=None):
+        cin, cout = ch
+        self.weight = glorot_uniform(cout, cin, device=device, seed=seed)
+        self.bias = torch.zeros(cout, dtype=torch.float32, device=device) if bias else None
+        self.sigma = sigma
+
+    def __call__(self, x):
+        return dense(x, self.weight, self.bias, self.sigma)
+
+
+class GNNChain:
+    """GNNChain(layers...) — GraphNeuralNetworks/src/layers/basic.jl:106-156: graph layers get (g, x), others x."""
+
+    def __init__(self, *layers):
+        self.layers = layers
+
+    def __call__(self, g, x):
+        for l in self.layers:
+            x = l(x) if isinstance(l, Dense) or not _takes_graph(l) else l(g, x)
+        return x
+
+
+def _takes_graph(l):
+    return isinstance(l, (GCNConv, GraphConv, SAGEConv, GATConv, GlobalPool))
+
+
+def glorot_uniform(rows, cols, device="cuda", seed=None):
+    """Flux.glorot_uniform: U(-s, s), s = sqrt(24 / (fan_in + fan_out)) / 2... i.e. sqrt(6 / (rows + cols))"""
+    gen = torch.Generator(device="cpu")
+    gen.manual_seed(0 if seed is None else int(seed))
+    s = math.sqrt(6.0 / (rows + cols))
+    w = (torch.rand((rows, cols), generator=gen, dtype=torch.float32) * 2 - 1) * s
+    return w.to(device)

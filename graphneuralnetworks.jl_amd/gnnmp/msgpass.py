@@ -1,0 +1,183 @@
+"""Message passing: propagate / apply_edges / aggregate_neighbors and the built-in message functions.
+
+Mirror of GNNlib/src/msgpass.jl (same names, argument order, error behaviour):
+  propagate(f, g, aggr; xi, xj, e)         msgpass.jl:71-79   (+ fast-path specialisations :215-238)
+  apply_edges(f, g; xi, xj, e)             msgpass.jl:121-129
+  aggregate_neighbors(g, aggr, m)          msgpass.jl:145-149
+  copy_xj, copy_xi, xi_dot_xj, xi_sub_xj, xj_sub_xi, e_mul_xj, w_mul_xj      msgpass.jl:162-208
+and of the leaf ops GNNGraphs/src/gatherscatter.jl:1-18 (`_gather`, `_scatter`, recursing over tuples / dicts / None).
+
+Where the reference's GPU extension (GNNlib/ext/GNNlibAMDGPUExt.jl:13-32) routes `copy_xj / e_mul_xj / w_mul_xj` to the
+generic three-pass gather -> message -> atomic-scatter path, this module calls ONE fused HIP kernel
+(`gnnmp_propagate_f32`) for every aggr in {+, mean, max, min}.  Arbitrary Python closures still work: they take the
+generic path built from the HIP gather and the deterministic plan-based HIP scatter.
+"""
+from __future__ import annotations
+
+import operator
+import statistics
+
+import torch
+
+from . import _lib as L
+from .graph import GNNGraph, Plan, check_num_edges, check_num_nodes, edge_index
+
+_AGGR = {
+    "+": L.SUM, "sum": L.SUM, "add": L.SUM, operator.add: L.SUM, sum: L.SUM, torch.sum: L.SUM, torch.add: L.SUM,
+    "mean": L.MEAN, statistics.mean: L.MEAN, torch.mean: L.MEAN,
+    "max": L.MAX, max: L.MAX, torch.max: L.MAX, torch.maximum: L.MAX,
+    "min": L.MIN, min: L.MIN, torch.min: L.MIN, torch.minimum: L.MIN,
+}
+
+
+def aggr_code(aggr) -> int:
+    try:
+        return _AGGR[aggr]
+    except (KeyError, TypeError):
+        raise ValueError(f"unsupported aggregation operator {aggr!r} (expected +, mean, max or min)")
+
+
+def _flat(x: torch.Tensor):
+    """[N, ...] -> contiguous float32 [N, D]"""
+    assert x.dtype == torch.float32, "gnnmp supports Float32 features"
+    x = x.contiguous()
+    return x.view(x.shape[0], -1) if x.dim() != 2 else x
+
+
+# ---------------------------------------------------------------------------------------------------------
+# leaf ops
+# ---------------------------------------------------------------------------------------------------------
+def _gather(x, i, index_base=1):
+    """GNNGraphs/src/gatherscatter.jl:1-5 — NNlib.gather on the last (here: first) dimension."""
+    if x is None:
+        return None
+    if isinstance(x, dict):
+        return {k: _gather(v, i, index_base) for k, v in x.items()}
+    if isinstance(x, tuple):
+        return tuple(_gather(v, i, index_base) for v in x)
+    if isinstance(x, list):
+        return [_gather(v, i, index_base) for v in x]
+    xf = _flat(x)
+    K, D = i.numel(), xf.shape[1]
+    out = torch.empty((K,) + tuple(x.shape[1:]), dtype=torch.float32, device=x.device)
+    L.check(L.load().gnnmp_gather_f32(L.ptr(xf), L.ptr(i), 8 if i.dtype == torch.int64 else 4, index_base, K,
+                                      L.ptr(out), D, L.stream_ptr()))
+    return out
+
+
+def _scatter_plan(aggr, src, plan: Plan):
+    """GNNGraphs/src/gatherscatter.jl:7-18 with idx = the plan's targets: deterministic, edge-order reduction."""
+    if src is None:
+        return None
+    if isinstance(src, dict):
+        return {k: _scatter_plan(aggr, v, plan) for k, v in src.items()}
+    if isinstance(src, tuple):
+        return tuple(_scatter_plan(aggr, v, plan) for v in src)
+    if isinstance(src, list):
+        return [_scatter_plan(aggr, v, plan) for v in src]
+    sf = _flat(src)
+    assert sf.shape[0] == plan.n_total
+    out = torch.empty((plan.n_dst,) + tuple(src.shape[1:]), dtype=torch.float32, device=src.device)
+    L.check(L.load().gnnmp_scatter_f32(plan.handle, aggr_code(aggr), L.ptr(sf), L.ptr(out), sf.shape[1],
+                                       L.stream_ptr()))
+    return out
+
+
+def _scatter(aggr, src, idx, n, index_base=1):
+    """NNlib.scatter(aggr, src, idx; dstsize = (..., n)) for an arbitrary index vector: builds a throw-away plan
+    (src = 1..K -> dst = idx) so that the reduction is in k order, like NNlib's CPU loop."""
+    if src is None:
+        return None
+    return _scatter_plan(aggr, src, _idx_plan(idx, n, index_base))
+
+
+def _idx_plan(idx, n, index_base):
+    K = idx.numel()
+    ar = torch.arange(index_base, K + index_base, dtype=idx.dtype, device=idx.device)
+    return Plan(ar, idx, K, n, index_base, False, validate=True)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# message functions — GNNlib/src/msgpass.jl:162-208
+# ---------------------------------------------------------------------------------------------------------
+def copy_xj(xi, xj, e):
+    return xj
+
+
+def copy_xi(xi, xj, e):
+    return xi
+
+
+def xi_dot_xj(xi, xj, e):
+    return (xi * xj).sum(dim=-1, keepdim=True)  # Julia dims = 1 is the fastest (here: last) feature dim
+
+
+def xi_sub_xj(xi, xj, e):
+    return xi - xj
+
+
+def xj_sub_xi(xi, xj, e):
+    return xj - xi
+
+
+def e_mul_xj(xi, xj, e):
+    assert e.dim() <= xj.dim()
+    # Julia reshapes e to (1,...,1, size(e)...) i.e. prepends singleton FEATURE dims; row-major: append them
+    # between the edge dim and the trailing feature dims that e does not have.
+    shape = (e.shape[0],) + (1,) * (xj.dim() - e.dim()) + tuple(e.shape[1:])
+    return e.reshape(shape) * xj
+
+
+def w_mul_xj(xi, xj, w):
+    if w is None:
+        return xj
+    return w.reshape((w.shape[0],) + (1,) * (xj.dim() - 1)) * xj
+
+
+# ---------------------------------------------------------------------------------------------------------
+# apply_edges / aggregate_neighbors / propagate
+# ---------------------------------------------------------------------------------------------------------
+def apply_edges(f, g: GNNGraph, xi=None, xj=None, e=None):
+    """msgpass.jl:121-129"""
+    check_num_nodes(g, (xj, xi))
+    check_num_edges(g, e)
+    s, t = edge_index(g)
+    xi = _gather(xi, t, g.index_base)
+    xj = _gather(xj, s, g.index_base)
+    return f(xi, xj, e)
+
+
+def aggregate_neighbors(g: GNNGraph, aggr, m):
+    """msgpass.jl:145-149"""
+    check_num_edges(g, m)
+    return _scatter_plan(aggr, m, g.plan(False))
+
+
+def _fused(g: GNNGraph, msg: int, aggr, xj, w, scale_src=None, scale_dst=None, add_self_loops=False):
+    plan = g.plan(add_self_loops)
+    xf = _flat(xj)
+    out = torch.empty((plan.n_dst,) + tuple(xj.shape[1:]), dtype=torch.float32, device=xj.device)
+    L.check(L.load().gnnmp_propagate_f32(plan.handle, msg, aggr_code(aggr), L.ptr(xf), L.ptr(w), L.ptr(scale_src),
+                                         L.ptr(scale_dst), L.ptr(out), xf.shape[1], L.stream_ptr()))
+    return out
+
+
+def propagate(f, g: GNNGraph, aggr, xi=None, xj=None, e=None):
+    """msgpass.jl:71-79.  `copy_xj`, `w_mul_xj` (graph weights) and `e_mul_xj` with a vector `e` take the fused kernel
+    for every aggr (the reference specialises only `+`, and only on the CPU: msgpass.jl:215-238)."""
+    if isinstance(xj, torch.Tensor):
+        if f is copy_xj:
+            check_num_nodes(g, (xj, xi))
+            check_num_edges(g, e)
+            return _fused(g, L.COPY_XJ, aggr, xj, None)
+        if f is w_mul_xj and e is None:
+            check_num_nodes(g, (xj, xi))
+            if g.w is None:
+                return _fused(g, L.COPY_XJ, aggr, xj, None)
+            return _fused(g, L.W_MUL_XJ, aggr, xj, g.w)
+        if f is e_mul_xj and isinstance(e, torch.Tensor) and e.dim() == 1:
+            check_num_nodes(g, (xj, xi))
+            check_num_edges(g, e)
+            return _fused(g, L.W_MUL_XJ, aggr, xj, e.to(torch.float32).contiguous())
+    m = apply_edges(f, g, xi, xj, e)
+    return aggregate_neighbors(g, aggr, m)

@@ -1,0 +1,223 @@
+/*
+ * gnnmp.h — C ABI of libgnnmp.so, the MI355X (gfx950) message-passing engine.
+ *
+ * This is the drop-in boundary for the GNNlib.jl hot path
+ *   propagate / apply_edges / aggregate_neighbors  (GNNlib/src/msgpass.jl:71-79,121-129,145-149)
+ * and the leaf ops it is built from
+ *   _gather / _scatter                             (GNNGraphs/src/gatherscatter.jl:4,12-18)
+ * The reference has no FFI: its device seam is the Julia package extension
+ * GNNlib/ext/GNNlibAMDGPUExt.jl:13-32 (methods of GNNlib.propagate on AnyROCMatrix).  A replacement
+ * extension `@ccall`s the symbols below (see INTEGRATION.md for the exact stub).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer, borrowed for the duration of the call only;
+ *     the caller allocates inputs AND outputs.  The only long-lived object is the opaque plan.
+ *   - feature arrays are Julia column-major (D, N)  ==  C row-major [N][D]: one node's / edge's
+ *     feature vector is contiguous.  fp32 only.
+ *   - index arrays are passed exactly as the reference holds them: Int64 or Int32 (idx_bytes = 8 | 4),
+ *     1-based (index_base = 1, Julia) or 0-based (index_base = 0).
+ *   - `stream` is a hipStream_t (NULL = the null stream).  Compute entry points launch on it and
+ *     return; they never call hipDeviceSynchronize and never allocate (exception: the first use of a
+ *     plan with a row longer than GNNMP_LONG_ROW at a larger D than before grows a plan-owned
+ *     workspace with hipMalloc).  gnnmp_plan_create synchronises `stream` (it is graph prep, done
+ *     once per graph, outside the timed path).
+ *   - return value: 0 = ok, negative = gnnmp_status; nothing throws, nothing aborts.
+ *     gnnmp_last_error() gives a thread-local message for the last failing call.
+ *   - determinism: no entry point except *_atomic_* uses floating-point atomics.  Per-destination
+ *     reductions run in the ORIGINAL COO edge order (the order NNlib.scatter uses on the CPU) for
+ *     rows of at most GNNMP_LONG_ROW edges — bit-identical to the reference CPU gather->scatter
+ *     path; longer rows are split into fixed chunks combined in fixed order (run-to-run
+ *     deterministic, within 1e-5 rel of the sequential sum).
+ */
+#ifndef GNNMP_H
+#define GNNMP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GNNMP_VERSION 100 /* 0.1.0 */
+
+typedef void *gnnmp_stream_t;           /* hipStream_t */
+typedef struct gnnmp_graph gnnmp_graph_t; /* opaque: dst-sorted CSR plan of one (s, t) edge index */
+
+typedef enum {
+    GNNMP_OK = 0,
+    GNNMP_EINVAL = -1,       /* bad argument (null pointer, bad enum, bad size)            */
+    GNNMP_EBOUNDS = -2,      /* index outside 1..N (validate != 0 only)                    */
+    GNNMP_EALLOC = -3,       /* hipMalloc failed                                           */
+    GNNMP_ELAUNCH = -4,      /* kernel launch / HIP runtime error                          */
+    GNNMP_EUNSUPPORTED = -5  /* valid request outside the build's envelope (e.g. E' >= 2^31) */
+} gnnmp_status;
+
+/* aggregation operator — the `aggr` argument of propagate / aggregate_neighbors / reduce_nodes
+ * (GNNGraphs/src/gatherscatter.jl:12-18 -> NNlib.scatter).  Empty destinations keep the identity:
+ * 0 for SUM and MEAN, -Inf for MAX, +Inf for MIN.  MEAN = sum / count (true division). */
+typedef enum { GNNMP_SUM = 0, GNNMP_MEAN = 1, GNNMP_MAX = 2, GNNMP_MIN = 3 } gnnmp_aggr;
+
+/* built-in message functions with a fused path (GNNlib/src/msgpass.jl:162,191-208).
+ * E_MUL_XJ with a vector `e` is W_MUL_XJ with w = e (msgpass.jl:223-228). */
+typedef enum { GNNMP_COPY_XJ = 0, GNNMP_W_MUL_XJ = 1 } gnnmp_msg;
+
+/* activation fused into gnnmp_dense_f32's epilogue (the layers' `σ`). */
+typedef enum { GNNMP_ACT_IDENTITY = 0, GNNMP_ACT_RELU = 1 } gnnmp_act;
+
+/* rows longer than this are split (see determinism note above) */
+#define GNNMP_LONG_ROW 512
+
+int gnnmp_version(void);
+const char *gnnmp_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Plan: the graph side of GNNGraph{COO_T} (GNNGraphs/src/gnngraph.jl:108-117) as the kernels want it.
+ * Built once per (s, t) pair; replaces the per-call `sparse(s,t,...)` rebuild of the reference fast path
+ * (GNNlib/src/msgpass.jl:215-218 -> GNNGraphs/src/convert.jl:221-237) and the per-call index
+ * concatenation of add_self_loops (GNNGraphs/src/transform.jl:12-28).
+ *
+ *   src, dst     : s and t, n_edges entries each (edge k goes src[k] -> dst[k]).
+ *   n_src, n_dst : number of source / destination nodes (equal for GNNGraph; different for the bipartite
+ *                  case of GNNlib/src/utils.jl:123-125 and for reduce_nodes-as-scatter).
+ *   add_self_loops != 0 : append the edges (i, i), i = 1..n (requires n_src == n_dst), AFTER the given
+ *                  edges, exactly like transform.jl:12-28 (never de-duplicates).  E' = n_edges + n.
+ *   validate != 0: check 1 <= s <= n_src, 1 <= t <= n_dst on the device (GNNGraphs/src/convert.jl:47-54)
+ *                  and return GNNMP_EBOUNDS instead of building.
+ * The plan stores: rowptr[n_dst+1], col[E'] (0-based source of each slot), eid[E'] (0-based original
+ * edge position of each slot; self loops are n_edges + i).  Slots of one destination keep the original
+ * edge order (stable sort).
+ * ---------------------------------------------------------------------------------------------- */
+int gnnmp_plan_create(gnnmp_graph_t **out, const void *src, const void *dst, int idx_bytes,
+                      int index_base, int64_t n_src, int64_t n_dst, int64_t n_edges,
+                      int add_self_loops, int validate, gnnmp_stream_t stream);
+int gnnmp_plan_destroy(gnnmp_graph_t *plan);
+/* info[0]=n_src info[1]=n_dst info[2]=n_edges (as given) info[3]=E' (with self loops)
+ * info[4]=max in-degree info[5]=number of split (long) rows info[6]=bytes of device memory held */
+int gnnmp_plan_info(const gnnmp_graph_t *plan, int64_t info[8]);
+/* copy the plan's index arrays into caller device buffers (any may be NULL): int32 rowptr[n_dst+1],
+ * col[E'], eid[E'] — bit-exact index outputs, used by the parity tests. */
+int gnnmp_plan_export(const gnnmp_graph_t *plan, int32_t *rowptr, int32_t *col, int32_t *eid,
+                      gnnmp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Index ops (bit-exact)
+ * ---------------------------------------------------------------------------------------------- */
+/* add_self_loops(g::GNNGraph{COO}) — GNNGraphs/src/transform.jl:12-28.
+ * out_src/out_dst have n_edges + n entries of the same width/base as the inputs; w / out_w may both be
+ * NULL (unweighted) or both non-NULL (appended weights are 1). */
+int gnnmp_add_self_loops(const void *src, const void *dst, int idx_bytes, int index_base,
+                         int64_t n_edges, int64_t n, void *out_src, void *out_dst, const float *w,
+                         float *out_w, gnnmp_stream_t stream);
+
+/* MLUtils.batch(::Vector{GNNGraph{COO}}) index part — GNNGraphs/src/transform.jl:682-709.
+ * src/dst hold the member graphs' edge indices concatenated (local numbering); edge_ptr[G+1] and
+ * node_ptr[G+1] are int64 device arrays of exclusive prefix sums of num_edges / num_nodes.
+ * Writes the offset indices (same width/base) and graph_indicator[N] (same width; values
+ * index_base .. index_base+G-1, i.e. 1..G for Julia). */
+int gnnmp_batch_coo(const void *src, const void *dst, int idx_bytes, int index_base,
+                    const int64_t *edge_ptr, const int64_t *node_ptr, int64_t n_graphs,
+                    void *out_src, void *out_dst, void *graph_indicator, gnnmp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Leaf ops: _gather / _scatter  (GNNGraphs/src/gatherscatter.jl:4,12-18)
+ * ---------------------------------------------------------------------------------------------- */
+/* out[k][:] = x[idx[k]][:]  for k in [0,K)  — NNlib.gather; pure copy, bit-exact. */
+int gnnmp_gather_f32(const float *x, const void *idx, int idx_bytes, int index_base, int64_t K,
+                     float *out, int64_t D, gnnmp_stream_t stream);
+/* out[i][:] = aggr_{k : t_k = i, in edge order} m[k][:]   — NNlib.scatter(aggr, m, t; dstsize=(D, n_dst))
+ * with t = the plan's dst.  m is [E'][D] in ORIGINAL edge order (self-loop rows last). */
+int gnnmp_scatter_f32(gnnmp_graph_t *plan, int aggr, const float *m, float *out, int64_t D,
+                      gnnmp_stream_t stream);
+/* What NNlib's KernelAbstractions scatter does on GPU arrays today: one atomic per element, fp32 '+'
+ * order not defined.  Kept as the measured comparator and for callers that have no plan.
+ * `out` must be pre-filled with the identity by the caller.  aggr in {SUM, MAX, MIN}. */
+int gnnmp_scatter_atomic_f32(int aggr, const float *m, const void *idx, int idx_bytes,
+                             int index_base, int64_t K, float *out, int64_t D,
+                             gnnmp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused propagate  (GNNlib/src/msgpass.jl:71-79; fast-path specialisations :215-238)
+ *
+ *   out[i][:] = scale_dst[i] * aggr_{p in row i} ( w[eid_p] * ( scale_src[col_p] * xj[col_p][:] ) )
+ *
+ * msg = COPY_XJ ignores w.  w has n_edges entries in ORIGINAL edge order (self loops added by the plan
+ * have weight 1, as GNNlib/src/layers/conv.jl:28-33 and transform.jl:22-24 pad).  scale_src / scale_dst
+ * (nullable) are the GCN normalisation vectors `cout`, `cin` of GNNlib/src/layers/conv.jl:57-67; every
+ * product is rounded separately (no FMA contraction) so the result equals the reference's materialised
+ * `xj .* cout'` -> propagate -> `x .* cin'` sequence bit for bit on rows <= GNNMP_LONG_ROW.
+ * ---------------------------------------------------------------------------------------------- */
+int gnnmp_propagate_f32(gnnmp_graph_t *plan, int msg, int aggr, const float *xj, const float *w,
+                        const float *scale_src, const float *scale_dst, float *out, int64_t D,
+                        gnnmp_stream_t stream);
+
+/* degree(g, Float32; dir = :in, edge_weight) — GNNGraphs/src/query.jl:314-331,355-369.
+ * w == NULL: counts (exact integers).  w != NULL: n_edges weights in original order, summed in edge
+ * order; plan-added self loops count 1. */
+int gnnmp_degree_f32(gnnmp_graph_t *plan, const float *w, float *deg, gnnmp_stream_t stream);
+
+/* out[i] = 1/sqrt(deg[i])  — the default norm_fn of GCNConv (GraphNeuralNetworks/src/layers/conv.jl:99);
+ * evaluated as the correctly rounded sqrt then the correctly rounded division, like Julia's broadcast. */
+int gnnmp_inv_sqrt_f32(const float *deg, float *out, int64_t n, gnnmp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * softmax_edge_neighbors(g, e) — GNNlib/src/utils.jl:84-97.  logits and alpha are [E'][H] in ORIGINAL
+ * edge order.  Per destination and channel: max, exp(e - max), sum in edge order, true division.
+ * ---------------------------------------------------------------------------------------------- */
+int gnnmp_edge_softmax_f32(gnnmp_graph_t *plan, const float *logits, float *alpha, int64_t H,
+                           gnnmp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * GATConv attention path — GNNlib/src/layers/conv.jl:112-167 from `apply_edges` to
+ * `aggregate_neighbors`, fused.
+ *   Wx       : [N][H][C]  (Julia reshape(dense_x(x), C, H, N))
+ *   a        : [H][2C]    (Julia l.a of size (2C, H)); a[h][0:C] pairs with the TARGET Wx_i,
+ *                          a[h][C:2C] with the SOURCE Wx_j (order of vcat(Wxi, Wxj), conv.jl:157)
+ * gnnmp_gat_node_scores_f32: score_dst[n][h] = sum_c a[h][c]*Wx[n][h][c],
+ *                            score_src[n][h] = sum_c a[h][C+c]*Wx[n][h][c]   (either out may be NULL)
+ * gnnmp_gat_aggregate_f32  : logit_p[h] = leakyrelu(score_dst[i][h] + score_src[col_p][h], slope)
+ *                            alpha = softmax over row i (as gnnmp_edge_softmax_f32)
+ *                            out[i][h][:] = sum_p alpha_p[h] * Wx_src[col_p][h][:]   (edge order)
+ *   alpha_out (nullable): [E'][H] attention coefficients in original edge order.
+ *   bias (nullable, [H*C]) and act: the layer's `σ.(x .+ bias)` (conv.jl:147) fused into the store for the
+ *   concat = true case.
+ * ---------------------------------------------------------------------------------------------- */
+int gnnmp_gat_node_scores_f32(const float *Wx, const float *a, float *score_dst, float *score_src,
+                              int64_t N, int64_t H, int64_t C, gnnmp_stream_t stream);
+int gnnmp_gat_aggregate_f32(gnnmp_graph_t *plan, const float *Wx_src, const float *score_dst,
+                            const float *score_src, float negative_slope, const float *bias, int act,
+                            float *out, float *alpha_out, int64_t H, int64_t C,
+                            gnnmp_stream_t stream);
+
+/* out[n][:] = act(x[n][:] + bias[:])  — the `σ.(x .+ bias)` tail of a layer body when it is not fused into
+ * the producing kernel (GNNlib/src/layers/conv.jl:71,147).  bias nullable; out may alias x. */
+int gnnmp_bias_act_f32(const float *x, const float *bias, int act, float *out, int64_t N, int64_t D,
+                       gnnmp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * reduce_nodes(aggr, g, x) / global_pool — GNNlib/src/utils.jl:12-16, GNNlib/src/layers/pool.jl:3-5,
+ * for a SORTED graph_indicator (what MLUtils.batch builds, transform.jl:691-699): contiguous segments.
+ * seg_ids[N] has values index_base .. index_base+G-1, non-decreasing.  out is [G][D].
+ * (An unsorted indicator goes through gnnmp_plan_create(src = 1..N, dst = indicator) + gnnmp_propagate_f32.)
+ * ---------------------------------------------------------------------------------------------- */
+int gnnmp_segment_pool_f32(int aggr, const float *x, const void *seg_ids, int idx_bytes,
+                           int index_base, float *out, int64_t D, int64_t N, int64_t G,
+                           gnnmp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Dense feature contraction of the layer bodies (the only MFMA work on the path):
+ *   out[n][:] = act( W1 * x1[n][:]  (+ W2 * x2[n][:])  (+ bias) )
+ * W1 is [Dout][D1], W2 [Dout][D2] row-major (Julia weight' is NOT taken: Julia's (Dout, Din) column-major
+ * weight is C row-major [Din][Dout]; pass w_layout = 1 for that, 0 for C row-major [Dout][Din]).
+ * Covers `weight * x` (conv.jl:39,69), `weight1*xi .+ weight2*m` (conv.jl:106),
+ * `weight * vcat(xi, m)` (conv.jl:281; W1 = first Din columns, W2 = last Din, given by ldw) and
+ * `dense_x` (conv.jl:127).  fp32 in, fp32 accumulate on v_mfma_f32_32x32x2_f32 (exact fp32).
+ * ldw1/ldw2: leading dimension (elements between consecutive rows of the stored matrix).
+ * ---------------------------------------------------------------------------------------------- */
+int gnnmp_dense_f32(const float *x1, const float *W1, int64_t D1, int64_t ldw1, const float *x2,
+                    const float *W2, int64_t D2, int64_t ldw2, int w_layout, const float *bias,
+                    int act, float *out, int64_t N, int64_t Dout, gnnmp_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GNNMP_H */

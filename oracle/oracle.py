@@ -1,0 +1,326 @@
+"""CPU oracle for the GNNlib.jl message-passing hot path — TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this module, and only
+as the checker / the reported CPU baseline.  The product (``graphneuralnetworks.jl_amd/``) never does.
+
+It wraps ``libgnn_oracle.so`` (``gnn_oracle.c``: the loops whose ORDER matters — gather, scatter, CSC SpMM, GAT
+logits) and composes the four layer bodies in numpy exactly in the order the reference does.  Pin status and the
+list of reference known-answer tests that pin it: see the header of ``gnn_oracle.c``.
+
+Conventions: feature arrays are ``float32`` C-contiguous ``[N, D]`` (= Julia ``(D, N)`` column-major); index
+vectors are ``int64`` and 1-based, as Julia holds them.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libgnn_oracle.so")
+
+SUM, MEAN, MAX, MIN = 0, 1, 2, 3
+_AGGR = {"+": SUM, "sum": SUM, "add": SUM, "mean": MEAN, "max": MAX, "min": MIN,
+         SUM: SUM, MEAN: MEAN, MAX: MAX, MIN: MIN}
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "gnn_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(_LIB_PATH)
+        _lib.orc_gather.restype = ctypes.c_int
+        _lib.orc_scatter.restype = ctypes.c_int
+        _lib.orc_degree.restype = ctypes.c_int
+        _lib.orc_propagate.restype = ctypes.c_int
+        _lib.orc_spmm_csc.restype = ctypes.c_int
+        _lib.orc_softmax_edge_neighbors.restype = ctypes.c_int
+        for name in ("orc_add_self_loops", "orc_batch", "orc_gat_logits", "orc_gat_weight_messages",
+                     "orc_scale_rows", "orc_inv_sqrt", "orc_matmul"):
+            getattr(_lib, name).restype = None
+    return _lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _i(v):
+    return ctypes.c_int64(int(v))
+
+
+def _check(rc, what):
+    if rc == -1:
+        raise IndexError(f"{what}: index out of range")
+    if rc != 0:
+        raise MemoryError(f"{what}: rc={rc}")
+
+
+# ---------------------------------------------------------------------------------------------------------
+# primitives
+# ---------------------------------------------------------------------------------------------------------
+def gather(x, idx):
+    """NNlib.gather — GNNGraphs/src/gatherscatter.jl:4.  x [N, ...] -> [K, ...]"""
+    x = _f32(x)
+    idx = _i64(idx)
+    n = x.shape[0]
+    D = int(np.prod(x.shape[1:], dtype=np.int64))
+    out = np.empty((idx.shape[0],) + x.shape[1:], np.float32)
+    _check(lib().orc_gather(_p(x), _i(n), _i(D), _p(idx), _i(idx.shape[0]), _p(out)), "gather")
+    return out
+
+
+def scatter(aggr, src, idx, n=None):
+    """NNlib.scatter(aggr, src, idx; dstsize) — GNNGraphs/src/gatherscatter.jl:12-18.
+    n omitted => maximum(idx), like NNlib (GNNlib/src/utils.jl:15)."""
+    src = _f32(src)
+    idx = _i64(idx)
+    assert src.shape[0] == idx.shape[0]
+    if n is None:
+        n = int(idx.max()) if idx.size else 0
+    D = int(np.prod(src.shape[1:], dtype=np.int64))
+    out = np.empty((n,) + src.shape[1:], np.float32)
+    _check(lib().orc_scatter(_AGGR[aggr], _p(src), _i(D), _p(idx), _i(idx.shape[0]), _i(n), _p(out)), "scatter")
+    return out
+
+
+def degree(idx, n, w=None):
+    """degree(g, Float32; dir, edge_weight) — GNNGraphs/src/query.jl:355-369 (idx = t for :in, s for :out)."""
+    idx = _i64(idx)
+    w = None if w is None else _f32(w)
+    out = np.empty((n,), np.float32)
+    _check(lib().orc_degree(_p(idx), _p(w), _i(idx.shape[0]), _i(n), _p(out)), "degree")
+    return out
+
+
+def add_self_loops(s, t, n, w=None):
+    """add_self_loops(g::GNNGraph{COO}) — GNNGraphs/src/transform.jl:12-28."""
+    s = _i64(s)
+    t = _i64(t)
+    E = s.shape[0]
+    s2 = np.empty(E + n, np.int64)
+    t2 = np.empty(E + n, np.int64)
+    w = None if w is None else _f32(w)
+    w2 = None if w is None else np.empty(E + n, np.float32)
+    lib().orc_add_self_loops(_p(s), _p(t), _p(w), _i(E), _i(n), _p(s2), _p(t2), _p(w2))
+    return s2, t2, w2
+
+
+def batch(graphs):
+    """MLUtils.batch(::Vector{GNNGraph{COO}}) — GNNGraphs/src/transform.jl:682-709.
+    graphs: list of (s, t, num_nodes).  Returns s, t, graph_indicator, num_nodes."""
+    ne = np.array([0] + [len(g[0]) for g in graphs], np.int64).cumsum()
+    nn = np.array([0] + [int(g[2]) for g in graphs], np.int64).cumsum()
+    s = _i64(np.concatenate([_i64(g[0]) for g in graphs])) if graphs else np.zeros(0, np.int64)
+    t = _i64(np.concatenate([_i64(g[1]) for g in graphs])) if graphs else np.zeros(0, np.int64)
+    s2 = np.empty_like(s)
+    t2 = np.empty_like(t)
+    gi = np.empty(int(nn[-1]), np.int64)
+    lib().orc_batch(_p(s), _p(t), _p(ne), _p(nn), _i(len(graphs)), _p(s2), _p(t2), _p(gi))
+    return s2, t2, gi, int(nn[-1])
+
+
+def propagate(aggr, s, t, n, xj, w=None, n_dst=None):
+    """Generic propagate (gather -> message -> scatter) with copy_xj (w None) or w_mul_xj / e_mul_xj (vector w)
+    — GNNlib/src/msgpass.jl:71-79,121-129,145-149,162,191-208.  This is what the reference runs for any aggr and,
+    on GPU arrays, also for `+` (GNNlib/ext/GNNlibAMDGPUExt.jl:13-32)."""
+    s = _i64(s)
+    t = _i64(t)
+    xj = _f32(xj)
+    w = None if w is None else _f32(w)
+    n_dst = n if n_dst is None else n_dst
+    D = int(np.prod(xj.shape[1:], dtype=np.int64))
+    out = np.empty((n_dst,) + xj.shape[1:], np.float32)
+    _check(lib().orc_propagate(_AGGR[aggr], _p(s), _p(t), _i(s.shape[0]), _i(xj.shape[0]), _i(n_dst), _p(xj),
+                               _i(D), _p(w), _p(out)), "propagate")
+    return out
+
+
+def spmm_csc(s, t, n, x, w=None):
+    """CPU fast path `xj * adjacency_matrix(g)` — GNNlib/src/msgpass.jl:215-238, convert.jl:221-237."""
+    s = _i64(s)
+    t = _i64(t)
+    x = _f32(x)
+    w = None if w is None else _f32(w)
+    out = np.empty_like(x)
+    _check(lib().orc_spmm_csc(_p(s), _p(t), _p(w), _i(s.shape[0]), _i(n), _p(x), _i(x.shape[1]), _p(out)), "spmm_csc")
+    return out
+
+
+def softmax_edge_neighbors(t, n, e):
+    """softmax_edge_neighbors(g, e) — GNNlib/src/utils.jl:84-97.  e [E, H] (or [E])."""
+    t = _i64(t)
+    e = _f32(e)
+    H = int(np.prod(e.shape[1:], dtype=np.int64))
+    out = np.empty_like(e)
+    _check(lib().orc_softmax_edge_neighbors(_p(t), _i(t.shape[0]), _i(n), _p(e), _i(H), _p(out)), "softmax_edge_neighbors")
+    return out
+
+
+def reduce_nodes(aggr, graph_indicator, x, num_graphs=None):
+    """reduce_nodes(aggr, g, x) = NNlib.scatter(aggr, x, graph_indicator) — GNNlib/src/utils.jl:12-16."""
+    return scatter(aggr, x, graph_indicator, num_graphs)
+
+
+def scale_rows(x, c):
+    x = _f32(x)
+    c = _f32(c)
+    out = np.empty_like(x)
+    lib().orc_scale_rows(_p(x), _p(c), _i(x.shape[0]), _i(x.shape[1]), _p(out))
+    return out
+
+
+def inv_sqrt(d):
+    d = _f32(d)
+    out = np.empty_like(d)
+    lib().orc_inv_sqrt(_p(d), _i(d.shape[0]), _p(out))
+    return out
+
+
+def matmul(W, x, blas=True):
+    """`weight * x` for weight (Dout, Din), x [N, Din] -> [N, Dout].  blas=True uses numpy/OpenBLAS sgemm (what the
+    reference does); blas=False the plain k-ordered C loop."""
+    W = _f32(W)
+    x = _f32(x)
+    if blas:
+        return _f32(x @ W.T)
+    y = np.empty((x.shape[0], W.shape[0]), np.float32)
+    lib().orc_matmul(_p(W), _p(x), _i(x.shape[0]), _i(W.shape[0]), _i(W.shape[1]), _p(y))
+    return y
+
+
+def _act(sigma, x):
+    if sigma in (None, "identity"):
+        return x
+    if sigma == "relu":
+        return np.maximum(x, np.float32(0))
+    if sigma == "tanh":
+        return np.tanh(x).astype(np.float32)
+    raise ValueError(sigma)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# layer bodies (GNNlib/src/layers/conv.jl, pool.jl)
+# ---------------------------------------------------------------------------------------------------------
+def gcn_conv(s, t, n, x, weight, bias=None, sigma=None, add_self_loops_=True, use_edge_weight=False,
+             graph_w=None, edge_weight=None, fast_path=False, blas=True):
+    """gcn_conv — GNNlib/src/layers/conv.jl:14-72.  graph_w: the graph's own weights (used iff use_edge_weight);
+    edge_weight: the optional call argument.  fast_path selects the CPU SpMM specialisation (msgpass.jl:215-238)
+    instead of the generic gather/scatter."""
+    s = _i64(s)
+    t = _i64(t)
+    x = _f32(x)
+    weight = _f32(weight)
+    if edge_weight is not None and len(edge_weight) != len(s):
+        raise ValueError("Wrong number of edge weights")  # ArgumentError, conv.jl:6-10
+    gw = graph_w
+    if add_self_loops_:
+        s, t, gw = add_self_loops(s, t, n, gw)
+        if edge_weight is not None:
+            edge_weight = np.concatenate([_f32(edge_weight), np.ones(n, np.float32)])  # conv.jl:28-33
+    Dout, Din = weight.shape
+    if Dout < Din:
+        x = matmul(weight, x, blas)
+    if edge_weight is not None:
+        d = degree(t, n, edge_weight)
+    else:
+        d = degree(t, n, gw if use_edge_weight else None)
+    c = inv_sqrt(d)
+    xj = scale_rows(x, c)
+    if edge_weight is not None:
+        wmsg = edge_weight
+    elif use_edge_weight:
+        wmsg = gw
+    else:
+        wmsg = None
+    if fast_path:
+        x = spmm_csc(s, t, n, xj, wmsg)
+    else:
+        x = propagate(SUM, s, t, n, xj, wmsg)
+    x = scale_rows(x, c)
+    if Dout >= Din:
+        x = matmul(weight, x, blas)
+    if bias is not None:
+        x = x + _f32(bias)[None, :]
+    return _act(sigma, x)
+
+
+def graph_conv(s, t, n, x, weight1, weight2, bias=None, sigma=None, aggr=SUM, blas=True):
+    """graph_conv — GNNlib/src/layers/conv.jl:102-108."""
+    x = _f32(x)
+    m = propagate(aggr, s, t, n, x)
+    y = matmul(weight1, x, blas) + matmul(weight2, m, blas)
+    if bias is not None:
+        y = y + _f32(bias)[None, :]
+    return _act(sigma, y)
+
+
+def sage_conv(s, t, n, x, weight, bias=None, sigma=None, aggr=MEAN, blas=True):
+    """sage_conv — GNNlib/src/layers/conv.jl:277-283.  weight (Dout, 2*Din)."""
+    x = _f32(x)
+    m = propagate(aggr, s, t, n, x)
+    y = matmul(weight, np.concatenate([x, m], axis=1), blas)
+    if bias is not None:
+        y = y + _f32(bias)[None, :]
+    return _act(sigma, y)
+
+
+def gat_conv(s, t, n, x, dense_x_weight, a, bias=None, sigma=None, heads=1, concat=True, negative_slope=0.2,
+             add_self_loops_=True, blas=True, return_alpha=False):
+    """gat_conv + gat_message — GNNlib/src/layers/conv.jl:112-167.
+    dense_x_weight (C*H, Din); a (2C, H) in Julia shape, i.e. numpy [2C, H]."""
+    s = _i64(s)
+    t = _i64(t)
+    x = _f32(x)
+    a = _f32(a)
+    H = heads
+    C = dense_x_weight.shape[0] // H
+    if add_self_loops_:
+        s, t, _ = add_self_loops(s, t, n)
+    Wx = matmul(dense_x_weight, x, blas).reshape(n, H, C)       # reshape(dense_x(x), C, H, N)
+    Wxi = gather(Wx, t)                                          # msgpass.jl:125
+    Wxj = gather(Wx, s)                                          # msgpass.jl:126
+    a_hc = _f32(a.T)                                             # [H][2C]
+    E = s.shape[0]
+    logit = np.empty((E, H), np.float32)
+    lib().orc_gat_logits(_p(Wxi), _p(Wxj), _p(a_hc), _i(E), _i(H), _i(C), ctypes.c_float(negative_slope), _p(logit))
+    alpha = softmax_edge_neighbors(t, n, logit)                  # utils.jl:84-97
+    beta = np.empty_like(Wxj)
+    lib().orc_gat_weight_messages(_p(alpha), _p(Wxj), _i(E), _i(H), _i(C), _p(beta))
+    y = scatter(SUM, beta.reshape(E, H * C), t, n).reshape(n, H, C)   # aggregate_neighbors(g, +, β)
+    if not concat:
+        # mean(x, dims = 2): sum over heads then divide
+        acc = y[:, 0, :].copy()
+        for h in range(1, H):
+            acc = acc + y[:, h, :]
+        y = acc / np.float32(H)
+    y = y.reshape(n, -1)
+    if bias is not None:
+        y = y + _f32(bias)[None, :]
+    y = _act(sigma, y)
+    return (y, alpha) if return_alpha else y
+
+
+def global_pool(aggr, graph_indicator, x, num_graphs=None):
+    """global_pool — GNNlib/src/layers/pool.jl:3-5."""
+    return reduce_nodes(aggr, graph_indicator, x, num_graphs)
