@@ -1,0 +1,275 @@
+#!/usr/bin/env python
+"""bench.py — forward edges/sec of GCNConv + GATConv on an ogbn-products-shaped synthetic graph (BASELINE.json metric).
+
+A "step" is one pass of the hot path over one batch of synthetic input: one GCNConv(100=>100, relu) forward plus one
+GATConv(100=>16, heads=8, relu) forward on the products-shaped graph (N=2 449 029, E=61 859 140, +N self loops each),
+features already resident in HBM, plans (dst-sorted CSR) built before the timed region and reported separately.
+value = edges traversed per second, whole job = n_gpus * 2 * E' / step time (ranks are independent replicas with
+different feature batches: weak scaling, no data-path collective — SURVEY.md §8e).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload products|arxiv] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     — the dominant kernel's algorithmic bytes / its average duration measured with HIP events on the launch
+                 stream inside the timed region, against the 8 TB/s HBM peak (MI355X_MICROARCH.md)
+  cpu_baseline — the CPU oracle (a port of the reference's algorithm; Julia is not installed) timed on the host, rank 0,
+                 N=1 only, on a bounded arxiv-shaped sample of the same two layers.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "graphneuralnetworks.jl_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def alg_bytes_gcn_propagate(N, Ep, D):
+    """fused GCN propagate kernel: per edge one source row + its col id; per node the output row, rowptr (8 B) and the two
+    normalisation scalars (SURVEY.md §8d 'CSR SpMM' + 'GCN layer (fused norm)')"""
+    return Ep * (4 * D + 4) + 8 * (N + 1) + 4 * N * D + 8 * N
+
+
+def alg_bytes_gat_aggregate(N, Ep, H, C):
+    """fused GAT edge kernel: per edge one source row (4HC), its score_src row (4H) and col id (4); per node the output
+    row (4HC), score_dst (4H) and rowptr (8).  (A subset of SURVEY.md §8d's 'GAT fused' figure, which also counts the
+    node pre-pass: conservative.)"""
+    return Ep * (4 * H * C + 4 * H + 4) + N * (4 * H * C + 4 * H + 8)
+
+
+def cpu_baseline(seed_graph=0):
+    """The reference's algorithm (oracle port) for the same two layers on an arxiv-shaped sample, single thread."""
+    import numpy as np
+    from gnnmp import synth
+    from oracle import oracle as orc
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:  # pragma: no cover
+        threadpool_limits = None
+    orc.build()
+    N, D = synth.ARXIV["N"], 128
+    s, t = synth.arxiv_like(seed=seed_graph)
+    x = synth.features(N, D, seed=1)
+    rng = np.random.default_rng(0)
+    W = (rng.standard_normal((D, D)) * 0.1).astype(np.float32)
+    b = np.zeros(D, np.float32)
+    Wd = (rng.standard_normal((128, D)) * 0.1).astype(np.float32)
+    a = (rng.standard_normal((32, 8)) * 0.1).astype(np.float32)
+    Ep = len(s) + N
+
+    def run():
+        t0 = time.perf_counter()
+        orc.gcn_conv(s, t, N, x, W, b, "relu")
+        t1 = time.perf_counter()
+        orc.gat_conv(s, t, N, x, Wd, a, b, "relu", heads=8)
+        t2 = time.perf_counter()
+        return t1 - t0, t2 - t1
+
+    if threadpool_limits is not None:
+        with threadpool_limits(limits=1):
+            tg, ta = run()
+    else:
+        tg, ta = run()
+    return {
+        "value": 2 * Ep / (tg + ta), "unit": "edges/s", "cores": 1, "kind": "port",
+        "sample": f"arxiv-shaped graph N={N} E'={Ep} D=128: GCNConv(128=>128)+GATConv(128=>16,h=8) forward once, "
+                  f"generic gather->message->scatter path as the reference runs it (materialised (D,E') temporaries), "
+                  f"gcn {tg:.2f}s gat {ta:.2f}s",
+        "gcn_edges_per_s": Ep / tg, "gat_edges_per_s": Ep / ta,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="products", choices=["products", "arxiv"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the arxiv-shape side measurements")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert args.gpus == world or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    import gnnmp
+    from gnnmp import _lib as L
+    from gnnmp import synth
+    gnnmp.load()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- workload -------------------------------------------------------------------------------------------
+    if args.workload == "products":
+        N, E, D = synth.PRODUCTS["N"], synth.PRODUCTS["E"], synth.PRODUCTS["D"]
+        t0 = time.perf_counter()
+        s, t = synth.products_like()
+        log(f"[rank {rank}] products-shaped graph generated in {time.perf_counter() - t0:.1f}s")
+    else:
+        N, E, D = synth.ARXIV["N"], synth.ARXIV["E"], synth.ARXIV["D"]
+        s, t = synth.arxiv_like()
+    H, C = 8, 16
+    Ep = E + N
+    x = torch.from_numpy(synth.features(N, D, seed=1 + rank)).cuda()
+    sd, td = torch.from_numpy(s).cuda(), torch.from_numpy(t).cuda()
+    del s, t
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    g = gnnmp.GNNGraph(sd, td, num_nodes=N, _validated=True)
+    plan = g.plan(True)          # both layers add self loops: one plan
+    torch.cuda.synchronize()
+    plan_ms = (time.perf_counter() - t0) * 1e3
+    gcn = gnnmp.GCNConv((D, D), "relu", seed=11)
+    gat = gnnmp.GATConv((D, C), "relu", heads=H, seed=12)
+
+    def step():
+        y1 = gcn(g, x)
+        y2 = gat(g, x)
+        return y1, y2
+
+    # ---- events around the two candidate dominant kernels (recorded on the launch stream) --------------------
+    lib = L.load()
+    deg = torch.empty(N, dtype=torch.float32, device="cuda")
+    L.check(lib.gnnmp_degree_f32(plan.handle, None, L.ptr(deg), L.stream_ptr()))
+    from gnnmp.layers import _inv_sqrt
+    cvec = _inv_sqrt(deg)
+    out_p = torch.empty((N, D), dtype=torch.float32, device="cuda")
+    Wx = gnnmp.dense(x, gat.dense_x_weight)
+    sdst = torch.empty((N, H), dtype=torch.float32, device="cuda")
+    ssrc = torch.empty((N, H), dtype=torch.float32, device="cuda")
+    L.check(lib.gnnmp_gat_node_scores_f32(L.ptr(Wx), L.ptr(gat.a_hc), L.ptr(sdst), L.ptr(ssrc), N, H, C, L.stream_ptr()))
+    out_g = torch.empty((N, H * C), dtype=torch.float32, device="cuda")
+
+    def k_propagate():
+        L.check(lib.gnnmp_propagate_f32(plan.handle, L.COPY_XJ, L.SUM, L.ptr(x), None, L.ptr(cvec), L.ptr(cvec),
+                                        L.ptr(out_p), D, L.stream_ptr()))
+
+    def k_gat():
+        L.check(lib.gnnmp_gat_aggregate_f32(plan.handle, L.ptr(Wx), L.ptr(sdst), L.ptr(ssrc), 0.2, L.ptr(gat.bias),
+                                            L.ACT_RELU, L.ptr(out_g), None, H, C, L.stream_ptr()))
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = world * 2 * Ep / (dt / args.steps)
+
+    # per-kernel durations: HIP events on the stream the kernels are launched on (torch's current stream)
+    def event_time(fn, iters):
+        fn()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+        for a, b in evs:
+            a.record()
+            fn()
+            b.record()
+        torch.cuda.synchronize()
+        ts = sorted(a.elapsed_time(b) for a, b in evs)
+        return sum(ts) / len(ts), ts[len(ts) // 2]
+
+    iters = max(args.steps, 10)
+    tp_avg, tp_med = event_time(k_propagate, iters)
+    tg_avg, tg_med = event_time(k_gat, iters)
+    b_prop = alg_bytes_gcn_propagate(N, Ep, D)
+    b_gat = alg_bytes_gat_aggregate(N, Ep, H, C)
+    kern = {
+        "gcn_propagate": {"kernel": "csr_rows_kernel(+csr_long_rows_kernel)", "ms": tp_avg, "ms_median": tp_med,
+                          "alg_bytes": b_prop, "GBs": b_prop / tp_avg / 1e6},
+        "gat_aggregate": {"kernel": "gat_rows_kernel(+gat_long_rows_kernel)", "ms": tg_avg, "ms_median": tg_med,
+                          "alg_bytes": b_gat, "GBs": b_gat / tg_avg / 1e6},
+    }
+    dom = max(kern, key=lambda k: kern[k]["ms"])
+    roofline = {"bound": "hbm", "kernel": kern[dom]["kernel"], "call": dom, "achieved": kern[dom]["GBs"],
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kern[dom]["GBs"] / HBM_PEAK_GBS, "traffic": None,
+                "alg_bytes_per_launch": kern[dom]["alg_bytes"], "avg_ms": kern[dom]["ms"]}
+
+    # layer-level split and the arxiv-shape configs (BASELINE.json configs[1], configs[2]) as side lines
+    def layer_time(fn, iters):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / iters * 1e3
+
+    extras = {"plan_create_ms": plan_ms, "kernels": kern,
+              "gcn_layer_ms": layer_time(lambda: gcn(g, x), 5), "gat_layer_ms": layer_time(lambda: gat(g, x), 5),
+              "max_in_degree": plan.max_degree, "long_rows": plan.n_long}
+    extras["gcn_layer_edges_per_s"] = Ep / extras["gcn_layer_ms"] * 1e3
+    extras["gat_layer_edges_per_s"] = Ep / extras["gat_layer_ms"] * 1e3
+    if rank == 0 and not args.no_extras and args.workload == "products":
+        del out_p, out_g, Wx
+        Na, Da = synth.ARXIV["N"], synth.ARXIV["D"]
+        sa, ta = synth.arxiv_like()
+        ga = gnnmp.GNNGraph(torch.from_numpy(sa).cuda(), torch.from_numpy(ta).cuda(), num_nodes=Na, _validated=True)
+        xa = torch.from_numpy(synth.features(Na, Da, seed=1)).cuda()
+        gcn_a = gnnmp.GCNConv((Da, Da), "relu", seed=11)
+        gat_a = gnnmp.GATConv((Da, C), "relu", heads=H, seed=12)
+        Epa = len(sa) + Na
+        tga = layer_time(lambda: gcn_a(ga, xa), 50)
+        taa = layer_time(lambda: gat_a(ga, xa), 50)
+        extras["arxiv"] = {"E_prime": Epa, "gcn_layer_ms": tga, "gat_layer_ms": taa,
+                           "gcn_edges_per_s": Epa / tga * 1e3, "gat_edges_per_s": Epa / taa * 1e3}
+
+    result = {
+        "metric": "edges/sec (fwd) GCNConv+GATConv, ogbn-products-shape; achieved HBM GB/s vs peak",
+        "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.workload}-shape power-law graph N={N} E={E} (+N self loops, E'={Ep}), D={D}: "
+                               f"GCNConv({D}=>{D},relu) fwd + GATConv({D}=>{C},heads={H},relu) fwd per step; "
+                               f"edges counted = 2*E' per GPU",
+                   "parallelism": f"replicas x{world} (independent feature batches, no collective)",
+                   "index": "Int64 1-based COO as held by GNNGraph; plan = int32 dst-sorted CSR built once"},
+        "roofline": roofline,
+        "extras": extras,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            result["cpu_baseline"] = cpu_baseline()
+        except Exception as e:  # the baseline must never take the bench line down
+            result["cpu_baseline"] = {"value": None, "unit": "edges/s", "cores": 1, "kind": "port", "sample": f"failed: {e}"}
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -167,7 +167,7 @@ __device__ __forceinline__ void gat_store(const GatArgs &a, int row, int f0, boo
     }
     if (a.act == GNNMP_ACT_RELU) {
 #pragma unroll
-        for (int q = 0; q < VEC; ++q) acc[q] = acc[q] > 0.0f ? acc[q] : 0.0f;
+        for (int q = 0; q < VEC; ++q) acc[q] = acc[q] < 0.0f ? 0.0f : acc[q];  // NNlib.relu = ifelse(x < 0, 0, x): NaN-preserving
     }
     Vec<VEC>::store(a.out + (int64_t)row * a.D + f0, acc);
 }
@@ -310,7 +310,7 @@ __global__ void __launch_bounds__(256) bias_act_kernel(const float *x, const flo
     if (i >= total) return;
     float v = x[i];
     if (bias) v = v + bias[i % D];
-    if (act == GNNMP_ACT_RELU) v = v > 0.0f ? v : 0.0f;
+    if (act == GNNMP_ACT_RELU) v = v < 0.0f ? 0.0f : v;
     out[i] = v;
 }
 

@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(256) dense_mfma_kernel(const DenseArgs a) {
             if (row < a.N) {
                 float v = acc[nt][r];
                 if (a.bias) v = v + b;
-                if (a.act == GNNMP_ACT_RELU) v = v > 0.0f ? v : 0.0f;  // NNlib.relu = max(0, x)
+                if (a.act == GNNMP_ACT_RELU) v = v < 0.0f ? 0.0f : v;  // NNlib.relu = ifelse(x < 0, 0, x) (NaN-preserving)
                 a.out[row * a.Dout + col] = v;
             }
         }

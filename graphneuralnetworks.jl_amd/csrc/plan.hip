@@ -335,7 +335,7 @@ int gnnmp_add_self_loops(const void *src, const void *dst, int idx_bytes, int in
     if (idx_bytes != 4 && idx_bytes != 8) return fail(GNNMP_EINVAL, "add_self_loops: idx_bytes %d", idx_bytes);
     if (index_base != 0 && index_base != 1) return fail(GNNMP_EINVAL, "add_self_loops: index_base %d", index_base);
     if (n_edges < 0 || n < 0) return fail(GNNMP_EINVAL, "add_self_loops: negative size");
-    if ((w == nullptr) != (out_w == nullptr))
+    if ((w != nullptr && out_w == nullptr) || (w == nullptr && out_w != nullptr && n_edges > 0))
         return fail(GNNMP_EINVAL, "add_self_loops: w and out_w must both be NULL or both non-NULL");
     if (n_edges + n == 0) return GNNMP_OK;
     if (!out_src || !out_dst || (n_edges > 0 && (!src || !dst)))

@@ -293,7 +293,9 @@ __global__ void degree_weighted_kernel(const int32_t *rowptr, const int32_t *eid
 }
 __global__ void inv_sqrt_kernel(const float *deg, float *out, int64_t n) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = __fdiv_rn(1.0f, __fsqrt_rn(deg[i]));
+    // plain sqrtf and '/': hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt makes both IEEE-rounded
+    // (HIP's __fsqrt_rn maps to the native, 1-ulp sqrt: measured 13 % mismatches vs the CPU).
+    if (i < n) out[i] = 1.0f / sqrtf(deg[i]);
 }
 
 }  // namespace gnnmp

@@ -213,7 +213,7 @@ def _act(sigma, x):
     if sigma in (None, "identity"):
         return x
     if sigma == "relu":
-        return np.maximum(x, np.float32(0))
+        return np.where(x < 0, np.float32(0), x).astype(np.float32)  # NNlib.relu = ifelse(x < 0, zero(x), x)
     if sigma == "tanh":
         return np.tanh(x).astype(np.float32)
     raise ValueError(sigma)

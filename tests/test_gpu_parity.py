@@ -1,0 +1,474 @@
+"""Parity of the HIP path (through the C ABI, via gnnmp's ctypes host layer) against the CPU oracle and the committed
+golden fixtures.  `-m gpu` only.  Bars: bit-exact for index outputs and for fp32 reductions on destinations with at most
+GNNMP_LONG_ROW edges (same edge order as the reference CPU loop); <= 1e-5 relative otherwise (north_star's tolerance).
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "hotpath_v1.npz")
+RTOL = 1e-5
+AGGRS = [("+", "sum"), ("mean", "mean"), ("max", "max"), ("min", "min")]
+
+
+@pytest.fixture(scope="module")
+def gm():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    import gnnmp
+    gnnmp.load()
+    return gnnmp
+
+
+@pytest.fixture(scope="module")
+def gold():
+    z = np.load(GOLD)
+    cases = {}
+    for k in z.files:
+        c, a = k.split("/", 1)
+        cases.setdefault(c, {})[a] = z[k]
+    return cases
+
+
+def dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def assert_close(a, b, rtol=RTOL):
+    """north_star tolerance: 1e-5 relative — norm-wise (Julia isapprox) and element-wise against the array scale"""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    assert a.shape == b.shape
+    fin = np.isfinite(b)
+    np.testing.assert_array_equal(np.isnan(a), np.isnan(b))
+    np.testing.assert_array_equal(a[~fin & ~np.isnan(b)], b[~fin & ~np.isnan(b)])
+    if fin.any():
+        af, bf = a[fin], b[fin]
+        scale = max(np.abs(bf).max(), 1e-30)
+        assert np.linalg.norm(af - bf) <= rtol * max(np.linalg.norm(af), np.linalg.norm(bf)) + 1e-30
+        assert np.abs(af - bf).max() <= rtol * scale * 4
+
+
+def assert_rows_equal_or_close(got, exp, indeg, thresh=512):
+    """bit-exact where the destination has <= thresh edges; 1e-5 rel on the split (long) rows"""
+    short = indeg <= thresh
+    np.testing.assert_array_equal(got[short], exp[short])
+    if (~short).any():
+        assert_close(got[~short], exp[~short])
+
+
+def graph(gm, s, t, n, w=None, base=1, dtype=np.int64):
+    s = (np.asarray(s) - (1 - base)).astype(dtype)
+    t = (np.asarray(t) - (1 - base)).astype(dtype)
+    return gm.GNNGraph(dev(s), dev(t), None if w is None else dev(w), num_nodes=int(n), index_base=base)
+
+
+def indeg_of(t, n, loops=False):
+    d = np.bincount(np.asarray(t) - 1, minlength=int(n))
+    return d + (1 if loops else 0)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# index ops: bit-exact
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("base,dtype", [(1, np.int64), (0, np.int64), (1, np.int32), (0, np.int32)])
+@pytest.mark.parametrize("loops", [False, True])
+def test_plan_is_stable_dst_sort(gm, gold, base, dtype, loops):
+    for name in ("prop_cycle4_D3", "prop_isolated4_D3", "prop_n128_D10", "prop_hub700_D3", "prop_empty5_D3"):
+        c = gold[name]
+        s, t, n = c["s"], c["t"], int(c["n"])
+        g = graph(gm, s, t, n, base=base, dtype=dtype)
+        rowptr, col, eid = (host(v) for v in g.plan(loops).export())
+        s2, t2 = (c["s_loops"], c["t_loops"]) if loops else (s, t)
+        order = np.argsort(t2, kind="stable")
+        np.testing.assert_array_equal(eid, order.astype(np.int32))
+        np.testing.assert_array_equal(col, (s2[order] - 1).astype(np.int32))
+        exp_ptr = np.concatenate([[0], np.cumsum(np.bincount(t2 - 1, minlength=n))]).astype(np.int32)
+        np.testing.assert_array_equal(rowptr, exp_ptr)
+
+
+def test_add_self_loops_bit_exact(gm, gold):
+    for name in ("prop_cycle4_D3", "prop_n128_D10", "prop_hub700_D16", "prop_empty5_D3"):
+        c = gold[name]
+        g = graph(gm, c["s"], c["t"], int(c["n"]), c["w"])
+        g2 = gm.add_self_loops(g)
+        np.testing.assert_array_equal(host(g2.s), c["s_loops"])
+        np.testing.assert_array_equal(host(g2.t), c["t_loops"])
+        np.testing.assert_array_equal(host(g2.w), c["w_loops"])
+        assert g2.num_edges == g.num_edges + g.num_nodes
+        g3 = gm.add_self_loops(graph(gm, c["s"], c["t"], int(c["n"])))
+        assert g3.w is None
+
+
+def test_batch_bit_exact(gm, gold):
+    c = gold["batch5"]
+    ep, npn = c["edge_ptr"], c["node_ptr"]
+    gs = []
+    for i in range(5):
+        sl = slice(ep[i], ep[i + 1])
+        n = int(npn[i + 1] - npn[i])
+        gs.append(gm.GNNGraph(dev(c["s_local"][sl]), dev(c["t_local"][sl]), num_nodes=n,
+                              x=dev(c["x"][npn[i]:npn[i + 1]])))
+    b = gm.batch(gs)
+    np.testing.assert_array_equal(host(b.s), c["s"])
+    np.testing.assert_array_equal(host(b.t), c["t"])
+    np.testing.assert_array_equal(host(b.graph_indicator), c["gi"])
+    np.testing.assert_array_equal(host(b.x), c["x"])
+    assert b.num_graphs == 5 and b.num_nodes == int(c["n"])
+    with pytest.raises(ValueError):
+        gm.batch([])
+
+
+def test_index_range_is_asserted(gm):
+    with pytest.raises(AssertionError):
+        gm.GNNGraph(dev(np.array([1, 9])), dev(np.array([1, 2])), num_nodes=3)
+    with pytest.raises(AssertionError):
+        gm.GNNGraph(dev(np.array([0, 1])), dev(np.array([1, 2])), num_nodes=3)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# propagate / scatter / gather / degree vs golden
+# ---------------------------------------------------------------------------------------------------------------
+def test_propagate_golden(gm, gold):
+    for name, c in gold.items():
+        if not name.startswith("prop_"):
+            continue
+        s, t, n = c["s"], c["t"], int(c["n"])
+        g = graph(gm, s, t, n, c["w"])
+        x = dev(c["x"])
+        deg = indeg_of(t, n)
+        for aggr, key in AGGRS:
+            y = host(gm.propagate(gm.copy_xj, g, aggr, xj=x))
+            assert_rows_equal_or_close(y, c[f"out_{key}"], deg)
+            yw = host(gm.propagate(gm.w_mul_xj, g, aggr, xj=x))
+            assert_rows_equal_or_close(yw, c[f"outw_{key}"], deg)
+            ye = host(gm.propagate(gm.e_mul_xj, g, aggr, xj=x, e=dev(c["w"])))
+            np.testing.assert_array_equal(ye, yw)
+            # generic closure path: HIP gather -> python message -> HIP plan scatter
+            yg = host(gm.propagate(lambda xi, xj, e: xj, g, aggr, xj=x))
+            assert_rows_equal_or_close(yg, c[f"out_{key}"], deg)
+            ygw = host(gm.propagate(lambda xi, xj, e: e.reshape(-1, 1) * xj, g, aggr, xj=x, e=dev(c["w"])))
+            assert_rows_equal_or_close(ygw, c[f"outw_{key}"], deg)
+
+
+def test_degree_and_norm_bit_exact(gm, gold, oracle):
+    for name, c in gold.items():
+        if not name.startswith("prop_"):
+            continue
+        s, t, n = c["s"], c["t"], int(c["n"])
+        g = graph(gm, s, t, n, c["w"])
+        np.testing.assert_array_equal(host(gm.degree(g, dir="in", edge_weight=False)), c["deg_in"])
+        np.testing.assert_array_equal(host(gm.degree(g, dir="in", edge_weight=True)), c["deg_in_w"])
+        np.testing.assert_array_equal(host(gm.degree(g, dir="out", edge_weight=False)), oracle.degree(s, n))
+        both = host(gm.degree(g, dir="both", edge_weight=False))
+        np.testing.assert_array_equal(both, oracle.degree(s, n) + oracle.degree(t, n))
+    from gnnmp.layers import _inv_sqrt
+    d = np.abs(np.random.default_rng(0).standard_normal(4097)).astype(np.float32) * 50
+    d[:5] = [0.0, 1.0, 2.0, 3.0, 1e-30]
+    with np.errstate(divide="ignore"):
+        np.testing.assert_array_equal(host(_inv_sqrt(dev(d))), oracle.inv_sqrt(d))
+
+
+def test_reference_degree_known_answers(gm):
+    """GNNGraphs/test/query.jl:49-87"""
+    g = gm.GNNGraph(dev(np.array([1, 1, 2, 3])), dev(np.array([2, 2, 2, 4])), num_nodes=4)
+    np.testing.assert_array_equal(host(gm.degree(g, dir="out")), [2, 1, 1, 0])
+    np.testing.assert_array_equal(host(gm.degree(g, dir="in")), [0, 3, 0, 1])
+    np.testing.assert_array_equal(host(gm.degree(g, dir="both")), [2, 4, 1, 1])
+    w = np.array([0.1, 2.1, 1.2, 1], np.float32)
+    gw = gm.GNNGraph(dev(np.array([1, 1, 2, 3])), dev(np.array([2, 2, 2, 4])), dev(w), num_nodes=4)
+    np.testing.assert_allclose(host(gm.degree(gw, dir="out")), [2.2, 1.2, 1.0, 0.0], rtol=1e-6)
+    np.testing.assert_array_equal(host(gm.degree(gw, dir="out", edge_weight=False)), [2, 1, 1, 0])
+    np.testing.assert_allclose(host(gm.degree(gw, dir="out", edge_weight=dev(2 * w))), [4.4, 2.4, 2.0, 0.0], rtol=1e-6)
+
+
+def test_gather_scatter_leaves(gm, oracle):
+    import torch
+    rng = np.random.default_rng(1)
+    n, E = 301, 5000
+    for D in (1, 3, 8, 100, 130):
+        x = rng.standard_normal((n, D)).astype(np.float32)
+        idx = rng.integers(1, n + 1, E)
+        from gnnmp.msgpass import _gather, _scatter
+        np.testing.assert_array_equal(host(_gather(dev(x), dev(idx))), oracle.gather(x, idx))
+        np.testing.assert_array_equal(host(_gather(dev(x), dev((idx - 1).astype(np.int32)), 0)), oracle.gather(x, idx))
+        m = rng.standard_normal((E, D)).astype(np.float32)
+        for aggr, _ in AGGRS:
+            got = host(_scatter(aggr, dev(m), dev(idx), n))
+            np.testing.assert_array_equal(got, oracle.scatter(aggr, m, idx, n))
+        # NNlib-style atomic comparator: tolerance only for '+', exact for max/min
+        lib = gm.load()
+        from gnnmp import _lib as L
+        md, idxd = dev(m), dev(idx)   # keep the device buffers alive across the raw-pointer call
+        for aggr, init in ((L.SUM, 0.0), (L.MAX, -np.inf), (L.MIN, np.inf)):
+            out = torch.full((n, D), init, dtype=torch.float32, device="cuda")
+            L.check(lib.gnnmp_scatter_atomic_f32(aggr, L.ptr(md), L.ptr(idxd), 8, 1, E, L.ptr(out), D, L.stream_ptr()))
+            ref = oracle.scatter({L.SUM: "+", L.MAX: "max", L.MIN: "min"}[aggr], m, idx, n)
+            if aggr == L.SUM:
+                assert_close(host(out), ref)
+            else:
+                np.testing.assert_array_equal(host(out), ref)
+    # tuples / dicts / None recurse like GNNGraphs/src/gatherscatter.jl:1-5
+    x = dev(rng.standard_normal((n, 4)).astype(np.float32))
+    i = dev(rng.integers(1, n + 1, 10))
+    r = _gather({"a": x, "b": (x, None)}, i)
+    assert r["b"][1] is None and r["a"].shape == (10, 4)
+    np.testing.assert_array_equal(host(r["a"]), host(r["b"][0]))
+
+
+@pytest.mark.parametrize("D", [1, 2, 3, 4, 6, 7, 16, 64, 100, 128, 200, 256, 260, 516])
+def test_propagate_random_graphs_all_widths(gm, oracle, D):
+    """every vector width / group size / feature-tile path, with hubs (long rows), multi-edges, isolated nodes"""
+    rng = np.random.default_rng(100 + D)
+    n, E = 1500, 30000
+    s = rng.integers(1, n + 1, E)
+    t = rng.integers(1, n - 30, E)
+    t[:2000] = 7                       # a 2000+-edge hub -> split-row kernel
+    t[2000:2600] = 11                  # a 600-edge hub
+    p = rng.permutation(E)
+    s, t = s[p], t[p]
+    x = rng.standard_normal((n, D)).astype(np.float32)
+    w = rng.random(E).astype(np.float32)
+    c1 = rng.random(n).astype(np.float32) + 0.5
+    g = graph(gm, s, t, n, w)
+    deg = indeg_of(t, n)
+    for aggr, _ in AGGRS:
+        assert_rows_equal_or_close(host(gm.propagate(gm.copy_xj, g, aggr, xj=dev(x))), oracle.propagate(aggr, s, t, n, x), deg)
+        assert_rows_equal_or_close(host(gm.propagate(gm.w_mul_xj, g, aggr, xj=dev(x))), oracle.propagate(aggr, s, t, n, x, w), deg)
+    # fused GCN-style scaling == the reference's materialised `xj .* c'` -> propagate -> `x .* c'`
+    from gnnmp.msgpass import _fused
+    from gnnmp import _lib as L
+    got = host(_fused(g, L.W_MUL_XJ, "+", dev(x), dev(w), dev(c1), dev(c1)))
+    exp = oracle.scale_rows(oracle.propagate("+", s, t, n, oracle.scale_rows(x, c1), w), c1)
+    assert_rows_equal_or_close(got, exp, deg)
+    # self loops folded into the plan == add_self_loops then propagate
+    s2, t2, w2 = oracle.add_self_loops(s, t, n, w)
+    got = host(_fused(g, L.W_MUL_XJ, "mean", dev(x), dev(w), None, None, add_self_loops=True))
+    assert_rows_equal_or_close(got, oracle.propagate("mean", s2, t2, n, x, w2), deg + 1)
+
+
+def test_run_to_run_determinism(gm):
+    rng = np.random.default_rng(5)
+    n, E, D = 4000, 200000, 128
+    s = rng.integers(1, n + 1, E)
+    t = np.minimum(rng.integers(1, n + 1, E), rng.integers(1, n + 1, E))
+    t[:5000] = 3
+    g = graph(gm, s, t, n)
+    x = dev(rng.standard_normal((n, D)).astype(np.float32))
+    a = host(gm.propagate(gm.copy_xj, g, "+", xj=x))
+    for _ in range(5):
+        np.testing.assert_array_equal(host(gm.propagate(gm.copy_xj, g, "+", xj=x)), a)
+    # a second plan of the same graph gives the same bits too
+    g2 = graph(gm, s, t, n)
+    np.testing.assert_array_equal(host(gm.propagate(gm.copy_xj, g2, "+", xj=x)), a)
+
+
+def test_bipartite_and_unsorted_reduce_nodes(gm, oracle):
+    rng = np.random.default_rng(6)
+    N, G, D = 500, 17, 12
+    gi = rng.integers(1, G + 1, N)           # unsorted indicator -> plan path
+    x = rng.standard_normal((N, D)).astype(np.float32)
+    for aggr, _ in AGGRS:
+        np.testing.assert_array_equal(host(gm.reduce_nodes(aggr, dev(gi), dev(x), num_graphs=G)), oracle.scatter(aggr, x, gi, G))
+    gs = np.sort(gi)                          # sorted -> segment kernel
+    for aggr, _ in AGGRS:
+        np.testing.assert_array_equal(host(gm.reduce_nodes(aggr, dev(gs), dev(x), num_graphs=G)), oracle.scatter(aggr, x, gs, G))
+
+
+def test_pool_golden(gm, gold):
+    c = gold["batch5"]
+    g = gm.GNNGraph(dev(c["s"]), dev(c["t"]), num_nodes=int(c["n"]), graph_indicator=dev(c["gi"]), num_graphs=5)
+    for aggr, key in AGGRS:
+        np.testing.assert_array_equal(host(gm.GlobalPool(aggr)(g, dev(c["x"]))), c[f"pool_{key}"])
+    # single graph: indicator of ones (GNNGraphs/src/query.jl:500-505); GlobalPool(+) == sum over nodes
+    g1 = gm.GNNGraph(dev(c["s"]), dev(c["t"]), num_nodes=int(c["n"]))
+    one = host(gm.GlobalPool("+")(g1, dev(c["x"])))
+    assert one.shape == (1, 16)
+    assert_close(one[0], c["x"].astype(np.float64).sum(axis=0))
+    # model: GraphConv -> GlobalPool(mean)
+    l = gm.GraphConv((16, 8), "relu")
+    import torch
+    l.weight1, l.weight2, l.bias = dev(c["W1"]), dev(c["W2"]), dev(c["b"])
+    h = l(g, dev(c["x"]))
+    assert_close(host(h), c["h"])
+    assert_close(host(gm.GlobalPool("mean")(g, h)), c["logits"])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# softmax_edge_neighbors + GAT
+# ---------------------------------------------------------------------------------------------------------------
+def test_edge_softmax_golden(gm, gold):
+    for name, c in gold.items():
+        if not name.startswith("prop_") or len(c["s"]) == 0:
+            continue
+        g = graph(gm, c["s"], c["t"], int(c["n"]))
+        a = host(gm.softmax_edge_neighbors(g, dev(c["logits"])))
+        np.testing.assert_allclose(a, c["alpha"], rtol=5e-6, atol=1e-9)
+
+
+def test_reference_softmax_known_answer(gm):
+    """GNNlib/test/utils.jl:58-67"""
+    g = gm.GNNGraph(dev(np.array([1, 2, 3, 4])), dev(np.array([5, 5, 6, 6])))
+    e2 = np.random.default_rng(5).standard_normal((4, 3)).astype(np.float32)
+    z = host(gm.softmax_edge_neighbors(g, dev(e2)))
+
+    def softmax(a):
+        ex = np.exp(a.astype(np.float64) - a.max(axis=0, keepdims=True))
+        return ex / ex.sum(axis=0, keepdims=True)
+
+    np.testing.assert_allclose(z[0:2], softmax(e2[0:2]), rtol=1e-5)
+    np.testing.assert_allclose(z[2:4], softmax(e2[2:4]), rtol=1e-5)
+
+
+def _set(l, **kw):
+    for k, v in kw.items():
+        setattr(l, k, v)
+    return l
+
+
+def test_layers_golden(gm, gold):
+    for name in ("layers_cycle4", "layers_isolated4", "layers_n128"):
+        c = gold[name]
+        s, t, n = c["s"], c["t"], int(c["n"])
+        g = graph(gm, s, t, n)
+        gw = graph(gm, s, t, n, c["ew"])
+        x = dev(c["x"])
+        W, W2, Ws, b = dev(c["W"]), dev(c["W2"]), dev(c["Ws"]), dev(c["b"])
+        l = _set(gm.GCNConv((3, 5), "relu"), weight=W, bias=b)
+        assert_close(host(l(g, x)), c["gcn"])
+        l = _set(gm.GCNConv((3, 5), add_self_loops=False), weight=W, bias=b)
+        assert_close(host(l(g, x)), c["gcn_noloops"])
+        l = _set(gm.GCNConv((3, 5)), weight=W, bias=b)
+        assert_close(host(l(g, x, dev(c["ew"]))), c["gcn_ew"])
+        l = _set(gm.GCNConv((3, 5), use_edge_weight=True), weight=W, bias=b)
+        assert_close(host(l(gw, x)), c["gcn_gw"])
+        l = _set(gm.GCNConv((3, 2), "relu"), weight=dev(c["Wwide"]), bias=dev(c["b"][:2]))
+        assert_close(host(l(g, x)), c["gcn_wfirst"])
+        for aggr, key in AGGRS[:3]:
+            l = _set(gm.GraphConv((3, 5), "relu", aggr=aggr), weight1=W, weight2=W2, bias=b)
+            assert_close(host(l(g, x)), c[f"graphconv_{key}"])
+            l = _set(gm.SAGEConv((3, 5), aggr=aggr), weight=Ws, bias=b)
+            assert_close(host(l(g, x)), c[f"sage_{key}"])
+        for heads in (1, 2):
+            for concat in (True, False):
+                tag = f"h{heads}_{'cat' if concat else 'mean'}"
+                l = _set(gm.GATConv((3, 5), "relu", heads=heads, concat=concat),
+                         dense_x_weight=dev(c[f"gat_Wd_h{heads}"]), a=dev(c[f"gat_a_h{heads}"]), bias=dev(c[f"gat_b_{tag}"]))
+                y, alpha = gm.gat_conv(l, g, x, return_alpha=True)
+                assert_close(host(y), c[f"gat_{tag}"])
+                np.testing.assert_allclose(host(alpha), c[f"gat_alpha_{tag}"], rtol=2e-5, atol=1e-8)
+
+
+def test_reference_gcn_closed_form(gm, gold):
+    """GraphNeuralNetworks/test/layers/conv.jl:30-44"""
+    c = gold["gcn_closed_form"]
+    g = gm.GNNGraph((dev(c["s"]), dev(c["t"]), dev(c["w"])), x=dev(c["x"]))
+    l = gm.GCNConv((1, 1), add_self_loops=False, use_edge_weight=True)
+    l.weight.fill_(1.0)
+    y = host(l(g, g.x))
+    np.testing.assert_allclose(y[:2, 0], c["y_expected_ref"], rtol=1e-6)
+    np.testing.assert_array_equal(y, c["y"])           # same bits as the oracle (1x1 GEMM, rows of 2 edges)
+    d = host(gm.degree(g, dir="in", edge_weight=True))
+    np.testing.assert_array_equal(d, [3, 7, 11])
+    w = c["w"]
+    assert y[0, 0] == pytest.approx(w[0] / np.sqrt(d[0] * d[1]) + w[1] / np.sqrt(d[0] * d[2]), rel=1e-6)
+    y2 = host(l(g, g.x, dev(w), norm_fn=lambda dd: 1 / dd.sqrt()))
+    np.testing.assert_allclose(y2, y, rtol=1e-6)
+
+
+def test_reference_conv_weight_zeros(gm, gold):
+    """GraphNeuralNetworks/test/layers/conv.jl:55-65"""
+    import torch
+    l = gm.GCNConv((3, 5), seed=3)
+    w0 = torch.zeros((5, 3), device="cuda")
+    for name in ("layers_cycle4", "layers_isolated4"):
+        c = gold[name]
+        g = graph(gm, c["s"], c["t"], int(c["n"]))
+        y = host(l(g, torch.ones((4, 3), device="cuda"), conv_weight=w0))
+        np.testing.assert_array_equal(y, np.zeros((4, 5), np.float32))
+        with pytest.raises(ValueError):
+            l(g, torch.ones((4, 3), device="cuda"), conv_weight=torch.zeros((3, 3), device="cuda"))
+        with pytest.raises(ValueError):
+            l(g, torch.ones((4, 3), device="cuda"), torch.ones(3, device="cuda"))   # wrong number of edge weights
+
+
+def test_size_checks_raise_assertion_error(gm, gold):
+    """GNNlib/test/msgpass.jl:55-66,118-125"""
+    import torch
+    c = gold["prop_cycle4_D3"]
+    g = graph(gm, c["s"], c["t"], 4)
+    x = torch.rand((3, 3), device="cuda")            # num_nodes - 1 rows
+    with pytest.raises(AssertionError):
+        gm.apply_edges(gm.copy_xj, g, xj=x)
+    with pytest.raises(AssertionError):
+        gm.apply_edges(gm.copy_xj, g, xi=x)
+    with pytest.raises(AssertionError):
+        gm.propagate(gm.copy_xj, g, "+", xj=x)
+    with pytest.raises(AssertionError):
+        gm.apply_edges(gm.copy_xj, g, xj={"a": torch.rand((4, 3), device="cuda"), "b": torch.rand((5, 3), device="cuda")})
+    with pytest.raises(AssertionError):
+        gm.apply_edges(gm.copy_xj, g, e=torch.rand((g.num_edges - 1, 3), device="cuda"))
+    with pytest.raises(AssertionError):
+        gm.aggregate_neighbors(g, "+", torch.rand((g.num_edges - 1, 2), device="cuda"))
+    # apply_edges returns what the closure returns (msgpass.jl:30-53)
+    m = gm.apply_edges(lambda xi, xj, e: torch.ones((e.shape[0], 3), device="cuda"), g, e=torch.rand((g.num_edges, 3), device="cuda"))
+    assert bool((m == 1).all()) and m.shape == (g.num_edges, 3)
+    # isolated nodes keep their row (msgpass.jl:21-26)
+    g1 = gm.GNNGraph(dev(np.arange(1, 6)), dev(np.arange(1, 6)), num_nodes=6)
+    y1 = gm.propagate(lambda xi, xj, e: xj, g1, "+", xj=torch.rand((6, 1), device="cuda"))
+    assert y1.shape == (6, 1) and float(y1[5, 0]) == 0.0
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# dense (MFMA) kernel
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,Din,Dout", [(1, 3, 5), (130, 100, 100), (1000, 128, 128), (257, 1433, 64), (300, 16, 130),
+                                         (513, 200, 256), (64, 7, 2)])
+def test_dense_vs_float64(gm, N, Din, Dout):
+    rng = np.random.default_rng(N + Din)
+    x = rng.standard_normal((N, Din)).astype(np.float32)
+    W = (rng.standard_normal((Dout, Din)) / np.sqrt(Din)).astype(np.float32)
+    b = rng.standard_normal(Dout).astype(np.float32)
+    ref = x.astype(np.float64) @ W.astype(np.float64).T
+    assert_close(host(gm.dense(dev(x), dev(W))), ref)
+    assert_close(host(gm.dense(dev(x), dev(W), dev(b), "relu")), np.maximum(ref + b, 0))
+    # two-segment form: W * vcat(x, m) with W sliced by columns
+    m = rng.standard_normal((N, Din)).astype(np.float32)
+    Ws = (rng.standard_normal((Dout, 2 * Din)) / np.sqrt(2 * Din)).astype(np.float32)
+    ref2 = np.concatenate([x, m], 1).astype(np.float64) @ Ws.astype(np.float64).T + b
+    Wd = dev(Ws)
+    assert_close(host(gm.dense(dev(x), Wd[:, :Din], dev(b), None, x2=dev(m), W2=Wd[:, Din:])), ref2)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# arxiv-shape end to end vs the oracle (BASELINE.json configs 2 and 3)
+# ---------------------------------------------------------------------------------------------------------------
+def test_arxiv_shape_gcn_and_gat_vs_oracle(gm, oracle):
+    from gnnmp import synth
+    N = synth.ARXIV["N"]
+    s, t = synth.arxiv_like()
+    x = synth.features(N, 128, seed=1)
+    g = gm.GNNGraph(dev(s), dev(t), num_nodes=N)
+    deg = indeg_of(t, N, loops=True)
+    # the aggregation alone, self loops folded in: bit-exact on short rows
+    from gnnmp.msgpass import _fused
+    from gnnmp import _lib as L
+    s2, t2, _ = oracle.add_self_loops(s, t, N)
+    assert_rows_equal_or_close(host(_fused(g, L.COPY_XJ, "+", dev(x), None, add_self_loops=True)),
+                               oracle.propagate("+", s2, t2, N, x), deg)
+    l = gm.GCNConv((128, 128), "relu", seed=11)
+    y = host(l(g, dev(x)))
+    ref = oracle.gcn_conv(s, t, N, x, host(l.weight), host(l.bias), "relu")
+    assert_close(y, ref)
+    lg = gm.GATConv((128, 16), "relu", heads=8, seed=12)
+    yg = host(lg(g, dev(x)))
+    refg = oracle.gat_conv(s, t, N, x, host(lg.dense_x_weight), host(lg.a), host(lg.bias), "relu", heads=8)
+    assert_close(yg, refg)
