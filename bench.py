@@ -35,16 +35,17 @@ def log(*a):
 
 
 def alg_bytes_gcn_propagate(N, Ep, D):
-    """fused GCN propagate kernel: per edge one source row + its col id; per node the output row, rowptr (8 B) and the two
-    normalisation scalars (SURVEY.md §8d 'CSR SpMM' + 'GCN layer (fused norm)')"""
+    """fused GCN propagate kernel (csr_rows_kernel): per edge one source row + its col id (SURVEY.md §8d 'CSR SpMM':
+    4D + 4); per node the output row, rowptr (8 B) and the two normalisation scalars ('GCN layer (fused norm)': + 8 N).
+    The slot-ordered source coefficient the kernel actually streams (4 B/edge more) is NOT counted: conservative."""
     return Ep * (4 * D + 4) + 8 * (N + 1) + 4 * N * D + 8 * N
 
 
 def alg_bytes_gat_aggregate(N, Ep, H, C):
-    """fused GAT edge kernel: per edge one source row (4HC), its score_src row (4H) and col id (4); per node the output
-    row (4HC), score_dst (4H) and rowptr (8).  (A subset of SURVEY.md §8d's 'GAT fused' figure, which also counts the
-    node pre-pass: conservative.)"""
-    return Ep * (4 * H * C + 4 * H + 4) + N * (4 * H * C + 4 * H + 8)
+    """one-pass GAT kernel (gat_fused_rows_kernel): per edge one source row (4HC) and its col id (4); per node the
+    output row (4HC), the node's own Wx row for the target half of the logit (4HC) and rowptr (8).  Below SURVEY.md
+    §8d's 'GAT fused' figure (which budgets 8H + 16 B/edge of scores and Int64 indices): conservative."""
+    return Ep * (4 * H * C + 4) + N * (8 * H * C + 8)
 
 
 def cpu_baseline(seed_graph=0):
@@ -155,24 +156,20 @@ def main():
 
     # ---- events around the two candidate dominant kernels (recorded on the launch stream) --------------------
     lib = L.load()
-    deg = torch.empty(N, dtype=torch.float32, device="cuda")
-    L.check(lib.gnnmp_degree_f32(plan.handle, None, L.ptr(deg), L.stream_ptr()))
-    from gnnmp.layers import _inv_sqrt
-    cvec = _inv_sqrt(deg)
+    step()                        # fills the per-graph normalisation cache (slot-ordered coefficients)
+    cvec, c_slot, _ = g._cache[("gcn_norm", True, False)]
     out_p = torch.empty((N, D), dtype=torch.float32, device="cuda")
     Wx = gnnmp.dense(x, gat.dense_x_weight)
-    sdst = torch.empty((N, H), dtype=torch.float32, device="cuda")
-    ssrc = torch.empty((N, H), dtype=torch.float32, device="cuda")
-    L.check(lib.gnnmp_gat_node_scores_f32(L.ptr(Wx), L.ptr(gat.a_hc), L.ptr(sdst), L.ptr(ssrc), N, H, C, L.stream_ptr()))
+    a_hc = gat.a_hc               # keep alive: raw pointers below
     out_g = torch.empty((N, H * C), dtype=torch.float32, device="cuda")
 
     def k_propagate():
-        L.check(lib.gnnmp_propagate_f32(plan.handle, L.COPY_XJ, L.SUM, L.ptr(x), None, L.ptr(cvec), L.ptr(cvec),
-                                        L.ptr(out_p), D, L.stream_ptr()))
+        L.check(lib.gnnmp_propagate_slots_f32(plan.handle, L.SUM, L.ptr(x), None, L.ptr(c_slot), L.ptr(cvec),
+                                              L.ptr(out_p), D, L.stream_ptr()))
 
     def k_gat():
-        L.check(lib.gnnmp_gat_aggregate_f32(plan.handle, L.ptr(Wx), L.ptr(sdst), L.ptr(ssrc), 0.2, L.ptr(gat.bias),
-                                            L.ACT_RELU, L.ptr(out_g), None, H, C, L.stream_ptr()))
+        L.check(lib.gnnmp_gat_conv_f32(plan.handle, L.ptr(Wx), None, L.ptr(a_hc), 0.2, L.ptr(gat.bias), L.ACT_RELU,
+                                       L.ptr(out_g), H, C, L.stream_ptr()))
 
     for _ in range(args.warmup):
         step()
@@ -207,9 +204,9 @@ def main():
     b_prop = alg_bytes_gcn_propagate(N, Ep, D)
     b_gat = alg_bytes_gat_aggregate(N, Ep, H, C)
     kern = {
-        "gcn_propagate": {"kernel": "csr_rows_kernel(+csr_long_rows_kernel)", "ms": tp_avg, "ms_median": tp_med,
+        "gcn_propagate": {"kernel": "csr_rows_kernel", "ms": tp_avg, "ms_median": tp_med,
                           "alg_bytes": b_prop, "GBs": b_prop / tp_avg / 1e6},
-        "gat_aggregate": {"kernel": "gat_rows_kernel(+gat_long_rows_kernel)", "ms": tg_avg, "ms_median": tg_med,
+        "gat_aggregate": {"kernel": "gat_fused_rows_kernel", "ms": tg_avg, "ms_median": tg_med,
                           "alg_bytes": b_gat, "GBs": b_gat / tg_avg / 1e6},
     }
     dom = max(kern, key=lambda k: kern[k]["ms"])

@@ -124,13 +124,28 @@ struct gnnmp_graph {
     int32_t *rowptr = nullptr;  // [n_dst + 1]
     int32_t *col = nullptr;     // [n_total] 0-based source of each slot
     int32_t *eid = nullptr;     // [n_total] 0-based original edge position of each slot
-    // rows longer than the long-row threshold (sorted ascending), handled one workgroup per row
-    int32_t *long_rows = nullptr;
+    // rows longer than long_thresh (sorted ascending) are cut into n_chunks balanced chunks of at most
+    // long_thresh slots; the row kernels process chunks like ordinary (virtual) rows into a partial buffer and a
+    // small combine kernel folds the partials of each long row in chunk order.
+    int32_t *long_rows = nullptr;   // [n_long]
+    int32_t *long_cptr = nullptr;   // [n_long + 1] chunk range of each long row
+    int32_t *chunk_row = nullptr;   // [n_chunks]
+    int32_t *chunk_beg = nullptr;   // [n_chunks]
+    int32_t *chunk_end = nullptr;   // [n_chunks]
     int n_long = 0;
+    int n_chunks = 0;
     int long_thresh = GNNMP_LONG_ROW;
     int64_t max_degree = 0;
     int64_t bytes = 0;
+    // plan-owned workspace for the chunk partials (grown on demand; one stream at a time per plan)
+    float *ws = nullptr;
+    size_t ws_floats = 0;
 };
+
+namespace gnnmp {
+// make sure plan->ws holds at least `floats` floats (hipMalloc on growth; hipFree waits for in-flight work)
+int ensure_workspace(gnnmp_graph *p, size_t floats);
+}
 
 namespace gnnmp {
 // vector width usable for rows of D floats at these base pointers

@@ -1,0 +1,317 @@
+// gat_fused.hip — the whole GATConv attention path in ONE pass over the edges:
+//   GNNlib/src/layers/conv.jl:136-141  apply_edges(gat_message) -> softmax_edge_neighbors -> α .* Wxj -> aggregate_neighbors(+)
+//   gat_message :152-167               logα = leakyrelu( sum(a .* vcat(Wxi, Wxj), dims = 1) )
+//
+// What makes it one pass: the source row Wx_j (4*H*C bytes) has to be fetched for the weighted sum anyway, and the
+// source half of the logit, a[C:2C,h] . Wx_j[:,h], is a function of exactly that row.  The lanes that hold head h's
+// channels (C/VEC of them, adjacent) form the dot product in registers with an xor butterfly (DPP quad/row permutes,
+// no LDS), so there is no (N,H) score array to gather (a random 64-byte sector per edge on top of the row) and no node
+// pre-pass.  The neighbourhood softmax is computed online (running max m, running denominator, rescale when the max
+// grows), so the row's edges are visited once instead of the reference's six (H,E') passes + three (C,H,E') passes:
+//     out_i[h,:] = ( sum_j exp(l_ij - m_i) * Wx_j[h,:] ) / ( sum_j exp(l_ij - m_i) )
+// Algebraically the reference's  sum_j (exp(l_ij - max_i) / den_i) * Wx_j ; the fp32 rounding differs (<= 1e-6 rel
+// measured, north_star allows 1e-5).  Callers that need the reference's exact operation order, the α coefficients, or a
+// head width whose lane count is not a power of two go through the three-pass kernels of attention.hip (same ABI entry
+// falls back automatically).
+//
+// Long rows: same chunking as propagate.hip — a chunk is a virtual row that emits (acc, m, den) partials; the combine
+// kernel merges them with the usual log-sum-exp rescale.
+#include "common.h"
+
+namespace gnnmp {
+
+struct GatFusedArgs {
+    const int32_t *rowptr;
+    const int32_t *col;
+    const float *Wx_src;  // [n_src][D]
+    const float *Wx_dst;  // [n_dst][D]
+    const float *a;       // [H][2C]
+    const float *bias;    // [D] or null
+    float *out;           // [n_dst][D]
+    float *partial;       // [n_chunks][D + 2*D/VEC]
+    const int32_t *chunk_row, *chunk_beg, *chunk_end;
+    const int32_t *long_rows, *long_cptr;
+    int n_chunks, n_long;
+    int H, C, D;
+    int n_rows;
+    int log2g;
+    int lph;              // lanes per head = C / VEC (power of two)
+    int act;
+    float slope;
+    int long_thresh;
+    int cpx;
+    int waves;
+};
+
+__device__ __forceinline__ float lrelu(float x, float slope) { return x > 0.0f ? x : x * slope; }
+
+// sum over the lanes of one head (adjacent, power-of-two count): every lane ends with the same bits
+__device__ __forceinline__ float head_sum(float d, int lph) {
+    for (int o = 1; o < lph; o <<= 1) d += __shfl_xor(d, o, 64);
+    return d;
+}
+
+template <int VEC, int U>
+__device__ __forceinline__ void gat_online_range(const GatFusedArgs &a, int beg, int end, int lig,
+                                                 int gbase, int G, int f0, bool active,
+                                                 const float as[VEC], float sd, float &m, float &den,
+                                                 float acc[VEC]) {
+    for (int base = beg; base < end; base += G) {
+        const int p = base + lig;
+        const int c = p < end ? a.col[p] : 0;
+        const int n = min(G, end - base);
+        for (int j = 0; j < n; j += U) {
+            float v[U][VEC];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int cj = __shfl(c, gbase + min(j + u, n - 1), 64);
+                if (active && (j + u < n)) {
+                    Vec<VEC>::load(a.Wx_src + (int64_t)cj * a.D + f0, v[u]);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) v[u][q] = 0.0f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (j + u < n) {
+                    float d = 0.0f;
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) d = fmaf(as[q], v[u][q], d);
+                    d = head_sum(d, a.lph);
+                    const float l = lrelu(sd + d, a.slope);
+                    if (l > m) {  // the running max grows: rescale what has been accumulated (exp(-inf) = 0 first time)
+                        const float sc = expf(m - l);
+                        den *= sc;
+#pragma unroll
+                        for (int q = 0; q < VEC; ++q) acc[q] *= sc;
+                        m = l;
+                    }
+                    const float pe = expf(l - m);
+                    den += pe;
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) acc[q] = fmaf(pe, v[u][q], acc[q]);
+                }
+            }
+        }
+    }
+}
+
+template <int VEC>
+__device__ __forceinline__ void gat_fused_store(const GatFusedArgs &a, int row, int f0, bool active,
+                                                float acc[VEC]) {
+    if (!active) return;
+    if (a.bias) {
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) acc[q] = acc[q] + a.bias[f0 + q];
+    }
+    if (a.act == GNNMP_ACT_RELU) {
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) acc[q] = acc[q] < 0.0f ? 0.0f : acc[q];
+    }
+    Vec<VEC>::store(a.out + (int64_t)row * a.D + f0, acc);
+}
+
+template <int VEC, int U>
+__global__ void __launch_bounds__(256) gat_fused_rows_kernel(const GatFusedArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int G = 1 << a.log2g;
+    const int lig = lane & (G - 1);
+    const int grp = lane >> a.log2g;
+    const int gbase = lane - lig;
+    const int rpw = 64 >> a.log2g;
+    const int chunk = a.cpx ? xcd_remap(blockIdx.x, a.cpx, 1) : (int)blockIdx.x;
+    const int64_t v64 = ((int64_t)chunk * a.waves + wave) * rpw + grp;
+    if (v64 >= (int64_t)a.n_rows + a.n_chunks) return;
+    const int v = (int)v64;
+    const int f0 = ((int)blockIdx.y * G + lig) * VEC;
+    const bool active = f0 < a.D;
+    const bool is_chunk = v < a.n_chunks;
+    int row, beg, end;
+    if (is_chunk) {
+        row = a.chunk_row[v];
+        beg = a.chunk_beg[v];
+        end = a.chunk_end[v];
+    } else {
+        row = v - a.n_chunks;
+        beg = a.rowptr[row];
+        end = a.rowptr[row + 1];
+        if (end - beg > a.long_thresh) return;
+    }
+    // this lane's slice of the attention vector: target half a[h][c0 .. c0+VEC), source half a[h][C+c0 ..)
+    float ad[VEC], as[VEC], vi[VEC];
+    if (active) {
+        const int h = f0 / a.C, c0 = f0 - h * a.C;
+        const float *ah = a.a + (int64_t)h * 2 * a.C + c0;
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+            ad[q] = ah[q];
+            as[q] = ah[a.C + q];
+        }
+        Vec<VEC>::load(a.Wx_dst + (int64_t)row * a.D + f0, vi);
+    } else {
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) ad[q] = as[q] = vi[q] = 0.0f;
+    }
+    float sd = 0.0f;
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) sd = fmaf(ad[q], vi[q], sd);
+    sd = head_sum(sd, a.lph);
+
+    float m = -__builtin_inff(), den = 0.0f;
+    float acc[VEC];
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) acc[q] = 0.0f;
+    gat_online_range<VEC, U>(a, beg, end, lig, gbase, G, f0, active, as, sd, m, den, acc);
+    if (is_chunk) {
+        if (active) {
+            const int LN = a.D / VEC;
+            float *pc = a.partial + (int64_t)v * (a.D + 2 * LN);
+            Vec<VEC>::store(pc + f0, acc);
+            pc[a.D + f0 / VEC] = m;
+            pc[a.D + LN + f0 / VEC] = den;
+        }
+        return;
+    }
+    if (end > beg) {
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) acc[q] = acc[q] / den;
+    }
+    gat_fused_store<VEC>(a, row, f0, active, acc);
+}
+
+template <int VEC>
+__global__ void __launch_bounds__(256) gat_fused_combine_kernel(const GatFusedArgs a) {
+    const int G = 1 << a.log2g;
+    const int lig = threadIdx.x & (G - 1);
+    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> a.log2g;
+    if (r >= a.n_long) return;
+    const int f0 = ((int)blockIdx.y * G + lig) * VEC;
+    if (f0 >= a.D) return;
+    const int row = a.long_rows[r];
+    const int c0 = a.long_cptr[r], c1 = a.long_cptr[r + 1];
+    const int LN = a.D / VEC;
+    const int64_t S = a.D + 2 * LN;
+    float M = -__builtin_inff();
+    for (int c = c0; c < c1; ++c) M = fmaxf(M, a.partial[c * S + a.D + f0 / VEC]);
+    float den = 0.0f, acc[VEC];
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) acc[q] = 0.0f;
+    for (int c = c0; c < c1; ++c) {
+        const float *pc = a.partial + c * S;
+        const float sc = expf(pc[a.D + f0 / VEC] - M);
+        den = fmaf(pc[a.D + LN + f0 / VEC], sc, den);
+        float v[VEC];
+        Vec<VEC>::load(pc + f0, v);
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) acc[q] = fmaf(v[q], sc, acc[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) acc[q] = acc[q] / den;
+    gat_fused_store<VEC>(a, row, f0, true, acc);
+}
+
+template <int VEC>
+static int launch_gat_fused(GatFusedArgs a, hipStream_t stream) {
+    const int G = 1 << a.log2g;
+    const int rpw = 64 / G;
+    int waves = knob(KNOB_BLOCK_WAVES);
+    if (waves < 1 || waves > 4) waves = 4;
+    a.waves = waves;
+    const int rows_per_block = rpw * waves;
+    const int64_t nvirt = (int64_t)a.n_rows + a.n_chunks;
+    const int64_t chunks = (nvirt + rows_per_block - 1) / rows_per_block;
+    if (chunks > 0) {
+        int64_t gx = chunks;
+        a.cpx = 0;
+        if (knob(KNOB_XCD_REMAP) && chunks >= 64) {
+            a.cpx = (int)((chunks + 7) / 8);
+            gx = (int64_t)a.cpx * 8;
+        }
+        dim3 grid((unsigned)gx, 1);
+        if (knob(KNOB_UNROLL) == 8)
+            gat_fused_rows_kernel<VEC, 8><<<grid, 64 * waves, 0, stream>>>(a);
+        else if (knob(KNOB_UNROLL) == 2)
+            gat_fused_rows_kernel<VEC, 2><<<grid, 64 * waves, 0, stream>>>(a);
+        else
+            gat_fused_rows_kernel<VEC, 4><<<grid, 64 * waves, 0, stream>>>(a);
+        GNNMP_LAUNCH_CHECK("gat_fused_rows_kernel");
+    }
+    if (a.n_long > 0) {
+        const int64_t threads = (int64_t)a.n_long << a.log2g;
+        gat_fused_combine_kernel<VEC><<<(unsigned)((threads + 255) / 256), 256, 0, stream>>>(a);
+        GNNMP_LAUNCH_CHECK("gat_fused_combine_kernel");
+    }
+    return GNNMP_OK;
+}
+
+}  // namespace gnnmp
+
+using namespace gnnmp;
+
+extern "C" int gnnmp_gat_conv_f32(gnnmp_graph_t *plan, const float *Wx_src, const float *Wx_dst,
+                                  const float *a, float negative_slope, const float *bias, int act,
+                                  float *out, int64_t H, int64_t C, gnnmp_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!plan) return fail(GNNMP_EINVAL, "gat_conv: null plan");
+    if (H <= 0 || C <= 0 || H * C > (1 << 20)) return fail(GNNMP_EINVAL, "gat_conv: bad H/C");
+    if (act != GNNMP_ACT_IDENTITY && act != GNNMP_ACT_RELU) return fail(GNNMP_EINVAL, "gat_conv: bad act %d", act);
+    if (plan->n_dst == 0) return GNNMP_OK;
+    if (!Wx_dst) Wx_dst = Wx_src;
+    if (!out || !a || !Wx_dst || (plan->n_total > 0 && !Wx_src)) return fail(GNNMP_EINVAL, "gat_conv: null pointer");
+    if (Wx_dst == Wx_src && plan->n_src != plan->n_dst)
+        return fail(GNNMP_EINVAL, "gat_conv: bipartite plan needs Wx_dst");
+    const int D = (int)(H * C);
+    int vec = pick_vec(D, Wx_src, out);
+    if ((reinterpret_cast<uintptr_t>(Wx_dst) & (4 * vec - 1)) != 0) vec = 1;
+    while (vec > 1 && (C % vec) != 0) vec >>= 1;
+    const int lph = (int)(C / vec);
+    const int lanes = D / vec;
+    const bool pow2 = (lph & (lph - 1)) == 0;
+    if (!pow2 || lanes > 64) {
+        // head width not a power-of-two lane count (or wider than a wave): three-pass kernels on node scores
+        const size_t need = (size_t)(plan->n_dst + plan->n_src) * (size_t)H;
+        if (int rc = ensure_workspace(plan, need)) return rc;
+        float *sdst = plan->ws, *ssrc = plan->ws + (size_t)plan->n_dst * (size_t)H;
+        if (int rc = gnnmp_gat_node_scores_f32(Wx_dst, a, sdst, nullptr, plan->n_dst, H, C, stream_)) return rc;
+        if (int rc = gnnmp_gat_node_scores_f32(Wx_src, a, nullptr, ssrc, plan->n_src, H, C, stream_)) return rc;
+        return gnnmp_gat_aggregate_f32(plan, Wx_src, sdst, ssrc, negative_slope, bias, act, out, nullptr, H, C, stream_);
+    }
+    if (plan->n_chunks > 0) {
+        if (int rc = ensure_workspace(plan, (size_t)plan->n_chunks * (size_t)(D + 2 * lanes))) return rc;
+    }
+    GatFusedArgs g;
+    g.rowptr = plan->rowptr;
+    g.col = plan->col;
+    g.Wx_src = Wx_src;
+    g.Wx_dst = Wx_dst;
+    g.a = a;
+    g.bias = bias;
+    g.out = out;
+    g.partial = plan->ws;
+    g.chunk_row = plan->chunk_row;
+    g.chunk_beg = plan->chunk_beg;
+    g.chunk_end = plan->chunk_end;
+    g.long_rows = plan->long_rows;
+    g.long_cptr = plan->long_cptr;
+    g.n_chunks = plan->n_chunks;
+    g.n_long = plan->n_long;
+    g.H = (int)H;
+    g.C = (int)C;
+    g.D = D;
+    g.n_rows = (int)plan->n_dst;
+    g.log2g = pick_log2g(lanes);
+    while ((1 << g.log2g) < lanes) ++g.log2g;  // one feature tile: the head butterfly needs the whole row in one group
+    g.lph = lph;
+    g.act = act;
+    g.slope = negative_slope;
+    g.long_thresh = plan->long_thresh;
+    g.cpx = 0;
+    g.waves = 4;
+    switch (vec) {
+        case 4: return launch_gat_fused<4>(g, stream);
+        case 2: return launch_gat_fused<2>(g, stream);
+        default: return launch_gat_fused<1>(g, stream);
+    }
+}

@@ -15,7 +15,7 @@
 namespace gnnmp {
 
 static thread_local char g_err[512] = "";
-static int g_knobs[KNOB_COUNT] = {0, -1, 0, 1, GNNMP_LONG_ROW, 4, 0, 0};
+static int g_knobs[KNOB_COUNT] = {0, -1, 0, 1, 0, 4, 0, 0};
 
 int fail(int status, const char *fmt, ...) {
     va_list ap;
@@ -29,6 +29,17 @@ int hip_fail(hipError_t e, const char *what) {
     return e == hipErrorOutOfMemory ? GNNMP_EALLOC : GNNMP_ELAUNCH;
 }
 int knob(int k) { return (k >= 0 && k < KNOB_COUNT) ? g_knobs[k] : 0; }
+
+int ensure_workspace(gnnmp_graph *p, size_t floats) {
+    if (floats <= p->ws_floats) return GNNMP_OK;
+    if (p->ws) (void)hipFree(p->ws);  // hipFree waits for work that may still read the old buffer
+    p->ws = nullptr;
+    p->ws_floats = 0;
+    hipError_t e = hipMalloc((void **)&p->ws, sizeof(float) * floats);
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc(plan workspace)");
+    p->ws_floats = floats;
+    return GNNMP_OK;
+}
 
 // ---- kernels -----------------------------------------------------------------------------------
 
@@ -79,17 +90,31 @@ __global__ void plan_col(const void *src, int idx_bytes, int base, int64_t E, in
     col[p] = (int32_t)s;
 }
 
-// collect rows longer than `thresh`; meta[0] = count (atomic), meta[1] = max degree
+// collect rows longer than `thresh` as (row, beg, end) triples; meta[0] = count (atomic), meta[1] = max degree
 __global__ void plan_long_rows(const int32_t *rowptr, int64_t n_dst, int thresh, int32_t *list,
                                int cap, int *meta) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_dst) return;
-    int len = rowptr[i + 1] - rowptr[i];
+    const int beg = rowptr[i], end = rowptr[i + 1];
+    const int len = end - beg;
     atomicMax(&meta[1], len);
     if (len > thresh) {
         int pos = atomicAdd(&meta[0], 1);
-        if (pos < cap) list[pos] = (int32_t)i;
+        if (pos < cap) {
+            list[3 * pos] = (int32_t)i;
+            list[3 * pos + 1] = beg;
+            list[3 * pos + 2] = end;
+        }
     }
+}
+
+// out[p] = v[col[p]] (by == 0, node vector) or v[eid[p]] with 1.0 for plan-added self loops (by == 1, edge vector)
+__global__ void slot_gather_kernel(const int32_t *idx, const float *v, int64_t Etot, int64_t n_valid,
+                                   float *out) {
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= Etot) return;
+    const int64_t k = idx[p];
+    out[p] = k < n_valid ? v[k] : 1.0f;
 }
 
 __global__ void self_loops_kernel(const void *src, const void *dst, int idx_bytes, int base,
@@ -166,6 +191,11 @@ int gnnmp_plan_destroy(gnnmp_graph_t *p) {
     if (p->col) (void)hipFree(p->col);
     if (p->eid) (void)hipFree(p->eid);
     if (p->long_rows) (void)hipFree(p->long_rows);
+    if (p->long_cptr) (void)hipFree(p->long_cptr);
+    if (p->chunk_row) (void)hipFree(p->chunk_row);
+    if (p->chunk_beg) (void)hipFree(p->chunk_beg);
+    if (p->chunk_end) (void)hipFree(p->chunk_end);
+    if (p->ws) (void)hipFree(p->ws);
     delete p;
     return GNNMP_OK;
 }
@@ -197,7 +227,16 @@ int gnnmp_plan_create(gnnmp_graph_t **out, const void *src, const void *dst, int
     p->n_edges = n_edges;
     p->n_total = Etot;
     p->self_loops = add_self_loops ? 1 : 0;
-    p->long_thresh = knob(KNOB_LONG_ROW) > 0 ? knob(KNOB_LONG_ROW) : GNNMP_LONG_ROW;
+    // Long-row threshold: a row is reduced sequentially by one lane group, ~0.25 us per edge once HBM latency is the
+    // limit, while the whole kernel moves an edge every ~0.1 ns; rows above ~4e-5 * E' edges would become the tail.
+    // Clamped to [GNNMP_MIN_LONG_ROW, GNNMP_LONG_ROW]; rows up to this length keep the exact reference edge order.
+    if (knob(KNOB_LONG_ROW) > 0) {
+        p->long_thresh = knob(KNOB_LONG_ROW);
+    } else {
+        int th = GNNMP_MIN_LONG_ROW;
+        while (th < GNNMP_LONG_ROW && (double)th < 4e-5 * (double)Etot) th <<= 1;
+        p->long_thresh = th;
+    }
 
     uint32_t *keys_in = nullptr, *keys_out = nullptr, *vals_in = nullptr;
     void *tmp = nullptr;
@@ -262,7 +301,7 @@ int gnnmp_plan_create(gnnmp_graph_t **out, const void *src, const void *dst, int
     {
         // long rows: at most Etot / thresh of them
         int cap = (int)std::min<int64_t>(Etot / std::max(1, p->long_thresh) + 1, n_dst + 1);
-        PLAN_HIP(hipMalloc((void **)&long_tmp, sizeof(int32_t) * (size_t)std::max(cap, 1)));
+        PLAN_HIP(hipMalloc((void **)&long_tmp, sizeof(int32_t) * 3 * (size_t)std::max(cap, 1)));
         if (n_dst > 0) {
             plan_long_rows<<<nblocks(n_dst, BS), BS, 0, stream>>>(p->rowptr, n_dst, p->long_thresh,
                                                                   long_tmp, cap, flags + 1);
@@ -274,12 +313,37 @@ int gnnmp_plan_create(gnnmp_graph_t **out, const void *src, const void *dst, int
         p->max_degree = meta[1];
         p->n_long = std::min(meta[0], cap);
         if (p->n_long > 0) {
-            std::vector<int32_t> h((size_t)p->n_long);
-            PLAN_HIP(hipMemcpy(h.data(), long_tmp, sizeof(int32_t) * h.size(), hipMemcpyDeviceToHost));
-            std::sort(h.begin(), h.end());  // atomics filled it in arbitrary order: make it canonical
-            PLAN_HIP(hipMalloc((void **)&p->long_rows, sizeof(int32_t) * h.size()));
-            PLAN_HIP(hipMemcpy(p->long_rows, h.data(), sizeof(int32_t) * h.size(), hipMemcpyHostToDevice));
-            p->bytes += (int64_t)(sizeof(int32_t) * h.size());
+            struct Tri { int32_t row, beg, end; };
+            std::vector<Tri> h((size_t)p->n_long);
+            PLAN_HIP(hipMemcpy(h.data(), long_tmp, sizeof(Tri) * h.size(), hipMemcpyDeviceToHost));
+            // atomics filled the list in arbitrary order: make it canonical (ascending row)
+            std::sort(h.begin(), h.end(), [](const Tri &a, const Tri &b) { return a.row < b.row; });
+            std::vector<int32_t> rows, cptr, crow, cbeg, cend;
+            cptr.push_back(0);
+            for (const Tri &t : h) {
+                const int len = t.end - t.beg;
+                const int nch = (len + p->long_thresh - 1) / p->long_thresh;
+                const int csz = (len + nch - 1) / nch;  // balanced chunks, each <= long_thresh slots
+                for (int c = 0; c < nch; ++c) {
+                    crow.push_back(t.row);
+                    cbeg.push_back(t.beg + c * csz);
+                    cend.push_back(std::min(t.beg + (c + 1) * csz, t.end));
+                }
+                rows.push_back(t.row);
+                cptr.push_back((int32_t)crow.size());
+            }
+            p->n_chunks = (int)crow.size();
+            auto upload = [&](int32_t **dst, const std::vector<int32_t> &v) -> hipError_t {
+                hipError_t e = hipMalloc((void **)dst, sizeof(int32_t) * v.size());
+                if (e != hipSuccess) return e;
+                p->bytes += (int64_t)(sizeof(int32_t) * v.size());
+                return hipMemcpy(*dst, v.data(), sizeof(int32_t) * v.size(), hipMemcpyHostToDevice);
+            };
+            PLAN_HIP(upload(&p->long_rows, rows));
+            PLAN_HIP(upload(&p->long_cptr, cptr));
+            PLAN_HIP(upload(&p->chunk_row, crow));
+            PLAN_HIP(upload(&p->chunk_beg, cbeg));
+            PLAN_HIP(upload(&p->chunk_end, cend));
         }
     }
 
@@ -299,6 +363,21 @@ done:
     return GNNMP_OK;
 }
 
+int gnnmp_plan_slot_gather_f32(gnnmp_graph_t *p, int by, const float *v, float *out_slot,
+                               gnnmp_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!p) return fail(GNNMP_EINVAL, "plan_slot_gather: null plan");
+    if (by != 0 && by != 1) return fail(GNNMP_EINVAL, "plan_slot_gather: `by` must be 0 (node) or 1 (edge)");
+    if (p->n_total == 0) return GNNMP_OK;
+    if (!v || !out_slot) return fail(GNNMP_EINVAL, "plan_slot_gather: null pointer");
+    if (by == 0)
+        slot_gather_kernel<<<nblocks(p->n_total, 256), 256, 0, stream>>>(p->col, v, p->n_total, p->n_src, out_slot);
+    else
+        slot_gather_kernel<<<nblocks(p->n_total, 256), 256, 0, stream>>>(p->eid, v, p->n_total, p->n_edges, out_slot);
+    GNNMP_LAUNCH_CHECK("slot_gather_kernel");
+    return GNNMP_OK;
+}
+
 int gnnmp_plan_info(const gnnmp_graph_t *p, int64_t info[8]) {
     if (!p || !info) return fail(GNNMP_EINVAL, "plan_info: null argument");
     info[0] = p->n_src;
@@ -306,7 +385,7 @@ int gnnmp_plan_info(const gnnmp_graph_t *p, int64_t info[8]) {
     info[2] = p->n_edges;
     info[3] = p->n_total;
     info[4] = p->max_degree;
-    info[5] = p->n_long;
+    info[5] = p->n_long;  // rows that are split
     info[6] = p->bytes;
     info[7] = p->long_thresh;
     return GNNMP_OK;

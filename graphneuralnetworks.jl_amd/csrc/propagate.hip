@@ -6,12 +6,14 @@
 // HBM-bound (0.33-0.48 flop/B): the design goal is to keep every lane's 16-byte row loads in flight.
 //   - one GROUP of G = 2^k lanes owns one destination row; lane l of the group owns VEC consecutive features
 //     (G*VEC >= D; D=128 -> 32 lanes x float4, two rows per wave; D=100 -> 25 of 32 lanes active).
-//   - the row's source ids are loaded coalesced, G at a time, one per lane, and broadcast inside the group with
-//     ds_bpermute (__shfl) — the CDNA cross-lane path, no LDS allocation, no barrier.
+//   - the row's source ids (and the per-edge factors, when given in slot order) are loaded coalesced, G at a time,
+//     one per lane, and broadcast inside the group with ds_bpermute (__shfl) — the CDNA cross-lane path, no LDS
+//     allocation, no barrier.
 //   - U row loads are issued back to back before the first add; the adds then run in ORIGINAL edge order,
 //     one fp32 accumulator chain per feature => bit-identical to NNlib's CPU scatter loop, no atomics.
-//   - rows longer than the plan's threshold are skipped here and reduced by one 1024-thread workgroup each
-//     (fixed partition, fixed combine order through LDS).
+//   - rows longer than the plan's threshold are cut into balanced chunks (plan.hip); a chunk is processed by the SAME
+//     kernel as a virtual row whose result goes to a partial buffer, and a small second kernel folds each long row's
+//     partials in chunk order.  The dominant kernel therefore touches every edge exactly once and has no tail.
 //   - block -> row-chunk mapping is XCD-aware (contiguous destination ranges per XCD / L2).
 #include "common.h"
 
@@ -19,23 +21,28 @@ namespace gnnmp {
 
 struct ReduceArgs {
     const int32_t *rowptr;
-    const int32_t *idx;   // per slot: source row of x to read (plan->col, or plan->eid for scatter)
-    const int32_t *eid;   // per slot: original edge position (weights lookup); may be null if !w
-    const float *x;       // [n_src][D]
-    const float *w;       // [n_edges] original order, nullable
-    const float *ss;      // [n_src] nullable
-    const float *sd;      // [n_dst] nullable
-    float *out;           // [n_dst][D]
-    const int32_t *long_rows;
+    const int32_t *idx;      // per slot: source row of x to read (plan->col, or plan->eid for scatter)
+    const int32_t *eid;      // per slot: original edge position (weights lookup); unused unless w
+    const float *x;          // [n_src][D]
+    const float *w;          // [n_edges] original order, nullable
+    const float *ss;         // [n_src] nullable
+    const float *w_slot;     // [E'] slot order, nullable (takes precedence over w)
+    const float *ss_slot;    // [E'] slot order, nullable (takes precedence over ss)
+    const float *sd;         // [n_dst] nullable
+    float *out;              // [n_dst][D]
+    float *partial;          // [n_chunks][D]
+    const int32_t *chunk_row, *chunk_beg, *chunk_end;
+    const int32_t *long_rows, *long_cptr;
+    int n_chunks;
     int n_long;
     int D;
     int n_rows;
-    int n_edges;          // weights exist for eid < n_edges; others are 1
+    int n_edges;             // weights exist for eid < n_edges; others are 1
     int log2g;
     int mean;
     int long_thresh;
-    int cpx;              // chunks per XCD (grid.x = 8*cpx) ; 0 = no remap
-    int waves;            // waves per block
+    int cpx;                 // chunks per XCD (grid.x = 8*cpx) ; 0 = no remap
+    int waves;               // waves per block
 };
 
 // reduce slots [beg, end) of one destination into acc[VEC]; all lanes of the group call this together.
@@ -50,11 +57,16 @@ __device__ __forceinline__ void reduce_range(const ReduceArgs &a, int beg, int e
         if (p < end) {
             c = a.idx[p];
             if (SCALED) {
-                if (a.w) {
+                if (a.w_slot) {
+                    wv = a.w_slot[p];
+                } else if (a.w) {
                     const int e = a.eid[p];
                     if (e < a.n_edges) wv = a.w[e];
                 }
-                if (a.ss) sv = a.ss[c];
+                if (a.ss_slot)
+                    sv = a.ss_slot[p];
+                else if (a.ss)
+                    sv = a.ss[c];
             }
         }
         const int n = min(G, end - base);
@@ -111,6 +123,7 @@ __device__ __forceinline__ void finalize_store(const ReduceArgs &a, int row, int
     if (active) Vec<VEC>::store(a.out + (int64_t)row * a.D + f0, acc);
 }
 
+// virtual rows: [0, n_chunks) are chunks of long rows (raw partials), [n_chunks, n_chunks + n_rows) ordinary rows.
 template <int VEC, int OP, bool SCALED, int U>
 __global__ void __launch_bounds__(256) csr_rows_kernel(const ReduceArgs a) {
     const int lane = threadIdx.x & 63;
@@ -121,58 +134,50 @@ __global__ void __launch_bounds__(256) csr_rows_kernel(const ReduceArgs a) {
     const int gbase = lane - lig;
     const int rpw = 64 >> a.log2g;
     const int chunk = a.cpx ? xcd_remap(blockIdx.x, a.cpx, 1) : (int)blockIdx.x;
-    const int64_t row64 = ((int64_t)chunk * a.waves + wave) * rpw + grp;
-    if (row64 >= a.n_rows) return;
-    const int row = (int)row64;
+    const int64_t v64 = ((int64_t)chunk * a.waves + wave) * rpw + grp;
+    if (v64 >= (int64_t)a.n_rows + a.n_chunks) return;
+    const int v = (int)v64;
     const int f0 = ((int)blockIdx.y * G + lig) * VEC;
     const bool active = f0 < a.D;
-    const int beg = a.rowptr[row];
-    const int end = a.rowptr[row + 1];
-    if (end - beg > a.long_thresh) return;  // handled by csr_long_rows_kernel
     float acc[VEC];
 #pragma unroll
     for (int q = 0; q < VEC; ++q) acc[q] = op_identity<OP>();
+    if (v < a.n_chunks) {
+        reduce_range<VEC, OP, SCALED, U>(a, a.chunk_beg[v], a.chunk_end[v], lig, gbase, G, f0, active, acc);
+        if (active) Vec<VEC>::store(a.partial + (int64_t)v * a.D + f0, acc);
+        return;
+    }
+    const int row = v - a.n_chunks;
+    const int beg = a.rowptr[row];
+    const int end = a.rowptr[row + 1];
+    if (end - beg > a.long_thresh) return;  // split row: its chunks are virtual rows, folded by csr_combine_kernel
     reduce_range<VEC, OP, SCALED, U>(a, beg, end, lig, gbase, G, f0, active, acc);
     finalize_store<VEC, OP>(a, row, end - beg, f0, active, acc);
 }
 
-// one 1024-thread workgroup per long row: group q of NG = 1024/G reduces the q-th contiguous part of the
-// row in edge order; the NG partial vectors are combined in q order through LDS.
-template <int VEC, int OP, bool SCALED, int U>
-__global__ void __launch_bounds__(1024) csr_long_rows_kernel(const ReduceArgs a) {
-    extern __shared__ float lds[];  // [NG][G*VEC]
-    const int lane = threadIdx.x & 63;
+// one lane group per long row: fold its chunk partials in chunk order, then the usual epilogue.
+template <int VEC, int OP>
+__global__ void __launch_bounds__(256) csr_combine_kernel(const ReduceArgs a) {
     const int G = 1 << a.log2g;
-    const int lig = lane & (G - 1);
-    const int gbase = lane - lig;
-    const int q = threadIdx.x >> a.log2g;
-    const int NG = 1024 >> a.log2g;
-    const int row = a.long_rows[blockIdx.x];
+    const int lig = threadIdx.x & (G - 1);
+    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> a.log2g;
+    if (r >= a.n_long) return;
     const int f0 = ((int)blockIdx.y * G + lig) * VEC;
     const bool active = f0 < a.D;
-    const int beg = a.rowptr[row];
-    const int end = a.rowptr[row + 1];
-    const int len = end - beg;
-    const int part = (len + NG - 1) / NG;
-    const int pb = min(beg + q * part, end);
-    const int pe = min(pb + part, end);
+    const int row = a.long_rows[r];
+    const int c0 = a.long_cptr[r], c1 = a.long_cptr[r + 1];
     float acc[VEC];
 #pragma unroll
-    for (int t = 0; t < VEC; ++t) acc[t] = op_identity<OP>();
-    reduce_range<VEC, OP, SCALED, U>(a, pb, pe, lig, gbase, G, f0, active, acc);
+    for (int q = 0; q < VEC; ++q) acc[q] = op_identity<OP>();
+    if (active) {
+        for (int c = c0; c < c1; ++c) {
+            float v[VEC];
+            Vec<VEC>::load(a.partial + (int64_t)c * a.D + f0, v);
 #pragma unroll
-    for (int t = 0; t < VEC; ++t) lds[(q * G + lig) * VEC + t] = acc[t];
-    __syncthreads();
-    if (q == 0) {
-#pragma unroll
-        for (int t = 0; t < VEC; ++t) acc[t] = op_identity<OP>();
-        for (int k = 0; k < NG; ++k) {
-#pragma unroll
-            for (int t = 0; t < VEC; ++t)
-                acc[t] = op_apply<OP>(acc[t], lds[(k * G + lig) * VEC + t]);
+            for (int q = 0; q < VEC; ++q) acc[q] = op_apply<OP>(acc[q], v[q]);
         }
-        finalize_store<VEC, OP>(a, row, len, f0, active, acc);
     }
+    finalize_store<VEC, OP>(a, row, a.rowptr[row + 1] - a.rowptr[row], f0, active, acc);
 }
 
 template <int VEC, int OP, bool SCALED, int U>
@@ -184,7 +189,8 @@ static int launch_reduce(const ReduceArgs &a0, hipStream_t stream) {
     if (waves < 1 || waves > 4) waves = 4;
     a.waves = waves;
     const int rows_per_block = rpw * waves;
-    const int64_t chunks = ((int64_t)a.n_rows + rows_per_block - 1) / rows_per_block;
+    const int64_t nvirt = (int64_t)a.n_rows + a.n_chunks;
+    const int64_t chunks = (nvirt + rows_per_block - 1) / rows_per_block;
     const int lanes_needed = (a.D + VEC - 1) / VEC;
     const int tiles = (lanes_needed + G - 1) / G;
     if (chunks > 0) {
@@ -199,10 +205,10 @@ static int launch_reduce(const ReduceArgs &a0, hipStream_t stream) {
         GNNMP_LAUNCH_CHECK("csr_rows_kernel");
     }
     if (a.n_long > 0) {
-        dim3 grid((unsigned)a.n_long, (unsigned)tiles);
-        const size_t lds = sizeof(float) * 1024 * VEC;
-        csr_long_rows_kernel<VEC, OP, SCALED, U><<<grid, 1024, lds, stream>>>(a);
-        GNNMP_LAUNCH_CHECK("csr_long_rows_kernel");
+        const int64_t threads = (int64_t)a.n_long << a.log2g;
+        dim3 grid((unsigned)((threads + 255) / 256), (unsigned)tiles);
+        csr_combine_kernel<VEC, OP><<<grid, 256, 0, stream>>>(a);
+        GNNMP_LAUNCH_CHECK("csr_combine_kernel");
     }
     return GNNMP_OK;
 }
@@ -230,8 +236,12 @@ static int dispatch_op(const ReduceArgs &a, int op, bool scaled, hipStream_t s) 
 
 // shared by propagate (idx = col) and scatter (idx = eid)
 int run_reduce(gnnmp_graph_t *p, const int32_t *idx, int aggr, const float *x, const float *w,
-               const float *ss, const float *sd, float *out, int64_t D, hipStream_t stream) {
+               const float *ss, const float *w_slot, const float *ss_slot, const float *sd, float *out,
+               int64_t D, hipStream_t stream) {
     if (p->n_dst == 0 || D == 0) return GNNMP_OK;
+    if (p->n_chunks > 0) {
+        if (int rc = ensure_workspace(p, (size_t)p->n_chunks * (size_t)D)) return rc;
+    }
     ReduceArgs a;
     a.rowptr = p->rowptr;
     a.idx = idx;
@@ -239,9 +249,17 @@ int run_reduce(gnnmp_graph_t *p, const int32_t *idx, int aggr, const float *x, c
     a.x = x;
     a.w = w;
     a.ss = ss;
+    a.w_slot = w_slot;
+    a.ss_slot = ss_slot;
     a.sd = sd;
     a.out = out;
+    a.partial = p->ws;
+    a.chunk_row = p->chunk_row;
+    a.chunk_beg = p->chunk_beg;
+    a.chunk_end = p->chunk_end;
     a.long_rows = p->long_rows;
+    a.long_cptr = p->long_cptr;
+    a.n_chunks = p->n_chunks;
     a.n_long = p->n_long;
     a.D = (int)D;
     a.n_rows = (int)p->n_dst;
@@ -253,7 +271,7 @@ int run_reduce(gnnmp_graph_t *p, const int32_t *idx, int aggr, const float *x, c
     const int vec = pick_vec(D, x, out);
     a.log2g = pick_log2g((D + vec - 1) / vec);
     const int op = (aggr == GNNMP_MAX) ? OP_MAX : (aggr == GNNMP_MIN ? OP_MIN : OP_SUM);
-    const bool scaled = (w != nullptr) || (ss != nullptr);
+    const bool scaled = w || ss || w_slot || ss_slot;
     switch (vec) {
         case 4: return dispatch_op<4>(a, op, scaled, stream);
         case 2: return dispatch_op<2>(a, op, scaled, stream);
@@ -321,7 +339,20 @@ int gnnmp_propagate_f32(gnnmp_graph_t *plan, int msg, int aggr, const float *xj,
     if (msg == GNNMP_W_MUL_XJ && !w && plan->n_edges > 0)
         return fail(GNNMP_EINVAL, "propagate: W_MUL_XJ needs w");
     if (msg == GNNMP_COPY_XJ) w = nullptr;
-    return run_reduce(plan, plan->col, aggr, xj, w, scale_src, scale_dst, out, D, (hipStream_t)stream);
+    return run_reduce(plan, plan->col, aggr, xj, w, scale_src, nullptr, nullptr, scale_dst, out, D,
+                      (hipStream_t)stream);
+}
+
+int gnnmp_propagate_slots_f32(gnnmp_graph_t *plan, int aggr, const float *xj, const float *w_slot,
+                              const float *ss_slot, const float *scale_dst, float *out, int64_t D,
+                              gnnmp_stream_t stream) {
+    if (!plan) return fail(GNNMP_EINVAL, "propagate_slots: null plan");
+    if (int rc = check_aggr(aggr, "propagate_slots")) return rc;
+    if (D < 0 || D > (1 << 20)) return fail(GNNMP_EINVAL, "propagate_slots: bad D %lld", (long long)D);
+    if (plan->n_dst > 0 && D > 0 && (!out || (!xj && plan->n_total > 0)))
+        return fail(GNNMP_EINVAL, "propagate_slots: null xj/out");
+    return run_reduce(plan, plan->col, aggr, xj, nullptr, nullptr, w_slot, ss_slot, scale_dst, out, D,
+                      (hipStream_t)stream);
 }
 
 int gnnmp_scatter_f32(gnnmp_graph_t *plan, int aggr, const float *m, float *out, int64_t D,
@@ -331,7 +362,8 @@ int gnnmp_scatter_f32(gnnmp_graph_t *plan, int aggr, const float *m, float *out,
     if (D < 0 || D > (1 << 20)) return fail(GNNMP_EINVAL, "scatter: bad D %lld", (long long)D);
     if (plan->n_dst > 0 && D > 0 && (!out || (!m && plan->n_total > 0)))
         return fail(GNNMP_EINVAL, "scatter: null m/out");
-    return run_reduce(plan, plan->eid, aggr, m, nullptr, nullptr, nullptr, out, D, (hipStream_t)stream);
+    return run_reduce(plan, plan->eid, aggr, m, nullptr, nullptr, nullptr, nullptr, nullptr, out, D,
+                      (hipStream_t)stream);
 }
 
 int gnnmp_degree_f32(gnnmp_graph_t *plan, const float *w, float *deg, gnnmp_stream_t stream_) {

@@ -23,8 +23,10 @@ SYMBOLS = (
     "gnnmp_plan_create", "gnnmp_plan_destroy", "gnnmp_plan_info", "gnnmp_plan_export",
     "gnnmp_add_self_loops", "gnnmp_batch_coo",
     "gnnmp_gather_f32", "gnnmp_scatter_f32", "gnnmp_scatter_atomic_f32",
-    "gnnmp_propagate_f32", "gnnmp_degree_f32", "gnnmp_inv_sqrt_f32",
-    "gnnmp_edge_softmax_f32", "gnnmp_gat_node_scores_f32", "gnnmp_gat_aggregate_f32", "gnnmp_bias_act_f32",
+    "gnnmp_propagate_f32", "gnnmp_propagate_slots_f32", "gnnmp_plan_slot_gather_f32",
+    "gnnmp_degree_f32", "gnnmp_inv_sqrt_f32",
+    "gnnmp_edge_softmax_f32", "gnnmp_gat_node_scores_f32", "gnnmp_gat_aggregate_f32", "gnnmp_gat_conv_f32",
+    "gnnmp_bias_act_f32",
     "gnnmp_segment_pool_f32", "gnnmp_dense_f32",
 )
 
@@ -62,6 +64,9 @@ def load():
         "gnnmp_scatter_f32": [vp, i, vp, vp, i64, vp],
         "gnnmp_scatter_atomic_f32": [i, vp, vp, i, i, i64, vp, i64, vp],
         "gnnmp_propagate_f32": [vp, i, i, vp, vp, vp, vp, vp, i64, vp],
+        "gnnmp_propagate_slots_f32": [vp, i, vp, vp, vp, vp, vp, i64, vp],
+        "gnnmp_plan_slot_gather_f32": [vp, i, vp, vp, vp],
+        "gnnmp_gat_conv_f32": [vp, vp, vp, vp, f, vp, i, vp, i64, i64, vp],
         "gnnmp_degree_f32": [vp, vp, vp, vp],
         "gnnmp_inv_sqrt_f32": [vp, vp, i64, vp],
         "gnnmp_edge_softmax_f32": [vp, vp, vp, i64, vp],

@@ -122,6 +122,7 @@ class GNNGraph:
             check_num_nodes(self, self.x)
         self.device = device
         self._plans = {}
+        self._cache = {}   # per-graph constants in plan slot order (GCN normalisation, graph weights)
         if not _validated:
             self.plan(False)  # builds the CSR plan and validates 1 <= s,t <= n (convert.jl:47-54)
 

@@ -105,11 +105,35 @@ def gcn_conv(l, g: GNNGraph, x, edge_weight=None, norm_fn=None, conv_weight=None
         w = g.w
     else:
         w = None
-    d = torch.empty(g.num_nodes, dtype=torch.float32, device=g.device)
-    L.check(L.load().gnnmp_degree_f32(plan.handle, L.ptr(w), L.ptr(d), L.stream_ptr()))
-    c = _inv_sqrt(d) if norm_fn is None else norm_fn(d).to(torch.float32).contiguous()
-    msg = L.COPY_XJ if w is None else L.W_MUL_XJ
-    x = _fused(g, msg, "+", x, w, scale_src=c, scale_dst=c, add_self_loops=loops)
+    lib = L.load()
+    cacheable = norm_fn is None and edge_weight is None
+    key = ("gcn_norm", loops, w is not None)
+    cached = g._cache.get(key) if cacheable else None
+    if cached is None:
+        d = torch.empty(g.num_nodes, dtype=torch.float32, device=g.device)
+        L.check(lib.gnnmp_degree_f32(plan.handle, L.ptr(w), L.ptr(d), L.stream_ptr()))
+        c = _inv_sqrt(d) if norm_fn is None else norm_fn(d).to(torch.float32).contiguous()
+        c_slot = w_slot = None
+        if cacheable:
+            # the coefficients depend only on the graph: lay them out once in the plan's slot order (coalesced reads
+            # in the kernel) — the reference recomputes degree and `xj .* cout'` on every call (conv.jl:52-59)
+            c_slot = torch.empty(plan.n_total, dtype=torch.float32, device=g.device)
+            L.check(lib.gnnmp_plan_slot_gather_f32(plan.handle, 0, L.ptr(c), L.ptr(c_slot), L.stream_ptr()))
+            if w is not None:
+                w_slot = torch.empty(plan.n_total, dtype=torch.float32, device=g.device)
+                L.check(lib.gnnmp_plan_slot_gather_f32(plan.handle, 1, L.ptr(w), L.ptr(w_slot), L.stream_ptr()))
+            g._cache[key] = (c, c_slot, w_slot)
+    else:
+        c, c_slot, w_slot = cached
+    if c_slot is not None:
+        xf = _flat(x)
+        out = torch.empty((plan.n_dst, xf.shape[1]), dtype=torch.float32, device=x.device)
+        L.check(lib.gnnmp_propagate_slots_f32(plan.handle, L.SUM, L.ptr(xf), L.ptr(w_slot), L.ptr(c_slot), L.ptr(c),
+                                              L.ptr(out), xf.shape[1], L.stream_ptr()))
+        x = out
+    else:
+        msg = L.COPY_XJ if w is None else L.W_MUL_XJ
+        x = _fused(g, msg, "+", x, w, scale_src=c, scale_dst=c, add_self_loops=loops)
     if Dout >= Din:
         return dense(x, weight, l.bias, l.sigma)
     return bias_act(x, l.bias, l.sigma)
@@ -188,7 +212,7 @@ class SAGEConv:
 # ---------------------------------------------------------------------------------------------------------
 # GATConv
 # ---------------------------------------------------------------------------------------------------------
-def gat_conv(l, g: GNNGraph, x, e=None, return_alpha=False):
+def gat_conv(l, g: GNNGraph, x, e=None, return_alpha=False, exact_order=False):
     """GNNlib/src/layers/conv.jl:112-167 (no edge features: dense_e === nothing).  dense_x GEMM -> node scores ->
     one fused edge-softmax + weighted aggregate over the (self-looped) plan."""
     check_num_nodes(g, x)
@@ -200,18 +224,25 @@ def gat_conv(l, g: GNNGraph, x, e=None, return_alpha=False):
     N = g.num_nodes
     Wx = dense(x, l.dense_x_weight)                        # reshape(dense_x(x), C, H, N)
     a_hc = l.a_hc                                          # [H][2C]
-    sd = torch.empty((N, H), dtype=torch.float32, device=x.device)
-    ss = torch.empty((N, H), dtype=torch.float32, device=x.device)
     lib = L.load()
-    L.check(lib.gnnmp_gat_node_scores_f32(L.ptr(Wx), L.ptr(a_hc), L.ptr(sd), L.ptr(ss), N, H, C, L.stream_ptr()))
     out = torch.empty((N, H * C), dtype=torch.float32, device=x.device)
-    alpha = torch.empty((plan.n_total, H), dtype=torch.float32, device=x.device) if return_alpha else None
     code, post = _act_code(l.sigma)
     fuse_tail = bool(l.concat)
     b = l.bias if (fuse_tail and l.bias is not None) else None
-    L.check(lib.gnnmp_gat_aggregate_f32(plan.handle, L.ptr(Wx), L.ptr(sd), L.ptr(ss), float(l.negative_slope),
-                                        L.ptr(b), code if fuse_tail else L.ACT_IDENTITY, L.ptr(out), L.ptr(alpha),
-                                        H, C, L.stream_ptr()))
+    alpha = None
+    if return_alpha or exact_order:
+        # the reference's operation order (max pass, denominator pass, α = num/den, β = α .* Wxj) and the α output
+        sd = torch.empty((N, H), dtype=torch.float32, device=x.device)
+        ss = torch.empty((N, H), dtype=torch.float32, device=x.device)
+        L.check(lib.gnnmp_gat_node_scores_f32(L.ptr(Wx), L.ptr(a_hc), L.ptr(sd), L.ptr(ss), N, H, C, L.stream_ptr()))
+        alpha = torch.empty((plan.n_total, H), dtype=torch.float32, device=x.device) if return_alpha else None
+        L.check(lib.gnnmp_gat_aggregate_f32(plan.handle, L.ptr(Wx), L.ptr(sd), L.ptr(ss), float(l.negative_slope),
+                                            L.ptr(b), code if fuse_tail else L.ACT_IDENTITY, L.ptr(out), L.ptr(alpha),
+                                            H, C, L.stream_ptr()))
+    else:
+        # one pass over the edges: in-register logits + online softmax (csrc/gat_fused.hip)
+        L.check(lib.gnnmp_gat_conv_f32(plan.handle, L.ptr(Wx), None, L.ptr(a_hc), float(l.negative_slope), L.ptr(b),
+                                       code if fuse_tail else L.ACT_IDENTITY, L.ptr(out), H, C, L.stream_ptr()))
     if fuse_tail:
         y = post(out) if post is not None else out
     else:

@@ -64,8 +64,12 @@ typedef enum { GNNMP_COPY_XJ = 0, GNNMP_W_MUL_XJ = 1 } gnnmp_msg;
 /* activation fused into gnnmp_dense_f32's epilogue (the layers' `σ`). */
 typedef enum { GNNMP_ACT_IDENTITY = 0, GNNMP_ACT_RELU = 1 } gnnmp_act;
 
-/* rows longer than this are split (see determinism note above) */
+/* Destinations with more edges than the plan's threshold are split into balanced chunks (see determinism note
+ * above).  The threshold is chosen per plan in [GNNMP_MIN_LONG_ROW, GNNMP_LONG_ROW] from the graph size
+ * (~4e-5 * E', so that no single sequential row can become the kernel's tail) and reported by gnnmp_plan_info
+ * (info[7]); rows of at most GNNMP_MIN_LONG_ROW edges are never split. */
 #define GNNMP_LONG_ROW 512
+#define GNNMP_MIN_LONG_ROW 64
 
 int gnnmp_version(void);
 const char *gnnmp_last_error(void);
@@ -150,6 +154,21 @@ int gnnmp_propagate_f32(gnnmp_graph_t *plan, int msg, int aggr, const float *xj,
                         const float *scale_src, const float *scale_dst, float *out, int64_t D,
                         gnnmp_stream_t stream);
 
+/* The same fused propagate with the per-edge factors already laid out in the plan's slot order:
+ *   w_slot[p]   = w[eid_p]          (1 for plan-added self loops)      — gnnmp_plan_slot_gather_f32(plan, 1, w, ...)
+ *   ss_slot[p]  = scale_src[col_p]                                    — gnnmp_plan_slot_gather_f32(plan, 0, scale_src, ...)
+ * (either may be NULL).  The products and their order are identical to gnnmp_propagate_f32, hence so are the bits;
+ * what changes is the traffic: a coalesced 4 B read per edge instead of a random 4 B gather (one 64 B sector) per
+ * edge.  The factors depend only on the graph (GCN's 1/sqrt(deg), the graph's own weights), so a caller computes them
+ * once per graph where the reference recomputes `xj .* cout'` on every call (GNNlib/src/layers/conv.jl:57-59). */
+int gnnmp_propagate_slots_f32(gnnmp_graph_t *plan, int aggr, const float *xj, const float *w_slot,
+                              const float *ss_slot, const float *scale_dst, float *out, int64_t D,
+                              gnnmp_stream_t stream);
+/* out_slot[p] = v[col_p] (by = 0: v is a node vector of n_src entries) or v[eid_p] (by = 1: v is an edge vector of
+ * n_edges entries in original order; plan-added self loops get 1.0).  out_slot has E' entries. */
+int gnnmp_plan_slot_gather_f32(gnnmp_graph_t *plan, int by, const float *v, float *out_slot,
+                               gnnmp_stream_t stream);
+
 /* degree(g, Float32; dir = :in, edge_weight) — GNNGraphs/src/query.jl:314-331,355-369.
  * w == NULL: counts (exact integers).  w != NULL: n_edges weights in original order, summed in edge
  * order; plan-added self loops count 1. */
@@ -187,6 +206,16 @@ int gnnmp_gat_aggregate_f32(gnnmp_graph_t *plan, const float *Wx_src, const floa
                             const float *score_src, float negative_slope, const float *bias, int act,
                             float *out, float *alpha_out, int64_t H, int64_t C,
                             gnnmp_stream_t stream);
+
+/* The production entry point for the same GATConv path: ONE pass over the edges, no node pre-pass, no score arrays.
+ * The source half of the logit is formed in registers from the source row that the weighted sum fetches anyway, the
+ * target half from row i of Wx_dst (NULL = Wx_src), and the neighbourhood softmax is computed online (running max and
+ * denominator).  Same mathematical function as gnnmp_gat_node_scores_f32 + gnnmp_gat_aggregate_f32; rounding differs
+ * at the 1e-6 level (north_star's bar for fp32 aggregation is 1e-5).  Head widths whose lane count is not a power of
+ * two fall back to those two kernels internally (scores in the plan's workspace). */
+int gnnmp_gat_conv_f32(gnnmp_graph_t *plan, const float *Wx_src, const float *Wx_dst, const float *a,
+                       float negative_slope, const float *bias, int act, float *out, int64_t H,
+                       int64_t C, gnnmp_stream_t stream);
 
 /* out[n][:] = act(x[n][:] + bias[:])  — the `σ.(x .+ bias)` tail of a layer body when it is not fused into
  * the producing kernel (GNNlib/src/layers/conv.jl:71,147).  bias nullable; out may alias x. */

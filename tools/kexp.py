@@ -92,15 +92,27 @@ def main():
         g = gnnmp.GNNGraph(torch.from_numpy(s).cuda(), torch.from_numpy(t).cuda(), num_nodes=N, _validated=True)
         plan = g.plan(False)
         bytes_p = Ecur * (4 * D + 4) + 8 * (N + 1) + 4 * N * D
-        bytes_g = Ecur * (4 * H * C + 4 * H + 4) + N * (4 * H * C + 4 * H + 8)
+        bytes_g = Ecur * (4 * H * C + 4) + N * (8 * H * C + 8)
+
+        cslot = torch.empty(plan.n_total, device="cuda")
+        L.check(lib.gnnmp_plan_slot_gather_f32(plan.handle, 0, L.ptr(cv), L.ptr(cslot), L.stream_ptr()))
+        a_hc = torch.randn((H, 2 * C), device="cuda") * 0.3
 
         def prop(scaled=False):
-            L.check(lib.gnnmp_propagate_f32(plan.handle, 0, 0, L.ptr(x), None, L.ptr(cv) if scaled else None,
-                                            L.ptr(cv) if scaled else None, L.ptr(out), D, L.stream_ptr()))
+            if scaled:
+                L.check(lib.gnnmp_propagate_slots_f32(plan.handle, 0, L.ptr(x), None, L.ptr(cslot), L.ptr(cv),
+                                                      L.ptr(out), D, L.stream_ptr()))
+            else:
+                L.check(lib.gnnmp_propagate_f32(plan.handle, 0, 0, L.ptr(x), None, None, None, L.ptr(out), D,
+                                                L.stream_ptr()))
 
-        def gat():
+        def gat3():
             L.check(lib.gnnmp_gat_aggregate_f32(plan.handle, L.ptr(Wx), L.ptr(sd), L.ptr(ss), 0.2, None, 0, L.ptr(og),
                                                 None, H, C, L.stream_ptr()))
+
+        def gat():
+            L.check(lib.gnnmp_gat_conv_f32(plan.handle, L.ptr(Wx), None, L.ptr(a_hc), 0.2, None, 0, L.ptr(og), H, C,
+                                           L.stream_ptr()))
 
         print(f"== {kind}: N={N} E={Ecur} D={D} maxdeg={plan.max_degree} long={plan.n_long}")
         variants = [dict()]
@@ -112,8 +124,9 @@ def main():
             tp = time_fn(prop)
             tps = time_fn(lambda: prop(True))
             tg = time_fn(gat)
+            tg3 = time_fn(gat3)
             print(f"  {str(v):48s} prop {tp:7.3f} ms {bytes_p / tp / 1e6:6.0f} GB/s | scaled {tps:7.3f} ms | "
-                  f"gat {tg:7.3f} ms {bytes_g / tg / 1e6:6.0f} GB/s")
+                  f"gat {tg:7.3f} ms {bytes_g / tg / 1e6:6.0f} GB/s | gat3pass {tg3:7.3f} ms")
         set_knobs()
         del g, plan
 
