@@ -30,6 +30,7 @@ enum Knob {
     KNOB_XCD_REMAP = 3,    // 1 = on (default), 0 = off
     KNOB_LONG_ROW = 4,     // long-row threshold (default GNNMP_LONG_ROW)
     KNOB_BLOCK_WAVES = 5,  // waves per block in the row kernels (default 4)
+    KNOB_DENSE_GENERIC = 6,  // 1 = force the K-chunked dense kernel (default 0: W-resident kernel when it fits)
     KNOB_COUNT = 8
 };
 int knob(int k);

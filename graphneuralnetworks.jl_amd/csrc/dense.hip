@@ -10,6 +10,8 @@
 // free and needs one VGPR per operand).  Block = 4 waves = 128 rows x up-to-128 output columns; each wave owns 32 rows
 // and up to four 32x32 accumulator tiles; x and W^T chunks of 32 k-values are staged in LDS (padded leading dimensions:
 // conflict-free ds_read_b32 for both MFMA operands).
+#include <algorithm>
+
 #include "common.h"
 
 namespace gnnmp {
@@ -143,6 +145,226 @@ __global__ void __launch_bounds__(256) dense_mfma_kernel(const DenseArgs a) {
     }
 }
 
+// ---- W-resident variant ------------------------------------------------------------------------------------------
+// For the layer shapes of the hot path (K, Dout <= a few hundred) the whole W^T fits in the CU's 160 KB LDS.  Each
+// persistent block loads it ONCE; after that no workgroup barrier is needed: every wave streams its own 32-row tiles of
+// x (a contiguous 32*K*4-byte block of HBM: perfectly coalesced 16-byte loads) through a wave-private LDS region laid out
+// for the MFMA A operand, runs K/2 k-steps of NT back-to-back v_mfma_f32_32x32x2_f32 (NT independent accumulator
+// chains keep the matrix pipe issuing every 64 cycles), and writes the finished 32 x ncols tile back through the same
+// region as whole rows (one contiguous block when the tile spans all output columns).  With two waves per SIMD one
+// wave's staging hides under the other's MFMAs.
+struct DenseWArgs {
+    DenseArgs d;
+    int n0;        // first output column of this launch's column tile (blockIdx.y adds NT*32)
+    int waves;     // waves per block
+    int xld;       // leading dimension of the wave-private x image (odd)
+    int old_;      // leading dimension of the wave-private output image (multiple of 4)
+    int tp;        // output column tiles per epilogue pass
+    int region;    // floats per wave region
+    int ktot_pad;  // rows of W^T image
+};
+
+template <int NT>
+__global__ void __launch_bounds__(512) dense_wlds_kernel(const DenseWArgs w) {
+    extern __shared__ __align__(16) float lds[];
+    const DenseArgs &a = w.d;
+    constexpr int WLD = NT * 32 + 1;
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = t >> 6;
+    const int nthreads = w.waves * 64;
+    const int n0 = w.n0 + (int)blockIdx.y * NT * 32;
+    const int ncols = min(NT * 32, a.Dout - n0);
+    float *Wt = lds;
+    float *reg = lds + (size_t)w.ktot_pad * WLD + (size_t)wave * w.region;
+
+    // ---- W^T image, once per block: Wt[koff + k][j] = W(n0 + j, k) ----
+    {
+        int koff = 0;
+        for (int seg = 0; seg < a.nseg; ++seg) {
+            const int K = a.K[seg], Kp = (K + 1) & ~1;
+            const float *__restrict__ W = a.W[seg];
+            const int64_t sj = a.w_layout == 0 ? a.ldw[seg] : 1;   // element strides of W(j, k): one load expression
+            const int64_t sk = a.w_layout == 0 ? 1 : a.ldw[seg];  // for both layouts (no per-element branch)
+            const int total = Kp * NT * 32;
+            constexpr int WB = 8;  // independent loads in flight per thread (same reason as the x staging below)
+            for (int idx0 = t; idx0 < total; idx0 += nthreads * WB) {
+                float v[WB];
+                int dst[WB];
+#pragma unroll
+                for (int u = 0; u < WB; ++u) {
+                    const int idx = idx0 + u * nthreads;
+                    const int idc = min(idx, total - 1);
+                    int j, k;
+                    if (a.w_layout == 0) { j = idc / Kp; k = idc - j * Kp; }   // consecutive threads walk k (contiguous in W)
+                    else                 { k = idc / (NT * 32); j = idc - k * (NT * 32); }
+                    dst[u] = idx < total ? (koff + k) * WLD + j : -1;
+                    const int jc = min(j, ncols - 1), kc = min(k, K - 1);  // clamped: the load itself is unconditional
+                    const float lv = W[(int64_t)(n0 + jc) * sj + (int64_t)kc * sk];
+                    v[u] = (j < ncols && k < K) ? lv : 0.0f;
+                }
+#pragma unroll
+                for (int u = 0; u < WB; ++u)
+                    if (dst[u] >= 0) Wt[dst[u]] = v[u];
+            }
+            koff += Kp;
+        }
+    }
+    __syncthreads();
+
+    const int64_t n_tiles = (a.N + 31) / 32;
+    const int XLD = w.xld, OLD = w.old_;
+    // this lane's bias entries (its accumulator columns never change): loaded once, not once per tile
+    float bcol[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int c = min(nt * 32 + (lane & 31), ncols - 1);
+        bcol[nt] = a.bias ? a.bias[n0 + c] : 0.0f;
+    }
+    for (int64_t tile = (int64_t)blockIdx.x * w.waves + wave; tile < n_tiles; tile += (int64_t)gridDim.x * w.waves) {
+        const int64_t m0 = tile * 32;
+        const int rows = (int)min<int64_t>(32, a.N - m0);
+        f32x16 acc[NT];
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+        int koff = 0;
+        for (int seg = 0; seg < a.nseg; ++seg) {
+            const int K = a.K[seg], Kp = (K + 1) & ~1;
+            const float *__restrict__ x = a.x[seg] + m0 * K;
+            // ---- stage the tile's rows (contiguous in HBM) into the A-operand image xs[row][k] ----
+            if (rows == 32 && (K & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) & 15) == 0)) {
+                // batches of SB independent 16-byte loads per lane, THEN the LDS writes: a plain load->write loop
+                // serialises one HBM round trip per iteration (measured: waves parked 42 % of their cycles, MFMA pipe
+                // 40 % busy)
+                constexpr int SB = 8;
+                const int n4 = 8 * K;  // 32 * K / 4
+                for (int i0 = lane; i0 < n4; i0 += 64 * SB) {
+                    float4 v[SB];
+#pragma unroll
+                    for (int u = 0; u < SB; ++u)  // unconditional (clamped) loads: a guarded load makes hipcc branch + wait per element
+                        v[u] = reinterpret_cast<const float4 *>(x)[min(i0 + u * 64, n4 - 1)];
+#pragma unroll
+                    for (int u = 0; u < SB; ++u) {
+                        const int i = i0 + u * 64;
+                        if (i < n4) {
+                            const int e = i * 4;
+                            const int row = e / K, k = e - row * K;
+                            float *d = reg + row * XLD + k;
+                            d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
+                        }
+                    }
+                }
+            } else {
+                const int total = 32 * K;
+                for (int e = lane; e < total; e += 64) {
+                    const int row = e / K, k = e - row * K;
+                    reg[row * XLD + k] = row < rows ? x[e] : 0.0f;
+                }
+            }
+            if (K & 1) {
+                if (lane < 32) reg[lane * XLD + K] = 0.0f;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // ---- K/2 k-steps ----
+            const float *xa = reg + (lane & 31) * XLD + (lane >> 5);
+            const float *wb = Wt + (koff + (lane >> 5)) * WLD + (lane & 31);
+            // software-pipelined by hand: the operands of k-step kk+2 are read from LDS before the MFMAs of k-step kk
+            // issue, so the LDS latency hides under 4 x 64 matrix-pipe cycles (hipcc leaves the plain loop
+            // read -> wait -> 2 MFMA -> read -> wait -> 2 MFMA).
+            float av = xa[0];
+            float bv[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bv[nt] = wb[nt * 32];
+            for (int kk = 0; kk < Kp; kk += 2) {
+                const int kn = (kk + 2 < Kp) ? kk + 2 : kk;   // last step re-reads itself (harmless)
+                const float an = xa[kn];
+                float bn[NT];
+                const float *wk = wb + kn * WLD;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bn[nt] = wk[nt * 32];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[nt], acc[nt], 0, 0, 0);
+                av = an;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bv[nt] = bn[nt];
+            }
+            koff += Kp;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        // ---- epilogue: bias + act, then whole rows through the region ----
+        // The region is sized for the x image; the output tile goes through it in passes of w.tp column tiles.
+        const int colb = lane & 31, rowb = 4 * (lane >> 5);
+        const bool vec_ok = (a.Dout & 3) == 0 && (n0 & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.out) & 15) == 0);
+        for (int c_lo = 0; c_lo < ncols; c_lo += w.tp * 32) {
+            const int c_hi = min(ncols, c_lo + w.tp * 32);
+            const int pc = c_hi - c_lo;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int c = nt * 32 + colb;
+                if (c >= c_lo && c < c_hi) {
+                    const float b = bcol[nt];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float v = acc[nt][r];
+                        if (a.bias) v = v + b;
+                        if (a.act == GNNMP_ACT_RELU) v = v < 0.0f ? 0.0f : v;
+                        reg[((r & 3) + 8 * (r >> 2) + rowb) * OLD + (c - c_lo)] = v;
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            float *o = a.out + m0 * a.Dout + n0 + c_lo;
+            if (vec_ok && (pc & 3) == 0) {
+                const int c4n = pc >> 2;
+                const int total = rows * c4n;
+                for (int i = lane; i < total; i += 64) {
+                    const int row = i / c4n, c4 = i - row * c4n;
+                    const float4 v = *reinterpret_cast<const float4 *>(reg + row * OLD + c4 * 4);
+                    *reinterpret_cast<float4 *>(o + (int64_t)row * a.Dout + c4 * 4) = v;
+                }
+            } else {
+                const int total = rows * pc;
+                for (int i = lane; i < total; i += 64) {
+                    const int row = i / pc, c = i - row * pc;
+                    o[(int64_t)row * a.Dout + c] = reg[row * OLD + c];
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+}
+
+template <int NT>
+static int launch_wlds(const DenseWArgs &w, size_t lds_bytes, int col_tiles, int64_t n_row_tiles, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_wlds_kernel<NT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(dense_wlds_kernel)");
+        attr_set = true;
+    }
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    int64_t gx = (n_row_tiles + w.waves - 1) / w.waves;
+    if (gx > cus) gx = cus;  // one persistent block per CU (the LDS image allows no more)
+    dim3 grid((unsigned)gx, (unsigned)col_tiles);
+    dense_wlds_kernel<NT><<<grid, 64 * w.waves, lds_bytes, stream>>>(w);
+    GNNMP_LAUNCH_CHECK("dense_wlds_kernel");
+    return GNNMP_OK;
+}
+
 }  // namespace gnnmp
 
 using namespace gnnmp;
@@ -168,6 +390,60 @@ extern "C" int gnnmp_dense_f32(const float *x1, const float *W1, int64_t D1, int
     a.out = out;
     a.N = N;
     a.Dout = (int)Dout;
+    // W-resident kernel when W^T (for one 128-column tile) plus at least one wave region fits the 160 KB LDS
+    {
+        const int k0p = ((int)D1 + 1) & ~1, k1p = ((int)D2 + 1) & ~1;
+        const int ktot = k0p + (D2 > 0 ? k1p : 0);
+        const int kmax = std::max(k0p, k1p);
+        const int full = (int)(Dout / 128), rem = (int)(Dout % 128);
+        const int nt_max = full > 0 ? 4 : (rem + 31) / 32;
+        const int xld = kmax + 1;                               // odd: conflict-free A-operand reads
+        const int ncols_max = full > 0 ? 128 : rem;
+        // the wave region is sized for the x image (>= one 32-column output tile); the output tile passes through it
+        // whole if it fits, else w.tp column tiles at a time
+        const int region_cols = (std::max(xld, 32) + 3) & ~3;
+        int tp = 4, old_ = (ncols_max + 3) & ~3;
+        if (old_ > region_cols) {
+            tp = region_cols / 32;
+            old_ = tp * 32;
+        }
+        const size_t region = (size_t)32 * (size_t)region_cols;
+        const size_t wbytes = (size_t)ktot * (size_t)(nt_max * 32 + 1) * sizeof(float);
+        const size_t budget = 160 * 1024;
+        int waves = 0;
+        for (int wv : {8, 4}) {  // fewer than one wave per SIMD cannot feed the matrix pipe: K-chunked kernel instead
+            if (wbytes + (size_t)wv * region * sizeof(float) <= budget) { waves = wv; break; }
+        }
+        if (waves > 0 && N >= 256 && knob(KNOB_DENSE_GENERIC) == 0) {
+            DenseWArgs w;
+            w.d = a;
+            w.waves = waves;
+            w.xld = xld;
+            w.old_ = old_;
+            w.tp = tp;
+            w.region = (int)region;
+            w.ktot_pad = ktot;
+            const int64_t n_row_tiles = (N + 31) / 32;
+            const size_t lds_bytes = wbytes + (size_t)waves * region * sizeof(float);
+            if (full > 0) {
+                w.n0 = 0;
+                if (int rc = launch_wlds<4>(w, lds_bytes, full, n_row_tiles, stream)) return rc;
+            }
+            if (rem > 0) {
+                w.n0 = full * 128;
+                const int nt = (rem + 31) / 32;
+                int rc = GNNMP_OK;
+                switch (nt) {
+                    case 1: rc = launch_wlds<1>(w, lds_bytes, 1, n_row_tiles, stream); break;
+                    case 2: rc = launch_wlds<2>(w, lds_bytes, 1, n_row_tiles, stream); break;
+                    case 3: rc = launch_wlds<3>(w, lds_bytes, 1, n_row_tiles, stream); break;
+                    default: rc = launch_wlds<4>(w, lds_bytes, 1, n_row_tiles, stream); break;
+                }
+                if (rc) return rc;
+            }
+            return GNNMP_OK;
+        }
+    }
     dim3 grid((unsigned)((N + BM - 1) / BM), (unsigned)((Dout + BN - 1) / BN));
     dense_mfma_kernel<<<grid, 256, 0, stream>>>(a);
     GNNMP_LAUNCH_CHECK("dense_mfma_kernel");

@@ -276,7 +276,12 @@ class GATConv:
 
     @property
     def a_hc(self):
-        return self.a.t().contiguous()  # [H][2C]: a[h][0:C] targets, a[h][C:2C] sources
+        """[H][2C] row-major image of `a` (a[h][0:C] targets, a[h][C:2C] sources); rebuilt only when `a` changes"""
+        key = (self.a.data_ptr(), self.a._version)
+        if getattr(self, "_a_hc_key", None) != key:
+            self._a_hc = self.a.t().contiguous()
+            self._a_hc_key = key
+        return self._a_hc
 
     def __call__(self, g, x, e=None):
         return gat_conv(self, g, x, e)
