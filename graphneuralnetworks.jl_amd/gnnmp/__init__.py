@@ -4,7 +4,7 @@ propagate / apply_edges / aggregate_neighbors hot path (include/g
 Host side only: every arithmetic step is a call into libgnnmp.so (hand-written HIP for gfx950).
 """
 from ._lib import GnnmpError, load, tune  # noqa: F401
-from .graph import (GNNGraph, Plan, add_self_loops, batch, check_num_edges, check_num_nodes, degree,  # noqa: F401
+from .graph import (GNNGraph, Plan, add_self_loops, batch, batch_arrays, check_num_edges, check_num_nodes, degree,  # noqa: F401
                     edge_index, get_edge_weight, graph_indicator, set_edge_weight)
 from .layers import (Dense, GATConv, GCNConv, GlobalPool, GNNChain, GraphConv, SAGEConv, bias_act, dense,  # noqa: F401
                      gat_conv, gcn_conv, global_pool, glorot_uniform, graph_conv, sage_conv)

@@ -257,6 +257,34 @@ def set_edge_weight(g: GNNGraph, w) -> GNNGraph:
     return g2
 
 
+def batch_arrays(members, xs=None, index_base=1, device=None) -> GNNGraph:
+    """MLUtils.batch for member graphs given as host records (s, t, num_nodes) with LOCAL numbering (what a DataLoader
+    collates, GNNGraphs/src/transform.jl:682-709): one upload of the concatenated indices, offsets and graph_indicator
+    computed on the device by gnnmp_batch_coo.  xs: optional list of per-graph feature arrays."""
+    import numpy as np
+    L.require_gpu()
+    device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    G = len(members)
+    if G == 0:
+        raise ValueError("Cannot batch an empty vector of graphs")
+    ne = np.zeros(G + 1, np.int64)
+    nn = np.zeros(G + 1, np.int64)
+    ne[1:] = np.cumsum([len(m[0]) for m in members])
+    nn[1:] = np.cumsum([int(m[2]) for m in members])
+    s_cat = torch.from_numpy(np.concatenate([np.asarray(m[0], np.int64) for m in members])).to(device)
+    t_cat = torch.from_numpy(np.concatenate([np.asarray(m[1], np.int64) for m in members])).to(device)
+    ned, nnd = torch.from_numpy(ne).to(device), torch.from_numpy(nn).to(device)
+    s2, t2 = torch.empty_like(s_cat), torch.empty_like(t_cat)
+    gi = torch.empty(int(nn[-1]), dtype=torch.int64, device=device)
+    L.check(L.load().gnnmp_batch_coo(L.ptr(s_cat), L.ptr(t_cat), 8, index_base, L.ptr(ned), L.ptr(nnd), G, L.ptr(s2),
+                                     L.ptr(t2), L.ptr(gi), L.stream_ptr()))
+    x = None
+    if xs is not None:
+        x = torch.from_numpy(np.concatenate([np.asarray(v, np.float32) for v in xs])).to(device)
+    return GNNGraph(s2, t2, None, num_nodes=int(nn[-1]), graph_indicator=gi, num_graphs=G, x=x, index_base=index_base,
+                    device=device, _validated=True)
+
+
 def batch(gs) -> GNNGraph:
     """MLUtils.batch(::Vector{GNNGraph{COO}}) — GNNGraphs/src/transform.jl:682-709: concatenates the edge indices with
     node offsets cumsum(num_nodes), builds graph_indicator, concatenates node features."""

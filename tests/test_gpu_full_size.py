@@ -1,0 +1,160 @@
+"""BASELINE.json's full sizes (products shape: N = 2 449 029, E = 61 859 140) on the GPU, checked through
+size-independent properties and through the oracle on a random sample of destinations; plus the batched model of config 5
+against the oracle.  `-m gpu` only; ~20 s on an MI355X."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gm():
+    import torch
+    assert torch.cuda.is_available()
+    import gnnmp
+    gnnmp.load()
+    return gnnmp
+
+
+@pytest.fixture(scope="module")
+def products(gm):
+    import torch
+    from gnnmp import synth
+    N, D = synth.PRODUCTS["N"], synth.PRODUCTS["D"]
+    s, t = synth.products_like()
+    g = gm.GNNGraph(torch.from_numpy(s).cuda(), torch.from_numpy(t).cuda(), num_nodes=N, _validated=True)
+    x = torch.from_numpy(synth.features(N, D, seed=1)).cuda()
+    return dict(s=s, t=t, g=g, x=x, N=N, D=D)
+
+
+def test_plan_at_full_size(gm, products):
+    g, N = products["g"], products["N"]
+    for loops in (False, True):
+        p = g.plan(loops)
+        assert p.n_total == g.num_edges + (N if loops else 0)
+        assert p.long_thresh == 512                      # 4e-5 * E' > 512 -> clamped
+        rowptr, col, eid = p.export()
+        assert int(rowptr[0]) == 0 and int(rowptr[-1]) == p.n_total
+        assert bool((rowptr[1:] >= rowptr[:-1]).all())   # sortedness
+        indeg = np.bincount(products["t"] - 1, minlength=N) + (1 if loops else 0)
+        np.testing.assert_array_equal((rowptr[1:] - rowptr[:-1]).cpu().numpy(), indeg)
+        assert p.max_degree == indeg.max()
+        # eid is a permutation of 0..E'-1 (checksum of a permutation) and is increasing inside each row (stability)
+        assert int(eid.to(dtype=__import__("torch").int64).sum()) == p.n_total * (p.n_total - 1) // 2
+        inner = (eid[1:] > eid[:-1])
+        boundary = __import__("torch").zeros(p.n_total - 1, dtype=__import__("torch").bool, device="cuda")
+        rp = rowptr[1:-1].long()
+        boundary[(rp[(rp > 0) & (rp < p.n_total)] - 1)] = True
+        assert bool((inner | boundary).all())
+
+
+def test_propagate_checksums_and_order_properties(gm, products):
+    import torch
+    g, x, s, N, D = products["g"], products["x"], products["s"], products["N"], products["D"]
+    ys = gm.propagate(gm.copy_xj, g, "+", xj=x)
+    # checksum of checksums: column sums of the output = out-degree-weighted column sums of the input
+    outdeg = torch.from_numpy(np.bincount(s - 1, minlength=N)).cuda().double()
+    exp = (outdeg[:, None] * x.double()).sum(0)
+    got = ys.double().sum(0)
+    scale = (outdeg[:, None] * x.double().abs()).sum(0)
+    assert float(((got - exp).abs() / scale).max()) < 1e-6
+    # linearity: A(x + 2y) = A x + 2 A y within fp32 rounding
+    y2 = torch.roll(x, 1, 0)
+    lhs = gm.propagate(gm.copy_xj, g, "+", xj=x + 2 * y2)
+    rhs = ys + 2 * gm.propagate(gm.copy_xj, g, "+", xj=y2)
+    assert float((lhs - rhs).norm() / rhs.norm()) < 1e-5
+    # min <= mean <= max on every destination; mean * count = sum
+    ymax = gm.propagate(gm.copy_xj, g, "max", xj=x)
+    ymin = gm.propagate(gm.copy_xj, g, "min", xj=x)
+    ymean = gm.propagate(gm.copy_xj, g, "mean", xj=x)
+    tol = 1e-5 * float(x.abs().max())
+    assert bool((ymin <= ymean + tol).all()) and bool((ymean <= ymax + tol).all())
+    cnt = torch.from_numpy(np.bincount(products["t"] - 1, minlength=N)).cuda().float()
+    assert float((ymean * cnt[:, None] - ys).norm() / ys.norm()) < 1e-5
+    # idempotence / determinism: same bits every time
+    assert torch.equal(gm.propagate(gm.copy_xj, g, "+", xj=x), ys)
+    # max of a constant feature map is that constant wherever a destination has an edge
+    c = torch.full((N, 4), 3.25, device="cuda")
+    assert bool((gm.propagate(gm.copy_xj, g, "max", xj=c)[cnt > 0] == 3.25).all())
+
+
+def test_sampled_destinations_match_oracle_bit_exactly(gm, oracle, products):
+    """oracle on the sub-problem made of 4000 random destinations and all their incoming edges (original edge order)"""
+    import torch
+    s, t, g, x, N = products["s"], products["t"], products["g"], products["x"], products["N"]
+    rng = np.random.default_rng(0)
+    rows = np.sort(rng.choice(N, 4000, replace=False)) + 1
+    sel = np.isin(t, rows)
+    ss, tt = s[sel], t[sel]
+    # relabel: destinations -> 1..4000, sources -> compact ids
+    tmap = np.zeros(N + 1, np.int64)
+    tmap[rows] = np.arange(1, len(rows) + 1)
+    src_ids, s_local = np.unique(ss, return_inverse=True)
+    xs = x[torch.from_numpy(src_ids - 1).cuda()].cpu().numpy()
+    w = rng.random(len(ss)).astype(np.float32)
+    ref = oracle.propagate("+", s_local + 1, tmap[tt], len(src_ids), xs, n_dst=len(rows))
+    got = gm.propagate(gm.copy_xj, g, "+", xj=x)[torch.from_numpy(rows - 1).cuda()].cpu().numpy()
+    deg = np.bincount(tmap[tt] - 1, minlength=len(rows))
+    short = deg <= 512
+    np.testing.assert_array_equal(got[short], ref[short])
+    if (~short).any():
+        assert np.abs(got[~short] - ref[~short]).max() <= 1e-5 * np.abs(ref).max()
+    # weighted, mean
+    wfull = np.zeros(len(s), np.float32)
+    wfull[sel] = w
+    gw = gm.set_edge_weight(g, torch.from_numpy(wfull).cuda())
+    refw = oracle.propagate("mean", s_local + 1, tmap[tt], len(src_ids), xs, w, n_dst=len(rows))
+    gotw = gm.propagate(gm.w_mul_xj, gw, "mean", xj=x)[torch.from_numpy(rows - 1).cuda()].cpu().numpy()
+    np.testing.assert_array_equal(gotw[short], refw[short])
+
+
+def test_gat_full_size_convexity(gm, products):
+    """softmax weights are a convex combination: if every node carries the same Wx row v, every destination with an edge
+    gets exactly-ish v back (any attention vector); checks the one-pass kernel's normalisation at full scale"""
+    import torch
+    g, N = products["g"], products["N"]
+    H, C = 8, 16
+    l = gm.GATConv((H * C, C), None, heads=H, bias=False, seed=3)
+    l.dense_x_weight = torch.eye(H * C, device="cuda")
+    v = torch.linspace(-2, 2, H * C, device="cuda")
+    y = l(g, v.repeat(N, 1))
+    assert float((y - v[None, :]).abs().max()) < 1e-5 * 2
+    # and it is deterministic
+    assert torch.equal(l(g, v.repeat(N, 1)), y)
+
+
+def test_batched_model_config5_vs_oracle(gm, oracle):
+    """config 5 at G = 512: GNNChain(GraphConv(16=>128,relu), GraphConv(128=>128,relu), GlobalPool(mean), Dense(128=>2))"""
+    import torch
+    from gnnmp import synth
+    G = 512
+    members = synth.batched_graphs(G=G, seed=9)
+    rng = np.random.default_rng(1)
+    xs = [rng.standard_normal((n, 16), dtype=np.float32) for _, _, n in members]
+    g = gm.batch_arrays(members, xs)
+    s, t, gi, n = oracle.batch(members)
+    np.testing.assert_array_equal(g.s.cpu().numpy(), s)
+    np.testing.assert_array_equal(g.t.cpu().numpy(), t)
+    np.testing.assert_array_equal(g.graph_indicator.cpu().numpy(), gi)
+    model = gm.GNNChain(gm.GraphConv((16, 128), "relu", seed=21), gm.GraphConv((128, 128), "relu", seed=22),
+                        gm.GlobalPool("mean"), gm.Dense((128, 2), seed=23))
+    y = model(g, g.x).cpu().numpy()
+    l1, l2, _, d = model.layers
+    x = np.concatenate(xs)
+    h = oracle.graph_conv(s, t, n, x, l1.weight1.cpu().numpy(), l1.weight2.cpu().numpy(), l1.bias.cpu().numpy(), "relu", "+")
+    h = oracle.graph_conv(s, t, n, h, l2.weight1.cpu().numpy(), l2.weight2.cpu().numpy(), l2.bias.cpu().numpy(), "relu", "+")
+    p = oracle.global_pool("mean", gi, h, G)
+    ref = oracle.matmul(d.weight.cpu().numpy(), p) + d.bias.cpu().numpy()[None, :]
+    assert y.shape == (G, 2)
+    assert np.linalg.norm(y - ref) <= 1e-5 * np.linalg.norm(ref)
+    # sharded == unsharded (single process, no collective): graphs are independent units
+    from gnnmp.parallel import gather_shard_outputs, shard_by_size
+    shards = shard_by_size([m[2] for m in members], 4)
+    outs = []
+    for r in range(4):
+        gr = gm.batch_arrays([members[i] for i in shards[r]], [xs[i] for i in shards[r]])
+        outs.append(model(gr, gr.x))
+    merged = torch.empty((G, 2), device="cuda")
+    for r in range(4):
+        merged[torch.as_tensor(shards[r], device="cuda")] = outs[r]
+    assert float((merged - torch.from_numpy(y).cuda()).abs().max()) <= 1e-6 * float(np.abs(y).max())

@@ -1,0 +1,104 @@
+"""N>1 path on CPU: world_size-2 `gloo` run of the graph-parallel forward (shard by graph -> local batch -> forward ->
+ONE all-gather of per-shard logits -> original order).  The per-shard forward here is the CPU oracle (this is a test:
+the product's forward_local is the HIP one and refuses to run without a GPU); what is under test is the host logic of
+gnnmp.parallel — sharding, padding, the collective, the permutation back."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _model_oracle(records, weights):
+    """GNNChain(GraphConv(16=>32,relu), GraphConv(32=>32,relu), GlobalPool(mean), Dense(32=>2)) on a list of member
+    graphs — examples/graph_classification_tudataset.jl:79-82 shape, via the CPU oracle"""
+    from oracle import oracle as orc
+    if len(records) == 0:
+        return torch.zeros((0, 2), dtype=torch.float32)
+    s, t, gi, n = orc.batch([(r["s"], r["t"], r["n"]) for r in records])
+    x = np.concatenate([r["x"] for r in records])
+    W1a, W1b, b1, W2a, W2b, b2, Wd, bd = weights
+    h = orc.graph_conv(s, t, n, x, W1a, W1b, b1, "relu", "+", blas=False)
+    h = orc.graph_conv(s, t, n, h, W2a, W2b, b2, "relu", "+", blas=False)
+    p = orc.global_pool("mean", gi, h, len(records))
+    y = orc.matmul(Wd, p, blas=False) + bd[None, :]
+    return torch.from_numpy(y.astype(np.float32))
+
+
+def _make_problem(G=37, seed=5):
+    from gnnmp import synth
+    rng = np.random.default_rng(seed)
+    gs = synth.batched_graphs(G=G, nmin=3, nmax=15, deg=2, seed=seed)
+    recs = [{"s": s, "t": t, "n": n, "x": rng.standard_normal((n, 16)).astype(np.float32)} for s, t, n in gs]
+    w = [rng.standard_normal(sh).astype(np.float32) * 0.3 for sh in
+         [(32, 16), (32, 16), (32,), (32, 32), (32, 32), (32,), (2, 32), (2,)]]
+    return recs, w
+
+
+def _worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gnnmp.parallel import graph_parallel_forward
+        recs, w = _make_problem()
+        out, mine = graph_parallel_forward(recs, lambda rs: _model_oracle(rs, w), rank, world, dist,
+                                           sizes=[r["n"] for r in recs])
+        ret[rank] = (out.numpy().copy(), list(mine))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_graph_parallel_forward_gloo(world):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    mgr = ctx.Manager()
+    ret = mgr.dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    recs, w = _make_problem()
+    full = _model_oracle(recs, w).numpy()          # single-process reference: all graphs in one batch
+    seen = []
+    for r in range(world):
+        out, mine = ret[r]
+        # graphs are independent units: sharding must not change a single bit of any graph's logits
+        np.testing.assert_array_equal(out, full)
+        seen += mine
+    assert sorted(seen) == list(range(len(recs)))  # a partition: every graph on exactly one rank
+
+
+def test_shard_by_size_is_balanced_and_deterministic():
+    from gnnmp.parallel import shard_by_size
+    rng = np.random.default_rng(0)
+    sizes = rng.integers(20, 41, size=8192)
+    for world in (1, 2, 4, 8):
+        sh = shard_by_size(sizes, world)
+        assert sh == shard_by_size(sizes, world)
+        assert sorted(i for s in sh for i in s) == list(range(len(sizes)))
+        counts = [len(s) for s in sh]
+        assert max(counts) - min(counts) <= 1
+        tot = [int(sizes[s].sum()) for s in sh]
+        assert (max(tot) - min(tot)) <= 0.005 * (sum(tot) / world)     # node counts within 0.5 %
+
+
+def test_gather_without_dist_is_identity_permutation():
+    from gnnmp.parallel import gather_shard_outputs, shard_by_size
+    sh = shard_by_size([5, 3, 9, 1], 1)
+    x = torch.arange(8, dtype=torch.float32).reshape(4, 2)
+    assert torch.equal(gather_shard_outputs(x, sh, 0, 1, None), x)
