@@ -160,6 +160,7 @@ struct DenseWArgs {
     int xld;       // leading dimension of the wave-private x image (odd)
     int old_;      // leading dimension of the wave-private output image (multiple of 4)
     int tp;        // output column tiles per epilogue pass
+    int ks;        // columns of x staged per k-chunk (multiple of 4; = K rounded up when the whole tile fits)
     int region;    // floats per wave region
     int ktot_pad;  // rows of W^T image
 };
@@ -221,7 +222,8 @@ __global__ void __launch_bounds__(512) dense_wlds_kernel(const DenseWArgs w) {
         const int c = min(nt * 32 + (lane & 31), ncols - 1);
         bcol[nt] = a.bias ? a.bias[n0 + c] : 0.0f;
     }
-    for (int64_t tile = (int64_t)blockIdx.x * w.waves + wave; tile < n_tiles; tile += (int64_t)gridDim.x * w.waves) {
+    const int64_t tile_stride = (int64_t)gridDim.x * w.waves;
+    for (int64_t tile = (int64_t)blockIdx.x * w.waves + wave; tile < n_tiles; tile += tile_stride) {
         const int64_t m0 = tile * 32;
         const int rows = (int)min<int64_t>(32, a.N - m0);
         f32x16 acc[NT];
@@ -233,70 +235,77 @@ __global__ void __launch_bounds__(512) dense_wlds_kernel(const DenseWArgs w) {
         for (int seg = 0; seg < a.nseg; ++seg) {
             const int K = a.K[seg], Kp = (K + 1) & ~1;
             const float *__restrict__ x = a.x[seg] + m0 * K;
-            // ---- stage the tile's rows (contiguous in HBM) into the A-operand image xs[row][k] ----
-            if (rows == 32 && (K & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) & 15) == 0)) {
-                // batches of SB independent 16-byte loads per lane, THEN the LDS writes: a plain load->write loop
-                // serialises one HBM round trip per iteration (measured: waves parked 42 % of their cycles, MFMA pipe
-                // 40 % busy)
-                constexpr int SB = 8;
-                const int n4 = 8 * K;  // 32 * K / 4
-                for (int i0 = lane; i0 < n4; i0 += 64 * SB) {
-                    float4 v[SB];
+            const bool vec = rows == 32 && (K & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+            // The 32 x K tile goes through the wave's region in k-chunks of w.ks columns (w.ks = K when the whole image
+            // fits; smaller chunks buy the LDS for two waves per SIMD — measured 148 -> see DESIGN.md on the arxiv shape).
+            for (int kc0 = 0; kc0 < Kp; kc0 += w.ks) {
+                const int kcn = min(w.ks, K - kc0);          // real columns in this chunk (may be odd at the tail)
+                const int kcp = min(w.ks, Kp - kc0);         // even number of k-steps' worth
+                // ---- stage x[m0 : m0+32][kc0 : kc0+kcn] into the A-operand image xs[row][k] ----
+                if (vec && (kcn & 3) == 0) {
+                    // batches of SB independent 16-byte loads per lane, THEN the LDS writes: a plain load->write loop
+                    // serialises one HBM round trip per iteration (measured: waves parked 42 % of their cycles)
+                    constexpr int SB = 8;
+                    const int q = kcn >> 2;                  // float4 per row in this chunk
+                    const int n4 = 32 * q;
+                    for (int i0 = lane; i0 < n4; i0 += 64 * SB) {
+                        float4 v[SB];
+                        int dsto[SB];
 #pragma unroll
-                    for (int u = 0; u < SB; ++u)  // unconditional (clamped) loads: a guarded load makes hipcc branch + wait per element
-                        v[u] = reinterpret_cast<const float4 *>(x)[min(i0 + u * 64, n4 - 1)];
+                        for (int u = 0; u < SB; ++u) {       // unconditional (clamped) loads: no per-element branch + wait
+                            const int i = min(i0 + u * 64, n4 - 1);
+                            const int row = i / q, c4 = i - row * q;
+                            v[u] = *reinterpret_cast<const float4 *>(x + (int64_t)row * K + kc0 + c4 * 4);
+                            dsto[u] = (i0 + u * 64 < n4) ? row * XLD + c4 * 4 : -1;
+                        }
 #pragma unroll
-                    for (int u = 0; u < SB; ++u) {
-                        const int i = i0 + u * 64;
-                        if (i < n4) {
-                            const int e = i * 4;
-                            const int row = e / K, k = e - row * K;
-                            float *d = reg + row * XLD + k;
-                            d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
+                        for (int u = 0; u < SB; ++u) {
+                            if (dsto[u] >= 0) {
+                                float *d = reg + dsto[u];
+                                d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
+                            }
                         }
                     }
+                } else {
+                    const int total = 32 * kcn;
+                    for (int e = lane; e < total; e += 64) {
+                        const int row = e / kcn, k = e - row * kcn;
+                        reg[row * XLD + k] = row < rows ? x[(int64_t)row * K + kc0 + k] : 0.0f;
+                    }
                 }
-            } else {
-                const int total = 32 * K;
-                for (int e = lane; e < total; e += 64) {
-                    const int row = e / K, k = e - row * K;
-                    reg[row * XLD + k] = row < rows ? x[e] : 0.0f;
+                if (kcn < kcp) {                             // odd K: the last k-step's second column is zero
+                    if (lane < 32) reg[lane * XLD + kcn] = 0.0f;
                 }
-            }
-            if (K & 1) {
-                if (lane < 32) reg[lane * XLD + K] = 0.0f;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            // ---- K/2 k-steps ----
-            const float *xa = reg + (lane & 31) * XLD + (lane >> 5);
-            const float *wb = Wt + (koff + (lane >> 5)) * WLD + (lane & 31);
-            // software-pipelined by hand: the operands of k-step kk+2 are read from LDS before the MFMAs of k-step kk
-            // issue, so the LDS latency hides under 4 x 64 matrix-pipe cycles (hipcc leaves the plain loop
-            // read -> wait -> 2 MFMA -> read -> wait -> 2 MFMA).
-            float av = xa[0];
-            float bv[NT];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                // ---- kcp/2 k-steps, software-pipelined by hand: the operands of k-step kk+2 are read from LDS before
+                // the MFMAs of k-step kk issue (hipcc leaves the plain loop read -> wait -> 2 MFMA -> read -> wait -> 2 MFMA)
+                const float *xa = reg + (lane & 31) * XLD + (lane >> 5);
+                const float *wb = Wt + (koff + kc0 + (lane >> 5)) * WLD + (lane & 31);
+                float av = xa[0];
+                float bv[NT];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bv[nt] = wb[nt * 32];
-            for (int kk = 0; kk < Kp; kk += 2) {
-                const int kn = (kk + 2 < Kp) ? kk + 2 : kk;   // last step re-reads itself (harmless)
-                const float an = xa[kn];
-                float bn[NT];
-                const float *wk = wb + kn * WLD;
+                for (int nt = 0; nt < NT; ++nt) bv[nt] = wb[nt * 32];
+                for (int kk = 0; kk < kcp; kk += 2) {
+                    const int kn = (kk + 2 < kcp) ? kk + 2 : kk;   // last step re-reads itself (harmless)
+                    const float an = xa[kn];
+                    float bn[NT];
+                    const float *wk = wb + kn * WLD;
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bn[nt] = wk[nt * 32];
+                    for (int nt = 0; nt < NT; ++nt) bn[nt] = wk[nt * 32];
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[nt], acc[nt], 0, 0, 0);
-                av = an;
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[nt], acc[nt], 0, 0, 0);
+                    av = an;
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bv[nt] = bn[nt];
+                    for (int nt = 0; nt < NT; ++nt) bv[nt] = bn[nt];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
             koff += Kp;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
         // ---- epilogue: bias + act, then whole rows through the region ----
         // The region is sized for the x image; the output tile goes through it in passes of w.tp column tiles.
@@ -364,7 +373,6 @@ static int launch_wlds(const DenseWArgs &w, size_t lds_bytes, int col_tiles, int
     GNNMP_LAUNCH_CHECK("dense_wlds_kernel");
     return GNNMP_OK;
 }
-
 }  // namespace gnnmp
 
 using namespace gnnmp;
@@ -397,8 +405,26 @@ extern "C" int gnnmp_dense_f32(const float *x1, const float *W1, int64_t D1, int
         const int kmax = std::max(k0p, k1p);
         const int full = (int)(Dout / 128), rem = (int)(Dout % 128);
         const int nt_max = full > 0 ? 4 : (rem + 31) / 32;
-        const int xld = kmax + 1;                               // odd: conflict-free A-operand reads
         const int ncols_max = full > 0 ? 128 : rem;
+        const size_t wbytes = (size_t)ktot * (size_t)(nt_max * 32 + 1) * sizeof(float);
+        const size_t budget = 160 * 1024;
+        // Wave regions: prefer 8 waves per CU (two per SIMD: one wave's staging hides under the other's MFMAs).  If the
+        // whole 32 x K image does not leave room for 8 regions, stage x in k-chunks (ks columns at a time); only if even
+        // 64-column chunks do not fit, fall back to 4 waves with the largest chunk that fits.
+        int waves = 0, ks = 0;
+        for (int wv : {8, 4}) {  // fewer than one wave per SIMD cannot feed the matrix pipe: K-chunked kernel instead
+            if (wbytes >= budget) break;
+            const int cols_fit = (int)((budget - wbytes) / ((size_t)wv * 32 * sizeof(float)));  // floats per region row
+            int kfit = ((cols_fit - 1) & ~3);               // leave the +1 (odd leading dimension)
+            kfit = std::min(kfit, (kmax + 3) & ~3);
+            if (kfit >= ((kmax + 3) & ~3) || kfit >= 48) {
+                const int nkc = (kmax + kfit - 1) / kfit;     // balanced chunks, multiple of 4
+                ks = (((kmax + nkc - 1) / nkc) + 3) & ~3;
+                waves = wv;
+                break;
+            }
+        }
+        const int xld = ks + 1;                                 // odd: conflict-free A-operand reads
         // the wave region is sized for the x image (>= one 32-column output tile); the output tile passes through it
         // whole if it fits, else w.tp column tiles at a time
         const int region_cols = (std::max(xld, 32) + 3) & ~3;
@@ -408,12 +434,7 @@ extern "C" int gnnmp_dense_f32(const float *x1, const float *W1, int64_t D1, int
             old_ = tp * 32;
         }
         const size_t region = (size_t)32 * (size_t)region_cols;
-        const size_t wbytes = (size_t)ktot * (size_t)(nt_max * 32 + 1) * sizeof(float);
-        const size_t budget = 160 * 1024;
-        int waves = 0;
-        for (int wv : {8, 4}) {  // fewer than one wave per SIMD cannot feed the matrix pipe: K-chunked kernel instead
-            if (wbytes + (size_t)wv * region * sizeof(float) <= budget) { waves = wv; break; }
-        }
+        if (waves > 0 && wbytes + (size_t)waves * region * sizeof(float) > budget) waves = 0;
         if (waves > 0 && N >= 256 && knob(KNOB_DENSE_GENERIC) == 0) {
             DenseWArgs w;
             w.d = a;
@@ -421,6 +442,7 @@ extern "C" int gnnmp_dense_f32(const float *x1, const float *W1, int64_t D1, int
             w.xld = xld;
             w.old_ = old_;
             w.tp = tp;
+            w.ks = ks;
             w.region = (int)region;
             w.ktot_pad = ktot;
             const int64_t n_row_tiles = (N + 31) / 32;

@@ -25,9 +25,11 @@ for (N, K, Dout, two) in [(2449029, 100, 100, False), (2449029, 100, 128, False)
     flops = 2.0 * N * Dout * (2 * K if two else K)
     byts = 4.0 * N * ((2 * K if two else K) + Dout)
     res = []
-    for knob in (0, 1):
-        gnnmp.tune(6, knob)
+    for name, k6, k7 in (("wlds+pf", 0, 1), ("wlds", 0, 0), ("chunk", 1, 1)):
+        gnnmp.tune(6, k6)
+        gnnmp.tune(7, k7)
         ms = t(f)
-        res.append(f"{'wlds' if knob == 0 else 'chunk'} {ms:7.3f} ms {flops/ms/1e9:6.1f} TF {byts/ms/1e6:6.0f} GB/s")
+        res.append(f"{name} {ms:7.3f} ms {flops/ms/1e9:6.1f} TF {byts/ms/1e6:6.0f} GB/s")
     gnnmp.tune(6, 0)
+    gnnmp.tune(7, 1)
     print(f"N={N} K={K}{'x2' if two else ''} Dout={Dout}: " + " | ".join(res))
