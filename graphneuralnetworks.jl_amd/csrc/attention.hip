@@ -269,7 +269,7 @@ static int launch_gat(GatArgs a, hipStream_t stream) {
     if (chunks > 0) {
         int64_t gx = chunks;
         a.cpx = 0;
-        if (knob(KNOB_XCD_REMAP) && chunks >= 64) {
+        if (use_xcd_remap(a.n_rows, a.D, chunks)) {
             a.cpx = (int)((chunks + 7) / 8);
             gx = (int64_t)a.cpx * 8;
         }

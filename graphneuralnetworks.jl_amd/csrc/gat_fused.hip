@@ -34,6 +34,7 @@ struct GatFusedArgs {
     int n_chunks, n_long;
     int H, C, D;
     int n_rows;
+    int n_src;
     int log2g;
     int lph;              // lanes per head = C / VEC (power of two)
     int act;
@@ -245,17 +246,17 @@ static int launch_gat_fused(GatFusedArgs a, hipStream_t stream) {
     if (chunks > 0) {
         int64_t gx = chunks;
         a.cpx = 0;
-        if (knob(KNOB_XCD_REMAP) && chunks >= 64) {
+        if (use_xcd_remap(a.n_src, a.D, chunks)) {
             a.cpx = (int)((chunks + 7) / 8);
             gx = (int64_t)a.cpx * 8;
         }
         dim3 grid((unsigned)gx, 1);
-        if (knob(KNOB_UNROLL) == 8)
-            gat_fused_rows_kernel<VEC, 8><<<grid, 64 * waves, 0, stream>>>(a);
+        if (knob(KNOB_UNROLL) == 4)
+            gat_fused_rows_kernel<VEC, 4><<<grid, 64 * waves, 0, stream>>>(a);
         else if (knob(KNOB_UNROLL) == 2)
             gat_fused_rows_kernel<VEC, 2><<<grid, 64 * waves, 0, stream>>>(a);
         else
-            gat_fused_rows_kernel<VEC, 4><<<grid, 64 * waves, 0, stream>>>(a);
+            gat_fused_rows_kernel<VEC, 8><<<grid, 64 * waves, 0, stream>>>(a);
         GNNMP_LAUNCH_CHECK("gat_fused_rows_kernel");
     }
     if (a.n_long > 0) {
@@ -321,6 +322,7 @@ extern "C" int gnnmp_gat_conv_f32(gnnmp_graph_t *plan, const float *Wx_src, cons
     g.C = (int)C;
     g.D = D;
     g.n_rows = (int)plan->n_dst;
+    g.n_src = (int)plan->n_src;
     g.log2g = pick_log2g(lanes);
     while ((1 << g.log2g) < lanes) ++g.log2g;  // one feature tile: the head butterfly needs the whole row in one group
     g.lph = lph;

@@ -37,6 +37,7 @@ struct ReduceArgs {
     int n_long;
     int D;
     int n_rows;
+    int n_src;               // rows of x (XCD-remap heuristic)
     int n_edges;             // weights exist for eid < n_edges; others are 1
     int log2g;
     int mean;
@@ -205,7 +206,7 @@ static int launch_reduce(const ReduceArgs &a0, hipStream_t stream) {
     if (chunks > 0) {
         int64_t gx = chunks;
         a.cpx = 0;
-        if (knob(KNOB_XCD_REMAP) && chunks >= 64) {
+        if (use_xcd_remap(a.n_src, a.D, chunks)) {
             a.cpx = (int)((chunks + 7) / 8);
             gx = (int64_t)a.cpx * 8;
         }
@@ -226,8 +227,8 @@ template <int VEC, int OP, bool SCALED>
 static int dispatch_u(const ReduceArgs &a, hipStream_t s) {
     switch (knob(KNOB_UNROLL)) {
         case 2: return launch_reduce<VEC, OP, SCALED, 2>(a, s);
-        case 8: return launch_reduce<VEC, OP, SCALED, 8>(a, s);
-        default: return launch_reduce<VEC, OP, SCALED, 4>(a, s);
+        case 4: return launch_reduce<VEC, OP, SCALED, 4>(a, s);
+        default: return launch_reduce<VEC, OP, SCALED, 8>(a, s);
     }
 }
 template <int VEC, int OP>
@@ -272,6 +273,7 @@ int run_reduce(gnnmp_graph_t *p, const int32_t *idx, int aggr, const float *x, c
     a.n_long = p->n_long;
     a.D = (int)D;
     a.n_rows = (int)p->n_dst;
+    a.n_src = (int)p->n_src;
     a.n_edges = (int)p->n_edges;
     a.mean = (aggr == GNNMP_MEAN);
     a.long_thresh = p->long_thresh;

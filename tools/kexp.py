@@ -20,7 +20,7 @@ from gnnmp import _lib as L  # noqa: E402
 from gnnmp import synth  # noqa: E402
 
 KNOBS = {"vec": 0, "log2g": 1, "unroll": 2, "xcd": 3, "long": 4, "waves": 5}
-DEFAULTS = {"vec": 0, "log2g": -1, "unroll": 0, "xcd": 1, "long": 512, "waves": 4}
+DEFAULTS = {"vec": 0, "log2g": -1, "unroll": 0, "xcd": 1, "long": 0, "waves": 4}
 
 
 def set_knobs(**kw):
@@ -118,7 +118,8 @@ def main():
         variants = [dict()]
         if not args.quick:
             variants += [dict(unroll=2), dict(unroll=8), dict(waves=1), dict(waves=2), dict(xcd=0),
-                         dict(vec=2, log2g=6), dict(vec=2, log2g=6, unroll=8), dict(vec=4, log2g=5, unroll=8, waves=2)]
+                         dict(xcd=0, unroll=8), dict(xcd=0, waves=1), dict(xcd=0, waves=2), dict(xcd=0, unroll=8, waves=1),
+                         dict(xcd=0, unroll=8, waves=2), dict(vec=2, log2g=6)]
         for v in variants:
             set_knobs(**v)
             tp = time_fn(prop)
