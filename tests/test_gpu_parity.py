@@ -527,3 +527,79 @@ def test_arxiv_shape_gcn_and_gat_vs_oracle(gm, oracle):
     yg = host(lg(g, dev(x)))
     refg = oracle.gat_conv(s, t, N, x, host(lg.dense_x_weight), host(lg.a), host(lg.bias), "relu", heads=8)
     assert_close(yg, refg)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the remaining built-in message functions (GNNlib/src/msgpass.jl:167-196) through the generic path, Int32 / 0-based
+# graphs end to end, and the Julia weight layout of the dense kernel
+# ---------------------------------------------------------------------------------------------------------------
+def test_builtin_message_functions_generic_path(gm, oracle):
+    rng = np.random.default_rng(21)
+    n, E, D = 300, 4000, 12
+    s = rng.integers(1, n + 1, E)
+    t = rng.integers(1, n + 1, E)
+    xi = rng.standard_normal((n, D)).astype(np.float32)
+    xj = rng.standard_normal((n, D)).astype(np.float32)
+    e2 = rng.standard_normal((E, D)).astype(np.float32)
+    g = graph(gm, s, t, n)
+    gi, gj = oracle.gather(xi, t), oracle.gather(xj, s)
+    cases = [
+        (gm.copy_xi, dict(xi=dev(xi)), gi),
+        (gm.xi_sub_xj, dict(xi=dev(xi), xj=dev(xj)), gi - gj),
+        (gm.xj_sub_xi, dict(xi=dev(xi), xj=dev(xj)), gj - gi),
+        (gm.xi_dot_xj, dict(xi=dev(xi), xj=dev(xj)), (gi * gj).sum(axis=1, keepdims=True)),
+        (gm.e_mul_xj, dict(xj=dev(xj), e=dev(e2)), e2 * gj),                       # matrix e: generic path
+    ]
+    for f, kw, m in cases:
+        for aggr, _ in AGGRS:
+            got = host(gm.propagate(f, g, aggr, **kw))
+            ref = oracle.scatter(aggr, m.astype(np.float32), t, n)
+            if f is gm.xi_dot_xj:
+                assert_close(got, ref)              # torch's row-sum order is not NNlib's
+            else:
+                np.testing.assert_array_equal(got, ref)
+    # apply_edges alone, tuple inputs (msgpass.jl:30-53: NamedTuple input)
+    m = gm.apply_edges(lambda xi_, xj_, e_: xj_[1] - 2 * xj_[0], g, xj=(dev(xj), dev(2 * xj)))
+    assert float(m.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("base,dtype", [(0, np.int32), (1, np.int32), (0, np.int64)])
+def test_layers_with_int32_and_zero_based_indices(gm, oracle, base, dtype):
+    rng = np.random.default_rng(31)
+    n, E, D = 500, 6000, 20
+    s = rng.integers(1, n + 1, E)
+    t = rng.integers(1, n + 1, E)
+    x = rng.standard_normal((n, D)).astype(np.float32)
+    g = graph(gm, s, t, n, base=base, dtype=dtype)
+    l = gm.GCNConv((D, 24), "relu", seed=1)
+    assert_close(host(l(g, dev(x))), oracle.gcn_conv(s, t, n, x, host(l.weight), host(l.bias), "relu"))
+    ls = gm.SAGEConv((D, 8), "relu", seed=2)
+    assert_close(host(ls(g, dev(x))), oracle.sage_conv(s, t, n, x, host(ls.weight), host(ls.bias), "relu", "mean"))
+    la = gm.GATConv((D, 8), None, heads=4, seed=3)
+    assert_close(host(la(g, dev(x))), oracle.gat_conv(s, t, n, x, host(la.dense_x_weight), host(la.a), host(la.bias), None, heads=4))
+    g2 = gm.add_self_loops(g)
+    s2, t2, _ = oracle.add_self_loops(s, t, n)
+    np.testing.assert_array_equal(host(g2.s).astype(np.int64) + (1 - base), s2)
+    np.testing.assert_array_equal(host(g2.t).astype(np.int64) + (1 - base), t2)
+    np.testing.assert_array_equal(host(gm.propagate(gm.copy_xj, g2, "+", xj=dev(x))), oracle.propagate("+", s2, t2, n, x))
+
+
+def test_dense_julia_weight_layout(gm):
+    """w_layout = 1: the Julia (Dout, Din) column-major weight is C row-major [Din][Dout] — what the extension passes"""
+    import torch
+    from gnnmp import _lib as L
+    rng = np.random.default_rng(41)
+    for N, Din, Dout in ((777, 100, 100), (300, 37, 130), (5, 16, 7)):
+        x = rng.standard_normal((N, Din)).astype(np.float32)
+        W = (rng.standard_normal((Dout, Din)) / np.sqrt(Din)).astype(np.float32)
+        b = rng.standard_normal(Dout).astype(np.float32)
+        ref = np.maximum(x.astype(np.float64) @ W.astype(np.float64).T + b, 0)
+        xd, bd = dev(x), dev(b)
+        Wj = dev(np.ascontiguousarray(W.T))            # [Din][Dout]: the bytes Julia holds for a (Dout, Din) matrix
+        out = torch.empty((N, Dout), dtype=torch.float32, device="cuda")
+        for knob in (0, 1):                            # W-resident and K-chunked kernels
+            gm.tune(6, knob)
+            L.check(gm.load().gnnmp_dense_f32(L.ptr(xd), L.ptr(Wj), Din, Dout, None, None, 0, 0, 1, L.ptr(bd), L.ACT_RELU,
+                                              L.ptr(out), N, Dout, L.stream_ptr()))
+            assert_close(host(out), ref)
+        gm.tune(6, 0)
