@@ -290,6 +290,32 @@ int run_reduce(gnnmp_graph_t *p, const int32_t *idx, int aggr, const float *x, c
     }
 }
 
+// fold plan->ws ([n_chunks][D] partial sums written by another kernel in the same virtual-row layout) into out's long rows
+int run_combine_sum(gnnmp_graph_t *p, float *out, int64_t D, hipStream_t stream) {
+    if (p->n_long == 0) return GNNMP_OK;
+    ReduceArgs a = {};
+    a.rowptr = p->rowptr;
+    a.out = out;
+    a.partial = p->ws;
+    a.long_rows = p->long_rows;
+    a.long_cptr = p->long_cptr;
+    a.n_long = p->n_long;
+    a.D = (int)D;
+    const int vec = pick_vec(D, p->ws, out);
+    a.log2g = pick_log2g((D + vec - 1) / vec);
+    const int G = 1 << a.log2g;
+    const int tiles = (int)(((D + vec - 1) / vec + G - 1) / G);
+    const int64_t threads = (int64_t)a.n_long << a.log2g;
+    dim3 grid((unsigned)((threads + 255) / 256), (unsigned)tiles);
+    switch (vec) {
+        case 4: csr_combine_kernel<4, OP_SUM><<<grid, 256, 0, stream>>>(a); break;
+        case 2: csr_combine_kernel<2, OP_SUM><<<grid, 256, 0, stream>>>(a); break;
+        default: csr_combine_kernel<1, OP_SUM><<<grid, 256, 0, stream>>>(a); break;
+    }
+    GNNMP_LAUNCH_CHECK("csr_combine_kernel");
+    return GNNMP_OK;
+}
+
 // ---- degree / norm ------------------------------------------------------------------------------
 __global__ void degree_count_kernel(const int32_t *rowptr, int64_t n, float *deg) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -1,0 +1,118 @@
+"""Adjoints of the fused propagate (SURVEY.md §8f rank 1 — the first "next" row after the forward path).
+
+The reference trains through Zygote + NNlib's rrules (∇gather = scatter(+), ∇scatter(+) = gather, ∇scatter(mean) =
+gather ./ count, ∇scatter(max|min) = (src .== gather(dst)) .* gather(Δ)) and, on the CPU fast path, the
+`adjacency_matrix` rrule (GNNGraphs/src/query.jl:244-278).  Here:
+
+  Δxj of propagate(copy_xj | w_mul_xj | e_mul_xj, g, + | mean)   = the SAME fused kernel on the transposed plan
+  Δxj of propagate(copy_xj, g, max | min)                        = gnnmp_propagate_maxmin_grad_f32 (transposed plan)
+  Δw  of w_mul_xj / e_mul_xj                                     = gnnmp_edge_dot_f32 (one dot product per edge)
+
+`propagate_ad` wraps them in a torch.autograd.Function so the host mirror can be differentiated end to end (the Julia
+extension would declare the same three calls as ChainRulesCore.rrules).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib as L
+from .graph import GNNGraph, Plan, check_num_nodes
+from .msgpass import _flat, aggr_code
+
+
+def plan_transposed(g: GNNGraph, add_self_loops: bool = False) -> Plan:
+    """plan of the reversed edge index (t, s): row j lists the edges that LEAVE j, in original edge order"""
+    key = ("T", bool(add_self_loops))
+    p = g._plans.get(key)
+    if p is None:
+        p = Plan(g.t, g.s, g.num_nodes, g.num_nodes, g.index_base, bool(add_self_loops), validate=False)
+        g._plans[key] = p
+    return p
+
+
+def _in_count(g: GNNGraph, add_self_loops: bool):
+    key = ("count", bool(add_self_loops))
+    c = g._cache.get(key)
+    if c is None:
+        c = torch.empty(g.num_nodes, dtype=torch.float32, device=g.device)
+        L.check(L.load().gnnmp_degree_f32(g.plan(add_self_loops).handle, None, L.ptr(c), L.stream_ptr()))
+        g._cache[key] = c
+    return c
+
+
+def propagate_grad_xj(g: GNNGraph, aggr, dy, w=None, scale_src=None, scale_dst=None, add_self_loops=False, xj=None,
+                      y=None):
+    """Δxj for out = scale_dst .* aggr_{k: t_k = i}( w_k * scale_src[s_k] * xj[s_k] ).  max/min need the forward input
+    `xj` and output `y` (copy_xj only, no scaling — what propagate(copy_xj, g, max) computes)."""
+    code = aggr_code(aggr)
+    lib = L.load()
+    pt = plan_transposed(g, add_self_loops)
+    dyf = _flat(dy)
+    D = dyf.shape[1]
+    dx = torch.empty((g.num_nodes,) + tuple(dy.shape[1:]), dtype=torch.float32, device=dy.device)
+    if code in (L.MAX, L.MIN):
+        assert w is None and scale_src is None and scale_dst is None and xj is not None and y is not None
+        L.check(lib.gnnmp_propagate_maxmin_grad_f32(pt.handle, L.ptr(_flat(xj)), L.ptr(_flat(y)), L.ptr(dyf), L.ptr(dx), D,
+                                                    L.stream_ptr()))
+        return dx
+    sd = scale_dst
+    if code == L.MEAN:
+        inv = 1.0 / _in_count(g, add_self_loops).clamp(min=1.0)   # N-element host-side plumbing
+        sd = inv if sd is None else (sd * inv).contiguous()
+    msg = L.COPY_XJ if w is None else L.W_MUL_XJ
+    L.check(lib.gnnmp_propagate_f32(pt.handle, msg, L.SUM, L.ptr(dyf), L.ptr(w), L.ptr(sd), L.ptr(scale_src), L.ptr(dx), D,
+                                    L.stream_ptr()))
+    return dx
+
+
+def propagate_grad_w(g: GNNGraph, dy, xj):
+    """Δw[k] = Δ[t_k] · xj[s_k]  (w_mul_xj / e_mul_xj with a vector e, aggr = +; for mean pre-scale Δ by 1/count)"""
+    dyf, xf = _flat(dy), _flat(xj)
+    out = torch.empty(g.num_edges, dtype=torch.float32, device=dy.device)
+    L.check(L.load().gnnmp_edge_dot_f32(L.ptr(dyf), L.ptr(xf), L.ptr(g.s), L.ptr(g.t), g.idx_bytes, g.index_base,
+                                        g.num_edges, dyf.shape[1], L.ptr(out), L.stream_ptr()))
+    return out
+
+
+class _PropagateFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xj, w, g, aggr):
+        code = aggr_code(aggr)
+        lib = L.load()
+        plan = g.plan(False)
+        xf = _flat(xj)
+        out = torch.empty((plan.n_dst, xf.shape[1]), dtype=torch.float32, device=xj.device)
+        msg = L.COPY_XJ if w is None else L.W_MUL_XJ
+        L.check(lib.gnnmp_propagate_f32(plan.handle, msg, code, L.ptr(xf), L.ptr(w), None, None, L.ptr(out), xf.shape[1],
+                                        L.stream_ptr()))
+        ctx.g, ctx.aggr, ctx.code = g, aggr, code
+        ctx.save_for_backward(xf, w if w is not None else torch.empty(0, device=xj.device), out)
+        ctx.has_w = w is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        xf, w, out = ctx.saved_tensors
+        g = ctx.g
+        w = w if ctx.has_w else None
+        dy = dy.contiguous()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            if ctx.code in (L.MAX, L.MIN):
+                assert w is None, "max/min adjoint is implemented for copy_xj"
+                dx = propagate_grad_xj(g, ctx.aggr, dy, xj=xf, y=out)
+            else:
+                dx = propagate_grad_xj(g, ctx.aggr, dy, w=w)
+        if ctx.has_w and ctx.needs_input_grad[1]:
+            assert ctx.code in (L.SUM, L.MEAN)
+            d = dy
+            if ctx.code == L.MEAN:
+                d = dy * (1.0 / _in_count(g, False).clamp(min=1.0))[:, None]
+            dw = propagate_grad_w(g, d, xf)
+        return dx, dw, None, None
+
+
+def propagate_ad(g: GNNGraph, aggr, xj, w=None):
+    """differentiable propagate(copy_xj | w_mul_xj, g, aggr; xj [, w]) — forward and backward both on the HIP kernels"""
+    check_num_nodes(g, xj)
+    return _PropagateFn.apply(xj, w, g, aggr)

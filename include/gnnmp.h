@@ -246,6 +246,27 @@ int gnnmp_dense_f32(const float *x1, const float *W1, int64_t D1, int64_t ldw1, 
                     const float *W2, int64_t D2, int64_t ldw2, int w_layout, const float *bias,
                     int act, float *out, int64_t N, int64_t Dout, gnnmp_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Adjoints.  The reference trains through NNlib's rrules: ∇gather = scatter(+),
+ * ∇scatter(+) = gather, ∇scatter(mean) = gather ./ count, ∇scatter(max|min) = (src .== gather(dst)) .* gather(Δ);
+ * the CPU fast path through the adjacency_matrix rrule (GNNGraphs/src/query.jl:244-278).
+ *
+ * The adjoint of the fused propagate w.r.t. xj needs no entry point of its own: build a plan of the TRANSPOSED edge
+ * index (gnnmp_plan_create(..., src = t, dst = s, ...)) and call
+ *   gnnmp_propagate_f32(plan_T, msg, GNNMP_SUM, Δ, w, scale_src = scale_dst_fwd (./ count for MEAN), scale_dst = scale_src_fwd, Δx, D)
+ * (same per-source edge order as NNlib's scatter(+, gather(Δ, t) .* w, s)).  The two that do:
+ * ---------------------------------------------------------------------------------------------- */
+/* out[k] = Σ_d a_dst[dst_k][d] * b_src[src_k][d] for every edge k (original order) — the adjoint w.r.t. the edge
+ * weights of w_mul_xj / e_mul_xj:  Δw = sum(Δm .* xj_gathered, dims = 1)  with Δm = gather(Δ, t). */
+int gnnmp_edge_dot_f32(const float *a_dst, const float *b_src, const void *src, const void *dst,
+                       int idx_bytes, int index_base, int64_t n_edges, int64_t D, float *out,
+                       gnnmp_stream_t stream);
+/* Adjoint of propagate(copy_xj, g, max|min) w.r.t. xj on the transposed plan:
+ *   Δx_j[d] = Σ_{k: s_k = j, edge order} (x_j[d] == y_{t_k}[d]) ? Δ_{t_k}[d] : 0      (ties all receive Δ, like NNlib)
+ * x: forward input [n][D], y: forward output, dy: incoming gradient, dx: output. */
+int gnnmp_propagate_maxmin_grad_f32(gnnmp_graph_t *plan_transposed, const float *x, const float *y,
+                                    const float *dy, float *dx, int64_t D, gnnmp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -324,3 +324,33 @@ def gat_conv(s, t, n, x, dense_x_weight, a, bias=None, sigma=None, heads=1, conc
 def global_pool(aggr, graph_indicator, x, num_graphs=None):
     """global_pool — GNNlib/src/layers/pool.jl:3-5."""
     return reduce_nodes(aggr, graph_indicator, x, num_graphs)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# adjoints — NNlib's rrules restated (what Zygote runs through the generic path; SURVEY.md §8f rank 1)
+#   ∇gather(x, idx): Δx = scatter(+, Δ, idx)                     ∇scatter(+): Δsrc = gather(Δ, idx)
+#   ∇scatter(mean):  Δsrc = gather(Δ, idx) ./ count[idx]          ∇scatter(max|min): (src .== gather(dst, idx)) .* gather(Δ, idx)
+# ---------------------------------------------------------------------------------------------------------
+def grad_propagate(aggr, s, t, n, dy, xj, w=None):
+    """(Δxj, Δw) of propagate(copy_xj | w_mul_xj, g, aggr; xj [, w]) for an incoming Δ = dy [n, D]"""
+    s = _i64(s)
+    t = _i64(t)
+    dy = _f32(dy)
+    xj = _f32(xj)
+    code = _AGGR[aggr]
+    dm = gather(dy, t)                                       # ∇scatter(+)
+    m = gather(xj, s)
+    if w is not None:
+        m = (_f32(w)[:, None] * m).astype(np.float32)
+    if code == MEAN:
+        cnt = np.bincount(t - 1, minlength=n).astype(np.float32)
+        dm = (dm / cnt[t - 1][:, None]).astype(np.float32)
+    elif code in (MAX, MIN):
+        y = scatter(aggr, m, t, n)
+        dm = ((m == gather(y, t)) * dm).astype(np.float32)
+    dw = None
+    if w is not None:
+        dw = (dm * gather(xj, s)).sum(axis=1).astype(np.float32)   # sum(Δm .* xj, dims = 1)
+        dm = (_f32(w)[:, None] * dm).astype(np.float32)
+    dx = scatter(SUM, dm, s, n)                              # ∇gather
+    return dx, dw

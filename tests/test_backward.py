@@ -1,0 +1,139 @@
+"""Adjoints.  CPU: the oracle's restated NNlib rrules against central finite differences in
+float64.  GPU: the HIP adjoints (transposed-plan propagate, edge-dot, max/min gradient) against the oracle, and through
+torch.autograd."""
+import numpy as np
+import pytest
+
+
+def _problem(seed=0, n=60, E=500, D=5):
+    rng = np.random.default_rng(seed)
+    s = rng.integers(1, n + 1, E)
+    t = rng.integers(1, n - 5, E)
+    x = rng.standard_normal((n, D)).astype(np.float32)
+    w = (rng.random(E) + 0.5).astype(np.float32)
+    r = rng.standard_normal((n, D)).astype(np.float32)
+    return s, t, n, x, w, r
+
+
+@pytest.mark.parametrize("aggr", ["+", "mean", "max", "min"])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_oracle_adjoint_matches_finite_differences(oracle, aggr, weighted):
+    if weighted and aggr in ("max", "min"):
+        pytest.skip("weighted max/min is not on the path")
+    s, t, n, x, w, r = _problem()
+    if aggr in ("max", "min"):
+        # NNlib's rule hands Δ to EVERY tied maximiser, so a multi-edge counts twice — a subgradient convention that a
+        # finite difference cannot see: compare on a simple graph
+        _, keep = np.unique(s * 1000 + t, return_index=True)
+        keep = np.sort(keep)
+        s, t, w = s[keep], t[keep], w[keep]
+    ww = w if weighted else None
+    has = np.bincount(t - 1, minlength=n) > 0          # empty destinations hold -Inf / +Inf under max / min
+    r = r * has[:, None]
+
+    def loss(xv, wv):
+        y = oracle.propagate(aggr, s, t, n, xv.astype(np.float32), None if wv is None else wv.astype(np.float32))
+        return float((y[has].astype(np.float64) * r[has]).sum())
+
+    dx, dw = oracle.grad_propagate(aggr, s, t, n, r, x, ww)
+    eps = 1e-2
+    rng = np.random.default_rng(1)
+    for _ in range(25):
+        i, d = int(rng.integers(0, n)), int(rng.integers(0, x.shape[1]))
+        xp, xm = x.copy(), x.copy()
+        xp[i, d] += eps
+        xm[i, d] -= eps
+        f0, fp, fm = loss(x, ww), loss(xp, ww), loss(xm, ww)
+        if abs((fp - f0) - (f0 - fm)) > 1e-3 * eps * max(1.0, abs(float(dx[i, d]))) * 50:
+            continue                                   # a kink of max/min inside [x - eps, x + eps]: not differentiable here
+        fd = (fp - fm) / (2 * eps)
+        assert fd == pytest.approx(float(dx[i, d]), rel=2e-2, abs=2e-2)
+    if weighted:
+        for _ in range(25):
+            k = int(rng.integers(0, len(s)))
+            wp, wm = w.copy(), w.copy()
+            wp[k] += eps
+            wm[k] -= eps
+            fd = (loss(x, wp) - loss(x, wm)) / (2 * eps)
+            assert fd == pytest.approx(float(dw[k]), rel=2e-2, abs=2e-2)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def gm():
+    import torch
+    assert torch.cuda.is_available()
+    import gnnmp
+    gnnmp.load()
+    return gnnmp
+
+
+def dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D", [1, 5, 16, 100, 128])
+def test_hip_adjoints_vs_oracle(gm, oracle, D):
+    from gnnmp import backward as bw
+    rng = np.random.default_rng(D)
+    n, E = 900, 20000
+    s = rng.integers(1, n + 1, E)
+    t = rng.integers(1, n - 10, E)
+    s[:1500] = 4                     # a source with 1500 outgoing edges: split row of the TRANSPOSED plan
+    t[2000:3200] = 9                 # and a hub destination
+    p = rng.permutation(E)
+    s, t = s[p], t[p]
+    x = rng.standard_normal((n, D)).astype(np.float32)
+    x[rng.integers(0, n, 50)] = x[0]                       # exact ties for max/min
+    w = (rng.random(E) + 0.5).astype(np.float32)
+    dy = rng.standard_normal((n, D)).astype(np.float32)
+    g = gm.GNNGraph(dev(s), dev(t), num_nodes=n)
+    outdeg = np.bincount(s - 1, minlength=n)
+    short = outdeg <= 64
+
+    def check(got, ref, exact_rows=short):
+        np.testing.assert_array_equal(got[exact_rows], ref[exact_rows])
+        scale = max(np.abs(ref).max(), 1e-30)
+        assert np.abs(got - ref).max() <= 4e-5 * scale
+
+    # Δxj, aggr = + (bit-exact where the source's out-degree is not split), with and without weights
+    dx, _ = oracle.grad_propagate("+", s, t, n, dy, x)
+    check(bw.propagate_grad_xj(g, "+", dev(dy)).cpu().numpy(), dx)
+    dxw, dw = oracle.grad_propagate("+", s, t, n, dy, x, w)
+    check(bw.propagate_grad_xj(g, "+", dev(dy), w=dev(w)).cpu().numpy(), dxw)
+    got_dw = bw.propagate_grad_w(g, dev(dy), dev(x)).cpu().numpy()
+    assert np.abs(got_dw - dw).max() <= 1e-5 * np.abs(dw).max() * 4
+    # mean: multiply-by-reciprocal vs NNlib's division: tolerance
+    dxm, _ = oracle.grad_propagate("mean", s, t, n, dy, x)
+    got = bw.propagate_grad_xj(g, "mean", dev(dy)).cpu().numpy()
+    assert np.linalg.norm(got - dxm) <= 1e-5 * np.linalg.norm(dxm)
+    # max / min (ties all receive the gradient)
+    for aggr in ("max", "min"):
+        y = gm.propagate(gm.copy_xj, g, aggr, xj=dev(x))
+        ref, _ = oracle.grad_propagate(aggr, s, t, n, dy, x)
+        check(bw.propagate_grad_xj(g, aggr, dev(dy), xj=dev(x), y=y).cpu().numpy(), ref)
+
+
+@pytest.mark.gpu
+def test_autograd_through_hip_propagate(gm, oracle):
+    import torch
+    from gnnmp.backward import propagate_ad
+    rng = np.random.default_rng(3)
+    n, E, D = 400, 6000, 12
+    s = rng.integers(1, n + 1, E)
+    t = rng.integers(1, n + 1, E)
+    x = rng.standard_normal((n, D)).astype(np.float32)
+    w = (rng.random(E) + 0.5).astype(np.float32)
+    r = rng.standard_normal((n, D)).astype(np.float32)
+    g = gm.GNNGraph(dev(s), dev(t), num_nodes=n)
+    for aggr, weighted in (("+", True), ("mean", True), ("+", False), ("max", False), ("min", False)):
+        xt = dev(x).requires_grad_(True)
+        wt = dev(w).requires_grad_(True) if weighted else None
+        y = propagate_ad(g, aggr, xt, wt)
+        (y * dev(r)).sum().backward()
+        dx, dw = oracle.grad_propagate(aggr, s, t, n, r, x, w if weighted else None)
+        assert np.linalg.norm(xt.grad.cpu().numpy() - dx) <= 1e-5 * np.linalg.norm(dx)
+        if weighted:
+            assert np.linalg.norm(wt.grad.cpu().numpy() - dw) <= 1e-5 * np.linalg.norm(dw)
