@@ -44,6 +44,80 @@ __global__ void __launch_bounds__(256) edge_dot_kernel(const float *a, const flo
     if (lig == 0) out[k] = acc;
 }
 
+// The same dot products in the plan's destination-sorted order: the destination row a[i] is loaded once per row (per
+// chunk for split rows) and stays in registers, only b[col_p] is gathered per edge — half the traffic of the COO-order
+// kernel above (measured 12.0 -> see DESIGN.md).  Results are written back in ORIGINAL edge order through eid.
+struct EdgeDotRowsArgs {
+    const int32_t *rowptr, *col, *eid;
+    const int32_t *chunk_row, *chunk_beg, *chunk_end;
+    const float *a, *b;
+    float *out;
+    int n_chunks, long_thresh, n_edges;
+    int D, n_rows, log2g, waves;
+};
+template <int VEC, int U>
+__global__ void __launch_bounds__(256) edge_dot_rows_kernel(const EdgeDotRowsArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int G = 1 << a.log2g;
+    const int lig = lane & (G - 1);
+    const int grp = lane >> a.log2g;
+    const int gbase = lane - lig;
+    const int rpw = 64 >> a.log2g;
+    const int64_t v64 = ((int64_t)blockIdx.x * a.waves + wave) * rpw + grp;
+    if (v64 >= (int64_t)a.n_rows + a.n_chunks) return;
+    const int v = (int)v64;
+    int row, beg, end;
+    if (v < a.n_chunks) {
+        row = a.chunk_row[v];
+        beg = a.chunk_beg[v];
+        end = a.chunk_end[v];
+    } else {
+        row = v - a.n_chunks;
+        beg = a.rowptr[row];
+        end = a.rowptr[row + 1];
+        if (end - beg > a.long_thresh) return;   // its chunks are separate virtual rows (outputs are per edge: no combine)
+    }
+    const int f0 = lig * VEC;                      // one feature tile: G * VEC >= D (checked by the launcher)
+    const bool active = f0 < a.D;
+    float av[VEC];
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) av[q] = 0.0f;
+    if (active) Vec<VEC>::load(a.a + (int64_t)row * a.D + f0, av);
+    for (int base = beg; base < end; base += G) {
+        const int p = base + lig;
+        int c = 0, e = 0;
+        if (p < end) {
+            c = a.col[p];
+            e = a.eid[p];
+        }
+        const int n = min(G, end - base);
+        float mine = 0.0f;                         // lane lig keeps the result of slot base + lig
+        for (int j = 0; j < n; j += U) {
+            float bv[U][VEC];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int cj = __shfl(c, gbase + min(j + u, n - 1), 64);
+                if (active) {
+                    Vec<VEC>::load(a.b + (int64_t)cj * a.D + f0, bv[u]);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) bv[u][q] = 0.0f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float d = 0.0f;
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) d = fmaf(av[q], bv[u][q], d);
+                for (int o = 1; o < G; o <<= 1) d += __shfl_xor(d, o, 64);
+                if (lig == j + u) mine = d;
+            }
+        }
+        if (p < end && e < a.n_edges) a.out[e] = mine;   // plan-added self loops carry no weight: no output slot
+    }
+}
+
 struct MaxMinGradArgs {
     const int32_t *rowptr;  // transposed plan: row j = source node, slots = the edges j -> i in original order
     const int32_t *col;     // destination i of each slot
@@ -144,6 +218,45 @@ int gnnmp_edge_dot_f32(const float *a_dst, const float *b_src, const void *src, 
         default: edge_dot_kernel<1><<<nb, 256, 0, stream>>>(a_dst, b_src, src, dst, idx_bytes, index_base, n_edges, (int)D, log2g, out); break;
     }
     GNNMP_LAUNCH_CHECK("edge_dot_kernel");
+    return GNNMP_OK;
+}
+
+int gnnmp_edge_dot_plan_f32(gnnmp_graph_t *plan, const float *a_dst, const float *b_src, float *out,
+                            int64_t D, gnnmp_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!plan) return fail(GNNMP_EINVAL, "edge_dot_plan: null plan");
+    if (D <= 0 || D > (1 << 20)) return fail(GNNMP_EINVAL, "edge_dot_plan: bad D");
+    if (plan->n_total == 0 || plan->n_dst == 0) return GNNMP_OK;
+    if (!a_dst || !b_src || !out) return fail(GNNMP_EINVAL, "edge_dot_plan: null pointer");
+    const int vec = pick_vec(D, a_dst, b_src);
+    const int lanes = (int)((D + vec - 1) / vec);
+    if (lanes > 64) return fail(GNNMP_EUNSUPPORTED, "edge_dot_plan: D = %lld needs more than one wave per row; use gnnmp_edge_dot_f32", (long long)D);
+    EdgeDotRowsArgs a;
+    a.rowptr = plan->rowptr;
+    a.col = plan->col;
+    a.eid = plan->eid;
+    a.chunk_row = plan->chunk_row;
+    a.chunk_beg = plan->chunk_beg;
+    a.chunk_end = plan->chunk_end;
+    a.a = a_dst;
+    a.b = b_src;
+    a.out = out;
+    a.n_chunks = plan->n_chunks;
+    a.long_thresh = plan->long_thresh;
+    a.n_edges = (int)plan->n_edges;
+    a.D = (int)D;
+    a.n_rows = (int)plan->n_dst;
+    a.log2g = 0;
+    while ((1 << a.log2g) < lanes) ++a.log2g;
+    a.waves = 4;
+    const int rows_per_block = (64 >> a.log2g) * a.waves;
+    const unsigned nb = (unsigned)(((int64_t)a.n_rows + a.n_chunks + rows_per_block - 1) / rows_per_block);
+    switch (vec) {
+        case 4: edge_dot_rows_kernel<4, 4><<<nb, 256, 0, stream>>>(a); break;
+        case 2: edge_dot_rows_kernel<2, 4><<<nb, 256, 0, stream>>>(a); break;
+        default: edge_dot_rows_kernel<1, 4><<<nb, 256, 0, stream>>>(a); break;
+    }
+    GNNMP_LAUNCH_CHECK("edge_dot_rows_kernel");
     return GNNMP_OK;
 }
 

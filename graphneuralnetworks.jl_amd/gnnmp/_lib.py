@@ -28,7 +28,7 @@ SYMBOLS = (
     "gnnmp_edge_softmax_f32", "gnnmp_gat_node_scores_f32", "gnnmp_gat_aggregate_f32", "gnnmp_gat_conv_f32",
     "gnnmp_bias_act_f32",
     "gnnmp_segment_pool_f32", "gnnmp_dense_f32",
-    "gnnmp_edge_dot_f32", "gnnmp_propagate_maxmin_grad_f32",
+    "gnnmp_edge_dot_f32", "gnnmp_edge_dot_plan_f32", "gnnmp_propagate_maxmin_grad_f32",
 )
 
 
@@ -77,6 +77,7 @@ def load():
         "gnnmp_segment_pool_f32": [i, vp, vp, i, i, vp, i64, i64, i64, vp],
         "gnnmp_dense_f32": [vp, vp, i64, i64, vp, vp, i64, i64, i, vp, i, vp, i64, i64, vp],
         "gnnmp_edge_dot_f32": [vp, vp, vp, vp, i, i, i64, i64, vp, vp],
+        "gnnmp_edge_dot_plan_f32": [vp, vp, vp, vp, i64, vp],
         "gnnmp_propagate_maxmin_grad_f32": [vp, vp, vp, vp, vp, i64, vp],
         "gnnmp_tune": [i, i],
     }

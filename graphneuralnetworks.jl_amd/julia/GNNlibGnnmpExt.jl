@@ -148,4 +148,34 @@ end
 # NOTE on `a`: Julia stores l.a of size (2C, H) column-major = C row-major [H][2C]: exactly the layout gnnmp.h asks for,
 # so `l.a` itself is passed — no permutedims.
 
+# ---- adjoints (needs ChainRulesCore as a further weakdep) ---------------------------------------------------------------
+# Zygote reaches the methods above only if they carry rrules.  The pullback of the fused propagate w.r.t. xj is the same
+# kernel on the plan of the reversed edge index; w.r.t. the edge weights it is one dot product per edge; max / min have
+# their own kernel.  (Mirror of graphneuralnetworks.jl_amd/gnnmp/backward.py, which is tested against NNlib's rules.)
+#
+# using ChainRulesCore
+# plan_t(g; self_loops = false) = (s, t = edge_index(g); Plan(t, s, g.num_nodes, g.num_nodes, self_loops))   # cached like plan()
+#
+# function ChainRulesCore.rrule(::typeof(fused_propagate), g, aggr::Union{typeof(+), typeof(mean)}, xj, w; kws...)
+#     y = fused_propagate(g, aggr, xj, w; kws...)
+#     function pullback(Δ)
+#         Δ = unthunk(Δ); D = size(Δ, 1)
+#         sd = aggr === mean ? 1f0 ./ max.(degree(g, Float32; dir = :in), 1f0) : nothing
+#         Δx = similar(xj)
+#         check(@ccall libgnnmp.gnnmp_propagate_f32(plan_t(g).handle::Ptr{Cvoid}, (w === nothing ? 0 : 1)::Cint, SUM::Cint,
+#                   devptr(Δ)::Ptr{Cvoid}, devptr(w)::Ptr{Cvoid}, devptr(sd)::Ptr{Cvoid}, C_NULL::Ptr{Cvoid},
+#                   devptr(Δx)::Ptr{Cvoid}, D::Int64, stream_ptr()::Ptr{Cvoid})::Cint)
+#         Δw = w === nothing ? NoTangent() : begin
+#             out = similar(w)
+#             Δs = sd === nothing ? Δ : Δ .* sd'
+#             check(@ccall libgnnmp.gnnmp_edge_dot_plan_f32(plan(g).handle::Ptr{Cvoid}, devptr(Δs)::Ptr{Cvoid},
+#                       devptr(xj)::Ptr{Cvoid}, devptr(out)::Ptr{Cvoid}, D::Int64, stream_ptr()::Ptr{Cvoid})::Cint)
+#             out
+#         end
+#         return NoTangent(), NoTangent(), NoTangent(), Δx, Δw
+#     end
+#     return y, pullback
+# end
+# (max / min: gnnmp_propagate_maxmin_grad_f32(plan_t(g).handle, xj, y, Δ, Δx, D, stream).)
+
 end # module

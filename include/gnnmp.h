@@ -261,6 +261,11 @@ int gnnmp_dense_f32(const float *x1, const float *W1, int64_t D1, int64_t ldw1, 
 int gnnmp_edge_dot_f32(const float *a_dst, const float *b_src, const void *src, const void *dst,
                        int idx_bytes, int index_base, int64_t n_edges, int64_t D, float *out,
                        gnnmp_stream_t stream);
+/* The same per-edge dot products walked in the plan's destination-sorted order (the destination row stays in registers
+ * for all of its edges: half the traffic); out[n_edges] is written in ORIGINAL edge order, plan-added self loops
+ * produce no output.  D * 4 bytes must fit one wave of 16-byte lanes (D <= 256), else GNNMP_EUNSUPPORTED. */
+int gnnmp_edge_dot_plan_f32(gnnmp_graph_t *plan, const float *a_dst, const float *b_src, float *out,
+                            int64_t D, gnnmp_stream_t stream);
 /* Adjoint of propagate(copy_xj, g, max|min) w.r.t. xj on the transposed plan:
  *   Δx_j[d] = Σ_{k: s_k = j, edge order} (x_j[d] == y_{t_k}[d]) ? Δ_{t_k}[d] : 0      (ties all receive Δ, like NNlib)
  * x: forward input [n][D], y: forward output, dy: incoming gradient, dx: output. */

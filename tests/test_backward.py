@@ -103,8 +103,9 @@ def test_hip_adjoints_vs_oracle(gm, oracle, D):
     check(bw.propagate_grad_xj(g, "+", dev(dy)).cpu().numpy(), dx)
     dxw, dw = oracle.grad_propagate("+", s, t, n, dy, x, w)
     check(bw.propagate_grad_xj(g, "+", dev(dy), w=dev(w)).cpu().numpy(), dxw)
-    got_dw = bw.propagate_grad_w(g, dev(dy), dev(x)).cpu().numpy()
-    assert np.abs(got_dw - dw).max() <= 1e-5 * np.abs(dw).max() * 4
+    for coo in (False, True):            # destination-sorted walk (plan) and plain COO-order kernel
+        got_dw = bw.propagate_grad_w(g, dev(dy), dev(x), coo_order=coo).cpu().numpy()
+        assert np.abs(got_dw - dw).max() <= 1e-5 * np.abs(dw).max() * 4
     # mean: multiply-by-reciprocal vs NNlib's division: tolerance
     dxm, _ = oracle.grad_propagate("mean", s, t, n, dy, x)
     got = bw.propagate_grad_xj(g, "mean", dev(dy)).cpu().numpy()

@@ -1,0 +1,33 @@
+#!/usr/bin/env python
+"""Times the adjoint kernels on the products shape (D = 100): dxj via the transposed plan, dw via edge_dot, max gradient."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "graphneuralnetworks.jl_amd")):
+    sys.path.insert(0, p)
+import torch, gnnmp
+from gnnmp import synth, backward as bw
+
+def t(fn, it=10):
+    fn(); torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(it)]
+    for a, b in ev:
+        a.record(); fn(); b.record()
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in ev)
+    return ts[len(ts) // 2]
+
+N, E, D = synth.PRODUCTS["N"], synth.PRODUCTS["E"], synth.PRODUCTS["D"]
+s, tt = synth.products_like()
+g = gnnmp.GNNGraph(torch.from_numpy(s).cuda(), torch.from_numpy(tt).cuda(), num_nodes=N, _validated=True)
+x = torch.randn((N, D), device="cuda"); dy = torch.randn((N, D), device="cuda"); w = torch.rand(E, device="cuda")
+y = gnnmp.propagate(gnnmp.copy_xj, g, "max", xj=x)
+fwd = t(lambda: gnnmp.propagate(gnnmp.copy_xj, g, "+", xj=x))
+dx = t(lambda: bw.propagate_grad_xj(g, "+", dy))
+dxw = t(lambda: bw.propagate_grad_xj(g, "+", dy, w=w))
+dw = t(lambda: bw.propagate_grad_w(g, dy, x))
+dwc = t(lambda: bw.propagate_grad_w(g, dy, x, coo_order=True))
+print(f"edge_dot: plan order {dw:.3f} ms, COO order {dwc:.3f} ms")
+dmax = t(lambda: bw.propagate_grad_xj(g, "max", dy, xj=x, y=y))
+b1 = E * (4 * D + 4) + N * (4 * D + 8)
+print(f"products D={D}: fwd(+) {fwd:.3f} ms | dxj(+) {dx:.3f} ms {b1/dx/1e6:.0f} GB/s | dxj(w) {dxw:.3f} ms | "
+      f"dw edge_dot {dw:.3f} ms {E*(8*D+20)/dw/1e6:.0f} GB/s | dxj(max) {dmax:.3f} ms {E*(8*D+4)/dmax/1e6:.0f} GB/s")
