@@ -121,6 +121,33 @@ __global__ void __launch_bounds__(256) segment_pool_kernel(const float *x, const
     }
 }
 
+// ---- small elementwise helpers so that no arithmetic of the layer bodies is left to the host framework --------------
+__global__ void __launch_bounds__(256) add_kernel(const float *a, const float *b, float *out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a[i] + b[i];
+}
+// out[n][c] = act( (Σ_h y[n][h][c]) / H + bias[c] )   — `mean(x, dims = 2)` of gat_conv with concat = false
+// (GNNlib/src/layers/conv.jl:143-147): heads summed in order h = 1..H, one true division, then σ.(x .+ bias)
+__global__ void __launch_bounds__(256) head_mean_kernel(const float *y, const float *bias, int act, float *out,
+                                                        int64_t N, int H, int C) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * C) return;
+    const int64_t n = i / C;
+    const int c = (int)(i - n * C);
+    const float *row = y + n * (int64_t)H * C + c;
+    float acc = row[0];
+    for (int h = 1; h < H; ++h) acc = acc + row[(int64_t)h * C];
+    float v = acc / (float)H;
+    if (bias) v = v + bias[c];
+    if (act == GNNMP_ACT_RELU) v = v < 0.0f ? 0.0f : v;
+    out[i] = v;
+}
+// flag[0] = 1 if idx[k] > idx[k+1] for some k
+__global__ void __launch_bounds__(256) unsorted_kernel(const void *idx, int idx_bytes, int64_t n, int *flag) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k + 1 < n && load_index(idx, k, idx_bytes, 0) > load_index(idx, k + 1, idx_bytes, 0)) *flag = 1;
+}
+
 }  // namespace gnnmp
 
 using namespace gnnmp;
@@ -168,6 +195,51 @@ int gnnmp_scatter_atomic_f32(int aggr, const float *m, const void *idx, int idx_
     else
         scatter_atomic_kernel<OP_MIN><<<nb, 256, 0, stream>>>(m, idx, idx_bytes, index_base, K, out, (int)D);
     GNNMP_LAUNCH_CHECK("scatter_atomic_kernel");
+    return GNNMP_OK;
+}
+
+int gnnmp_add_f32(const float *a, const float *b, float *out, int64_t n, gnnmp_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n < 0) return fail(GNNMP_EINVAL, "add: negative n");
+    if (n == 0) return GNNMP_OK;
+    if (!a || !b || !out) return fail(GNNMP_EINVAL, "add: null pointer");
+    add_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(a, b, out, n);
+    GNNMP_LAUNCH_CHECK("add_kernel");
+    return GNNMP_OK;
+}
+
+int gnnmp_head_mean_f32(const float *y, const float *bias, int act, float *out, int64_t N, int64_t H,
+                        int64_t C, gnnmp_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (N < 0 || H <= 0 || C <= 0) return fail(GNNMP_EINVAL, "head_mean: bad size");
+    if (act != GNNMP_ACT_IDENTITY && act != GNNMP_ACT_RELU) return fail(GNNMP_EINVAL, "head_mean: bad act %d", act);
+    if (N == 0) return GNNMP_OK;
+    if (!y || !out) return fail(GNNMP_EINVAL, "head_mean: null pointer");
+    head_mean_kernel<<<(unsigned)((N * C + 255) / 256), 256, 0, stream>>>(y, bias, act, out, N, (int)H, (int)C);
+    GNNMP_LAUNCH_CHECK("head_mean_kernel");
+    return GNNMP_OK;
+}
+
+int gnnmp_is_sorted(const void *idx, int idx_bytes, int64_t n, int *result_host, gnnmp_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (idx_bytes != 4 && idx_bytes != 8) return fail(GNNMP_EINVAL, "is_sorted: idx_bytes %d", idx_bytes);
+    if (!result_host || n < 0) return fail(GNNMP_EINVAL, "is_sorted: bad argument");
+    *result_host = 1;
+    if (n < 2) return GNNMP_OK;
+    if (!idx) return fail(GNNMP_EINVAL, "is_sorted: null pointer");
+    int *flag = nullptr;
+    GNNMP_HIP(hipMalloc((void **)&flag, sizeof(int)));
+    hipError_t e = hipMemsetAsync(flag, 0, sizeof(int), stream);
+    if (e == hipSuccess) {
+        unsorted_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(idx, idx_bytes, n, flag);
+        e = hipGetLastError();
+    }
+    int h = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    (void)hipFree(flag);
+    if (e != hipSuccess) return hip_fail(e, "is_sorted");
+    *result_host = h ? 0 : 1;
     return GNNMP_OK;
 }
 

@@ -29,6 +29,7 @@ SYMBOLS = (
     "gnnmp_bias_act_f32",
     "gnnmp_segment_pool_f32", "gnnmp_dense_f32",
     "gnnmp_edge_dot_f32", "gnnmp_edge_dot_plan_f32", "gnnmp_propagate_maxmin_grad_f32",
+    "gnnmp_head_mean_f32", "gnnmp_add_f32", "gnnmp_is_sorted",
 )
 
 
@@ -78,6 +79,9 @@ def load():
         "gnnmp_dense_f32": [vp, vp, i64, i64, vp, vp, i64, i64, i, vp, i, vp, i64, i64, vp],
         "gnnmp_edge_dot_f32": [vp, vp, vp, vp, i, i, i64, i64, vp, vp],
         "gnnmp_edge_dot_plan_f32": [vp, vp, vp, vp, i64, vp],
+        "gnnmp_head_mean_f32": [vp, vp, i, vp, i64, i64, i64, vp],
+        "gnnmp_add_f32": [vp, vp, vp, i64, vp],
+        "gnnmp_is_sorted": [vp, i, i64, ctypes.POINTER(i), vp],
         "gnnmp_propagate_maxmin_grad_f32": [vp, vp, vp, vp, vp, i64, vp],
         "gnnmp_tune": [i, i],
     }

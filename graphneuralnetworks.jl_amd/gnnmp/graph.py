@@ -225,7 +225,12 @@ def degree(g: GNNGraph, T=torch.float32, dir: str = "in", edge_weight=True):
                 g._plans["T"] = plan
         deg = torch.empty(g.num_nodes, dtype=torch.float32, device=g.device)
         L.check(lib.gnnmp_degree_f32(plan.handle, L.ptr(w), L.ptr(deg), L.stream_ptr()))
-        out = deg if out is None else out + deg
+        if out is None:
+            out = deg
+        else:
+            both = torch.empty_like(deg)
+            L.check(lib.gnnmp_add_f32(L.ptr(out), L.ptr(deg), L.ptr(both), deg.numel(), L.stream_ptr()))
+            out = both
     if T is not None and T != torch.float32:
         out = out.to(T)
     return out

@@ -246,12 +246,11 @@ def gat_conv(l, g: GNNGraph, x, e=None, return_alpha=False, exact_order=False):
     if fuse_tail:
         y = post(out) if post is not None else out
     else:
-        # mean(x, dims = 2) over heads (conv.jl:143-145): H is tiny; torch strided adds are plumbing-level elementwise
-        y3 = out.view(N, H, C)
-        acc = y3[:, 0, :].clone()
-        for h in range(1, H):
-            acc = acc + y3[:, h, :]
-        y = bias_act(acc / float(H), l.bias, l.sigma)
+        # mean(x, dims = 2) over heads, then σ.(x .+ bias) (conv.jl:143-147): one small kernel
+        y = torch.empty((N, C), dtype=torch.float32, device=x.device)
+        bb = None if l.bias is None or l.bias is False else l.bias.contiguous()
+        L.check(lib.gnnmp_head_mean_f32(L.ptr(out), L.ptr(bb), code, L.ptr(y), N, H, C, L.stream_ptr()))
+        y = post(y) if post is not None else y
     return (y, alpha) if return_alpha else y
 
 

@@ -30,7 +30,14 @@ def reduce_nodes(aggr, g, x, num_graphs=None, sorted_indicator=None):
         base = 1
         # NNlib.scatter without dstsize sizes the output by maximum(idx)
         G = int(gi.max()) - base + 1 if num_graphs is None else num_graphs
-        is_sorted = bool(sorted_indicator) if sorted_indicator is not None else bool((gi[1:] >= gi[:-1]).all())
+        if sorted_indicator is not None:
+            is_sorted = bool(sorted_indicator)
+        else:
+            import ctypes
+            res = ctypes.c_int(0)
+            L.check(L.load().gnnmp_is_sorted(L.ptr(gi), 8 if gi.dtype == torch.int64 else 4, gi.numel(), ctypes.byref(res),
+                                             L.stream_ptr()))
+            is_sorted = bool(res.value)
     xf = _flat(x)
     if not is_sorted:
         return _scatter_plan(aggr, x, _idx_plan(gi, G, base))

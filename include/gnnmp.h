@@ -217,6 +217,16 @@ int gnnmp_gat_conv_f32(gnnmp_graph_t *plan, const float *Wx_src, const float *Wx
                        float negative_slope, const float *bias, int act, float *out, int64_t H,
                        int64_t C, gnnmp_stream_t stream);
 
+/* out[n][c] = act( mean_h y[n][h][c] + bias[c] ) — the concat = false tail of gat_conv (`mean(x, dims = 2)`,
+ * GNNlib/src/layers/conv.jl:143-147): heads added in order, one division by H, then σ.(x .+ bias). */
+int gnnmp_head_mean_f32(const float *y, const float *bias, int act, float *out, int64_t N, int64_t H,
+                        int64_t C, gnnmp_stream_t stream);
+/* out = a + b (n floats) — degree(g; dir = :both) = out-degree + in-degree (GNNGraphs/src/query.jl:362-367). */
+int gnnmp_add_f32(const float *a, const float *b, float *out, int64_t n, gnnmp_stream_t stream);
+/* *result_host = 1 iff idx[0..n) is non-decreasing (is a graph_indicator one that `batch` could have built?).
+ * Synchronises the stream (graph prep). */
+int gnnmp_is_sorted(const void *idx, int idx_bytes, int64_t n, int *result_host, gnnmp_stream_t stream);
+
 /* out[n][:] = act(x[n][:] + bias[:])  — the `σ.(x .+ bias)` tail of a layer body when it is not fused into
  * the producing kernel (GNNlib/src/layers/conv.jl:71,147).  bias nullable; out may alias x. */
 int gnnmp_bias_act_f32(const float *x, const float *bias, int act, float *out, int64_t N, int64_t D,
