@@ -417,7 +417,7 @@ extern "C" int gnnmp_dense_f32(const float *x1, const float *W1, int64_t D1, int
             const int cols_fit = (int)((budget - wbytes) / ((size_t)wv * 32 * sizeof(float)));  // floats per region row
             int kfit = ((cols_fit - 1) & ~3);               // leave the +1 (odd leading dimension)
             kfit = std::min(kfit, (kmax + 3) & ~3);
-            if (kfit >= ((kmax + 3) & ~3) || kfit >= 48) {
+            if (kfit >= ((kmax + 3) & ~3) || kfit >= 48) {   // (24-column chunks measured slower than 4 waves x 44)
                 const int nkc = (kmax + kfit - 1) / kfit;     // balanced chunks, multiple of 4
                 ks = (((kmax + nkc - 1) / nkc) + 3) & ~3;
                 waves = wv;
