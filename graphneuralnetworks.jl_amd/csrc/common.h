@@ -31,8 +31,10 @@ enum Knob {
     KNOB_LONG_ROW = 4,     // long-row threshold (default GNNMP_LONG_ROW)
     KNOB_BLOCK_WAVES = 5,  // waves per block in the row kernels (default 4)
     KNOB_DENSE_GENERIC = 6,  // 1 = force the K-chunked dense kernel (default 0: W-resident kernel when it fits)
-    KNOB_DENSE_PREFETCH = 7,  // 1 = register prefetch of the next x tile in the W-resident dense kernel
-                              // (default 0: measured SLOWER on MI355X, 1.13 vs 0.82 ms at 2.4M x 100 => 100)
+    KNOB_DENSE_PREFETCH = 7,  // W-resident dense kernel scheduling: bit 4 = per-SIMD matrix-pipe token, low 4 bits =
+                              // start skew of waves 4-7 in s_sleep(127) units.  Default 17 (token + 1): 0.83 -> 0.72 ms
+                              // at 2.4M x 100 => 100.  (A register prefetch of the next tile was tried and removed:
+                              // 1.13 vs 0.82 ms.)
     KNOB_COUNT = 8
 };
 int knob(int k);

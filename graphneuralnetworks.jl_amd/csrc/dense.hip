@@ -159,6 +159,8 @@ struct DenseWArgs {
     int waves;     // waves per block
     int xld;       // leading dimension of the wave-private x image (odd)
     int old_;      // leading dimension of the wave-private output image (multiple of 4)
+    int skew;      // s_sleep(127) repetitions for waves 4-7 before their first tile (0 = none)
+    int token;     // 1 = serialise the k-loops of the two waves of a SIMD with an LDS token
     int tp;        // output column tiles per epilogue pass
     int ks;        // columns of x staged per k-chunk (multiple of 4; = K rounded up when the whole tile fits)
     int region;    // floats per wave region
@@ -178,6 +180,10 @@ __global__ void __launch_bounds__(512) dense_wlds_kernel(const DenseWArgs w) {
     const int ncols = min(NT * 32, a.Dout - n0);
     float *Wt = lds;
     float *reg = lds + (size_t)w.ktot_pad * WLD + (size_t)wave * w.region;
+    // one matrix-pipe token per SIMD (waves i and i + 4 of an 8-wave block share a SIMD), after the wave regions
+    int *tok = reinterpret_cast<int *>(lds + (size_t)w.ktot_pad * WLD + (size_t)w.waves * w.region) + (wave & 3);
+    const bool paired = w.waves == 8 && w.token != 0;
+    if (t < 4) reinterpret_cast<int *>(lds + (size_t)w.ktot_pad * WLD + (size_t)w.waves * w.region)[t] = 0;
 
     // ---- W^T image, once per block: Wt[koff + k][j] = W(n0 + j, k) ----
     {
@@ -222,6 +228,13 @@ __global__ void __launch_bounds__(512) dense_wlds_kernel(const DenseWArgs w) {
         const int c = min(nt * 32 + (lane & 31), ncols - 1);
         bcol[nt] = a.bias ? a.bias[n0 + c] : 0.0f;
     }
+    // Phase skew.  PMC (SQ_WAIT_INST_ANY = exactly 2 x the MFMA time per wave) showed the two waves of a SIMD running
+    // in LOCKSTEP: both in the k-loop (alternating on the matrix pipe), then both staging (pipe idle) — 50 % pipe
+    // utilisation.  Delaying the second wave of every SIMD (waves 4-7 of an 8-wave block) by about half a tile period
+    // puts one wave's staging under the other's MFMAs.  Performance only: nothing depends on the timing.
+    if (w.skew > 0 && w.waves == 8 && __builtin_amdgcn_readfirstlane(wave) >= 4) {
+        for (int i = 0; i < w.skew; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     const int64_t tile_stride = (int64_t)gridDim.x * w.waves;
     for (int64_t tile = (int64_t)blockIdx.x * w.waves + wave; tile < n_tiles; tile += tile_stride) {
         const int64_t m0 = tile * 32;
@@ -245,23 +258,31 @@ __global__ void __launch_bounds__(512) dense_wlds_kernel(const DenseWArgs w) {
                 if (vec && (kcn & 3) == 0) {
                     // batches of SB independent 16-byte loads per lane, THEN the LDS writes: a plain load->write loop
                     // serialises one HBM round trip per iteration (measured: waves parked 42 % of their cycles)
-                    constexpr int SB = 8;
-                    const int q = kcn >> 2;                  // float4 per row in this chunk
-                    const int n4 = 32 * q;
-                    for (int i0 = lane; i0 < n4; i0 += 64 * SB) {
+                    // Lane -> (row, column) by shifts, no integer division: lpr = 2^k >= q lanes cover one row's q float4
+                    // (25 of 32 active at K = 100), 64 / lpr rows per load instruction.  (The linear i -> (i / q, i % q)
+                    // mapping cost ~40 VALU per element: 2 200 non-MFMA instructions per 200 MFMAs, PMC in profiles/.)
+                    constexpr int SB = 16;                   // the whole 32 x 128 chunk in ONE batch: one HBM round trip per tile
+                    const int q = kcn >> 2;                  // float4 per row in this chunk (<= 32: ks <= 128)
+                    int l2 = 0;
+                    while ((1 << l2) < q) ++l2;
+                    const int rpi = 64 >> l2;                // rows per instruction
+                    const int c4 = lane & ((1 << l2) - 1);
+                    const int rsub = lane >> l2;
+                    const bool on = c4 < q && rsub < 32;     // (rpi = 64 when q = 1: only the first 32 lanes hold rows)
+                    const float *xl = x + (int64_t)min(rsub, 31) * K + kc0 + (c4 < q ? c4 : 0) * 4;
+                    float *dl = reg + rsub * XLD + c4 * 4;
+                    const int nit = rpi >= 32 ? 1 : 32 / rpi;
+                    for (int it0 = 0; it0 < nit; it0 += SB) {
                         float4 v[SB];
-                        int dsto[SB];
 #pragma unroll
                         for (int u = 0; u < SB; ++u) {       // unconditional (clamped) loads: no per-element branch + wait
-                            const int i = min(i0 + u * 64, n4 - 1);
-                            const int row = i / q, c4 = i - row * q;
-                            v[u] = *reinterpret_cast<const float4 *>(x + (int64_t)row * K + kc0 + c4 * 4);
-                            dsto[u] = (i0 + u * 64 < n4) ? row * XLD + c4 * 4 : -1;
+                            const int it = min(it0 + u, nit - 1);
+                            v[u] = *reinterpret_cast<const float4 *>(xl + (int64_t)it * rpi * K);
                         }
 #pragma unroll
                         for (int u = 0; u < SB; ++u) {
-                            if (dsto[u] >= 0) {
-                                float *d = reg + dsto[u];
+                            if (on && it0 + u < nit) {
+                                float *d = dl + (it0 + u) * rpi * XLD;
                                 d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
                             }
                         }
@@ -283,23 +304,50 @@ __global__ void __launch_bounds__(512) dense_wlds_kernel(const DenseWArgs w) {
                 // the MFMAs of k-step kk issue (hipcc leaves the plain loop read -> wait -> 2 MFMA -> read -> wait -> 2 MFMA)
                 const float *xa = reg + (lane & 31) * XLD + (lane >> 5);
                 const float *wb = Wt + (koff + kc0 + (lane >> 5)) * WLD + (lane & 31);
-                float av = xa[0];
-                float bv[NT];
+                // Matrix-pipe token.  PMC showed the two waves of a SIMD in LOCKSTEP (SQ_WAIT_INST_ANY = exactly twice the
+                // MFMA time per wave: both alternate on the pipe during their k-loops, then both stage while the pipe idles:
+                // 50 % utilisation).  Taking a per-SIMD token around the k-loop serialises the two k-loops, so each runs at
+                // the full issue rate while the partner stages / stores: the pair falls into alternation by itself.
+                if (paired) {
+                    if (lane == 0) {
+                        while (atomicCAS(tok, 0, 1) != 0) __builtin_amdgcn_s_sleep(2);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+                // two register sets in ping-pong (no moves): set 1 is loaded while set 0 feeds the matrix pipe and back
+                float a0 = xa[0], a1;
+                float b0[NT], b1[NT];
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bv[nt] = wb[nt * 32];
-                for (int kk = 0; kk < kcp; kk += 2) {
-                    const int kn = (kk + 2 < kcp) ? kk + 2 : kk;   // last step re-reads itself (harmless)
-                    const float an = xa[kn];
-                    float bn[NT];
-                    const float *wk = wb + kn * WLD;
+                for (int nt = 0; nt < NT; ++nt) b0[nt] = wb[nt * 32];
+                int kk = 0;
+                for (; kk + 4 <= kcp; kk += 4) {
+                    {
+                        const float *wk = wb + (kk + 2) * WLD;
+                        a1 = xa[kk + 2];
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) bn[nt] = wk[nt * 32];
+                        for (int nt = 0; nt < NT; ++nt) b1[nt] = wk[nt * 32];
+                    }
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
-                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[nt], acc[nt], 0, 0, 0);
-                    av = an;
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0[nt], acc[nt], 0, 0, 0);
+                    {
+                        const int kn = min(kk + 4, kcp - 2);     // past the end: re-read the last step (unused)
+                        const float *wk = wb + kn * WLD;
+                        a0 = xa[kn];
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) bv[nt] = bn[nt];
+                        for (int nt = 0; nt < NT; ++nt) b0[nt] = wk[nt * 32];
+                    }
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1[nt], acc[nt], 0, 0, 0);
+                }
+                if (kk < kcp) {   // kcp % 4 == 2: one k-step left, its operands are already in set 0
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0[nt], acc[nt], 0, 0, 0);
+                }
+                if (paired) {
+                    if (lane == 0) atomicExch(tok, 0);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -333,12 +381,17 @@ __global__ void __launch_bounds__(512) dense_wlds_kernel(const DenseWArgs w) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             float *o = a.out + m0 * a.Dout + n0 + c_lo;
             if (vec_ok && (pc & 3) == 0) {
-                const int c4n = pc >> 2;
-                const int total = rows * c4n;
-                for (int i = lane; i < total; i += 64) {
-                    const int row = i / c4n, c4 = i - row * c4n;
-                    const float4 v = *reinterpret_cast<const float4 *>(reg + row * OLD + c4 * 4);
-                    *reinterpret_cast<float4 *>(o + (int64_t)row * a.Dout + c4 * 4) = v;
+                const int c4n = pc >> 2;                      // <= 32 float4 per row: same shift mapping as the staging
+                int l2 = 0;
+                while ((1 << l2) < c4n) ++l2;
+                const int rpi = 64 >> l2;
+                const int c4 = lane & ((1 << l2) - 1);
+                const int rsub = lane >> l2;
+                if (c4 < c4n) {
+                    for (int row = rsub; row < rows; row += rpi) {
+                        const float4 v = *reinterpret_cast<const float4 *>(reg + row * OLD + c4 * 4);
+                        *reinterpret_cast<float4 *>(o + (int64_t)row * a.Dout + c4 * 4) = v;
+                    }
                 }
             } else {
                 const int total = rows * pc;
@@ -407,7 +460,7 @@ extern "C" int gnnmp_dense_f32(const float *x1, const float *W1, int64_t D1, int
         const int nt_max = full > 0 ? 4 : (rem + 31) / 32;
         const int ncols_max = full > 0 ? 128 : rem;
         const size_t wbytes = (size_t)ktot * (size_t)(nt_max * 32 + 1) * sizeof(float);
-        const size_t budget = 160 * 1024;
+        const size_t budget = 160 * 1024 - 64;   // 4 pipe tokens live after the wave regions
         // Wave regions: prefer 8 waves per CU (two per SIMD: one wave's staging hides under the other's MFMAs).  If the
         // whole 32 x K image does not leave room for 8 regions, stage x in k-chunks (ks columns at a time); only if even
         // 64-column chunks do not fit, fall back to 4 waves with the largest chunk that fits.
@@ -417,6 +470,7 @@ extern "C" int gnnmp_dense_f32(const float *x1, const float *W1, int64_t D1, int
             const int cols_fit = (int)((budget - wbytes) / ((size_t)wv * 32 * sizeof(float)));  // floats per region row
             int kfit = ((cols_fit - 1) & ~3);               // leave the +1 (odd leading dimension)
             kfit = std::min(kfit, (kmax + 3) & ~3);
+            kfit = std::min(kfit, 128);                      // <= 32 float4 per staged row (shift-mapped staging)
             if (kfit >= ((kmax + 3) & ~3) || kfit >= 48) {   // (24-column chunks measured slower than 4 waves x 44)
                 const int nkc = (kmax + kfit - 1) / kfit;     // balanced chunks, multiple of 4
                 ks = (((kmax + nkc - 1) / nkc) + 3) & ~3;
@@ -443,10 +497,12 @@ extern "C" int gnnmp_dense_f32(const float *x1, const float *W1, int64_t D1, int
             w.old_ = old_;
             w.tp = tp;
             w.ks = ks;
+            w.skew = knob(KNOB_DENSE_PREFETCH) & 15;          // experiment knob (slot 7): low 4 bits = s_sleep(127) count,
+            w.token = (knob(KNOB_DENSE_PREFETCH) >> 4) & 1;   //                           bit 4 = matrix-pipe token
             w.region = (int)region;
             w.ktot_pad = ktot;
             const int64_t n_row_tiles = (N + 31) / 32;
-            const size_t lds_bytes = wbytes + (size_t)waves * region * sizeof(float);
+            const size_t lds_bytes = wbytes + (size_t)waves * region * sizeof(float) + 16;   // + 4 pipe tokens
             if (full > 0) {
                 w.n0 = 0;
                 if (int rc = launch_wlds<4>(w, lds_bytes, full, n_row_tiles, stream)) return rc;
