@@ -260,7 +260,7 @@ static int launch_gat(GatArgs a, hipStream_t stream) {
     const int G = 1 << a.log2g;
     const int rpw = 64 / G;
     int waves = knob(KNOB_BLOCK_WAVES);
-    if (waves < 1 || waves > 4) waves = 4;
+    if (waves < 1 || waves > 4) waves = 1;   // auto (see gat_fused.hip)
     a.waves = waves;
     const int rows_per_block = rpw * waves;
     const int64_t chunks = ((int64_t)a.n_rows + rows_per_block - 1) / rows_per_block;

@@ -29,13 +29,14 @@ enum Knob {
     KNOB_UNROLL = 2,       // 0 = auto (8: measured best on both bench shapes), else 2|4|8
     KNOB_XCD_REMAP = 3,    // 0 = off, 1 = auto (default: only when the gathered matrix fits the Infinity Cache), 2 = on
     KNOB_LONG_ROW = 4,     // long-row threshold (default GNNMP_LONG_ROW)
-    KNOB_BLOCK_WAVES = 5,  // waves per block in the row kernels (default 4)
+    KNOB_BLOCK_WAVES = 5,  // waves per block in the row kernels: 0 = auto (propagate 4, GAT 1), else 1..4
     KNOB_DENSE_GENERIC = 6,  // 1 = force the K-chunked dense kernel (default 0: W-resident kernel when it fits)
     KNOB_DENSE_PREFETCH = 7,  // W-resident dense kernel scheduling: bit 4 = per-SIMD matrix-pipe token, low 4 bits =
                               // start skew of waves 4-7 in s_sleep(127) units.  Default 17 (token + 1): 0.83 -> 0.72 ms
                               // at 2.4M x 100 => 100.  (A register prefetch of the next tile was tried and removed:
                               // 1.13 vs 0.82 ms.)
-    KNOB_COUNT = 8
+    KNOB_GAT_FAST_EXP = 8,   // 1 = v_exp_f32-based exp in the one-pass GAT kernel (experiment; default 0 = accurate expf)
+    KNOB_COUNT = 12
 };
 int knob(int k);
 

@@ -38,6 +38,7 @@ struct GatFusedArgs {
     int log2g;
     int lph;              // lanes per head = C / VEC (power of two)
     int act;
+    int fast_exp;
     float slope;
     int long_thresh;
     int cpx;
@@ -45,6 +46,7 @@ struct GatFusedArgs {
 };
 
 __device__ __forceinline__ float lrelu(float x, float slope) { return x > 0.0f ? x : x * slope; }
+__device__ __forceinline__ float gexp(float x, int fast) { return fast ? __expf(x) : expf(x); }
 
 // sum over the lanes of one head (adjacent, power-of-two count): every lane ends with the same bits
 __device__ __forceinline__ float head_sum(float d, int lph) {
@@ -82,13 +84,13 @@ __device__ __forceinline__ void gat_online_range(const GatFusedArgs &a, int beg,
                     d = head_sum(d, a.lph);
                     const float l = lrelu(sd + d, a.slope);
                     if (l > m) {  // the running max grows: rescale what has been accumulated (exp(-inf) = 0 first time)
-                        const float sc = expf(m - l);
+                        const float sc = gexp(m - l, a.fast_exp);
                         den *= sc;
 #pragma unroll
                         for (int q = 0; q < VEC; ++q) acc[q] *= sc;
                         m = l;
                     }
-                    const float pe = expf(l - m);
+                    const float pe = gexp(l - m, a.fast_exp);
                     den += pe;
 #pragma unroll
                     for (int q = 0; q < VEC; ++q) acc[q] = fmaf(pe, v[u][q], acc[q]);
@@ -238,7 +240,8 @@ static int launch_gat_fused(GatFusedArgs a, hipStream_t stream) {
     const int G = 1 << a.log2g;
     const int rpw = 64 / G;
     int waves = knob(KNOB_BLOCK_WAVES);
-    if (waves < 1 || waves > 4) waves = 4;
+    if (waves < 1 || waves > 4) waves = 1;   // auto: single-wave blocks (measured 5.21 vs 5.41 ms on products: finer
+                                              // grained retirement for a kernel whose rows differ 100x in length)
     a.waves = waves;
     const int rows_per_block = rpw * waves;
     const int64_t nvirt = (int64_t)a.n_rows + a.n_chunks;
@@ -327,6 +330,7 @@ extern "C" int gnnmp_gat_conv_f32(gnnmp_graph_t *plan, const float *Wx_src, cons
     while ((1 << g.log2g) < lanes) ++g.log2g;  // one feature tile: the head butterfly needs the whole row in one group
     g.lph = lph;
     g.act = act;
+    g.fast_exp = knob(KNOB_GAT_FAST_EXP);
     g.slope = negative_slope;
     g.long_thresh = plan->long_thresh;
     g.cpx = 0;
