@@ -1,0 +1,194 @@
+// dense_backward.hip — adjoints of the dense part of the layer bodies ("next"):
+//   y = σ.(W * x .+ b)   =>   Δz = Δy .* σ'(z),   ΔW = Δz * x',   Δb = sum(Δz, dims = 2),   Δx = W' * Δz
+// Δx is the FORWARD kernel with the weight read transposed (gnnmp_dense_f32(Δz, W, w_layout = 1)).  New here:
+//   act_grad_kernel   Δz = Δy .* (y > 0)            (NNlib: relu'(x) = x > 0; y > 0 <=> x > 0)
+//   colsum_*          Δb, deterministic two-stage column sums
+//   dense_gradw_*     ΔW[o][k] = Σ_n Δz[n][o] * x[n][k]: a GEMM whose reduction dimension is N (millions).  Both MFMA
+//                     operands of v_mfma_f32_32x32x2_f32 are then read straight from HBM in their natural row-major
+//                     layout (lane l holds Δz[n + l/32][o0 + l%32] and x[n + l/32][k0 + l%32]: 128-byte segments), no LDS.
+//                     Each block reduces a contiguous slab of rows into a private partial ΔW; a second kernel folds the
+//                     partials in slab order (no atomics: run-to-run identical).
+#include <algorithm>
+
+#include "common.h"
+
+namespace gnnmp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ void __launch_bounds__(256) act_grad_kernel(const float *dy, const float *y, int act, float *dz,
+                                                       int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float g = dy[i];
+    dz[i] = (act == GNNMP_ACT_RELU) ? (y[i] > 0.0f ? g : 0.0f) : g;
+}
+
+// stage 1: block b sums rows [b*R, (b+1)*R) of x[N][D] for every column -> part[b][D]
+__global__ void __launch_bounds__(256) colsum_partial_kernel(const float *x, int64_t N, int D, int64_t R,
+                                                             float *part) {
+    const int64_t r0 = (int64_t)blockIdx.x * R;
+    const int64_t r1 = min(N, r0 + R);
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+        float acc = 0.0f;
+        int64_t r = r0;
+        for (; r + 8 <= r1; r += 8) {          // 8 independent loads in flight, added in row order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = x[(r + u) * D + d];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = acc + v[u];
+        }
+        for (; r < r1; ++r) acc = acc + x[r * D + d];
+        part[(int64_t)blockIdx.x * D + d] = acc;
+    }
+}
+__global__ void __launch_bounds__(256) fold_partials_kernel(const float *part, int nparts, int64_t len,
+                                                            float *out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= len) return;
+    float acc = 0.0f;
+    for (int p = 0; p < nparts; ++p) acc = acc + part[(int64_t)p * len + i];
+    out[i] = acc;
+}
+
+struct GradWArgs {
+    const float *dz;   // [N][Dout]
+    const float *x;    // [N][K]
+    float *part;       // [slabs][Dout][K]
+    int64_t N;
+    int64_t rows_per_slab;
+    int Dout, K;
+};
+
+// block = 4 waves; wave w owns output row tile (blockIdx.y * 4 + w) (32 rows of ΔW = 32 columns of Δz) and the four
+// column tiles blockIdx.z * 4 .. + 3 (128 columns of x).  RP row pairs are loaded before their MFMAs are issued.
+template <int RP>
+__global__ void __launch_bounds__(256) dense_gradw_kernel(const GradWArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int o0 = ((int)blockIdx.y * 4 + wave) * 32;          // ΔW rows (Δz columns) of this wave
+    const int k0 = (int)blockIdx.z * 128;                       // ΔW columns (x columns) of this block
+    if (o0 >= a.Dout) return;
+    const int half = lane >> 5, li = lane & 31;
+    const bool o_ok = o0 + li < a.Dout;
+    bool k_ok[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) k_ok[t] = k0 + t * 32 + li < a.K;
+    f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    const int64_t n0 = (int64_t)blockIdx.x * a.rows_per_slab;
+    const int64_t n1 = min(a.N, n0 + a.rows_per_slab);
+    const float *dzp = a.dz + (o_ok ? o0 + li : 0);
+    const float *xp = a.x + k0 + li;
+    for (int64_t n = n0; n < n1; n += 2 * RP) {
+        float av[RP], bv[RP][4];
+#pragma unroll
+        for (int p = 0; p < RP; ++p) {                            // unconditional, clamped loads; masked afterwards
+            const int64_t row = n + 2 * p + half;
+            const int64_t rc = min(row, a.N - 1);
+            const bool r_ok = row < n1;
+            const float va = dzp[rc * a.Dout];
+            av[p] = (r_ok && o_ok) ? va : 0.0f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float vb = xp[rc * a.K + (k_ok[t] ? t * 32 : 0)];
+                bv[p][t] = (r_ok && k_ok[t]) ? vb : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < RP; ++p)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p], bv[p][t], acc[t], 0, 0, 0);
+    }
+    // C/D layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    float *part = a.part + (int64_t)blockIdx.x * a.Dout * a.K;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int col = k0 + t * 32 + li;
+        if (col >= a.K) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = o0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (row < a.Dout) part[(int64_t)row * a.K + col] = acc[t][r];
+        }
+    }
+}
+
+static int gradw_slabs(int64_t N) {
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int64_t by_rows = (N + 511) / 512;                      // at least 512 rows per slab
+    return (int)std::max<int64_t>(1, std::min<int64_t>(2 * (int64_t)cus, by_rows));
+}
+
+}  // namespace gnnmp
+
+using namespace gnnmp;
+
+extern "C" {
+
+int gnnmp_act_grad_f32(const float *dy, const float *y, int act, float *dz, int64_t n, gnnmp_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n < 0) return fail(GNNMP_EINVAL, "act_grad: negative n");
+    if (act != GNNMP_ACT_IDENTITY && act != GNNMP_ACT_RELU) return fail(GNNMP_EINVAL, "act_grad: bad act %d", act);
+    if (n == 0) return GNNMP_OK;
+    if (!dy || !dz || (act == GNNMP_ACT_RELU && !y)) return fail(GNNMP_EINVAL, "act_grad: null pointer");
+    act_grad_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(dy, y, act, dz, n);
+    GNNMP_LAUNCH_CHECK("act_grad_kernel");
+    return GNNMP_OK;
+}
+
+int64_t gnnmp_dense_grad_workspace(int64_t N, int64_t Dout, int64_t K) {
+    if (N <= 0 || Dout <= 0 || K <= 0) return 0;
+    return (int64_t)gradw_slabs(N) * std::max(Dout * K, Dout);
+}
+
+int gnnmp_dense_grad_w_f32(const float *dz, const float *x, int64_t N, int64_t Dout, int64_t K, float *dW,
+                           float *db, float *workspace, int64_t workspace_floats, gnnmp_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (N < 0 || Dout <= 0 || K <= 0 || Dout > (1 << 16) || K > (1 << 16)) return fail(GNNMP_EINVAL, "dense_grad_w: bad size");
+    if (!dW && !db) return fail(GNNMP_EINVAL, "dense_grad_w: nothing to compute");
+    if (N == 0) {
+        if (dW) GNNMP_HIP(hipMemsetAsync(dW, 0, sizeof(float) * Dout * K, stream));
+        if (db) GNNMP_HIP(hipMemsetAsync(db, 0, sizeof(float) * Dout, stream));
+        return GNNMP_OK;
+    }
+    if (!dz || (dW && !x) || !workspace) return fail(GNNMP_EINVAL, "dense_grad_w: null pointer");
+    const int slabs = gradw_slabs(N);
+    if (workspace_floats < gnnmp_dense_grad_workspace(N, Dout, K))
+        return fail(GNNMP_EINVAL, "dense_grad_w: workspace too small (%lld < %lld floats)", (long long)workspace_floats,
+                    (long long)gnnmp_dense_grad_workspace(N, Dout, K));
+    int64_t rps = (N + slabs - 1) / slabs;
+    rps = (rps + 1) & ~(int64_t)1;                               // even: row pairs never straddle slabs
+    if (dW) {
+        GradWArgs a;
+        a.dz = dz;
+        a.x = x;
+        a.part = workspace;
+        a.N = N;
+        a.rows_per_slab = rps;
+        a.Dout = (int)Dout;
+        a.K = (int)K;
+        dim3 grid((unsigned)slabs, (unsigned)((Dout + 127) / 128), (unsigned)((K + 127) / 128));
+        dense_gradw_kernel<4><<<grid, 256, 0, stream>>>(a);
+        GNNMP_LAUNCH_CHECK("dense_gradw_kernel");
+        const int64_t len = Dout * K;
+        fold_partials_kernel<<<(unsigned)((len + 255) / 256), 256, 0, stream>>>(workspace, slabs, len, dW);
+        GNNMP_LAUNCH_CHECK("fold_partials_kernel");
+    }
+    if (db) {
+        colsum_partial_kernel<<<(unsigned)slabs, 256, 0, stream>>>(dz, N, (int)Dout, rps, workspace);
+        GNNMP_LAUNCH_CHECK("colsum_partial_kernel");
+        fold_partials_kernel<<<(unsigned)((Dout + 255) / 256), 256, 0, stream>>>(workspace, slabs, Dout, db);
+        GNNMP_LAUNCH_CHECK("fold_partials_kernel");
+    }
+    return GNNMP_OK;
+}
+
+}  // extern "C"

@@ -30,6 +30,7 @@ SYMBOLS = (
     "gnnmp_segment_pool_f32", "gnnmp_dense_f32",
     "gnnmp_edge_dot_f32", "gnnmp_edge_dot_plan_f32", "gnnmp_propagate_maxmin_grad_f32",
     "gnnmp_head_mean_f32", "gnnmp_add_f32", "gnnmp_is_sorted",
+    "gnnmp_act_grad_f32", "gnnmp_dense_grad_workspace", "gnnmp_dense_grad_w_f32",
 )
 
 
@@ -83,12 +84,16 @@ def load():
         "gnnmp_add_f32": [vp, vp, vp, i64, vp],
         "gnnmp_is_sorted": [vp, i, i64, ctypes.POINTER(i), vp],
         "gnnmp_propagate_maxmin_grad_f32": [vp, vp, vp, vp, vp, i64, vp],
+        "gnnmp_act_grad_f32": [vp, vp, i, vp, i64, vp],
+        "gnnmp_dense_grad_w_f32": [vp, vp, i64, i64, i64, vp, vp, vp, i64, vp],
         "gnnmp_tune": [i, i],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
         fn.argtypes = args
         fn.restype = i
+    L.gnnmp_dense_grad_workspace.argtypes = [i64, i64, i64]
+    L.gnnmp_dense_grad_workspace.restype = i64
     _lib = L
     return L
 

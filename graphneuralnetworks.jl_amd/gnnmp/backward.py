@@ -121,3 +121,105 @@ def propagate_ad(g: GNNGraph, aggr, xj, w=None):
     """differentiable propagate(copy_xj | w_mul_xj, g, aggr; xj [, w]) — forward and backward both on the HIP kernels"""
     check_num_nodes(g, xj)
     return _PropagateFn.apply(xj, w, g, aggr)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# dense part and the whole GCNConv layer
+# ---------------------------------------------------------------------------------------------------------
+def _act_code(sigma):
+    from .layers import _act_code as ac
+    code, post = ac(sigma)
+    assert post is None, "the HIP adjoint covers identity and relu"
+    return code
+
+
+def act_grad(dy, y, sigma):
+    dz = torch.empty_like(dy)
+    L.check(L.load().gnnmp_act_grad_f32(L.ptr(dy), L.ptr(y), _act_code(sigma), L.ptr(dz), dy.numel(), L.stream_ptr()))
+    return dz
+
+
+def dense_grad_w(dz, x, need_w=True, need_b=True):
+    """(ΔW [Dout, K], Δb [Dout]) = (Δz' * x, colsum(Δz)) — fp32 MFMA, deterministic slab partials"""
+    if not need_w and not need_b:
+        return None, None
+    lib = L.load()
+    N, Dout = dz.shape
+    K = x.shape[1]
+    ws = torch.empty(max(1, lib.gnnmp_dense_grad_workspace(N, Dout, K)), dtype=torch.float32, device=dz.device)
+    dW = torch.empty((Dout, K), dtype=torch.float32, device=dz.device) if need_w else None
+    db = torch.empty(Dout, dtype=torch.float32, device=dz.device) if need_b else None
+    L.check(lib.gnnmp_dense_grad_w_f32(L.ptr(dz), L.ptr(x), N, Dout, K, L.ptr(dW), L.ptr(db), L.ptr(ws), ws.numel(),
+                                       L.stream_ptr()))
+    return dW, db
+
+
+def dense_grad_x(dz, W):
+    """Δx = Δz * W  ([N, Dout] x [Dout, K]): the forward kernel reading W transposed (w_layout = 1)"""
+    N, Dout = dz.shape
+    K = W.shape[1]
+    assert W.is_contiguous()
+    dx = torch.empty((N, K), dtype=torch.float32, device=dz.device)
+    L.check(L.load().gnnmp_dense_f32(L.ptr(dz), L.ptr(W), Dout, K, None, None, 0, 0, 1, None, L.ACT_IDENTITY, L.ptr(dx), N, K,
+                                     L.stream_ptr()))
+    return dx
+
+
+class _GCNConvFn(torch.autograd.Function):
+    """gcn_conv (GNNlib/src/layers/conv.jl:14-72, default norm, no edge weights) with HIP forward AND backward"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, g, sigma, add_self_loops):
+        from .layers import _inv_sqrt, bias_act, dense
+        lib = L.load()
+        plan = g.plan(add_self_loops)
+        d = torch.empty(g.num_nodes, dtype=torch.float32, device=g.device)
+        L.check(lib.gnnmp_degree_f32(plan.handle, None, L.ptr(d), L.stream_ptr()))
+        c = _inv_sqrt(d)
+
+        def P(h):
+            out = torch.empty((plan.n_dst, h.shape[1]), dtype=torch.float32, device=h.device)
+            L.check(lib.gnnmp_propagate_f32(plan.handle, L.COPY_XJ, L.SUM, L.ptr(h), None, L.ptr(c), L.ptr(c), L.ptr(out),
+                                            h.shape[1], L.stream_ptr()))
+            return out
+
+        Dout, Din = weight.shape
+        x = x.contiguous()
+        if Dout < Din:                       # W first (conv.jl:36-40)
+            h = dense(x, weight)
+            p = P(h)
+            y = bias_act(p, bias, sigma)
+            ctx.save_for_backward(x, weight, y, c)
+        else:
+            agg = P(x)
+            y = dense(agg, weight, bias, sigma)
+            ctx.save_for_backward(agg, weight, y, c)
+        ctx.g, ctx.sigma, ctx.loops, ctx.w_first, ctx.has_bias = g, sigma, add_self_loops, Dout < Din, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        saved, weight, y, c = ctx.saved_tensors
+        g = ctx.g
+        dz = act_grad(dy.contiguous(), y, ctx.sigma)
+
+        def PT(h):                            # adjoint of the normalised propagate: same kernel, reversed edges
+            return propagate_grad_xj(g, "+", h, scale_src=c, scale_dst=c, add_self_loops=ctx.loops)
+
+        if ctx.w_first:
+            x = saved
+            _, db = dense_grad_w(dz, dz, need_w=False, need_b=ctx.has_bias)
+            dh = PT(dz)
+            dW, _ = dense_grad_w(dh, x, need_b=False)
+            dx = dense_grad_x(dh, weight) if ctx.needs_input_grad[0] else None
+        else:
+            agg = saved
+            dW, db = dense_grad_w(dz, agg, need_b=ctx.has_bias)
+            dx = PT(dense_grad_x(dz, weight)) if ctx.needs_input_grad[0] else None
+        return dx, dW, (db if ctx.has_bias else None), None, None, None
+
+
+def gcn_conv_ad(l, g: GNNGraph, x):
+    """differentiable GCNConv forward (default normalisation, unweighted): gradients w.r.t. x, l.weight, l.bias"""
+    check_num_nodes(g, x)
+    return _GCNConvFn.apply(x, l.weight, l.bias, g, l.sigma, bool(l.add_self_loops))

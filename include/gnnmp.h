@@ -282,6 +282,17 @@ int gnnmp_edge_dot_plan_f32(gnnmp_graph_t *plan, const float *a_dst, const float
 int gnnmp_propagate_maxmin_grad_f32(gnnmp_graph_t *plan_transposed, const float *x, const float *y,
                                     const float *dy, float *dx, int64_t D, gnnmp_stream_t stream);
 
+/* Adjoints of the dense part  y = σ.(W * x .+ b):
+ *   gnnmp_act_grad_f32      Δz = Δy .* σ'(z)  (relu: Δy where y > 0, else 0; identity: copy).  dz may alias dy.
+ *   gnnmp_dense_grad_w_f32  ΔW[o][k] = Σ_n Δz[n][o] x[n][k]  ([Dout][K] row-major) and/or Δb[o] = Σ_n Δz[n][o]
+ *                           (either output may be NULL); fp32 MFMA, operands read straight from HBM, per-slab partials in
+ *                           `workspace` (gnnmp_dense_grad_workspace(N, Dout, K) floats) folded in slab order: no atomics.
+ *   Δx = W' * Δz is the forward kernel: gnnmp_dense_f32(Δz, W, D1 = Dout, ldw1 = K, ..., w_layout = 1, ..., Dout = K). */
+int gnnmp_act_grad_f32(const float *dy, const float *y, int act, float *dz, int64_t n, gnnmp_stream_t stream);
+int64_t gnnmp_dense_grad_workspace(int64_t N, int64_t Dout, int64_t K);
+int gnnmp_dense_grad_w_f32(const float *dz, const float *x, int64_t N, int64_t Dout, int64_t K, float *dW,
+                           float *db, float *workspace, int64_t workspace_floats, gnnmp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

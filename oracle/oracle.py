@@ -354,3 +354,40 @@ def grad_propagate(aggr, s, t, n, dy, xj, w=None):
         dm = (_f32(w)[:, None] * dm).astype(np.float32)
     dx = scatter(SUM, dm, s, n)                              # ∇gather
     return dx, dw
+
+
+def grad_gcn_conv(s, t, n, x, weight, bias, sigma, dy, add_self_loops_=True):
+    """(Δx, ΔW, Δb) of gcn_conv (default norm, unweighted), composed from the rules above + the dense rules
+    (Δz = Δy .* σ'(z), ΔW = Δz' * a, Δb = sum(Δz), Δa = Δz * W), float32 with float64 accumulation in the matmuls."""
+    s = _i64(s)
+    t = _i64(t)
+    x = _f32(x)
+    W = _f32(weight)
+    if add_self_loops_:
+        s, t, _ = add_self_loops(s, t, n)
+    c = inv_sqrt(degree(t, n))
+    Dout, Din = W.shape
+
+    def P(h):
+        return scale_rows(propagate(SUM, s, t, n, scale_rows(h, c)), c)
+
+    def PT(dh):
+        dxs, _ = grad_propagate(SUM, s, t, n, scale_rows(dh, c), np.zeros((n, dh.shape[1]), np.float32))
+        return scale_rows(dxs, c)
+
+    if Dout < Din:
+        h = matmul(W, x)
+        z = P(h) + (0 if bias is None else _f32(bias)[None, :])
+        dz = _f32(dy) * (z > 0) if sigma == "relu" else _f32(dy)
+        db = dz.astype(np.float64).sum(0).astype(np.float32)
+        dh = PT(dz.astype(np.float32))
+        dW = (dh.astype(np.float64).T @ x.astype(np.float64)).astype(np.float32)
+        dx = (dh.astype(np.float64) @ W.astype(np.float64)).astype(np.float32)
+    else:
+        a = P(x)
+        z = matmul(W, a) + (0 if bias is None else _f32(bias)[None, :])
+        dz = (_f32(dy) * (z > 0)).astype(np.float32) if sigma == "relu" else _f32(dy)
+        db = dz.astype(np.float64).sum(0).astype(np.float32)
+        dW = (dz.astype(np.float64).T @ a.astype(np.float64)).astype(np.float32)
+        dx = PT((dz.astype(np.float64) @ W.astype(np.float64)).astype(np.float32))
+    return dx, dW, db

@@ -138,3 +138,56 @@ def test_autograd_through_hip_propagate(gm, oracle):
         assert np.linalg.norm(xt.grad.cpu().numpy() - dx) <= 1e-5 * np.linalg.norm(dx)
         if weighted:
             assert np.linalg.norm(wt.grad.cpu().numpy() - dw) <= 1e-5 * np.linalg.norm(dw)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,K,Dout", [(1000, 100, 100), (4097, 37, 130), (300, 128, 16), (5, 3, 2), (70000, 16, 128)])
+def test_dense_adjoints_vs_float64(gm, N, K, Dout):
+    from gnnmp import backward as bw
+    rng = np.random.default_rng(N + K)
+    x = rng.standard_normal((N, K)).astype(np.float32)
+    W = (rng.standard_normal((Dout, K)) / np.sqrt(K)).astype(np.float32)
+    y = rng.standard_normal((N, Dout)).astype(np.float32)
+    dy = rng.standard_normal((N, Dout)).astype(np.float32)
+    dz = bw.act_grad(dev(dy), dev(y), "relu")
+    ref_dz = np.where(y > 0, dy, 0).astype(np.float32)
+    np.testing.assert_array_equal(dz.cpu().numpy(), ref_dz)
+    dW, db = bw.dense_grad_w(dz, dev(x))
+    ref_dW = ref_dz.astype(np.float64).T @ x.astype(np.float64)
+    ref_db = ref_dz.astype(np.float64).sum(0)
+    assert np.linalg.norm(dW.cpu().numpy() - ref_dW) <= 1e-5 * np.linalg.norm(ref_dW)
+    assert np.linalg.norm(db.cpu().numpy() - ref_db) <= 1e-5 * max(np.linalg.norm(ref_db), 1e-3 * np.sqrt(N))
+    dx = bw.dense_grad_x(dz, dev(W))
+    ref_dx = ref_dz.astype(np.float64) @ W.astype(np.float64)
+    assert np.linalg.norm(dx.cpu().numpy() - ref_dx) <= 1e-5 * np.linalg.norm(ref_dx)
+    # deterministic (no atomics)
+    dW2, db2 = bw.dense_grad_w(dz, dev(x))
+    assert bool((dW2 == dW).all()) and bool((db2 == db).all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Din,Dout", [(24, 24), (16, 40), (40, 8)])
+def test_gcn_layer_backward_vs_oracle(gm, oracle, Din, Dout):
+    import torch
+    from gnnmp.backward import gcn_conv_ad
+    rng = np.random.default_rng(Din * 100 + Dout)
+    n, E = 700, 9000
+    s = rng.integers(1, n + 1, E)
+    t = rng.integers(1, n + 1, E)
+    x = rng.standard_normal((n, Din)).astype(np.float32)
+    r = rng.standard_normal((n, Dout)).astype(np.float32)
+    g = gm.GNNGraph(dev(s), dev(t), num_nodes=n)
+    l = gm.GCNConv((Din, Dout), "relu", seed=5)
+    l.bias = dev(rng.standard_normal(Dout).astype(np.float32) * 0.1)
+    W0, b0 = l.weight.cpu().numpy(), l.bias.cpu().numpy()
+    xt = dev(x).requires_grad_(True)
+    l.weight.requires_grad_(True)
+    l.bias.requires_grad_(True)
+    y = gcn_conv_ad(l, g, xt)
+    ref_y = oracle.gcn_conv(s, t, n, x, W0, b0, "relu")
+    assert np.linalg.norm(y.detach().cpu().numpy() - ref_y) <= 1e-5 * np.linalg.norm(ref_y)
+    (y * dev(r)).sum().backward()
+    dx, dW, db = oracle.grad_gcn_conv(s, t, n, x, W0, b0, "relu", r)
+    for got, ref in ((xt.grad, dx), (l.weight.grad, dW), (l.bias.grad, db)):
+        gotn = got.cpu().numpy()
+        assert np.linalg.norm(gotn - ref) <= 2e-5 * np.linalg.norm(ref)
