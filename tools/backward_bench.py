@@ -31,3 +31,15 @@ dmax = t(lambda: bw.propagate_grad_xj(g, "max", dy, xj=x, y=y))
 b1 = E * (4 * D + 4) + N * (4 * D + 8)
 print(f"products D={D}: fwd(+) {fwd:.3f} ms | dxj(+) {dx:.3f} ms {b1/dx/1e6:.0f} GB/s | dxj(w) {dxw:.3f} ms | "
       f"dw edge_dot {dw:.3f} ms {E*(8*D+20)/dw/1e6:.0f} GB/s | dxj(max) {dmax:.3f} ms {E*(8*D+4)/dmax/1e6:.0f} GB/s")
+from gnnmp.backward import dense_grad_w, dense_grad_x, act_grad, gcn_conv_ad
+W = torch.randn((100, D), device="cuda") * 0.1
+dz = torch.randn((N, 100), device="cuda")
+tw = t(lambda: dense_grad_w(dz, x))
+tx = t(lambda: dense_grad_x(dz, W))
+ta = t(lambda: act_grad(dz, dz, "relu"))
+print(f"dense adjoints 2.4M x 100 => 100: dW+db {tw:.3f} ms ({2*N*100*D/tw/1e9:.1f} TF) | dX {tx:.3f} ms | act_grad {ta:.3f} ms")
+l = gnnmp.GCNConv((D, 100), "relu", seed=1); l.weight.requires_grad_(True); l.bias.requires_grad_(True)
+xr = x.clone().requires_grad_(True)
+def step():
+    y = gcn_conv_ad(l, g, xr); y.backward(dy)
+print(f"GCNConv forward+backward (autograd, HIP both ways): {t(step, 5):.3f} ms")
