@@ -297,8 +297,25 @@ def main():
               "max_in_degree": plan.max_degree, "long_rows": plan.n_long}
     extras["gcn_layer_edges_per_s"] = Ep / extras["gcn_layer_ms"] * 1e3
     extras["gat_layer_edges_per_s"] = Ep / extras["gat_layer_ms"] * 1e3
+    # the dense contractions (the only MFMA work on the path): events around gnnmp_dense_f32, against the fp32 MFMA peak
+    MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+    t_dg, _ = event_time(lambda: gnnmp.dense(out_p, gcn.weight, gcn.bias, "relu"), iters)
+    t_da, _ = event_time(lambda: gnnmp.dense(x, gat.dense_x_weight), iters)
+    extras["dense"] = {
+        "kernel": "dense_wlds_kernel (v_mfma_f32_32x32x2_f32)", "peak_TFs": MFMA_F32_PEAK_TF,
+        "gcn_W_x": {"shape": f"{N}x{D}=>{D}", "ms": t_dg, "TFs": 2.0 * N * D * D / t_dg / 1e9,
+                    "frac": 2.0 * N * D * D / t_dg / 1e9 / MFMA_F32_PEAK_TF},
+        "gat_dense_x": {"shape": f"{N}x{D}=>{H * C}", "ms": t_da, "TFs": 2.0 * N * D * H * C / t_da / 1e9,
+                        "frac": 2.0 * N * D * H * C / t_da / 1e9 / MFMA_F32_PEAK_TF}}
     if rank == 0 and not args.no_extras and args.workload == "products":
-        del out_p, out_g, Wx
+        # BASELINE.json config 4: SAGEConv(100 => 256) on the same graph (no self loops), aggr = mean and aggr = +
+        sage = gnnmp.SAGEConv((D, 256), "relu", aggr="mean", seed=13)
+        t_sm = layer_time(lambda: sage(g, x), 5)
+        sage.aggr = "+"
+        t_ss = layer_time(lambda: sage(g, x), 5)
+        extras["sage_products"] = {"E": E, "layer_ms_mean": t_sm, "layer_ms_sum": t_ss,
+                                   "edges_per_s_mean": E / t_sm * 1e3, "edges_per_s_sum": E / t_ss * 1e3}
+        del out_p, out_g, Wx, sage
         Na, Da = synth.ARXIV["N"], synth.ARXIV["D"]
         sa, ta = synth.arxiv_like()
         ga = gnnmp.GNNGraph(torch.from_numpy(sa).cuda(), torch.from_numpy(ta).cuda(), num_nodes=Na, _validated=True)

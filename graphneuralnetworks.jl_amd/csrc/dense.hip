@@ -7,9 +7,13 @@
 //
 // Shape: tall-skinny, out[N][Dout] with N ~ 1e5..1e7 and K, Dout ~ 16..256.  fp32 in / fp32 accumulate on
 // v_mfma_f32_32x32x2_f32 (exact fp32 fma chain in k order; 157 TF peak = the fp32 vector rate, but it leaves the VALU
-// free and needs one VGPR per operand).  Block = 4 waves = 128 rows x up-to-128 output columns; each wave owns 32 rows
-// and up to four 32x32 accumulator tiles; x and W^T chunks of 32 k-values are staged in LDS (padded leading dimensions:
-// conflict-free ds_read_b32 for both MFMA operands).
+// free and needs one VGPR per operand).  Two kernels:
+//   dense_wlds_kernel  (default) W^T resident in LDS for the lifetime of a persistent block, wave-private x staging, no
+//                      workgroup barrier in the main loop — used whenever W^T for a 128-column tile plus >= 4 wave
+//                      regions fit the 160 KB LDS (all layer shapes of the bench configs);
+//   dense_mfma_kernel  the K-chunked fallback (128 x 128 block tile, x and W^T chunks of 32 k-values through LDS with
+//                      two barriers per chunk) for large K (e.g. Cora's 1433 input features) and tiny N.
+// Both use padded / odd leading dimensions so that the ds_read_b32 of either MFMA operand is bank-conflict free.
 #include <algorithm>
 
 #include "common.h"
