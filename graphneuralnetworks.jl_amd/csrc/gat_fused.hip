@@ -29,6 +29,7 @@ struct GatFusedArgs {
     const float *bias;    // [D] or null
     float *out;           // [n_dst][D]
     float *partial;       // [n_chunks][D + 2*D/VEC]
+    float *stats;         // [n_dst][H][2] = (running max m, denominator) of every destination, or null (saved for the adjoint)
     const int32_t *chunk_row, *chunk_beg, *chunk_end;
     const int32_t *long_rows, *long_cptr;
     int n_chunks, n_long;
@@ -181,6 +182,11 @@ __global__ void __launch_bounds__(256) gat_fused_rows_kernel(const GatFusedArgs 
 #pragma unroll
         for (int q = 0; q < VEC; ++q) acc[q] = acc[q] / den;
     }
+    if (a.stats && active && (f0 % a.C) == 0) {
+        float *st = a.stats + ((int64_t)row * a.H + f0 / a.C) * 2;
+        st[0] = m;
+        st[1] = den;
+    }
     gat_fused_store<VEC>(a, row, f0, active, acc);
 }
 
@@ -232,6 +238,11 @@ __global__ void __launch_bounds__(256) gat_fused_combine_kernel(const GatFusedAr
     }
 #pragma unroll
     for (int q = 0; q < VEC; ++q) acc[q] = acc[q] / den;
+    if (a.stats && (f0 % a.C) == 0) {
+        float *st = a.stats + ((int64_t)row * a.H + f0 / a.C) * 2;
+        st[0] = M;
+        st[1] = den;
+    }
     gat_fused_store<VEC>(a, row, f0, true, acc);
 }
 
@@ -274,9 +285,9 @@ static int launch_gat_fused(GatFusedArgs a, hipStream_t stream) {
 
 using namespace gnnmp;
 
-extern "C" int gnnmp_gat_conv_f32(gnnmp_graph_t *plan, const float *Wx_src, const float *Wx_dst,
-                                  const float *a, float negative_slope, const float *bias, int act,
-                                  float *out, int64_t H, int64_t C, gnnmp_stream_t stream_) {
+static int gat_conv_impl(gnnmp_graph_t *plan, const float *Wx_src, const float *Wx_dst, const float *a,
+                         float negative_slope, const float *bias, int act, float *out, float *stats, int64_t H,
+                         int64_t C, gnnmp_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!plan) return fail(GNNMP_EINVAL, "gat_conv: null plan");
     if (H <= 0 || C <= 0 || H * C > (1 << 20)) return fail(GNNMP_EINVAL, "gat_conv: bad H/C");
@@ -293,6 +304,8 @@ extern "C" int gnnmp_gat_conv_f32(gnnmp_graph_t *plan, const float *Wx_src, cons
     const int lph = (int)(C / vec);
     const int lanes = D / vec;
     const bool pow2 = (lph & (lph - 1)) == 0;
+    if ((!pow2 || lanes > 64) && stats)
+        return fail(GNNMP_EUNSUPPORTED, "gat_conv: softmax statistics need a power-of-two lane count per head and H*C <= 256");
     if (!pow2 || lanes > 64) {
         // head width not a power-of-two lane count (or wider than a wave): three-pass kernels on node scores
         const size_t need = (size_t)(plan->n_dst + plan->n_src) * (size_t)H;
@@ -314,6 +327,7 @@ extern "C" int gnnmp_gat_conv_f32(gnnmp_graph_t *plan, const float *Wx_src, cons
     g.bias = bias;
     g.out = out;
     g.partial = plan->ws;
+    g.stats = stats;
     g.chunk_row = plan->chunk_row;
     g.chunk_beg = plan->chunk_beg;
     g.chunk_end = plan->chunk_end;
@@ -340,4 +354,16 @@ extern "C" int gnnmp_gat_conv_f32(gnnmp_graph_t *plan, const float *Wx_src, cons
         case 2: return launch_gat_fused<2>(g, stream);
         default: return launch_gat_fused<1>(g, stream);
     }
+}
+
+extern "C" int gnnmp_gat_conv_f32(gnnmp_graph_t *plan, const float *Wx_src, const float *Wx_dst, const float *a,
+                                  float negative_slope, const float *bias, int act, float *out, int64_t H, int64_t C,
+                                  gnnmp_stream_t stream) {
+    return gat_conv_impl(plan, Wx_src, Wx_dst, a, negative_slope, bias, act, out, nullptr, H, C, stream);
+}
+extern "C" int gnnmp_gat_conv_stats_f32(gnnmp_graph_t *plan, const float *Wx_src, const float *Wx_dst, const float *a,
+                                        float negative_slope, const float *bias, int act, float *out, float *stats,
+                                        int64_t H, int64_t C, gnnmp_stream_t stream) {
+    if (!stats) return fail(GNNMP_EINVAL, "gat_conv_stats: null stats");
+    return gat_conv_impl(plan, Wx_src, Wx_dst, a, negative_slope, bias, act, out, stats, H, C, stream);
 }

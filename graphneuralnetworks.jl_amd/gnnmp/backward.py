@@ -223,3 +223,63 @@ def gcn_conv_ad(l, g: GNNGraph, x):
     """differentiable GCNConv forward (default normalisation, unweighted): gradients w.r.t. x, l.weight, l.bias"""
     check_num_nodes(g, x)
     return _GCNConvFn.apply(x, l.weight, l.bias, g, l.sigma, bool(l.add_self_loops))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# GATConv
+# ---------------------------------------------------------------------------------------------------------
+class _GATConvFn(torch.autograd.Function):
+    """gat_conv (GNNlib/src/layers/conv.jl:112-167; concat = true, no edge features) with HIP forward AND backward.
+    The forward keeps (m, den) per destination and head instead of α; the backward is two edge passes
+    (csrc/gat_backward.hip) + the dense adjoints."""
+
+    @staticmethod
+    def forward(ctx, x, weight, a, bias, g, sigma, heads, slope, add_self_loops):
+        from .layers import dense
+        lib = L.load()
+        plan = g.plan(add_self_loops)
+        H = heads
+        C = weight.shape[0] // H
+        N = g.num_nodes
+        x = x.contiguous()
+        Wx = dense(x, weight)
+        a_hc = a.t().contiguous()                                   # [H][2C]
+        out = torch.empty((N, H * C), dtype=torch.float32, device=x.device)
+        stats = torch.empty((N, H, 2), dtype=torch.float32, device=x.device)
+        L.check(lib.gnnmp_gat_conv_stats_f32(plan.handle, L.ptr(Wx), None, L.ptr(a_hc), float(slope), L.ptr(bias),
+                                             _act_code(sigma), L.ptr(out), L.ptr(stats), H, C, L.stream_ptr()))
+        ctx.save_for_backward(x, weight, Wx, a_hc, stats, out)
+        ctx.g, ctx.sigma, ctx.H, ctx.C, ctx.slope, ctx.loops, ctx.has_bias = g, sigma, H, C, slope, add_self_loops, bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, Wx, a_hc, stats, y = ctx.saved_tensors
+        g, H, C = ctx.g, ctx.H, ctx.C
+        lib = L.load()
+        N = g.num_nodes
+        dz = act_grad(dy.contiguous(), y, ctx.sigma)
+        db = None
+        if ctx.has_bias and ctx.needs_input_grad[3]:
+            _, db = dense_grad_w(dz, dz, need_w=False, need_b=True)
+        plan, plan_t = g.plan(ctx.loops), plan_transposed(g, ctx.loops)
+        f32 = dict(dtype=torch.float32, device=dz.device)
+        line = torch.empty((N, H, 4), **f32)
+        dsd = torch.empty((N, H), **f32)
+        dss = torch.empty((N, H), **f32)
+        dWx = torch.empty((N, H * C), **f32)
+        da_hc = torch.empty((H, 2 * C), **f32)
+        L.check(lib.gnnmp_gat_conv_grad_f32(plan.handle, plan_t.handle, L.ptr(Wx), None, L.ptr(a_hc), float(ctx.slope),
+                                            L.ptr(stats), L.ptr(dz), L.ptr(line), L.ptr(dsd), L.ptr(dss), L.ptr(dWx), None,
+                                            L.ptr(da_hc), H, C, L.stream_ptr()))
+        dW = dense_grad_w(dWx, x, need_b=False)[0] if ctx.needs_input_grad[1] else None
+        dx = dense_grad_x(dWx, weight) if ctx.needs_input_grad[0] else None
+        return dx, dW, da_hc.t(), db, None, None, None, None, None
+
+
+def gat_conv_ad(l, g: GNNGraph, x):
+    """differentiable GATConv forward (concat = true, no edge features): gradients w.r.t. x, l.dense_x_weight, l.a, l.bias"""
+    check_num_nodes(g, x)
+    assert l.concat, "the HIP adjoint covers concat = true"
+    return _GATConvFn.apply(x, l.dense_x_weight, l.a, l.bias, g, l.sigma, l.heads, l.negative_slope,
+                            bool(l.add_self_loops))

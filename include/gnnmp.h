@@ -217,6 +217,26 @@ int gnnmp_gat_conv_f32(gnnmp_graph_t *plan, const float *Wx_src, const float *Wx
                        float negative_slope, const float *bias, int act, float *out, int64_t H,
                        int64_t C, gnnmp_stream_t stream);
 
+/* Training forward of the same path: as gnnmp_gat_conv_f32, and additionally saves the neighbourhood-softmax statistics
+ * stats[i][h] = (m_i, den_i) — the running maximum of the logits and Σ_j exp(l_ij - m_i) — 8 bytes per destination and
+ * head instead of the reference's (H, E') α array that Zygote keeps alive for the pullback.  Needs a power-of-two lane
+ * count per head and H*C <= 256 (GNNMP_EUNSUPPORTED otherwise). */
+int gnnmp_gat_conv_stats_f32(gnnmp_graph_t *plan, const float *Wx_src, const float *Wx_dst, const float *a,
+                             float negative_slope, const float *bias, int act, float *out, float *stats,
+                             int64_t H, int64_t C, gnnmp_stream_t stream);
+
+/* Pullback of the attention path (what Zygote composes from the rrules of gather / leakyrelu / softmax_edge_neighbors /
+ * scatter(+) for conv.jl:136-141,152-167).  dout = Δ w.r.t. the aggregated (pre-bias, pre-σ) output [n_dst][H*C];
+ * plan_t = plan of the reversed edge index (same self-loop flag); stats from gnnmp_gat_conv_stats_f32.
+ * Scratch/outputs supplied by the caller: line [n_dst][H][4] (16-byte aligned), dsd [n_dst][H] (Δ of the target logit
+ * half), dss [n_src][H] (Δ of the source half).  Results: dWx_src [n_src][H*C]; dWx_dst [n_dst][H*C] for a bipartite
+ * layer (Wx_dst != Wx_src) — with Wx_dst NULL / == Wx_src pass dWx_dst = NULL and dWx_src holds the whole ΔWx;
+ * da [H][2C] (may be NULL).  Two passes over the edges, no atomics, run-to-run identical. */
+int gnnmp_gat_conv_grad_f32(gnnmp_graph_t *plan, gnnmp_graph_t *plan_t, const float *Wx_src, const float *Wx_dst,
+                            const float *a, float negative_slope, const float *stats, const float *dout,
+                            float *line, float *dsd, float *dss, float *dWx_src, float *dWx_dst, float *da,
+                            int64_t H, int64_t C, gnnmp_stream_t stream);
+
 /* out[n][c] = act( mean_h y[n][h][c] + bias[c] ) — the concat = false tail of gat_conv (`mean(x, dims = 2)`,
  * GNNlib/src/layers/conv.jl:143-147): heads added in order, one division by H, then σ.(x .+ bias). */
 int gnnmp_head_mean_f32(const float *y, const float *bias, int act, float *out, int64_t N, int64_t H,

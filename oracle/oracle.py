@@ -391,3 +391,57 @@ def grad_gcn_conv(s, t, n, x, weight, bias, sigma, dy, add_self_loops_=True):
         dW = (dz.astype(np.float64).T @ a.astype(np.float64)).astype(np.float32)
         dx = PT((dz.astype(np.float64) @ W.astype(np.float64)).astype(np.float32))
     return dx, dW, db
+
+
+def grad_gat_conv(s, t, n, x, dense_x_weight, a, bias, sigma, dy, heads=1, negative_slope=0.2, add_self_loops_=True):
+    """(Δx, ΔW, Δa, Δb) of gat_conv (concat = true, no edge features; conv.jl:112-167), composed rule by rule in the order
+    Zygote walks the forward backwards: σ, bias, ∇scatter(+) (Δβ = Δ[t]), β = α .* Wxj, the softmax_edge_neighbors
+    pullback  Δl = α .* (Δα - Σ_{N(i)} α Δα)  (utils.jl:84-97 is exp / scatter / gather / division, this is what their
+    rules multiply out to), leakyrelu', the `sum(a .* vcat(Wxi, Wxj))` contraction, ∇gather (scatter(+) to t and to s) and
+    the dense rules.  float64 arithmetic on the float32 inputs, results cast to float32.  a: Julia shape (2C, H)."""
+    s = _i64(s)
+    t = _i64(t)
+    if add_self_loops_:
+        s, t, _ = add_self_loops(s, t, n)
+    si, ti = s - 1, t - 1
+    H = heads
+    W = np.asarray(dense_x_weight, np.float64)
+    C = W.shape[0] // H
+    x64 = np.asarray(x, np.float64)
+    a64 = np.asarray(a, np.float64)
+    ad, as_ = a64[:C].T, a64[C:].T                                # [H, C] target / source halves
+    Wx = (x64 @ W.T).reshape(n, H, C)
+    Wxi, Wxj = Wx[ti], Wx[si]
+    z = (Wxi * ad).sum(-1) + (Wxj * as_).sum(-1)                  # [E', H]
+    l = np.where(z > 0, z, negative_slope * z)
+    m = np.full((n, H), -np.inf)
+    np.maximum.at(m, ti, l)
+    p = np.exp(l - m[ti])
+    den = np.zeros((n, H))
+    np.add.at(den, ti, p)
+    alpha = p / den[ti]
+    o = np.zeros((n, H, C))
+    np.add.at(o, ti, alpha[..., None] * Wxj)
+    y = o.reshape(n, H * C) + (0 if bias is None else np.asarray(bias, np.float64)[None, :])
+    dz = np.asarray(dy, np.float64) * (y > 0) if sigma == "relu" else np.asarray(dy, np.float64)
+    db = dz.sum(0)
+    delta = dz.reshape(n, H, C)
+    dbeta = delta[ti]                                             # ∇scatter(+)
+    dalpha = (dbeta * Wxj).sum(-1)
+    dWxj = alpha[..., None] * dbeta
+    sa = np.zeros((n, H))
+    np.add.at(sa, ti, alpha * dalpha)
+    dzl = alpha * (dalpha - sa[ti]) * np.where(z > 0, 1.0, negative_slope)
+    dWxi = dzl[..., None] * ad[None]
+    dWxj = dWxj + dzl[..., None] * as_[None]
+    da_d = (dzl[..., None] * Wxi).sum(0)
+    da_s = (dzl[..., None] * Wxj).sum(0)
+    dWx = np.zeros((n, H, C))
+    np.add.at(dWx, ti, dWxi)                                      # ∇gather(Wx, t)
+    np.add.at(dWx, si, dWxj)                                      # ∇gather(Wx, s)
+    dWx = dWx.reshape(n, H * C)
+    dW = dWx.T @ x64
+    dx = dWx @ W
+    da = np.concatenate([da_d.T, da_s.T], axis=0)                 # (2C, H)
+    f = np.float32
+    return dx.astype(f), dW.astype(f), da.astype(f), db.astype(f)

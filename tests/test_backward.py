@@ -191,3 +191,88 @@ def test_gcn_layer_backward_vs_oracle(gm, oracle, Din, Dout):
     for got, ref in ((xt.grad, dx), (l.weight.grad, dW), (l.bias.grad, db)):
         gotn = got.cpu().numpy()
         assert np.linalg.norm(gotn - ref) <= 2e-5 * np.linalg.norm(ref)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# GATConv
+def _gat_problem(seed, n=40, E=260, Din=6, H=2, C=4):
+    rng = np.random.default_rng(seed)
+    s = rng.integers(1, n + 1, E)
+    t = rng.integers(1, n + 1, E)
+    keep = s != t                      # GATConv removes nothing itself; keep the self-looped graph simple
+    s, t = s[keep], t[keep]
+    x = rng.standard_normal((n, Din)).astype(np.float32)
+    W = (rng.standard_normal((H * C, Din)) / np.sqrt(Din)).astype(np.float32)
+    a = (rng.standard_normal((2 * C, H)) * 0.7).astype(np.float32)
+    b = (rng.standard_normal(H * C) * 0.1).astype(np.float32)
+    r = rng.standard_normal((n, H * C)).astype(np.float32)
+    return s, t, n, x, W, a, b, r, H
+
+
+@pytest.mark.parametrize("sigma", [None, "relu"])
+def test_oracle_gat_adjoint_matches_finite_differences(oracle, sigma):
+    s, t, n, x, W, a, b, r, H = _gat_problem(11)
+
+    def loss(xv, Wv, av, bv):
+        y = oracle.gat_conv(s, t, n, xv, Wv, av, bv, sigma, heads=H)
+        return float((y.astype(np.float64) * r).sum())
+
+    dx, dW, da, db = oracle.grad_gat_conv(s, t, n, x, W, a, b, sigma, r, heads=H)
+    eps = 1e-2
+    rng = np.random.default_rng(2)
+    args = [x, W, a, b]
+    checked = 0
+    for which, grad in ((0, dx), (1, dW), (2, da), (3, db)):
+        for _ in range(12):
+            idx = tuple(int(rng.integers(0, d)) for d in args[which].shape)
+            ap = [v.copy() for v in args]
+            am = [v.copy() for v in args]
+            ap[which][idx] += eps
+            am[which][idx] -= eps
+            f0, fp, fm = loss(*args), loss(*ap), loss(*am)
+            if abs((fp - f0) - (f0 - fm)) > 0.05 * eps * max(1.0, abs(float(grad[idx]))):
+                continue                # a relu / leakyrelu kink inside the stencil
+            fd = (fp - fm) / (2 * eps)
+            assert fd == pytest.approx(float(grad[idx]), rel=3e-2, abs=3e-2)
+            checked += 1
+    assert checked >= 30
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,C,Din,sigma", [(2, 4, 6, "relu"), (8, 16, 100, "relu"), (1, 64, 32, None), (4, 8, 20, None),
+                                          (3, 2, 5, "relu"), (1, 1, 3, None)])
+def test_gat_layer_backward_vs_oracle(gm, oracle, H, C, Din, sigma):
+    import torch
+    from gnnmp.backward import gat_conv_ad
+    rng = np.random.default_rng(H * 1000 + C)
+    n, E = 1500, 24000
+    s = rng.integers(1, n + 1, E)
+    t = rng.integers(1, n + 1, E)
+    t[:3000] = 7                      # hub destination: split row of the forward plan
+    s[5000:7500] = 11                 # hub source: split row of the transposed plan
+    p = rng.permutation(E)
+    s, t = s[p], t[p]
+    x = rng.standard_normal((n, Din)).astype(np.float32)
+    r = rng.standard_normal((n, H * C)).astype(np.float32)
+    g = gm.GNNGraph(dev(s), dev(t), num_nodes=n)
+    l = gm.GATConv((Din, C), sigma, heads=H, seed=3)
+    l.bias = dev((rng.standard_normal(H * C) * 0.1).astype(np.float32))
+    W0, a0, b0 = l.dense_x_weight.cpu().numpy(), l.a.cpu().numpy(), l.bias.cpu().numpy()
+    xt = dev(x).requires_grad_(True)
+    for prm in (l.dense_x_weight, l.a, l.bias):
+        prm.requires_grad_(True)
+    y = gat_conv_ad(l, g, xt)
+    ref_y = oracle.gat_conv(s, t, n, x, W0, a0, b0, sigma, heads=H)
+    assert np.linalg.norm(y.detach().cpu().numpy() - ref_y) <= 1e-5 * np.linalg.norm(ref_y)
+    (y * dev(r)).sum().backward()
+    dx, dW, da, db = oracle.grad_gat_conv(s, t, n, x, W0, a0, b0, sigma, r, heads=H)
+    for name, got, ref in (("dx", xt.grad, dx), ("dW", l.dense_x_weight.grad, dW), ("da", l.a.grad, da),
+                           ("db", l.bias.grad, db)):
+        gotn = got.cpu().numpy()
+        assert gotn.shape == ref.shape, name
+        assert np.linalg.norm(gotn - ref) <= 3e-5 * np.linalg.norm(ref), name
+    # run-to-run identical (no atomics anywhere on the path)
+    xt2 = dev(x).requires_grad_(True)
+    l.dense_x_weight.grad = None
+    (gat_conv_ad(l, g, xt2) * dev(r)).sum().backward()
+    assert bool((xt2.grad == xt.grad).all())
