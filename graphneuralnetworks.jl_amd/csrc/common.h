@@ -115,6 +115,30 @@ struct Vec<1> {
     static __device__ __forceinline__ void store(float *p, const float v[1]) { *p = v[0]; }
 };
 
+// Sum over aligned groups of LPH adjacent lanes (LPH a power of two; the lanes that hold one attention head).  Every lane
+// of the group ends with the same bits.  Stages 1, 2 are quad permutes, 4 and 8 the half-row / row mirrors (after the
+// quad stages the mirror partner holds the other half's sum, so it is as good as xor) — all DPP modifiers folded into
+// the v_add, no LDS crossbar traffic and nothing to wait for; only the 16- and 32-lane stages need ds_bpermute.
+// LPH = 0: lane count known only at run time (`lph`), plain xor butterfly.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+template <int LPH>
+__device__ __forceinline__ float group_sum(float d, int lph) {
+    if (LPH == 0) {
+        for (int o = 1; o < lph; o <<= 1) d += __shfl_xor(d, o, 64);
+        return d;
+    }
+    if (LPH >= 2) d += dpp_mov<0xB1>(d);    // quad_perm [1,0,3,2]
+    if (LPH >= 4) d += dpp_mov<0x4E>(d);    // quad_perm [2,3,0,1]
+    if (LPH >= 8) d += dpp_mov<0x141>(d);   // row_half_mirror
+    if (LPH >= 16) d += dpp_mov<0x140>(d);  // row_mirror
+    if (LPH >= 32) d += __shfl_xor(d, 16, 64);
+    if (LPH >= 64) d += __shfl_xor(d, 32, 64);
+    return d;
+}
+
 // block -> logical chunk remap so that each XCD (block b runs on XCD b % 8) walks a contiguous range of
 // destination rows; grid must be launched with 8 * cpx blocks.
 __device__ __forceinline__ int xcd_remap(int b, int cpx, int enabled) {

@@ -80,35 +80,36 @@ __device__ __forceinline__ bool virtual_row(const GatBwdArgs &a, int &v, bool &i
     return true;
 }
 
-template <int VEC, int U>
+template <int VEC, int U, int LPH>
 __global__ void __launch_bounds__(256) gat_bwd_dst_kernel(const GatBwdArgs a) {
     int v, row, beg, end, lig, gbase, G;
     bool is_chunk;
     if (!virtual_row(a, v, is_chunk, row, beg, end, lig, gbase, G)) return;
     const int f0 = lig * VEC;
     const bool active = f0 < a.D;
-    const int h = active ? f0 / a.C : 0;
+    const int fc = active ? f0 : 0;   // idle lanes (D/VEC not a power of two) shadow lane 0 with zero coefficients
+    const int h = fc / a.C;
     float ad[VEC], as[VEC], vi[VEC], di[VEC];
-#pragma unroll
-    for (int q = 0; q < VEC; ++q) ad[q] = as[q] = 0.0f;
-    if (active) {
-        const float *ah = a.a + (int64_t)h * 2 * a.C + (f0 - h * a.C);
+    {
+        const float *ah = a.a + (int64_t)h * 2 * a.C + (fc - h * a.C);
 #pragma unroll
         for (int q = 0; q < VEC; ++q) {
-            ad[q] = ah[q];
-            as[q] = ah[a.C + q];
+            ad[q] = active ? ah[q] : 0.0f;
+            as[q] = active ? ah[a.C + q] : 0.0f;
         }
     }
-    load_or_zero<VEC>(a.Wx_dst + (int64_t)row * a.D + f0, active, vi);
-    load_or_zero<VEC>(a.dout + (int64_t)row * a.D + f0, active, di);
+    Vec<VEC>::load(a.Wx_dst + (int64_t)row * a.D + fc, vi);
+    Vec<VEC>::load(a.dout + (int64_t)row * a.D + fc, di);
     float sd = 0.0f;
 #pragma unroll
     for (int q = 0; q < VEC; ++q) sd = fmaf(ad[q], vi[q], sd);
-    for (int o = 1; o < a.lph; o <<= 1) sd += __shfl_xor(sd, o, 64);
+    sd = group_sum<LPH>(sd, a.lph);
     const float m = a.stats[((int64_t)row * a.H + h) * 2];
     const float den = a.stats[((int64_t)row * a.H + h) * 2 + 1];
     const float rden = 1.0f / den;
 
+    // branch-free body: the U loads, the 2U dot products, their butterflies and the U exponentials are independent
+    // chains the scheduler interleaves; slots past the end of the row re-read the last edge and get α = 0
     float S1 = 0.0f, S2 = 0.0f, S3 = 0.0f;
     for (int base = beg; base < end; base += G) {
         const int p = base + lig;
@@ -119,29 +120,34 @@ __global__ void __launch_bounds__(256) gat_bwd_dst_kernel(const GatBwdArgs a) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int cj = __shfl(c, gbase + min(j + u, n - 1), 64);
-                load_or_zero<VEC>(a.Wx_src + (int64_t)cj * a.D + f0, active, w[u]);
+                Vec<VEC>::load(a.Wx_src + (int64_t)cj * a.D + fc, w[u]);
+            }
+            float d[U], g[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                d[u] = 0.0f;
+                g[u] = 0.0f;
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) {
+                    d[u] = fmaf(as[q], w[u][q], d[u]);
+                    g[u] = fmaf(di[q], w[u][q], g[u]);
+                }
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                if (j + u < n) {
-                    float d = 0.0f, g = 0.0f;
+                d[u] = group_sum<LPH>(d[u], a.lph);
+                g[u] = group_sum<LPH>(g[u], a.lph);
+            }
 #pragma unroll
-                    for (int q = 0; q < VEC; ++q) {
-                        d = fmaf(as[q], w[u][q], d);
-                        g = fmaf(di[q], w[u][q], g);
-                    }
-                    for (int o = 1; o < a.lph; o <<= 1) {
-                        d += __shfl_xor(d, o, 64);
-                        g += __shfl_xor(g, o, 64);
-                    }
-                    const float z = sd + d;
-                    const float al = expf(lrelu_b(z, a.slope) - m) * rden;
-                    const float s = z > 0.0f ? 1.0f : a.slope;
-                    const float ag = al * g;
-                    S1 += ag;
-                    S2 = fmaf(ag, s, S2);
-                    S3 = fmaf(al, s, S3);
-                }
+            for (int u = 0; u < U; ++u) {
+                const float z = sd + d[u];
+                float al = expf(lrelu_b(z, a.slope) - m) * rden;
+                al = (j + u < n) ? al : 0.0f;
+                const float s = z > 0.0f ? 1.0f : a.slope;
+                const float ag = al * g[u];
+                S1 += ag;
+                S2 = fmaf(ag, s, S2);
+                S3 = fmaf(al, s, S3);
             }
         }
     }
@@ -197,30 +203,29 @@ __device__ __forceinline__ void gat_bwd_src_store(const GatBwdArgs &a, int row, 
     if ((f0 % a.C) == 0) a.dss[(int64_t)row * a.H + h] = dss;
 }
 
-template <int VEC, int U>
+template <int VEC, int U, int LPH>
 __global__ void __launch_bounds__(256) gat_bwd_src_kernel(const GatBwdArgs a) {
     int v, row, beg, end, lig, gbase, G;
     bool is_chunk;
     if (!virtual_row(a, v, is_chunk, row, beg, end, lig, gbase, G)) return;
     const int f0 = lig * VEC;
     const bool active = f0 < a.D;
-    const int h = active ? f0 / a.C : 0;
+    const int fc = active ? f0 : 0;
+    const int h = fc / a.C;
     float ad[VEC], as[VEC], wj[VEC];
-#pragma unroll
-    for (int q = 0; q < VEC; ++q) ad[q] = as[q] = 0.0f;
-    if (active) {
-        const float *ah = a.a + (int64_t)h * 2 * a.C + (f0 - h * a.C);
+    {
+        const float *ah = a.a + (int64_t)h * 2 * a.C + (fc - h * a.C);
 #pragma unroll
         for (int q = 0; q < VEC; ++q) {
-            ad[q] = ah[q];
-            as[q] = ah[a.C + q];
+            ad[q] = active ? ah[q] : 0.0f;
+            as[q] = active ? ah[a.C + q] : 0.0f;
         }
     }
-    load_or_zero<VEC>(a.Wx_src + (int64_t)row * a.D + f0, active, wj);
+    Vec<VEC>::load(a.Wx_src + (int64_t)row * a.D + fc, wj);
     float ss = 0.0f;
 #pragma unroll
     for (int q = 0; q < VEC; ++q) ss = fmaf(as[q], wj[q], ss);
-    for (int o = 1; o < a.lph; o <<= 1) ss += __shfl_xor(ss, o, 64);
+    ss = group_sum<LPH>(ss, a.lph);
 
     float acc[VEC], dss = 0.0f;
 #pragma unroll
@@ -235,23 +240,27 @@ __global__ void __launch_bounds__(256) gat_bwd_src_kernel(const GatBwdArgs a) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int ci = __shfl(c, gbase + min(j + u, n - 1), 64);
-                load_or_zero<VEC>(a.dout + (int64_t)ci * a.D + f0, active, dv[u]);
+                Vec<VEC>::load(a.dout + (int64_t)ci * a.D + fc, dv[u]);
                 ln[u] = *reinterpret_cast<const float4 *>(a.line + ((int64_t)ci * a.H + h) * 4);
             }
+            float g[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                if (j + u < n) {
-                    float g = 0.0f;
+                g[u] = 0.0f;
 #pragma unroll
-                    for (int q = 0; q < VEC; ++q) g = fmaf(dv[u][q], wj[q], g);
-                    for (int o = 1; o < a.lph; o <<= 1) g += __shfl_xor(g, o, 64);
-                    const float z = ln[u].x + ss;
-                    const float al = expf(lrelu_b(z, a.slope) - ln[u].y) * ln[u].z;
-                    const float s = z > 0.0f ? 1.0f : a.slope;
-                    dss = fmaf(al * (g - ln[u].w), s, dss);
+                for (int q = 0; q < VEC; ++q) g[u] = fmaf(dv[u][q], wj[q], g[u]);
+            }
 #pragma unroll
-                    for (int q = 0; q < VEC; ++q) acc[q] = fmaf(al, dv[u][q], acc[q]);
-                }
+            for (int u = 0; u < U; ++u) g[u] = group_sum<LPH>(g[u], a.lph);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float z = ln[u].x + ss;
+                float al = expf(lrelu_b(z, a.slope) - ln[u].y) * ln[u].z;
+                al = (j + u < n) ? al : 0.0f;
+                const float s = z > 0.0f ? 1.0f : a.slope;
+                dss = fmaf(al * (g[u] - ln[u].w), s, dss);
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) acc[q] = fmaf(al, dv[u][q], acc[q]);
             }
         }
     }
@@ -345,16 +354,25 @@ __global__ void __launch_bounds__(256) gat_wcolsum_partial_kernel(const float *x
         part[(int64_t)blockIdx.x * D + d] = acc;
     }
 }
-// stage 2: da[h][off + c] = Σ_p part[p][h*C + c]
+// stage 2: da[h][off + c] = Σ_p part[p][h*C + c].  One block per column: thread k adds parts k, k+256, ... in order,
+// then a fixed-shape tree over the 256 partial sums in LDS (deterministic; a serial walk over 2048 parts cost 0.48 ms).
 __global__ void __launch_bounds__(256) gat_wcolsum_fold_kernel(const float *part, int nparts, int H, int C, int off,
                                                                float *da) {
-    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float red[256];
+    const int d = blockIdx.x;
     const int D = H * C;
-    if (d >= D) return;
     float acc = 0.0f;
-    for (int p = 0; p < nparts; ++p) acc = acc + part[(int64_t)p * D + d];
-    const int h = d / C;
-    da[(int64_t)h * 2 * C + off + (d - h * C)] = acc;
+    for (int p = threadIdx.x; p < nparts; p += 256) acc = acc + part[(int64_t)p * D + d];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] = red[threadIdx.x] + red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const int h = d / C;
+        da[(int64_t)h * 2 * C + off + (d - h * C)] = red[0];
+    }
 }
 
 static void fill_plan(GatBwdArgs &g, const gnnmp_graph *p) {
@@ -372,7 +390,7 @@ static void fill_plan(GatBwdArgs &g, const gnnmp_graph *p) {
     g.partial = p->ws;
 }
 
-template <int VEC>
+template <int VEC, int LPH>
 static int launch_gat_bwd(GatBwdArgs g, gnnmp_graph *plan, gnnmp_graph *plan_t, float *dWx_dst, float *da,
                           hipStream_t stream) {
     const int G = 1 << g.log2g;
@@ -380,7 +398,6 @@ static int launch_gat_bwd(GatBwdArgs g, gnnmp_graph *plan, gnnmp_graph *plan_t, 
     int waves = knob(KNOB_BLOCK_WAVES);
     if (waves < 1 || waves > 4) waves = 1;
     g.waves = waves;
-    const int lanes = g.D / VEC;
     const int unroll = knob(KNOB_UNROLL);
     // ---- pass 1: destinations (forward plan)
     fill_plan(g, plan);
@@ -389,9 +406,9 @@ static int launch_gat_bwd(GatBwdArgs g, gnnmp_graph *plan, gnnmp_graph *plan_t, 
         const int64_t blocks = (nvirt + (int64_t)rpw * waves - 1) / ((int64_t)rpw * waves);
         if (blocks > 0) {
             if (unroll == 4)
-                gat_bwd_dst_kernel<VEC, 4><<<(unsigned)blocks, 64 * waves, 0, stream>>>(g);
+                gat_bwd_dst_kernel<VEC, 4, LPH><<<(unsigned)blocks, 64 * waves, 0, stream>>>(g);
             else
-                gat_bwd_dst_kernel<VEC, 8><<<(unsigned)blocks, 64 * waves, 0, stream>>>(g);
+                gat_bwd_dst_kernel<VEC, 8, LPH><<<(unsigned)blocks, 64 * waves, 0, stream>>>(g);
             GNNMP_LAUNCH_CHECK("gat_bwd_dst_kernel");
         }
         if (g.n_long > 0) {
@@ -406,10 +423,12 @@ static int launch_gat_bwd(GatBwdArgs g, gnnmp_graph *plan, gnnmp_graph *plan_t, 
         const int64_t nvirt = (int64_t)g.n_rows + g.n_chunks;
         const int64_t blocks = (nvirt + (int64_t)rpw * waves - 1) / ((int64_t)rpw * waves);
         if (blocks > 0) {
+            // 20 bytes of operands per lane and edge here (Δ slice + the statistics line): 4 in flight keeps 6 waves/SIMD
+            // (7.0 ms on the products shape against 8.4 ms with 8 in flight at 4 waves/SIMD)
             if (unroll == 8)
-                gat_bwd_src_kernel<VEC, 8><<<(unsigned)blocks, 64 * waves, 0, stream>>>(g);
+                gat_bwd_src_kernel<VEC, 8, LPH><<<(unsigned)blocks, 64 * waves, 0, stream>>>(g);
             else
-                gat_bwd_src_kernel<VEC, 4><<<(unsigned)blocks, 64 * waves, 0, stream>>>(g);
+                gat_bwd_src_kernel<VEC, 4, LPH><<<(unsigned)blocks, 64 * waves, 0, stream>>>(g);
             GNNMP_LAUNCH_CHECK("gat_bwd_src_kernel");
         }
         if (g.n_long > 0) {
@@ -418,7 +437,6 @@ static int launch_gat_bwd(GatBwdArgs g, gnnmp_graph *plan, gnnmp_graph *plan_t, 
             GNNMP_LAUNCH_CHECK("gat_bwd_src_combine_kernel");
         }
     }
-    (void)lanes;
     // ---- rank-one target term for bipartite layers
     if (dWx_dst) {
         const int64_t n = (int64_t)plan->n_dst * g.D;
@@ -437,7 +455,7 @@ static int launch_gat_bwd(GatBwdArgs g, gnnmp_graph *plan, gnnmp_graph *plan_t, 
                 gat_wcolsum_partial_kernel<<<nparts, 256, 0, stream>>>(x, s, N, g.H, g.C, R, plan->ws);
                 GNNMP_LAUNCH_CHECK("gat_wcolsum_partial_kernel");
             }
-            gat_wcolsum_fold_kernel<<<(g.D + 255) / 256, 256, 0, stream>>>(plan->ws, nparts, g.H, g.C, side * g.C, da);
+            gat_wcolsum_fold_kernel<<<g.D, 256, 0, stream>>>(plan->ws, nparts, g.H, g.C, side * g.C, da);
             GNNMP_LAUNCH_CHECK("gat_wcolsum_fold_kernel");
         }
     }
@@ -501,9 +519,16 @@ extern "C" int gnnmp_gat_conv_grad_f32(gnnmp_graph_t *plan, gnnmp_graph_t *plan_
     g.lph = lph;
     g.waves = 1;
     g.slope = negative_slope;
-    switch (vec) {
-        case 4: return launch_gat_bwd<4>(g, plan, plan_t, dWx_dst, da, stream);
-        case 2: return launch_gat_bwd<2>(g, plan, plan_t, dWx_dst, da, stream);
-        default: return launch_gat_bwd<1>(g, plan, plan_t, dWx_dst, da, stream);
+    if (vec == 4) {   // the usual case (C a multiple of 4): compile-time lane count per head -> DPP butterflies
+        switch (lph) {
+            case 1: return launch_gat_bwd<4, 1>(g, plan, plan_t, dWx_dst, da, stream);
+            case 2: return launch_gat_bwd<4, 2>(g, plan, plan_t, dWx_dst, da, stream);
+            case 4: return launch_gat_bwd<4, 4>(g, plan, plan_t, dWx_dst, da, stream);
+            case 8: return launch_gat_bwd<4, 8>(g, plan, plan_t, dWx_dst, da, stream);
+            case 16: return launch_gat_bwd<4, 16>(g, plan, plan_t, dWx_dst, da, stream);
+            default: return launch_gat_bwd<4, 0>(g, plan, plan_t, dWx_dst, da, stream);
+        }
     }
+    if (vec == 2) return launch_gat_bwd<2, 0>(g, plan, plan_t, dWx_dst, da, stream);
+    return launch_gat_bwd<1, 0>(g, plan, plan_t, dWx_dst, da, stream);
 }

@@ -49,15 +49,14 @@ struct GatFusedArgs {
 __device__ __forceinline__ float lrelu(float x, float slope) { return x > 0.0f ? x : x * slope; }
 __device__ __forceinline__ float gexp(float x, int fast) { return fast ? __expf(x) : expf(x); }
 
-// sum over the lanes of one head (adjacent, power-of-two count): every lane ends with the same bits
-__device__ __forceinline__ float head_sum(float d, int lph) {
-    for (int o = 1; o < lph; o <<= 1) d += __shfl_xor(d, o, 64);
-    return d;
-}
 
-template <int VEC, int U>
+// One batch = U edges: U independent row loads, U dot products, their butterflies (DPP when the lane count per head LPH
+// is a compile-time constant), ONE rescale of the running state to the batch maximum and U exponentials — no branch
+// anywhere, so the scheduler interleaves all of it under the loads.  Slots past the end of the row re-read the last
+// edge with logit -inf (weight exactly 0).
+template <int VEC, int U, int LPH>
 __device__ __forceinline__ void gat_online_range(const GatFusedArgs &a, int beg, int end, int lig,
-                                                 int gbase, int G, int f0, bool active,
+                                                 int gbase, int G, int fc,
                                                  const float as[VEC], float sd, float &m, float &den,
                                                  float acc[VEC]) {
     for (int base = beg; base < end; base += G) {
@@ -69,33 +68,34 @@ __device__ __forceinline__ void gat_online_range(const GatFusedArgs &a, int beg,
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int cj = __shfl(c, gbase + min(j + u, n - 1), 64);
-                if (active && (j + u < n)) {
-                    Vec<VEC>::load(a.Wx_src + (int64_t)cj * a.D + f0, v[u]);
-                } else {
-#pragma unroll
-                    for (int q = 0; q < VEC; ++q) v[u][q] = 0.0f;
-                }
+                Vec<VEC>::load(a.Wx_src + (int64_t)cj * a.D + fc, v[u]);
             }
+            float l[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                if (j + u < n) {
-                    float d = 0.0f;
+                l[u] = 0.0f;
 #pragma unroll
-                    for (int q = 0; q < VEC; ++q) d = fmaf(as[q], v[u][q], d);
-                    d = head_sum(d, a.lph);
-                    const float l = lrelu(sd + d, a.slope);
-                    if (l > m) {  // the running max grows: rescale what has been accumulated (exp(-inf) = 0 first time)
-                        const float sc = gexp(m - l, a.fast_exp);
-                        den *= sc;
+                for (int q = 0; q < VEC; ++q) l[u] = fmaf(as[q], v[u][q], l[u]);
+            }
 #pragma unroll
-                        for (int q = 0; q < VEC; ++q) acc[q] *= sc;
-                        m = l;
-                    }
-                    const float pe = gexp(l - m, a.fast_exp);
-                    den += pe;
+            for (int u = 0; u < U; ++u) l[u] = group_sum<LPH>(l[u], a.lph);
+            float mn = m;
 #pragma unroll
-                    for (int q = 0; q < VEC; ++q) acc[q] = fmaf(pe, v[u][q], acc[q]);
-                }
+            for (int u = 0; u < U; ++u) {
+                l[u] = (j + u < n) ? lrelu(sd + l[u], a.slope) : -__builtin_inff();
+                mn = fmaxf(mn, l[u]);
+            }
+            const float sc = gexp(m - mn, a.fast_exp);   // exp(0) = 1 when the maximum did not move, exp(-inf) = 0 the first time
+            den *= sc;
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) acc[q] *= sc;
+            m = mn;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float pe = gexp(l[u] - m, a.fast_exp);
+                den += pe;
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) acc[q] = fmaf(pe, v[u][q], acc[q]);
             }
         }
     }
@@ -116,7 +116,7 @@ __device__ __forceinline__ void gat_fused_store(const GatFusedArgs &a, int row, 
     Vec<VEC>::store(a.out + (int64_t)row * a.D + f0, acc);
 }
 
-template <int VEC, int U>
+template <int VEC, int U, int LPH>
 __global__ void __launch_bounds__(256) gat_fused_rows_kernel(const GatFusedArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -143,31 +143,30 @@ __global__ void __launch_bounds__(256) gat_fused_rows_kernel(const GatFusedArgs 
         end = a.rowptr[row + 1];
         if (end - beg > a.long_thresh) return;
     }
-    // this lane's slice of the attention vector: target half a[h][c0 .. c0+VEC), source half a[h][C+c0 ..)
+    // this lane's slice of the attention vector: target half a[h][c0 .. c0+VEC), source half a[h][C+c0 ..); idle lanes
+    // (D/VEC not a power of two) shadow lane 0 with zero coefficients so that no load below needs a predicate
+    const int fc = active ? f0 : 0;
     float ad[VEC], as[VEC], vi[VEC];
-    if (active) {
-        const int h = f0 / a.C, c0 = f0 - h * a.C;
+    {
+        const int h = fc / a.C, c0 = fc - h * a.C;
         const float *ah = a.a + (int64_t)h * 2 * a.C + c0;
 #pragma unroll
         for (int q = 0; q < VEC; ++q) {
-            ad[q] = ah[q];
-            as[q] = ah[a.C + q];
+            ad[q] = active ? ah[q] : 0.0f;
+            as[q] = active ? ah[a.C + q] : 0.0f;
         }
-        Vec<VEC>::load(a.Wx_dst + (int64_t)row * a.D + f0, vi);
-    } else {
-#pragma unroll
-        for (int q = 0; q < VEC; ++q) ad[q] = as[q] = vi[q] = 0.0f;
+        Vec<VEC>::load(a.Wx_dst + (int64_t)row * a.D + fc, vi);
     }
     float sd = 0.0f;
 #pragma unroll
     for (int q = 0; q < VEC; ++q) sd = fmaf(ad[q], vi[q], sd);
-    sd = head_sum(sd, a.lph);
+    sd = group_sum<LPH>(sd, a.lph);
 
     float m = -__builtin_inff(), den = 0.0f;
     float acc[VEC];
 #pragma unroll
     for (int q = 0; q < VEC; ++q) acc[q] = 0.0f;
-    gat_online_range<VEC, U>(a, beg, end, lig, gbase, G, f0, active, as, sd, m, den, acc);
+    gat_online_range<VEC, U, LPH>(a, beg, end, lig, gbase, G, fc, as, sd, m, den, acc);
     if (is_chunk) {
         if (active) {
             const int LN = a.D / VEC;
@@ -265,12 +264,24 @@ static int launch_gat_fused(GatFusedArgs a, hipStream_t stream) {
             gx = (int64_t)a.cpx * 8;
         }
         dim3 grid((unsigned)gx, 1);
-        if (knob(KNOB_UNROLL) == 4)
-            gat_fused_rows_kernel<VEC, 4><<<grid, 64 * waves, 0, stream>>>(a);
-        else if (knob(KNOB_UNROLL) == 2)
-            gat_fused_rows_kernel<VEC, 2><<<grid, 64 * waves, 0, stream>>>(a);
+        const int U = knob(KNOB_UNROLL);
+        const int blk = 64 * waves;
+        if (U == 4)
+            gat_fused_rows_kernel<VEC, 4, 0><<<grid, blk, 0, stream>>>(a);
+        else if (U == 2)
+            gat_fused_rows_kernel<VEC, 2, 0><<<grid, blk, 0, stream>>>(a);
+        else if (VEC == 4 && a.lph == 1)
+            gat_fused_rows_kernel<VEC, 8, 1><<<grid, blk, 0, stream>>>(a);
+        else if (VEC == 4 && a.lph == 2)
+            gat_fused_rows_kernel<VEC, 8, 2><<<grid, blk, 0, stream>>>(a);
+        else if (VEC == 4 && a.lph == 4)
+            gat_fused_rows_kernel<VEC, 8, 4><<<grid, blk, 0, stream>>>(a);
+        else if (VEC == 4 && a.lph == 8)
+            gat_fused_rows_kernel<VEC, 8, 8><<<grid, blk, 0, stream>>>(a);
+        else if (VEC == 4 && a.lph == 16)
+            gat_fused_rows_kernel<VEC, 8, 16><<<grid, blk, 0, stream>>>(a);
         else
-            gat_fused_rows_kernel<VEC, 8><<<grid, 64 * waves, 0, stream>>>(a);
+            gat_fused_rows_kernel<VEC, 8, 0><<<grid, blk, 0, stream>>>(a);
         GNNMP_LAUNCH_CHECK("gat_fused_rows_kernel");
     }
     if (a.n_long > 0) {
