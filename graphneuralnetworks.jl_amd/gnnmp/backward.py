@@ -158,10 +158,10 @@ def dense_grad_x(dz, W):
     """Δx = Δz * W  ([N, Dout] x [Dout, K]): the forward kernel reading W transposed (w_layout = 1)"""
     N, Dout = dz.shape
     K = W.shape[1]
-    assert W.is_contiguous()
+    assert W.stride(1) == 1 and W.shape[0] == Dout      # a column slice of a wider matrix is fine (sage_conv's halves)
     dx = torch.empty((N, K), dtype=torch.float32, device=dz.device)
-    L.check(L.load().gnnmp_dense_f32(L.ptr(dz), L.ptr(W), Dout, K, None, None, 0, 0, 1, None, L.ACT_IDENTITY, L.ptr(dx), N, K,
-                                     L.stream_ptr()))
+    L.check(L.load().gnnmp_dense_f32(L.ptr(dz), L.ptr(W), Dout, W.stride(0), None, None, 0, 0, 1, None, L.ACT_IDENTITY,
+                                     L.ptr(dx), N, K, L.stream_ptr()))
     return dx
 
 
@@ -223,6 +223,55 @@ def gcn_conv_ad(l, g: GNNGraph, x):
     """differentiable GCNConv forward (default normalisation, unweighted): gradients w.r.t. x, l.weight, l.bias"""
     check_num_nodes(g, x)
     return _GCNConvFn.apply(x, l.weight, l.bias, g, l.sigma, bool(l.add_self_loops))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# GraphConv / SAGEConv:  y = σ.(W1 * x .+ W2 * propagate(copy_xj, g, aggr; xj = x) .+ b)
+# ---------------------------------------------------------------------------------------------------------
+class _TwoWeightConvFn(torch.autograd.Function):
+    """graph_conv (conv.jl:102-108) and sage_conv (conv.jl:277-283; W = [W1 W2]) with HIP forward AND backward"""
+
+    @staticmethod
+    def forward(ctx, x, w1, w2, bias, g, sigma, aggr):
+        from .layers import dense
+        from .msgpass import _fused
+        x = x.contiguous()
+        m = _fused(g, L.COPY_XJ, aggr, x, None)
+        y = dense(x, w1, bias, sigma, x2=m, W2=w2)
+        ctx.save_for_backward(x, m, w1, w2, y)
+        ctx.g, ctx.sigma, ctx.aggr, ctx.has_bias = g, sigma, aggr, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, m, w1, w2, y = ctx.saved_tensors
+        g = ctx.g
+        dz = act_grad(dy.contiguous(), y, ctx.sigma)
+        dW1, db = dense_grad_w(dz, x, need_w=ctx.needs_input_grad[1], need_b=ctx.has_bias and ctx.needs_input_grad[3])
+        dW2 = dense_grad_w(dz, m, need_b=False)[0] if ctx.needs_input_grad[2] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dm = dense_grad_x(dz, w2)
+            if aggr_code(ctx.aggr) in (L.MAX, L.MIN):
+                dxm = propagate_grad_xj(g, ctx.aggr, dm, xj=x, y=m)
+            else:
+                dxm = propagate_grad_xj(g, ctx.aggr, dm)
+            dx = dense_grad_x(dz, w1)
+            L.check(L.load().gnnmp_add_f32(L.ptr(dx), L.ptr(dxm), L.ptr(dx), dx.numel(), L.stream_ptr()))
+        return dx, dW1, dW2, db, None, None, None
+
+
+def graph_conv_ad(l, g: GNNGraph, x):
+    """differentiable GraphConv forward: gradients w.r.t. x, l.weight1, l.weight2, l.bias"""
+    check_num_nodes(g, x)
+    return _TwoWeightConvFn.apply(x, l.weight1, l.weight2, l.bias, g, l.sigma, l.aggr)
+
+
+def sage_conv_ad(l, g: GNNGraph, x):
+    """differentiable SAGEConv forward: gradients w.r.t. x, l.weight ([W1 W2] column blocks), l.bias"""
+    check_num_nodes(g, x)
+    Din = x.shape[1]
+    return _TwoWeightConvFn.apply(x, l.weight[:, :Din], l.weight[:, Din:], l.bias, g, l.sigma, l.aggr)
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -445,3 +445,22 @@ def grad_gat_conv(s, t, n, x, dense_x_weight, a, bias, sigma, dy, heads=1, negat
     da = np.concatenate([da_d.T, da_s.T], axis=0)                 # (2C, H)
     f = np.float32
     return dx.astype(f), dW.astype(f), da.astype(f), db.astype(f)
+
+
+def grad_graph_conv(s, t, n, x, weight1, weight2, bias, sigma, dy, aggr=SUM):
+    """(Δx, ΔW1, ΔW2, Δb) of graph_conv (conv.jl:102-108); sage_conv (conv.jl:277-283) is the same with W = [W1 W2].
+    Dense rules in float64, the propagate pullback through grad_propagate above."""
+    x = _f32(x)
+    W1 = np.asarray(weight1, np.float64)
+    W2 = np.asarray(weight2, np.float64)
+    m = propagate(aggr, s, t, n, x)
+    z = x.astype(np.float64) @ W1.T + m.astype(np.float64) @ W2.T + (0 if bias is None else np.asarray(bias, np.float64)[None, :])
+    dz = np.asarray(dy, np.float64) * (z > 0) if sigma == "relu" else np.asarray(dy, np.float64)
+    db = dz.sum(0)
+    dW1 = dz.T @ x.astype(np.float64)
+    dW2 = dz.T @ m.astype(np.float64)
+    dm = (dz @ W2).astype(np.float32)
+    dxm, _ = grad_propagate(aggr, s, t, n, dm, x)
+    dx = dz @ W1 + dxm.astype(np.float64)
+    f = np.float32
+    return dx.astype(f), dW1.astype(f), dW2.astype(f), db.astype(f)

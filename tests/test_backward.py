@@ -276,3 +276,50 @@ def test_gat_layer_backward_vs_oracle(gm, oracle, H, C, Din, sigma):
     l.dense_x_weight.grad = None
     (gat_conv_ad(l, g, xt2) * dev(r)).sum().backward()
     assert bool((xt2.grad == xt.grad).all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,aggr", [("graph", "+"), ("graph", "max"), ("sage", "mean"), ("sage", "+")])
+def test_graph_and_sage_layer_backward_vs_oracle(gm, oracle, kind, aggr):
+    import torch
+    from gnnmp.backward import graph_conv_ad, sage_conv_ad
+    rng = np.random.default_rng(len(kind) * 7 + len(aggr))
+    n, E, Din, Dout = 800, 9000, 20, 36
+    s = rng.integers(1, n + 1, E)
+    t = rng.integers(1, n - 3, E)              # the last nodes receive nothing (empty rows: 0 under + / mean)
+    if aggr == "max":
+        # every node gets an in-edge (an empty row holds -Inf and 0 * -Inf = NaN in ΔW2, in the reference too), and the
+        # graph is simple (NNlib's tie rule hands Δ to both copies of a multi-edge)
+        s = np.concatenate([s, np.arange(1, n + 1)])
+        t = np.concatenate([t, np.roll(np.arange(1, n + 1), 1)])
+        _, keep = np.unique(s * 10000 + t, return_index=True)
+        s, t = s[np.sort(keep)], t[np.sort(keep)]
+    x = rng.standard_normal((n, Din)).astype(np.float32)
+    r = rng.standard_normal((n, Dout)).astype(np.float32)
+    g = gm.GNNGraph(dev(s), dev(t), num_nodes=n)
+    if kind == "graph":
+        l = gm.GraphConv((Din, Dout), "relu", aggr=aggr, seed=4)
+        params = [l.weight1, l.weight2, l.bias]
+        W1, W2 = l.weight1.cpu().numpy(), l.weight2.cpu().numpy()
+        fn = graph_conv_ad
+    else:
+        l = gm.SAGEConv((Din, Dout), "relu", aggr=aggr, seed=4)
+        params = [l.weight, l.bias]
+        Wn = l.weight.cpu().numpy()
+        W1, W2 = Wn[:, :Din], Wn[:, Din:]
+        fn = sage_conv_ad
+    l.bias = dev((rng.standard_normal(Dout) * 0.1).astype(np.float32))
+    params[-1] = l.bias
+    b0 = l.bias.cpu().numpy()
+    for prm in params:
+        prm.requires_grad_(True)
+    xt = dev(x).requires_grad_(True)
+    y = fn(l, g, xt)
+    (y * dev(r)).sum().backward()
+    dx, dW1, dW2, db = oracle.grad_graph_conv(s, t, n, x, W1, W2, b0, "relu", r, aggr=aggr)
+    got_w = [params[0].grad.cpu().numpy(), params[1].grad.cpu().numpy()] if kind == "graph" else \
+        [params[0].grad.cpu().numpy()[:, :Din], params[0].grad.cpu().numpy()[:, Din:]]
+    for name, got, ref in (("dx", xt.grad.cpu().numpy(), dx), ("dW1", got_w[0], dW1), ("dW2", got_w[1], dW2),
+                           ("db", l.bias.grad.cpu().numpy(), db)):
+        assert np.isfinite(got).all(), name
+        assert np.linalg.norm(got - ref) <= 3e-5 * np.linalg.norm(ref), name
