@@ -100,6 +100,8 @@ __global__ void __launch_bounds__(256) gat_bwd_dst_kernel(const GatBwdArgs a) {
     }
     Vec<VEC>::load(a.Wx_dst + (int64_t)row * a.D + fc, vi);
     Vec<VEC>::load(a.dout + (int64_t)row * a.D + fc, di);
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) di[q] = active ? di[q] : 0.0f;   // H = 1: idle lanes sit inside the head's butterfly
     float sd = 0.0f;
 #pragma unroll
     for (int q = 0; q < VEC; ++q) sd = fmaf(ad[q], vi[q], sd);
@@ -222,6 +224,8 @@ __global__ void __launch_bounds__(256) gat_bwd_src_kernel(const GatBwdArgs a) {
         }
     }
     Vec<VEC>::load(a.Wx_src + (int64_t)row * a.D + fc, wj);
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) wj[q] = active ? wj[q] : 0.0f;   // H = 1: idle lanes sit inside the head's butterfly
     float ss = 0.0f;
 #pragma unroll
     for (int q = 0; q < VEC; ++q) ss = fmaf(as[q], wj[q], ss);
@@ -490,8 +494,12 @@ extern "C" int gnnmp_gat_conv_grad_f32(gnnmp_graph_t *plan, gnnmp_graph_t *plan_
     if (((reinterpret_cast<uintptr_t>(Wx_dst) | reinterpret_cast<uintptr_t>(dout)) & (4 * vec - 1)) != 0) vec = 1;
     if ((reinterpret_cast<uintptr_t>(line) & 15) != 0) return fail(GNNMP_EINVAL, "gat_conv_grad: line must be 16-byte aligned");
     while (vec > 1 && (C % vec) != 0) vec >>= 1;
-    const int lph = (int)(C / vec);
+    int lph = (int)(C / vec);
     const int lanes = D / vec;
+    if (H == 1 && lanes <= 64) {   // a single head may spill over idle lanes: they carry zeros
+        lph = 1;
+        while (lph < lanes) lph <<= 1;
+    }
     if ((lph & (lph - 1)) != 0 || lanes > 64)
         return fail(GNNMP_EUNSUPPORTED, "gat_conv_grad: needs a power-of-two lane count per head and H*C <= 256 (C = %lld)", (long long)C);
     // workspaces: chunk partials of each pass in that plan's workspace; the da partials reuse the forward plan's

@@ -1,18 +1,26 @@
-// gat_fused.hip — the whole GATConv attention path in ONE pass over the edges:
+// gat_fused.hip — neighbourhood attention in ONE pass over the edges.  The headline instance is GATConv:
 //   GNNlib/src/layers/conv.jl:136-141  apply_edges(gat_message) -> softmax_edge_neighbors -> α .* Wxj -> aggregate_neighbors(+)
 //   gat_message :152-167               logα = leakyrelu( sum(a .* vcat(Wxi, Wxj), dims = 1) )
 //
 // What makes it one pass: the source row Wx_j (4*H*C bytes) has to be fetched for the weighted sum anyway, and the
 // source half of the logit, a[C:2C,h] . Wx_j[:,h], is a function of exactly that row.  The lanes that hold head h's
-// channels (C/VEC of them, adjacent) form the dot product in registers with an xor butterfly (DPP quad/row permutes,
-// no LDS), so there is no (N,H) score array to gather (a random 64-byte sector per edge on top of the row) and no node
-// pre-pass.  The neighbourhood softmax is computed online (running max m, running denominator, rescale when the max
-// grows), so the row's edges are visited once instead of the reference's six (H,E') passes + three (C,H,E') passes:
-//     out_i[h,:] = ( sum_j exp(l_ij - m_i) * Wx_j[h,:] ) / ( sum_j exp(l_ij - m_i) )
-// Algebraically the reference's  sum_j (exp(l_ij - max_i) / den_i) * Wx_j ; the fp32 rounding differs (<= 1e-6 rel
+// channels (C/VEC of them, adjacent) form the dot product in registers with a butterfly (DPP quad permutes / row
+// mirrors, no LDS: common.h group_sum), so there is no (N,H) score array to gather (a random 64-byte sector per edge on
+// top of the row) and no node pre-pass.  The neighbourhood softmax is computed online (running max m, running
+// denominator, one rescale per batch of U edges), so the row's edges are visited once instead of the reference's six
+// (H,E') passes + three (C,H,E') passes:
+//     out_i[h,:] = ( sum_j exp(l_ij - m_i) * V_j[h,:] ) / ( sum_j exp(l_ij - m_i) )
+// Algebraically the reference's  sum_j (exp(l_ij - max_i) / den_i) * V_j ; the fp32 rounding differs (<= 1e-6 rel
 // measured, north_star allows 1e-5).  Callers that need the reference's exact operation order, the α coefficients, or a
-// head width whose lane count is not a power of two go through the three-pass kernels of attention.hip (same ABI entry
-// falls back automatically).
+// head width whose lane count is not a power of two go through the three-pass kernels of attention.hip (the GAT ABI
+// entry falls back automatically).
+//
+// The same kernel serves the other attention layers of the reference that share the path; only
+// the per-edge logit differs (template parameter MODE, enum gnnmp_attn in gnnmp.h):
+//   GAT    l = leakyrelu(a_d . Q_i + a_s . K_j)                 V = K          conv.jl:152-167
+//   GATV2  l = a . leakyrelu(Q_i + K_j)                         V = K          conv.jl:202-214  (gatv2_message)
+//   DOT    l = (Q_i . K_j) / scale                              V separate     conv.jl:609-616  (transformer_message_uij)
+//   COS    l = scale * (x_i . x_j) / (|x_i| |x_j|), one head    V = K = Q = x  conv.jl:337-352  (agnn_conv)
 //
 // Long rows: same chunking as propagate.hip — a chunk is a virtual row that emits (acc, m, den) partials; the combine
 // kernel merges them with the usual log-sum-exp rescale.
@@ -23,9 +31,10 @@ namespace gnnmp {
 struct GatFusedArgs {
     const int32_t *rowptr;
     const int32_t *col;
-    const float *Wx_src;  // [n_src][D]
-    const float *Wx_dst;  // [n_dst][D]
-    const float *a;       // [H][2C]
+    const float *Wx_src;  // K [n_src][D]
+    const float *Wx_val;  // V [n_src][D] (== Wx_src unless MODE = DOT)
+    const float *Wx_dst;  // Q [n_dst][D]
+    const float *a;       // GAT [H][2C], GATV2 [H][C], else unused
     const float *bias;    // [D] or null
     float *out;           // [n_dst][D]
     float *partial;       // [n_chunks][D + 2*D/VEC]
@@ -37,10 +46,11 @@ struct GatFusedArgs {
     int n_rows;
     int n_src;
     int log2g;
-    int lph;              // lanes per head = C / VEC (power of two)
+    int lph;              // lanes per head = C / VEC (power of two; the whole group when H = 1)
     int act;
     int fast_exp;
     float slope;
+    float scale;          // DOT: divisor (sqrt(out)); COS: multiplier (β)
     int long_thresh;
     int cpx;
     int waves;
@@ -49,40 +59,65 @@ struct GatFusedArgs {
 __device__ __forceinline__ float lrelu(float x, float slope) { return x > 0.0f ? x : x * slope; }
 __device__ __forceinline__ float gexp(float x, int fast) { return fast ? __expf(x) : expf(x); }
 
+// what a lane keeps for the whole row: its coefficient slice, its slice of Q_i, and one per-head scalar
+template <int VEC>
+struct LaneRow {
+    float ca[VEC];  // GAT: a_s slice; GATV2: a slice
+    float vi[VEC];  // Q_i slice (GATV2, DOT, COS)
+    float s0;       // GAT: a_d . Q_i;  COS: |x_i|
+    float am;       // 1 for lanes that own features, 0 for idle lanes
+};
 
 // One batch = U edges: U independent row loads, U dot products, their butterflies (DPP when the lane count per head LPH
 // is a compile-time constant), ONE rescale of the running state to the batch maximum and U exponentials — no branch
 // anywhere, so the scheduler interleaves all of it under the loads.  Slots past the end of the row re-read the last
 // edge with logit -inf (weight exactly 0).
-template <int VEC, int U, int LPH>
+template <int VEC, int U, int LPH, int MODE>
 __device__ __forceinline__ void gat_online_range(const GatFusedArgs &a, int beg, int end, int lig,
-                                                 int gbase, int G, int fc,
-                                                 const float as[VEC], float sd, float &m, float &den,
-                                                 float acc[VEC]) {
+                                                 int gbase, int G, int fc, const LaneRow<VEC> &r,
+                                                 float &m, float &den, float acc[VEC]) {
     for (int base = beg; base < end; base += G) {
         const int p = base + lig;
         const int c = p < end ? a.col[p] : 0;
         const int n = min(G, end - base);
         for (int j = 0; j < n; j += U) {
-            float v[U][VEC];
+            float v[U][VEC];                                  // K_j
+            float w[MODE == GNNMP_ATTN_DOT ? U : 1][VEC];     // V_j when it is a different array
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int cj = __shfl(c, gbase + min(j + u, n - 1), 64);
                 Vec<VEC>::load(a.Wx_src + (int64_t)cj * a.D + fc, v[u]);
+                if (MODE == GNNMP_ATTN_DOT) Vec<VEC>::load(a.Wx_val + (int64_t)cj * a.D + fc, w[MODE == GNNMP_ATTN_DOT ? u : 0]);
             }
-            float l[U];
+            float l[U], nn[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 l[u] = 0.0f;
+                nn[u] = 0.0f;
 #pragma unroll
-                for (int q = 0; q < VEC; ++q) l[u] = fmaf(as[q], v[u][q], l[u]);
+                for (int q = 0; q < VEC; ++q) {
+                    if (MODE == GNNMP_ATTN_GAT) l[u] = fmaf(r.ca[q], v[u][q], l[u]);
+                    if (MODE == GNNMP_ATTN_GATV2) l[u] = fmaf(r.ca[q], lrelu(r.vi[q] + v[u][q], a.slope), l[u]);
+                    if (MODE == GNNMP_ATTN_DOT) l[u] = fmaf(r.vi[q], v[u][q], l[u]);
+                    if (MODE == GNNMP_ATTN_COS) {
+                        l[u] = fmaf(r.vi[q], v[u][q], l[u]);
+                        nn[u] = fmaf(v[u][q] * r.am, v[u][q], nn[u]);
+                    }
+                }
             }
 #pragma unroll
-            for (int u = 0; u < U; ++u) l[u] = group_sum<LPH>(l[u], a.lph);
+            for (int u = 0; u < U; ++u) {
+                l[u] = group_sum<LPH>(l[u], a.lph);
+                if (MODE == GNNMP_ATTN_COS) nn[u] = group_sum<LPH>(nn[u], a.lph);
+            }
             float mn = m;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                l[u] = (j + u < n) ? lrelu(sd + l[u], a.slope) : -__builtin_inff();
+                float lu = l[u];
+                if (MODE == GNNMP_ATTN_GAT) lu = lrelu(r.s0 + lu, a.slope);
+                if (MODE == GNNMP_ATTN_DOT) lu = lu / a.scale;
+                if (MODE == GNNMP_ATTN_COS) lu = a.scale * (lu / (r.s0 * sqrtf(nn[u])));
+                l[u] = (j + u < n) ? lu : -__builtin_inff();
                 mn = fmaxf(mn, l[u]);
             }
             const float sc = gexp(m - mn, a.fast_exp);   // exp(0) = 1 when the maximum did not move, exp(-inf) = 0 the first time
@@ -95,7 +130,8 @@ __device__ __forceinline__ void gat_online_range(const GatFusedArgs &a, int beg,
                 const float pe = gexp(l[u] - m, a.fast_exp);
                 den += pe;
 #pragma unroll
-                for (int q = 0; q < VEC; ++q) acc[q] = fmaf(pe, v[u][q], acc[q]);
+                for (int q = 0; q < VEC; ++q)
+                    acc[q] = fmaf(pe, MODE == GNNMP_ATTN_DOT ? w[MODE == GNNMP_ATTN_DOT ? u : 0][q] : v[u][q], acc[q]);
             }
         }
     }
@@ -116,7 +152,7 @@ __device__ __forceinline__ void gat_fused_store(const GatFusedArgs &a, int row, 
     Vec<VEC>::store(a.out + (int64_t)row * a.D + f0, acc);
 }
 
-template <int VEC, int U, int LPH>
+template <int VEC, int U, int LPH, int MODE>
 __global__ void __launch_bounds__(256) gat_fused_rows_kernel(const GatFusedArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -143,30 +179,50 @@ __global__ void __launch_bounds__(256) gat_fused_rows_kernel(const GatFusedArgs 
         end = a.rowptr[row + 1];
         if (end - beg > a.long_thresh) return;
     }
-    // this lane's slice of the attention vector: target half a[h][c0 .. c0+VEC), source half a[h][C+c0 ..); idle lanes
-    // (D/VEC not a power of two) shadow lane 0 with zero coefficients so that no load below needs a predicate
+    // this lane's slice of the attention vector and of Q_i; idle lanes (D/VEC not a power of two) shadow lane 0 with zero
+    // coefficients so that no load below needs a predicate
     const int fc = active ? f0 : 0;
-    float ad[VEC], as[VEC], vi[VEC];
+    LaneRow<VEC> r;
+    r.am = active ? 1.0f : 0.0f;
+    r.s0 = 0.0f;
     {
         const int h = fc / a.C, c0 = fc - h * a.C;
-        const float *ah = a.a + (int64_t)h * 2 * a.C + c0;
+        float qi[VEC];
+        Vec<VEC>::load(a.Wx_dst + (int64_t)row * a.D + fc, qi);
 #pragma unroll
         for (int q = 0; q < VEC; ++q) {
-            ad[q] = active ? ah[q] : 0.0f;
-            as[q] = active ? ah[a.C + q] : 0.0f;
+            r.vi[q] = active ? qi[q] : 0.0f;
+            r.ca[q] = 0.0f;
         }
-        Vec<VEC>::load(a.Wx_dst + (int64_t)row * a.D + fc, vi);
-    }
-    float sd = 0.0f;
+        if (MODE == GNNMP_ATTN_GAT) {
+            const float *ah = a.a + (int64_t)h * 2 * a.C + c0;
+            float sd = 0.0f;
 #pragma unroll
-    for (int q = 0; q < VEC; ++q) sd = fmaf(ad[q], vi[q], sd);
-    sd = group_sum<LPH>(sd, a.lph);
+            for (int q = 0; q < VEC; ++q) {
+                const float adq = active ? ah[q] : 0.0f;
+                r.ca[q] = active ? ah[a.C + q] : 0.0f;
+                sd = fmaf(adq, qi[q], sd);
+            }
+            r.s0 = group_sum<LPH>(sd, a.lph);
+        }
+        if (MODE == GNNMP_ATTN_GATV2) {
+            const float *ah = a.a + (int64_t)h * a.C + c0;
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) r.ca[q] = active ? ah[q] : 0.0f;
+        }
+        if (MODE == GNNMP_ATTN_COS) {
+            float n2 = 0.0f;
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) n2 = fmaf(r.vi[q], r.vi[q], n2);
+            r.s0 = sqrtf(group_sum<LPH>(n2, a.lph));
+        }
+    }
 
     float m = -__builtin_inff(), den = 0.0f;
     float acc[VEC];
 #pragma unroll
     for (int q = 0; q < VEC; ++q) acc[q] = 0.0f;
-    gat_online_range<VEC, U, LPH>(a, beg, end, lig, gbase, G, fc, as, sd, m, den, acc);
+    gat_online_range<VEC, U, LPH, MODE>(a, beg, end, lig, gbase, G, fc, r, m, den, acc);
     if (is_chunk) {
         if (active) {
             const int LN = a.D / VEC;
@@ -245,7 +301,25 @@ __global__ void __launch_bounds__(256) gat_fused_combine_kernel(const GatFusedAr
     gat_fused_store<VEC>(a, row, f0, true, acc);
 }
 
-template <int VEC>
+template <int VEC, int U, int MODE>
+static void launch_rows_lph(const GatFusedArgs &a, dim3 grid, int blk, hipStream_t stream) {
+    // compile-time lane count per head for the usual VEC = 4 shapes (DPP butterflies); anything else walks the xor
+    // butterfly with the run-time count
+    if (VEC == 4 && a.lph == 1)
+        gat_fused_rows_kernel<VEC, U, 1, MODE><<<grid, blk, 0, stream>>>(a);
+    else if (VEC == 4 && a.lph == 2)
+        gat_fused_rows_kernel<VEC, U, 2, MODE><<<grid, blk, 0, stream>>>(a);
+    else if (VEC == 4 && a.lph == 4)
+        gat_fused_rows_kernel<VEC, U, 4, MODE><<<grid, blk, 0, stream>>>(a);
+    else if (VEC == 4 && a.lph == 8)
+        gat_fused_rows_kernel<VEC, U, 8, MODE><<<grid, blk, 0, stream>>>(a);
+    else if (VEC == 4 && a.lph == 16)
+        gat_fused_rows_kernel<VEC, U, 16, MODE><<<grid, blk, 0, stream>>>(a);
+    else
+        gat_fused_rows_kernel<VEC, U, 0, MODE><<<grid, blk, 0, stream>>>(a);
+}
+
+template <int VEC, int MODE>
 static int launch_gat_fused(GatFusedArgs a, hipStream_t stream) {
     const int G = 1 << a.log2g;
     const int rpw = 64 / G;
@@ -266,22 +340,15 @@ static int launch_gat_fused(GatFusedArgs a, hipStream_t stream) {
         dim3 grid((unsigned)gx, 1);
         const int U = knob(KNOB_UNROLL);
         const int blk = 64 * waves;
-        if (U == 4)
-            gat_fused_rows_kernel<VEC, 4, 0><<<grid, blk, 0, stream>>>(a);
-        else if (U == 2)
-            gat_fused_rows_kernel<VEC, 2, 0><<<grid, blk, 0, stream>>>(a);
-        else if (VEC == 4 && a.lph == 1)
-            gat_fused_rows_kernel<VEC, 8, 1><<<grid, blk, 0, stream>>>(a);
-        else if (VEC == 4 && a.lph == 2)
-            gat_fused_rows_kernel<VEC, 8, 2><<<grid, blk, 0, stream>>>(a);
-        else if (VEC == 4 && a.lph == 4)
-            gat_fused_rows_kernel<VEC, 8, 4><<<grid, blk, 0, stream>>>(a);
-        else if (VEC == 4 && a.lph == 8)
-            gat_fused_rows_kernel<VEC, 8, 8><<<grid, blk, 0, stream>>>(a);
-        else if (VEC == 4 && a.lph == 16)
-            gat_fused_rows_kernel<VEC, 8, 16><<<grid, blk, 0, stream>>>(a);
-        else
-            gat_fused_rows_kernel<VEC, 8, 0><<<grid, blk, 0, stream>>>(a);
+        if (MODE == GNNMP_ATTN_DOT) {
+            launch_rows_lph<VEC, 4, MODE>(a, grid, blk, stream);   // two rows per edge in flight: half the batch
+        } else if (MODE == GNNMP_ATTN_GAT && U == 4) {
+            gat_fused_rows_kernel<VEC, 4, 0, MODE><<<grid, blk, 0, stream>>>(a);
+        } else if (MODE == GNNMP_ATTN_GAT && U == 2) {
+            gat_fused_rows_kernel<VEC, 2, 0, MODE><<<grid, blk, 0, stream>>>(a);
+        } else {
+            launch_rows_lph<VEC, 8, MODE>(a, grid, blk, stream);
+        }
         GNNMP_LAUNCH_CHECK("gat_fused_rows_kernel");
     }
     if (a.n_long > 0) {
@@ -292,39 +359,58 @@ static int launch_gat_fused(GatFusedArgs a, hipStream_t stream) {
     return GNNMP_OK;
 }
 
+template <int MODE>
+static int launch_mode(const GatFusedArgs &g, int vec, hipStream_t stream) {
+    switch (vec) {
+        case 4: return launch_gat_fused<4, MODE>(g, stream);
+        case 2: return launch_gat_fused<2, MODE>(g, stream);
+        default: return launch_gat_fused<1, MODE>(g, stream);
+    }
+}
+
 }  // namespace gnnmp
 
 using namespace gnnmp;
 
-static int gat_conv_impl(gnnmp_graph_t *plan, const float *Wx_src, const float *Wx_dst, const float *a,
-                         float negative_slope, const float *bias, int act, float *out, float *stats, int64_t H,
-                         int64_t C, gnnmp_stream_t stream_) {
+static int attn_conv_impl(gnnmp_graph_t *plan, int mode, const float *Q, const float *K, const float *V, const float *a,
+                          float negative_slope, float scale, const float *bias, int act, float *out, float *stats,
+                          int64_t H, int64_t C, gnnmp_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (!plan) return fail(GNNMP_EINVAL, "gat_conv: null plan");
-    if (H <= 0 || C <= 0 || H * C > (1 << 20)) return fail(GNNMP_EINVAL, "gat_conv: bad H/C");
-    if (act != GNNMP_ACT_IDENTITY && act != GNNMP_ACT_RELU) return fail(GNNMP_EINVAL, "gat_conv: bad act %d", act);
+    if (!plan) return fail(GNNMP_EINVAL, "attn_conv: null plan");
+    if (mode < GNNMP_ATTN_GAT || mode > GNNMP_ATTN_COS) return fail(GNNMP_EINVAL, "attn_conv: bad mode %d", mode);
+    if (H <= 0 || C <= 0 || H * C > (1 << 20)) return fail(GNNMP_EINVAL, "attn_conv: bad H/C");
+    if (mode == GNNMP_ATTN_COS && H != 1) return fail(GNNMP_EINVAL, "attn_conv: the cosine logit is single-head");
+    if (act != GNNMP_ACT_IDENTITY && act != GNNMP_ACT_RELU) return fail(GNNMP_EINVAL, "attn_conv: bad act %d", act);
     if (plan->n_dst == 0) return GNNMP_OK;
-    if (!Wx_dst) Wx_dst = Wx_src;
-    if (!out || !a || !Wx_dst || (plan->n_total > 0 && !Wx_src)) return fail(GNNMP_EINVAL, "gat_conv: null pointer");
-    if (Wx_dst == Wx_src && plan->n_src != plan->n_dst)
-        return fail(GNNMP_EINVAL, "gat_conv: bipartite plan needs Wx_dst");
+    if (!Q) Q = K;
+    if (!V) V = K;
+    if (mode != GNNMP_ATTN_DOT && V != K) return fail(GNNMP_EINVAL, "attn_conv: a separate value array needs mode DOT");
+    const bool needs_a = mode == GNNMP_ATTN_GAT || mode == GNNMP_ATTN_GATV2;
+    if (!out || (needs_a && !a) || !Q || (plan->n_total > 0 && !K)) return fail(GNNMP_EINVAL, "attn_conv: null pointer");
+    if (Q == K && plan->n_src != plan->n_dst) return fail(GNNMP_EINVAL, "attn_conv: bipartite plan needs a separate Q");
     const int D = (int)(H * C);
-    int vec = pick_vec(D, Wx_src, out);
-    if ((reinterpret_cast<uintptr_t>(Wx_dst) & (4 * vec - 1)) != 0) vec = 1;
+    int vec = pick_vec(D, K, out);
+    if (((reinterpret_cast<uintptr_t>(Q) | reinterpret_cast<uintptr_t>(V)) & (4 * vec - 1)) != 0) vec = 1;
     while (vec > 1 && (C % vec) != 0) vec >>= 1;
-    const int lph = (int)(C / vec);
+    int lph = (int)(C / vec);
     const int lanes = D / vec;
+    int log2g = 0;
+    while ((1 << log2g) < lanes) ++log2g;   // one feature tile: the head butterfly needs the whole row in one group
+    if (H == 1 && lanes <= 64) lph = 1 << log2g;   // a single head may spill over idle lanes: they carry zeros
     const bool pow2 = (lph & (lph - 1)) == 0;
-    if ((!pow2 || lanes > 64) && stats)
-        return fail(GNNMP_EUNSUPPORTED, "gat_conv: softmax statistics need a power-of-two lane count per head and H*C <= 256");
     if (!pow2 || lanes > 64) {
-        // head width not a power-of-two lane count (or wider than a wave): three-pass kernels on node scores
+        if (mode != GNNMP_ATTN_GAT || stats)
+            return fail(GNNMP_EUNSUPPORTED,
+                        "attn_conv: the one-pass kernel needs H*C <= 256 and a power-of-two lane count per head (C = %lld)",
+                        (long long)C);
+        // GAT with a head width that is not a power-of-two lane count (or wider than a wave): three-pass kernels on
+        // node scores
         const size_t need = (size_t)(plan->n_dst + plan->n_src) * (size_t)H;
         if (int rc = ensure_workspace(plan, need)) return rc;
         float *sdst = plan->ws, *ssrc = plan->ws + (size_t)plan->n_dst * (size_t)H;
-        if (int rc = gnnmp_gat_node_scores_f32(Wx_dst, a, sdst, nullptr, plan->n_dst, H, C, stream_)) return rc;
-        if (int rc = gnnmp_gat_node_scores_f32(Wx_src, a, nullptr, ssrc, plan->n_src, H, C, stream_)) return rc;
-        return gnnmp_gat_aggregate_f32(plan, Wx_src, sdst, ssrc, negative_slope, bias, act, out, nullptr, H, C, stream_);
+        if (int rc = gnnmp_gat_node_scores_f32(Q, a, sdst, nullptr, plan->n_dst, H, C, stream_)) return rc;
+        if (int rc = gnnmp_gat_node_scores_f32(K, a, nullptr, ssrc, plan->n_src, H, C, stream_)) return rc;
+        return gnnmp_gat_aggregate_f32(plan, K, sdst, ssrc, negative_slope, bias, act, out, nullptr, H, C, stream_);
     }
     if (plan->n_chunks > 0) {
         if (int rc = ensure_workspace(plan, (size_t)plan->n_chunks * (size_t)(D + 2 * lanes))) return rc;
@@ -332,8 +418,9 @@ static int gat_conv_impl(gnnmp_graph_t *plan, const float *Wx_src, const float *
     GatFusedArgs g;
     g.rowptr = plan->rowptr;
     g.col = plan->col;
-    g.Wx_src = Wx_src;
-    g.Wx_dst = Wx_dst;
+    g.Wx_src = K;
+    g.Wx_val = V;
+    g.Wx_dst = Q;
     g.a = a;
     g.bias = bias;
     g.out = out;
@@ -351,30 +438,38 @@ static int gat_conv_impl(gnnmp_graph_t *plan, const float *Wx_src, const float *
     g.D = D;
     g.n_rows = (int)plan->n_dst;
     g.n_src = (int)plan->n_src;
-    g.log2g = pick_log2g(lanes);
-    while ((1 << g.log2g) < lanes) ++g.log2g;  // one feature tile: the head butterfly needs the whole row in one group
+    g.log2g = log2g;
     g.lph = lph;
     g.act = act;
     g.fast_exp = knob(KNOB_GAT_FAST_EXP);
     g.slope = negative_slope;
+    g.scale = scale;
     g.long_thresh = plan->long_thresh;
     g.cpx = 0;
     g.waves = 4;
-    switch (vec) {
-        case 4: return launch_gat_fused<4>(g, stream);
-        case 2: return launch_gat_fused<2>(g, stream);
-        default: return launch_gat_fused<1>(g, stream);
+    switch (mode) {
+        case GNNMP_ATTN_GATV2: return launch_mode<GNNMP_ATTN_GATV2>(g, vec, stream);
+        case GNNMP_ATTN_DOT: return launch_mode<GNNMP_ATTN_DOT>(g, vec, stream);
+        case GNNMP_ATTN_COS: return launch_mode<GNNMP_ATTN_COS>(g, vec, stream);
+        default: return launch_mode<GNNMP_ATTN_GAT>(g, vec, stream);
     }
 }
 
 extern "C" int gnnmp_gat_conv_f32(gnnmp_graph_t *plan, const float *Wx_src, const float *Wx_dst, const float *a,
                                   float negative_slope, const float *bias, int act, float *out, int64_t H, int64_t C,
                                   gnnmp_stream_t stream) {
-    return gat_conv_impl(plan, Wx_src, Wx_dst, a, negative_slope, bias, act, out, nullptr, H, C, stream);
+    return attn_conv_impl(plan, GNNMP_ATTN_GAT, Wx_dst, Wx_src, nullptr, a, negative_slope, 1.0f, bias, act, out, nullptr,
+                          H, C, stream);
 }
 extern "C" int gnnmp_gat_conv_stats_f32(gnnmp_graph_t *plan, const float *Wx_src, const float *Wx_dst, const float *a,
                                         float negative_slope, const float *bias, int act, float *out, float *stats,
                                         int64_t H, int64_t C, gnnmp_stream_t stream) {
     if (!stats) return fail(GNNMP_EINVAL, "gat_conv_stats: null stats");
-    return gat_conv_impl(plan, Wx_src, Wx_dst, a, negative_slope, bias, act, out, stats, H, C, stream);
+    return attn_conv_impl(plan, GNNMP_ATTN_GAT, Wx_dst, Wx_src, nullptr, a, negative_slope, 1.0f, bias, act, out, stats, H,
+                          C, stream);
+}
+extern "C" int gnnmp_attn_conv_f32(gnnmp_graph_t *plan, int mode, const float *Q, const float *K, const float *V,
+                                   const float *a, float negative_slope, float scale, const float *bias, int act,
+                                   float *out, float *stats, int64_t H, int64_t C, gnnmp_stream_t stream) {
+    return attn_conv_impl(plan, mode, Q, K, V, a, negative_slope, scale, bias, act, out, stats, H, C, stream);
 }

@@ -126,6 +126,11 @@ __global__ void __launch_bounds__(256) add_kernel(const float *a, const float *b
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = a[i] + b[i];
 }
+// out = alpha .* x .+ y   — gin_conv's `(1 .+ ϵ) .* xi .+ m` (GNNlib/src/layers/conv.jl:250-256): product rounded, then sum
+__global__ void __launch_bounds__(256) axpy_kernel(float alpha, const float *x, const float *y, float *out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = alpha * x[i] + y[i];
+}
 // out[n][c] = act( (Σ_h y[n][h][c]) / H + bias[c] )   — `mean(x, dims = 2)` of gat_conv with concat = false
 // (GNNlib/src/layers/conv.jl:143-147): heads summed in order h = 1..H, one true division, then σ.(x .+ bias)
 __global__ void __launch_bounds__(256) head_mean_kernel(const float *y, const float *bias, int act, float *out,
@@ -205,6 +210,16 @@ int gnnmp_add_f32(const float *a, const float *b, float *out, int64_t n, gnnmp_s
     if (!a || !b || !out) return fail(GNNMP_EINVAL, "add: null pointer");
     add_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(a, b, out, n);
     GNNMP_LAUNCH_CHECK("add_kernel");
+    return GNNMP_OK;
+}
+
+int gnnmp_axpy_f32(float alpha, const float *x, const float *y, float *out, int64_t n, gnnmp_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n < 0) return fail(GNNMP_EINVAL, "axpy: negative n");
+    if (n == 0) return GNNMP_OK;
+    if (!x || !y || !out) return fail(GNNMP_EINVAL, "axpy: null pointer");
+    axpy_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(alpha, x, y, out, n);
+    GNNMP_LAUNCH_CHECK("axpy_kernel");
     return GNNMP_OK;
 }
 

@@ -10,6 +10,8 @@ from .layers import (Dense, GATConv, GCNConv, GlobalPool, GNNChain, GraphConv, S
                      gat_conv, gcn_conv, global_pool, glorot_uniform, graph_conv, sage_conv)
 from .msgpass import (aggregate_neighbors, apply_edges, copy_xi, copy_xj, e_mul_xj, propagate, w_mul_xj,  # noqa: F401
                       xi_dot_xj, xi_sub_xj, xj_sub_xi)
+from .layers_attn import (AGNNConv, GATv2Conv, GINConv, TransformerConv, agnn_conv, gatv2_conv, gin_conv,  # noqa: F401
+                          transformer_conv)
 from .utils import expand_srcdst, reduce_nodes, softmax_edge_neighbors  # noqa: F401
 
 __version__ = "0.1.0"

@@ -26,11 +26,11 @@ SYMBOLS = (
     "gnnmp_propagate_f32", "gnnmp_propagate_slots_f32", "gnnmp_plan_slot_gather_f32",
     "gnnmp_degree_f32", "gnnmp_inv_sqrt_f32",
     "gnnmp_edge_softmax_f32", "gnnmp_gat_node_scores_f32", "gnnmp_gat_aggregate_f32", "gnnmp_gat_conv_f32",
-    "gnnmp_gat_conv_stats_f32", "gnnmp_gat_conv_grad_f32",
+    "gnnmp_gat_conv_stats_f32", "gnnmp_gat_conv_grad_f32", "gnnmp_attn_conv_f32",
     "gnnmp_bias_act_f32",
     "gnnmp_segment_pool_f32", "gnnmp_dense_f32",
     "gnnmp_edge_dot_f32", "gnnmp_edge_dot_plan_f32", "gnnmp_propagate_maxmin_grad_f32",
-    "gnnmp_head_mean_f32", "gnnmp_add_f32", "gnnmp_is_sorted",
+    "gnnmp_head_mean_f32", "gnnmp_add_f32", "gnnmp_axpy_f32", "gnnmp_is_sorted",
     "gnnmp_act_grad_f32", "gnnmp_dense_grad_workspace", "gnnmp_dense_grad_w_f32",
 )
 
@@ -72,6 +72,7 @@ def load():
         "gnnmp_plan_slot_gather_f32": [vp, i, vp, vp, vp],
         "gnnmp_gat_conv_f32": [vp, vp, vp, vp, f, vp, i, vp, i64, i64, vp],
         "gnnmp_gat_conv_stats_f32": [vp, vp, vp, vp, f, vp, i, vp, vp, i64, i64, vp],
+        "gnnmp_attn_conv_f32": [vp, i, vp, vp, vp, vp, f, f, vp, i, vp, vp, i64, i64, vp],
         "gnnmp_gat_conv_grad_f32": [vp, vp, vp, vp, vp, f, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, vp],
         "gnnmp_degree_f32": [vp, vp, vp, vp],
         "gnnmp_inv_sqrt_f32": [vp, vp, i64, vp],
@@ -85,6 +86,7 @@ def load():
         "gnnmp_edge_dot_plan_f32": [vp, vp, vp, vp, i64, vp],
         "gnnmp_head_mean_f32": [vp, vp, i, vp, i64, i64, i64, vp],
         "gnnmp_add_f32": [vp, vp, vp, i64, vp],
+        "gnnmp_axpy_f32": [f, vp, vp, vp, i64, vp],
         "gnnmp_is_sorted": [vp, i, i64, ctypes.POINTER(i), vp],
         "gnnmp_propagate_maxmin_grad_f32": [vp, vp, vp, vp, vp, i64, vp],
         "gnnmp_act_grad_f32": [vp, vp, i, vp, i64, vp],

@@ -330,7 +330,7 @@ class GNNChain:
 
 
 def _takes_graph(l):
-    return isinstance(l, (GCNConv, GraphConv, SAGEConv, GATConv, GlobalPool))
+    return isinstance(l, (GCNConv, GraphConv, SAGEConv, GATConv, GlobalPool)) or getattr(l, "takes_graph", False)
 
 
 def glorot_uniform(rows, cols, device="cuda", seed=None):

@@ -63,6 +63,13 @@ typedef enum { GNNMP_COPY_XJ = 0, GNNMP_W_MUL_XJ = 1 } gnnmp_msg;
 
 /* activation fused into gnnmp_dense_f32's epilogue (the layers' `σ`). */
 typedef enum { GNNMP_ACT_IDENTITY = 0, GNNMP_ACT_RELU = 1 } gnnmp_act;
+/* per-edge attention logit of gnnmp_attn_conv_f32 (Q_i = row i of the target array, K_j = row j of the source array) */
+typedef enum {
+    GNNMP_ATTN_GAT = 0,   /* leakyrelu(a[h][0:C] . Q_i + a[h][C:2C] . K_j)      gat_message   conv.jl:152-167 */
+    GNNMP_ATTN_GATV2 = 1, /* a[h] . leakyrelu(Q_i + K_j)                        gatv2_message conv.jl:202-214 */
+    GNNMP_ATTN_DOT = 2,   /* (Q_i . K_j) / scale, values from a third array     transformer_message_uij conv.jl:609-616 */
+    GNNMP_ATTN_COS = 3    /* scale * cos(Q_i, K_j), single head                 agnn_conv     conv.jl:337-352 */
+} gnnmp_attn;
 
 /* Destinations with more edges than the plan's threshold are split into balanced chunks (see determinism note
  * above).  The threshold is chosen per plan in [GNNMP_MIN_LONG_ROW, GNNMP_LONG_ROW] from the graph size
@@ -225,6 +232,19 @@ int gnnmp_gat_conv_stats_f32(gnnmp_graph_t *plan, const float *Wx_src, const flo
                              float negative_slope, const float *bias, int act, float *out, float *stats,
                              int64_t H, int64_t C, gnnmp_stream_t stream);
 
+/* The same one-pass kernel for the other attention layers that share the path: GATv2Conv
+ * (gatv2_conv, conv.jl:171-214), TransformerConv's attention core (transformer_conv, conv.jl:553-616) and AGNNConv
+ * (agnn_conv, conv.jl:337-352).  out[i][h][:] = Σ_j softmax_{j in N(i)}(l_ij) V_j[h][:], then + bias and act.
+ *   Q [n_dst][H*C] (NULL = K), K [n_src][H*C], V [n_src][H*C] (NULL = K; a separate V only with GNNMP_ATTN_DOT)
+ *   a: GAT [H][2C], GATV2 [H][C] (Julia (C, H) as stored), otherwise ignored
+ *   scale: DOT divides the dot product by it (l.sqrt_out); COS multiplies the cosine by it (l.β); else ignored
+ *   stats: optional [n_dst][H][2] softmax statistics as in gnnmp_gat_conv_stats_f32
+ * Needs H*C <= 256 and either H == 1 or a power-of-two lane count per head (C in {1,2,4,8,16,32,64} with 16-byte rows);
+ * GNNMP_EUNSUPPORTED otherwise (mode GAT falls back to the three-pass kernels instead). */
+int gnnmp_attn_conv_f32(gnnmp_graph_t *plan, int mode, const float *Q, const float *K, const float *V,
+                        const float *a, float negative_slope, float scale, const float *bias, int act,
+                        float *out, float *stats, int64_t H, int64_t C, gnnmp_stream_t stream);
+
 /* Pullback of the attention path (what Zygote composes from the rrules of gather / leakyrelu / softmax_edge_neighbors /
  * scatter(+) for conv.jl:136-141,152-167).  dout = Δ w.r.t. the aggregated (pre-bias, pre-σ) output [n_dst][H*C];
  * plan_t = plan of the reversed edge index (same self-loop flag); stats from gnnmp_gat_conv_stats_f32.
@@ -243,6 +263,8 @@ int gnnmp_head_mean_f32(const float *y, const float *bias, int act, float *out, 
                         int64_t C, gnnmp_stream_t stream);
 /* out = a + b (n floats) — degree(g; dir = :both) = out-degree + in-degree (GNNGraphs/src/query.jl:362-367). */
 int gnnmp_add_f32(const float *a, const float *b, float *out, int64_t n, gnnmp_stream_t stream);
+/* out = alpha .* x .+ y (out may alias x or y) — `(1 .+ ϵ) .* xi .+ m` of gin_conv, GNNlib/src/layers/conv.jl:250-256 */
+int gnnmp_axpy_f32(float alpha, const float *x, const float *y, float *out, int64_t n, gnnmp_stream_t stream);
 /* *result_host = 1 iff idx[0..n) is non-decreasing (is a graph_indicator one that `batch` could have built?).
  * Synchronises the stream (graph prep). */
 int gnnmp_is_sorted(const void *idx, int idx_bytes, int64_t n, int *result_host, gnnmp_stream_t stream);
