@@ -25,6 +25,7 @@ struct ReduceArgs {
     const int32_t *eid;      // per slot: original edge position (weights lookup); unused unless w
     const float *x;          // [n_src][D]
     const float *w;          // [n_edges] original order, nullable
+    const float *emat;       // [n_edges][D] original order: per-edge, per-feature factor (e_mul_xj with a matrix e)
     const float *ss;         // [n_src] nullable
     const float *w_slot;     // [E'] slot order, nullable (takes precedence over w)
     const float *ss_slot;    // [E'] slot order, nullable (takes precedence over ss)
@@ -47,16 +48,17 @@ struct ReduceArgs {
 };
 
 // reduce slots [beg, end) of one destination into acc[VEC]; all lanes of the group call this together.
-template <int VEC, int OP, bool SCALED, int U>
+template <int VEC, int OP, bool SCALED, int U, bool EMAT = false>
 __device__ __forceinline__ void reduce_range(const ReduceArgs &a, int beg, int end, int lig,
                                              int gbase, int G, int f0, bool active,
                                              float acc[VEC]) {
     for (int base = beg; base < end; base += G) {
         const int p = base + lig;
-        int c = 0;
+        int c = 0, ev = 0;
         float wv = 1.0f, sv = 1.0f;
         if (p < end) {
             c = a.idx[p];
+            if (EMAT) ev = a.eid[p];
             if (SCALED) {
                 if (a.w_slot) {
                     wv = a.w_slot[p];
@@ -73,11 +75,23 @@ __device__ __forceinline__ void reduce_range(const ReduceArgs &a, int beg, int e
         const int n = min(G, end - base);
         for (int j = 0; j < n; j += U) {
             float v[U][VEC];
+            float em[EMAT ? U : 1][VEC];
             float wj[U], sj[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int jj = min(j + u, n - 1);
                 const int cj = __shfl(c, gbase + jj, 64);
+                if (EMAT) {
+                    // e .* xj with e (D, E'): the edge's own row of factors, by original edge position; self loops the
+                    // plan added carry no features and weigh 1
+                    const int ej = __shfl(ev, gbase + jj, 64);
+                    if (active && (j + u < n) && ej < a.n_edges) {
+                        Vec<VEC>::load(a.emat + (int64_t)ej * a.D + f0, em[EMAT ? u : 0]);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < VEC; ++q) em[EMAT ? u : 0][q] = 1.0f;
+                    }
+                }
                 if (SCALED) {
                     wj[u] = __shfl(wv, gbase + jj, 64);
                     sj[u] = __shfl(sv, gbase + jj, 64);
@@ -99,6 +113,7 @@ __device__ __forceinline__ void reduce_range(const ReduceArgs &a, int beg, int e
                             t = t * sj[u];  // xj .* cout'   (GNNlib/src/layers/conv.jl:59), rounded
                             t = wj[u] * t;  // w .* xj        (GNNlib/src/msgpass.jl:203-208), rounded
                         }
+                        if (EMAT) t = em[EMAT ? u : 0][q] * t;  // e .* xj (GNNlib/src/msgpass.jl:187-191)
                         acc[q] = op_apply<OP>(acc[q], t);
                     }
                 }
@@ -125,7 +140,7 @@ __device__ __forceinline__ void finalize_store(const ReduceArgs &a, int row, int
 }
 
 // virtual rows: [0, n_chunks) are chunks of long rows (raw partials), [n_chunks, n_chunks + n_rows) ordinary rows.
-template <int VEC, int OP, bool SCALED, int U>
+template <int VEC, int OP, bool SCALED, int U, bool EMAT = false>
 __global__ void __launch_bounds__(256) csr_rows_kernel(const ReduceArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -144,7 +159,7 @@ __global__ void __launch_bounds__(256) csr_rows_kernel(const ReduceArgs a) {
 #pragma unroll
     for (int q = 0; q < VEC; ++q) acc[q] = op_identity<OP>();
     if (v < a.n_chunks) {
-        reduce_range<VEC, OP, SCALED, U>(a, a.chunk_beg[v], a.chunk_end[v], lig, gbase, G, f0, active, acc);
+        reduce_range<VEC, OP, SCALED, U, EMAT>(a, a.chunk_beg[v], a.chunk_end[v], lig, gbase, G, f0, active, acc);
         if (active) Vec<VEC>::store(a.partial + (int64_t)v * a.D + f0, acc);
         return;
     }
@@ -152,7 +167,7 @@ __global__ void __launch_bounds__(256) csr_rows_kernel(const ReduceArgs a) {
     const int beg = a.rowptr[row];
     const int end = a.rowptr[row + 1];
     if (end - beg > a.long_thresh) return;  // split row: its chunks are virtual rows, folded by csr_combine_kernel
-    reduce_range<VEC, OP, SCALED, U>(a, beg, end, lig, gbase, G, f0, active, acc);
+    reduce_range<VEC, OP, SCALED, U, EMAT>(a, beg, end, lig, gbase, G, f0, active, acc);
     finalize_store<VEC, OP>(a, row, end - beg, f0, active, acc);
 }
 
@@ -190,7 +205,7 @@ __global__ void __launch_bounds__(256) csr_combine_kernel(const ReduceArgs a) {
     finalize_store<VEC, OP>(a, row, a.rowptr[row + 1] - a.rowptr[row], f0, active, acc);
 }
 
-template <int VEC, int OP, bool SCALED, int U>
+template <int VEC, int OP, bool SCALED, int U, bool EMAT = false>
 static int launch_reduce(const ReduceArgs &a0, hipStream_t stream) {
     ReduceArgs a = a0;
     const int G = 1 << a.log2g;
@@ -211,7 +226,7 @@ static int launch_reduce(const ReduceArgs &a0, hipStream_t stream) {
             gx = (int64_t)a.cpx * 8;
         }
         dim3 grid((unsigned)gx, (unsigned)tiles);
-        csr_rows_kernel<VEC, OP, SCALED, U><<<grid, 64 * waves, 0, stream>>>(a);
+        csr_rows_kernel<VEC, OP, SCALED, U, EMAT><<<grid, 64 * waves, 0, stream>>>(a);
         GNNMP_LAUNCH_CHECK("csr_rows_kernel");
     }
     if (a.n_long > 0) {
@@ -237,6 +252,13 @@ static int dispatch_scaled(const ReduceArgs &a, bool scaled, hipStream_t s) {
 }
 template <int VEC>
 static int dispatch_op(const ReduceArgs &a, int op, bool scaled, hipStream_t s) {
+    if (a.emat) {   // two rows per edge in flight: half the batch
+        switch (op) {
+            case OP_SUM: return launch_reduce<VEC, OP_SUM, false, 4, true>(a, s);
+            case OP_MAX: return launch_reduce<VEC, OP_MAX, false, 4, true>(a, s);
+            default: return launch_reduce<VEC, OP_MIN, false, 4, true>(a, s);
+        }
+    }
     switch (op) {
         case OP_SUM: return dispatch_scaled<VEC, OP_SUM>(a, scaled, s);
         case OP_MAX: return dispatch_scaled<VEC, OP_MAX>(a, scaled, s);
@@ -247,7 +269,7 @@ static int dispatch_op(const ReduceArgs &a, int op, bool scaled, hipStream_t s) 
 // shared by propagate (idx = col) and scatter (idx = eid)
 int run_reduce(gnnmp_graph_t *p, const int32_t *idx, int aggr, const float *x, const float *w,
                const float *ss, const float *w_slot, const float *ss_slot, const float *sd, float *out,
-               int64_t D, hipStream_t stream) {
+               int64_t D, hipStream_t stream, const float *emat = nullptr) {
     if (p->n_dst == 0 || D == 0) return GNNMP_OK;
     if (p->n_chunks > 0) {
         if (int rc = ensure_workspace(p, (size_t)p->n_chunks * (size_t)D)) return rc;
@@ -258,6 +280,7 @@ int run_reduce(gnnmp_graph_t *p, const int32_t *idx, int aggr, const float *x, c
     a.eid = p->eid;
     a.x = x;
     a.w = w;
+    a.emat = emat;
     a.ss = ss;
     a.w_slot = w_slot;
     a.ss_slot = ss_slot;
@@ -279,7 +302,8 @@ int run_reduce(gnnmp_graph_t *p, const int32_t *idx, int aggr, const float *x, c
     a.long_thresh = p->long_thresh;
     a.cpx = 0;
     a.waves = 4;
-    const int vec = pick_vec(D, x, out);
+    int vec = pick_vec(D, x, out);
+    if (emat && (reinterpret_cast<uintptr_t>(emat) & (4 * vec - 1)) != 0) vec = 1;
     a.log2g = pick_log2g((D + vec - 1) / vec);
     const int op = (aggr == GNNMP_MAX) ? OP_MAX : (aggr == GNNMP_MIN ? OP_MIN : OP_SUM);
     const bool scaled = w || ss || w_slot || ss_slot;
@@ -378,6 +402,17 @@ int gnnmp_propagate_f32(gnnmp_graph_t *plan, int msg, int aggr, const float *xj,
     if (msg == GNNMP_COPY_XJ) w = nullptr;
     return run_reduce(plan, plan->col, aggr, xj, w, scale_src, nullptr, nullptr, scale_dst, out, D,
                       (hipStream_t)stream);
+}
+
+int gnnmp_propagate_emul_f32(gnnmp_graph_t *plan, int aggr, const float *xj, const float *e, float *out, int64_t D,
+                             gnnmp_stream_t stream) {
+    if (!plan) return fail(GNNMP_EINVAL, "propagate_emul: null plan");
+    if (int rc = check_aggr(aggr, "propagate_emul")) return rc;
+    if (D < 0 || D > (1 << 20)) return fail(GNNMP_EINVAL, "propagate_emul: bad D %lld", (long long)D);
+    if (plan->n_dst > 0 && D > 0 && (!out || (!xj && plan->n_total > 0) || (!e && plan->n_edges > 0)))
+        return fail(GNNMP_EINVAL, "propagate_emul: null xj/e/out");
+    if (!e) return run_reduce(plan, plan->col, aggr, xj, nullptr, nullptr, nullptr, nullptr, nullptr, out, D, (hipStream_t)stream);
+    return run_reduce(plan, plan->col, aggr, xj, nullptr, nullptr, nullptr, nullptr, nullptr, out, D, (hipStream_t)stream, e);
 }
 
 int gnnmp_propagate_slots_f32(gnnmp_graph_t *plan, int aggr, const float *xj, const float *w_slot,

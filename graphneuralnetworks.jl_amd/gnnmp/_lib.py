@@ -22,8 +22,8 @@ SYMBOLS = (
     "gnnmp_version", "gnnmp_last_error",
     "gnnmp_plan_create", "gnnmp_plan_destroy", "gnnmp_plan_info", "gnnmp_plan_export",
     "gnnmp_add_self_loops", "gnnmp_batch_coo",
-    "gnnmp_gather_f32", "gnnmp_scatter_f32", "gnnmp_scatter_atomic_f32",
-    "gnnmp_propagate_f32", "gnnmp_propagate_slots_f32", "gnnmp_plan_slot_gather_f32",
+    "gnnmp_gather_f32", "gnnmp_edge_sub_f32", "gnnmp_scatter_f32", "gnnmp_scatter_atomic_f32",
+    "gnnmp_propagate_f32", "gnnmp_propagate_emul_f32", "gnnmp_propagate_slots_f32", "gnnmp_plan_slot_gather_f32",
     "gnnmp_degree_f32", "gnnmp_inv_sqrt_f32",
     "gnnmp_edge_softmax_f32", "gnnmp_gat_node_scores_f32", "gnnmp_gat_aggregate_f32", "gnnmp_gat_conv_f32",
     "gnnmp_gat_conv_stats_f32", "gnnmp_gat_conv_grad_f32", "gnnmp_attn_conv_f32",
@@ -65,9 +65,11 @@ def load():
         "gnnmp_add_self_loops": [vp, vp, i, i, i64, i64, vp, vp, vp, vp, vp],
         "gnnmp_batch_coo": [vp, vp, i, i, vp, vp, i64, vp, vp, vp, vp],
         "gnnmp_gather_f32": [vp, vp, i, i, i64, vp, i64, vp],
+        "gnnmp_edge_sub_f32": [vp, vp, vp, vp, i, i, i64, i, vp, i64, vp],
         "gnnmp_scatter_f32": [vp, i, vp, vp, i64, vp],
         "gnnmp_scatter_atomic_f32": [i, vp, vp, i, i, i64, vp, i64, vp],
         "gnnmp_propagate_f32": [vp, i, i, vp, vp, vp, vp, vp, i64, vp],
+        "gnnmp_propagate_emul_f32": [vp, i, vp, vp, vp, i64, vp],
         "gnnmp_propagate_slots_f32": [vp, i, vp, vp, vp, vp, vp, i64, vp],
         "gnnmp_plan_slot_gather_f32": [vp, i, vp, vp, vp],
         "gnnmp_gat_conv_f32": [vp, vp, vp, vp, f, vp, i, vp, i64, i64, vp],

@@ -142,6 +142,21 @@ def apply_edges(f, g: GNNGraph, xi=None, xj=None, e=None):
     check_num_nodes(g, (xj, xi))
     check_num_edges(g, e)
     s, t = edge_index(g)
+    if isinstance(xi, torch.Tensor) and isinstance(xj, torch.Tensor) and xi.shape[1:] == xj.shape[1:]:
+        # the two-row message functions in one pass over the edges (no gathered (D, E) temporaries)
+        if f is xi_dot_xj and xi.dim() == 2:
+            out = torch.empty((g.num_edges, 1), dtype=torch.float32, device=xi.device)
+            L.check(L.load().gnnmp_edge_dot_f32(L.ptr(xi.contiguous()), L.ptr(xj.contiguous()), L.ptr(s), L.ptr(t),
+                                                g.idx_bytes, g.index_base, g.num_edges, xi.shape[1], L.ptr(out),
+                                                L.stream_ptr()))
+            return out
+        if f is xi_sub_xj or f is xj_sub_xi:
+            xif, xjf = _flat(xi), _flat(xj)
+            out = torch.empty((g.num_edges,) + tuple(xi.shape[1:]), dtype=torch.float32, device=xi.device)
+            L.check(L.load().gnnmp_edge_sub_f32(L.ptr(xif), L.ptr(xjf), L.ptr(s), L.ptr(t), g.idx_bytes, g.index_base,
+                                                g.num_edges, 1 if f is xj_sub_xi else 0, L.ptr(out), xif.shape[1],
+                                                L.stream_ptr()))
+            return out
     xi = _gather(xi, t, g.index_base)
     xj = _gather(xj, s, g.index_base)
     return f(xi, xj, e)
@@ -179,5 +194,16 @@ def propagate(f, g: GNNGraph, aggr, xi=None, xj=None, e=None):
             check_num_nodes(g, (xj, xi))
             check_num_edges(g, e)
             return _fused(g, L.W_MUL_XJ, aggr, xj, e.to(torch.float32).contiguous())
+        if f is e_mul_xj and isinstance(e, torch.Tensor) and e.dim() == xj.dim() and e.shape[1:] == xj.shape[1:] \
+                and e.dtype == torch.float32:
+            # matrix e (D, E): one row of factors per edge, fetched by edge id inside the fused kernel
+            check_num_nodes(g, (xj, xi))
+            check_num_edges(g, e)
+            xf, ef = _flat(xj), _flat(e)
+            plan = g.plan(False)
+            out = torch.empty((plan.n_dst,) + tuple(xj.shape[1:]), dtype=torch.float32, device=xj.device)
+            L.check(L.load().gnnmp_propagate_emul_f32(plan.handle, aggr_code(aggr), L.ptr(xf), L.ptr(ef), L.ptr(out),
+                                                      xf.shape[1], L.stream_ptr()))
+            return out
     m = apply_edges(f, g, xi, xj, e)
     return aggregate_neighbors(g, aggr, m)

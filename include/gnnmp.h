@@ -135,6 +135,11 @@ int gnnmp_batch_coo(const void *src, const void *dst, int idx_bytes, int index_b
 /* out[k][:] = x[idx[k]][:]  for k in [0,K)  — NNlib.gather; pure copy, bit-exact. */
 int gnnmp_gather_f32(const float *x, const void *idx, int idx_bytes, int index_base, int64_t K,
                      float *out, int64_t D, gnnmp_stream_t stream);
+/* out[k][:] = xi[t_k][:] - xj[s_k][:]  (xj_minus_xi = 0: xi_sub_xj) or xj[s_k][:] - xi[t_k][:] (1: xj_sub_xi) for every
+ * edge k — apply_edges with those message functions (GNNlib/src/msgpass.jl:177-185) without materialising the two
+ * gathered (D, E) arrays.  (xi_dot_xj, :172, is gnnmp_edge_dot_f32 below.) */
+int gnnmp_edge_sub_f32(const float *xi, const float *xj, const void *s, const void *t, int idx_bytes, int index_base,
+                       int64_t K, int xj_minus_xi, float *out, int64_t D, gnnmp_stream_t stream);
 /* out[i][:] = aggr_{k : t_k = i, in edge order} m[k][:]   — NNlib.scatter(aggr, m, t; dstsize=(D, n_dst))
  * with t = the plan's dst.  m is [E'][D] in ORIGINAL edge order (self-loop rows last). */
 int gnnmp_scatter_f32(gnnmp_graph_t *plan, int aggr, const float *m, float *out, int64_t D,
@@ -160,6 +165,13 @@ int gnnmp_scatter_atomic_f32(int aggr, const float *m, const void *idx, int idx_
 int gnnmp_propagate_f32(gnnmp_graph_t *plan, int msg, int aggr, const float *xj, const float *w,
                         const float *scale_src, const float *scale_dst, float *out, int64_t D,
                         gnnmp_stream_t stream);
+
+/* propagate(e_mul_xj, g, aggr; xj, e) with a MATRIX e of size (D, E) — GNNlib/src/msgpass.jl:187-191 (`e .* xj`): every
+ * edge carries its own row of D factors, e[k][:] in original edge order.  out[i] = aggr_{k: t_k = i} e[k] .* xj[s_k];
+ * edges the plan added as self loops weigh 1.  Two rows per edge are fetched (the factor row by edge id, the feature row
+ * by source id); the (D, E') product is never written. */
+int gnnmp_propagate_emul_f32(gnnmp_graph_t *plan, int aggr, const float *xj, const float *e, float *out, int64_t D,
+                             gnnmp_stream_t stream);
 
 /* The same fused propagate with the per-edge factors already laid out in the plan's slot order:
  *   w_slot[p]   = w[eid_p]          (1 for plan-added self loops)      — gnnmp_plan_slot_gather_f32(plan, 1, w, ...)
