@@ -288,7 +288,7 @@ static int launch_gat(GatArgs a, hipStream_t stream) {
 // ---- standalone softmax_edge_neighbors: one thread per (destination, channel) ---------------------
 __global__ void __launch_bounds__(256) edge_softmax_kernel(const int32_t *rowptr, const int32_t *eid,
                                                            const float *logits, float *alpha,
-                                                           int64_t NH, int H) {
+                                                           int64_t NH, int H, float den_add) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= NH) return;
     const int64_t row = t / H;
@@ -300,7 +300,7 @@ __global__ void __launch_bounds__(256) edge_softmax_kernel(const int32_t *rowptr
     for (int p = beg; p < end; ++p) den = den + expf(logits[(int64_t)eid[p] * H + h] - mx);
     for (int p = beg; p < end; ++p) {
         const int64_t o = (int64_t)eid[p] * H + h;
-        alpha[o] = expf(logits[o] - mx) / den;
+        alpha[o] = expf(logits[o] - mx) / (den_add != 0.0f ? den + den_add : den);
     }
 }
 
@@ -402,7 +402,21 @@ int gnnmp_edge_softmax_f32(gnnmp_graph_t *plan, const float *logits, float *alph
     if (!logits || !alpha) return fail(GNNMP_EINVAL, "edge_softmax: null pointer");
     const int64_t NH = plan->n_dst * H;
     edge_softmax_kernel<<<(unsigned)((NH + 255) / 256), 256, 0, stream>>>(plan->rowptr, plan->eid,
-                                                                           logits, alpha, NH, (int)H);
+                                                                           logits, alpha, NH, (int)H, 0.0f);
+    GNNMP_LAUNCH_CHECK("edge_softmax_kernel");
+    return GNNMP_OK;
+}
+
+int gnnmp_segment_softmax_f32(gnnmp_graph_t *plan, const float *x, float *out, int64_t D, float den_add,
+                              gnnmp_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!plan) return fail(GNNMP_EINVAL, "segment_softmax: null plan");
+    if (D <= 0) return fail(GNNMP_EINVAL, "segment_softmax: bad D");
+    if (plan->n_dst == 0 || plan->n_total == 0) return GNNMP_OK;
+    if (!x || !out) return fail(GNNMP_EINVAL, "segment_softmax: null pointer");
+    const int64_t ND = plan->n_dst * D;
+    edge_softmax_kernel<<<(unsigned)((ND + 255) / 256), 256, 0, stream>>>(plan->rowptr, plan->eid, x, out, ND, (int)D,
+                                                                           den_add);
     GNNMP_LAUNCH_CHECK("edge_softmax_kernel");
     return GNNMP_OK;
 }

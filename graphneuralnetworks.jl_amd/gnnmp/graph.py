@@ -196,7 +196,18 @@ def graph_indicator(g: GNNGraph, edges: bool = False):
     if gi is None:
         gi = torch.full((g.num_nodes,), g.index_base, dtype=g.s.dtype, device=g.device)
     if edges:
-        raise NotImplementedError("graph_indicator(g, edges=true) feeds softmax_edges/reduce_edges only: out of scope")
+        # graph_indicator(g)[s] (query.jl:507-509): a bit copy of index words, done by the float gather on a reinterpreted
+        # view (one or two 32-bit words per index)
+        ge = g._cache.get("edge_indicator")
+        if ge is None:
+            words = 2 if gi.dtype == torch.int64 else 1
+            src = gi.contiguous().view(torch.float32).view(g.num_nodes, words)
+            out = torch.empty((g.num_edges, words), dtype=torch.float32, device=g.device)
+            L.check(L.load().gnnmp_gather_f32(L.ptr(src), L.ptr(g.s), g.idx_bytes, g.index_base, g.num_edges, L.ptr(out),
+                                              words, L.stream_ptr()))
+            ge = out.view(gi.dtype).view(g.num_edges)
+            g._cache["edge_indicator"] = ge
+        return ge
     return gi
 
 

@@ -56,6 +56,57 @@ def softmax_edge_neighbors(g: GNNGraph, e):
     return out.view(e.shape)
 
 
+def reduce_edges(aggr, g: GNNGraph, e):
+    """reduce_edges(aggr, g, e) = NNlib.scatter(aggr, e, graph_indicator(g)[s]) — utils.jl:37-42"""
+    assert e.shape[0] == g.num_edges
+    gi = graph_indicator(g, edges=True)
+    return _scatter_plan(aggr, e, _segment_plan(g, gi, "edges"))
+
+
+def _segment_plan(g: GNNGraph, gi, which):
+    """plan whose destinations are the graphs of a batch: element k (a node or an edge) -> graph gi[k]; cached on g"""
+    key = ("segments", which)
+    p = g._plans.get(key)
+    if p is None:
+        p = _idx_plan(gi, g.num_graphs, g.index_base)
+        g._plans[key] = p
+    return p
+
+
+def _segment_softmax(g: GNNGraph, x, gi, which, den_add):
+    xf = _flat(x)
+    out = torch.empty_like(xf)
+    L.check(L.load().gnnmp_segment_softmax_f32(_segment_plan(g, gi, which).handle, L.ptr(xf), L.ptr(out), xf.shape[1],
+                                               float(den_add), L.stream_ptr()))
+    return out.view(x.shape)
+
+
+def softmax_nodes(g: GNNGraph, x):
+    """Graph-wise softmax of the node features — utils.jl:49-57"""
+    assert x.shape[0] == g.num_nodes
+    return _segment_softmax(g, x, graph_indicator(g), "nodes", 0.0)
+
+
+def softmax_edges(g: GNNGraph, e):
+    """Graph-wise softmax of the edge features — utils.jl:64-72 (divides by den .+ eps(Float32))"""
+    assert e.shape[0] == g.num_edges
+    return _segment_softmax(g, e, graph_indicator(g, edges=True), "edges", torch.finfo(torch.float32).eps)
+
+
+def broadcast_nodes(g: GNNGraph, x):
+    """(*, num_graphs) -> (*, num_nodes): gather(x, graph_indicator(g)) — utils.jl:104-108"""
+    assert x.shape[0] == g.num_graphs
+    from .msgpass import _gather
+    return _gather(x, graph_indicator(g), g.index_base)
+
+
+def broadcast_edges(g: GNNGraph, x):
+    """(*, num_graphs) -> (*, num_edges): gather(x, graph_indicator(g, edges = true)) — utils.jl:116-120"""
+    assert x.shape[0] == g.num_graphs
+    from .msgpass import _gather
+    return _gather(x, graph_indicator(g, edges=True), g.index_base)
+
+
 def expand_srcdst(g, x):
     """utils.jl:123-125"""
     if isinstance(x, torch.Tensor) and x.dim() == 2:

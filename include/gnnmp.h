@@ -203,6 +203,12 @@ int gnnmp_inv_sqrt_f32(const float *deg, float *out, int64_t n, gnnmp_stream_t s
  * ---------------------------------------------------------------------------------------------- */
 int gnnmp_edge_softmax_f32(gnnmp_graph_t *plan, const float *logits, float *alpha, int64_t H,
                            gnnmp_stream_t stream);
+/* softmax_nodes(g, x) / softmax_edges(g, e) — GNNlib/src/utils.jl:49-72: the same three steps over the segments of a
+ * graph indicator.  plan = a plan whose destination index is the indicator (src = 1..K, dst = indicator, n_dst =
+ * num_graphs); x, out [K][D] in original order.  den_add is added to the denominator when non-zero: softmax_edges
+ * divides by `den .+ eps(T)` (utils.jl:71), softmax_nodes by `den` (utils.jl:57). */
+int gnnmp_segment_softmax_f32(gnnmp_graph_t *plan, const float *x, float *out, int64_t D, float den_add,
+                              gnnmp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * GATConv attention path — GNNlib/src/layers/conv.jl:112-167 from `apply_edges` to
