@@ -12,6 +12,8 @@
 
 namespace gnnmp {
 
+int run_softmax(gnnmp_graph_t *p, const float *e, float *alpha, int64_t D, float den_add, hipStream_t stream);  // propagate.hip
+
 __device__ __forceinline__ float leaky_relu(float x, float slope) {
     return x > 0.0f ? x : x * slope;  // NNlib.leakyrelu
 }
@@ -286,24 +288,6 @@ static int launch_gat(GatArgs a, hipStream_t stream) {
 }
 
 // ---- standalone softmax_edge_neighbors: one thread per (destination, channel) ---------------------
-__global__ void __launch_bounds__(256) edge_softmax_kernel(const int32_t *rowptr, const int32_t *eid,
-                                                           const float *logits, float *alpha,
-                                                           int64_t NH, int H, float den_add) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= NH) return;
-    const int64_t row = t / H;
-    const int h = (int)(t - row * H);
-    const int beg = rowptr[row], end = rowptr[row + 1];
-    float mx = -__builtin_inff();
-    for (int p = beg; p < end; ++p) mx = jl_max(mx, logits[(int64_t)eid[p] * H + h]);
-    float den = 0.0f;
-    for (int p = beg; p < end; ++p) den = den + expf(logits[(int64_t)eid[p] * H + h] - mx);
-    for (int p = beg; p < end; ++p) {
-        const int64_t o = (int64_t)eid[p] * H + h;
-        alpha[o] = expf(logits[o] - mx) / (den_add != 0.0f ? den + den_add : den);
-    }
-}
-
 __global__ void __launch_bounds__(256) bias_act_kernel(const float *x, const float *bias, int act,
                                                        float *out, int64_t total, int D) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -395,30 +379,22 @@ int gnnmp_bias_act_f32(const float *x, const float *bias, int act, float *out, i
 
 int gnnmp_edge_softmax_f32(gnnmp_graph_t *plan, const float *logits, float *alpha, int64_t H,
                            gnnmp_stream_t stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
     if (!plan) return fail(GNNMP_EINVAL, "edge_softmax: null plan");
-    if (H <= 0) return fail(GNNMP_EINVAL, "edge_softmax: bad H");
+    if (H <= 0 || H > (1 << 20)) return fail(GNNMP_EINVAL, "edge_softmax: bad H");
     if (plan->n_dst == 0 || plan->n_total == 0) return GNNMP_OK;
     if (!logits || !alpha) return fail(GNNMP_EINVAL, "edge_softmax: null pointer");
-    const int64_t NH = plan->n_dst * H;
-    edge_softmax_kernel<<<(unsigned)((NH + 255) / 256), 256, 0, stream>>>(plan->rowptr, plan->eid,
-                                                                           logits, alpha, NH, (int)H, 0.0f);
-    GNNMP_LAUNCH_CHECK("edge_softmax_kernel");
-    return GNNMP_OK;
+    if (plan->self_loops) return fail(GNNMP_EINVAL, "edge_softmax: the plan must not add self loops (e has one row per edge of g)");
+    return run_softmax(plan, logits, alpha, H, 0.0f, (hipStream_t)stream_);
 }
 
 int gnnmp_segment_softmax_f32(gnnmp_graph_t *plan, const float *x, float *out, int64_t D, float den_add,
                               gnnmp_stream_t stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
     if (!plan) return fail(GNNMP_EINVAL, "segment_softmax: null plan");
-    if (D <= 0) return fail(GNNMP_EINVAL, "segment_softmax: bad D");
+    if (D <= 0 || D > (1 << 20)) return fail(GNNMP_EINVAL, "segment_softmax: bad D");
     if (plan->n_dst == 0 || plan->n_total == 0) return GNNMP_OK;
     if (!x || !out) return fail(GNNMP_EINVAL, "segment_softmax: null pointer");
-    const int64_t ND = plan->n_dst * D;
-    edge_softmax_kernel<<<(unsigned)((ND + 255) / 256), 256, 0, stream>>>(plan->rowptr, plan->eid, x, out, ND, (int)D,
-                                                                           den_add);
-    GNNMP_LAUNCH_CHECK("edge_softmax_kernel");
-    return GNNMP_OK;
+    if (plan->self_loops) return fail(GNNMP_EINVAL, "segment_softmax: the plan must not add self loops");
+    return run_softmax(plan, x, out, D, den_add, (hipStream_t)stream_);
 }
 
 }  // extern "C"

@@ -26,6 +26,9 @@ struct ReduceArgs {
     const float *x;          // [n_src][D]
     const float *w;          // [n_edges] original order, nullable
     const float *emat;       // [n_edges][D] original order: per-edge, per-feature factor (e_mul_xj with a matrix e)
+    const float *rowsub;     // [n_dst][D]: the message is exp(x - rowsub[row]) (softmax numerator, utils.jl:94)
+    const float *rowden;     // [n_dst][D]: softmax_write_kernel divides by it
+    float den_add;           // softmax_edges adds eps(T) to the denominator (utils.jl:71)
     const float *ss;         // [n_src] nullable
     const float *w_slot;     // [E'] slot order, nullable (takes precedence over w)
     const float *ss_slot;    // [E'] slot order, nullable (takes precedence over ss)
@@ -48,10 +51,14 @@ struct ReduceArgs {
 };
 
 // reduce slots [beg, end) of one destination into acc[VEC]; all lanes of the group call this together.
-template <int VEC, int OP, bool SCALED, int U, bool EMAT = false>
+template <int VEC, int OP, bool SCALED, int U, bool EMAT = false, bool EXPSUB = false>
 __device__ __forceinline__ void reduce_range(const ReduceArgs &a, int beg, int end, int lig,
                                              int gbase, int G, int f0, bool active,
-                                             float acc[VEC]) {
+                                             float acc[VEC], int row = 0) {
+    float sub[VEC];
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) sub[q] = 0.0f;
+    if (EXPSUB && active) Vec<VEC>::load(a.rowsub + (int64_t)row * a.D + f0, sub);
     for (int base = beg; base < end; base += G) {
         const int p = base + lig;
         int c = 0, ev = 0;
@@ -114,6 +121,7 @@ __device__ __forceinline__ void reduce_range(const ReduceArgs &a, int beg, int e
                             t = wj[u] * t;  // w .* xj        (GNNlib/src/msgpass.jl:203-208), rounded
                         }
                         if (EMAT) t = em[EMAT ? u : 0][q] * t;  // e .* xj (GNNlib/src/msgpass.jl:187-191)
+                        if (EXPSUB) t = expf(t - sub[q]);        // num = exp.(e .- max_) (GNNlib/src/utils.jl:94)
                         acc[q] = op_apply<OP>(acc[q], t);
                     }
                 }
@@ -140,7 +148,7 @@ __device__ __forceinline__ void finalize_store(const ReduceArgs &a, int row, int
 }
 
 // virtual rows: [0, n_chunks) are chunks of long rows (raw partials), [n_chunks, n_chunks + n_rows) ordinary rows.
-template <int VEC, int OP, bool SCALED, int U, bool EMAT = false>
+template <int VEC, int OP, bool SCALED, int U, bool EMAT = false, bool EXPSUB = false>
 __global__ void __launch_bounds__(256) csr_rows_kernel(const ReduceArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -159,7 +167,8 @@ __global__ void __launch_bounds__(256) csr_rows_kernel(const ReduceArgs a) {
 #pragma unroll
     for (int q = 0; q < VEC; ++q) acc[q] = op_identity<OP>();
     if (v < a.n_chunks) {
-        reduce_range<VEC, OP, SCALED, U, EMAT>(a, a.chunk_beg[v], a.chunk_end[v], lig, gbase, G, f0, active, acc);
+        reduce_range<VEC, OP, SCALED, U, EMAT, EXPSUB>(a, a.chunk_beg[v], a.chunk_end[v], lig, gbase, G, f0, active, acc,
+                                                       EXPSUB ? a.chunk_row[v] : 0);
         if (active) Vec<VEC>::store(a.partial + (int64_t)v * a.D + f0, acc);
         return;
     }
@@ -167,8 +176,71 @@ __global__ void __launch_bounds__(256) csr_rows_kernel(const ReduceArgs a) {
     const int beg = a.rowptr[row];
     const int end = a.rowptr[row + 1];
     if (end - beg > a.long_thresh) return;  // split row: its chunks are virtual rows, folded by csr_combine_kernel
-    reduce_range<VEC, OP, SCALED, U, EMAT>(a, beg, end, lig, gbase, G, f0, active, acc);
+    reduce_range<VEC, OP, SCALED, U, EMAT, EXPSUB>(a, beg, end, lig, gbase, G, f0, active, acc, row);
     finalize_store<VEC, OP>(a, row, end - beg, f0, active, acc);
+}
+
+// softmax_edge_neighbors, last step (GNNlib/src/utils.jl:96): alpha[k] = exp(e[k] - max_[t_k]) / den[t_k] for every edge of
+// the (virtual) row, written back in ORIGINAL edge order.  idx = the plan's eid (rows of e / alpha).
+template <int VEC, int U>
+__global__ void __launch_bounds__(256) softmax_write_kernel(const ReduceArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int G = 1 << a.log2g;
+    const int lig = lane & (G - 1);
+    const int grp = lane >> a.log2g;
+    const int gbase = lane - lig;
+    const int rpw = 64 >> a.log2g;
+    const int64_t v64 = ((int64_t)blockIdx.x * a.waves + wave) * rpw + grp;
+    if (v64 >= (int64_t)a.n_rows + a.n_chunks) return;
+    const int v = (int)v64;
+    const int f0 = ((int)blockIdx.y * G + lig) * VEC;
+    const bool active = f0 < a.D;
+    int row, beg, end;
+    if (v < a.n_chunks) {
+        row = a.chunk_row[v];
+        beg = a.chunk_beg[v];
+        end = a.chunk_end[v];
+    } else {
+        row = v - a.n_chunks;
+        beg = a.rowptr[row];
+        end = a.rowptr[row + 1];
+        if (end - beg > a.long_thresh) return;
+    }
+    float mx[VEC], den[VEC];
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) mx[q] = den[q] = 1.0f;
+    if (active) {
+        Vec<VEC>::load(a.rowsub + (int64_t)row * a.D + f0, mx);
+        Vec<VEC>::load(a.rowden + (int64_t)row * a.D + f0, den);
+    }
+    if (a.den_add != 0.0f) {
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) den[q] = den[q] + a.den_add;
+    }
+    float *outp = a.out;
+    for (int base = beg; base < end; base += G) {
+        const int p = base + lig;
+        const int c = p < end ? a.idx[p] : 0;
+        const int n = min(G, end - base);
+        for (int j = 0; j < n; j += U) {
+            float x[U][VEC];
+            int cj[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                cj[u] = __shfl(c, gbase + min(j + u, n - 1), 64);
+                if (active) Vec<VEC>::load(a.x + (int64_t)cj[u] * a.D + f0, x[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (active && (j + u < n)) {
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) x[u][q] = expf(x[u][q] - mx[q]) / den[q];
+                    Vec<VEC>::store(outp + (int64_t)cj[u] * a.D + f0, x[u]);
+                }
+            }
+        }
+    }
 }
 
 // one lane group per long row: fold its chunk partials in chunk order, then the usual epilogue.
@@ -205,7 +277,7 @@ __global__ void __launch_bounds__(256) csr_combine_kernel(const ReduceArgs a) {
     finalize_store<VEC, OP>(a, row, a.rowptr[row + 1] - a.rowptr[row], f0, active, acc);
 }
 
-template <int VEC, int OP, bool SCALED, int U, bool EMAT = false>
+template <int VEC, int OP, bool SCALED, int U, bool EMAT = false, bool EXPSUB = false>
 static int launch_reduce(const ReduceArgs &a0, hipStream_t stream) {
     ReduceArgs a = a0;
     const int G = 1 << a.log2g;
@@ -226,7 +298,7 @@ static int launch_reduce(const ReduceArgs &a0, hipStream_t stream) {
             gx = (int64_t)a.cpx * 8;
         }
         dim3 grid((unsigned)gx, (unsigned)tiles);
-        csr_rows_kernel<VEC, OP, SCALED, U, EMAT><<<grid, 64 * waves, 0, stream>>>(a);
+        csr_rows_kernel<VEC, OP, SCALED, U, EMAT, EXPSUB><<<grid, 64 * waves, 0, stream>>>(a);
         GNNMP_LAUNCH_CHECK("csr_rows_kernel");
     }
     if (a.n_long > 0) {
@@ -252,6 +324,7 @@ static int dispatch_scaled(const ReduceArgs &a, bool scaled, hipStream_t s) {
 }
 template <int VEC>
 static int dispatch_op(const ReduceArgs &a, int op, bool scaled, hipStream_t s) {
+    if (a.rowsub) return launch_reduce<VEC, OP_SUM, false, 8, false, true>(a, s);   // softmax denominator
     if (a.emat) {   // two rows per edge in flight: half the batch
         switch (op) {
             case OP_SUM: return launch_reduce<VEC, OP_SUM, false, 4, true>(a, s);
@@ -269,7 +342,7 @@ static int dispatch_op(const ReduceArgs &a, int op, bool scaled, hipStream_t s) 
 // shared by propagate (idx = col) and scatter (idx = eid)
 int run_reduce(gnnmp_graph_t *p, const int32_t *idx, int aggr, const float *x, const float *w,
                const float *ss, const float *w_slot, const float *ss_slot, const float *sd, float *out,
-               int64_t D, hipStream_t stream, const float *emat = nullptr) {
+               int64_t D, hipStream_t stream, const float *emat = nullptr, const float *rowsub = nullptr) {
     if (p->n_dst == 0 || D == 0) return GNNMP_OK;
     if (p->n_chunks > 0) {
         if (int rc = ensure_workspace(p, (size_t)p->n_chunks * (size_t)D)) return rc;
@@ -281,6 +354,9 @@ int run_reduce(gnnmp_graph_t *p, const int32_t *idx, int aggr, const float *x, c
     a.x = x;
     a.w = w;
     a.emat = emat;
+    a.rowsub = rowsub;
+    a.rowden = nullptr;
+    a.den_add = 0.0f;
     a.ss = ss;
     a.w_slot = w_slot;
     a.ss_slot = ss_slot;
@@ -312,6 +388,49 @@ int run_reduce(gnnmp_graph_t *p, const int32_t *idx, int aggr, const float *x, c
         case 2: return dispatch_op<2>(a, op, scaled, stream);
         default: return dispatch_op<1>(a, op, scaled, stream);
     }
+}
+
+// softmax over the rows of a plan in the reference's three steps (utils.jl:84-97 / :49-72): max_ = scatter(max, e, t),
+// den = scatter(+, exp.(e .- max_[t]), t) (edge order), alpha = num ./ den.  Every step is the balanced row-group walk
+// (chunked long rows), so a 17 000-edge hub costs what 17 000 edges cost, not a serial tail.
+int run_softmax(gnnmp_graph_t *p, const float *e, float *alpha, int64_t D, float den_add, hipStream_t stream) {
+    if (p->n_dst == 0 || p->n_total == 0 || D == 0) return GNNMP_OK;
+    const size_t nd = (size_t)p->n_dst * (size_t)D, pc = (size_t)p->n_chunks * (size_t)D;
+    if (int rc = ensure_workspace(p, pc + 2 * nd)) return rc;
+    float *mx = p->ws + pc, *den = mx + nd;
+    if (int rc = run_reduce(p, p->eid, GNNMP_MAX, e, nullptr, nullptr, nullptr, nullptr, nullptr, mx, D, stream)) return rc;
+    if (int rc = run_reduce(p, p->eid, GNNMP_SUM, e, nullptr, nullptr, nullptr, nullptr, nullptr, den, D, stream, nullptr, mx))
+        return rc;
+    ReduceArgs a = {};
+    a.rowptr = p->rowptr;
+    a.idx = p->eid;
+    a.x = e;
+    a.out = alpha;
+    a.rowsub = mx;
+    a.rowden = den;
+    a.den_add = den_add;
+    a.chunk_row = p->chunk_row;
+    a.chunk_beg = p->chunk_beg;
+    a.chunk_end = p->chunk_end;
+    a.n_chunks = p->n_chunks;
+    a.D = (int)D;
+    a.n_rows = (int)p->n_dst;
+    a.long_thresh = p->long_thresh;
+    a.waves = 4;
+    int vec = pick_vec(D, e, alpha);
+    a.log2g = pick_log2g((D + vec - 1) / vec);
+    const int G = 1 << a.log2g;
+    const int tiles = (int)(((D + vec - 1) / vec + G - 1) / G);
+    const int64_t nvirt = (int64_t)a.n_rows + a.n_chunks;
+    const int64_t rows_per_block = (int64_t)(64 / G) * a.waves;
+    dim3 grid((unsigned)((nvirt + rows_per_block - 1) / rows_per_block), (unsigned)tiles);
+    switch (vec) {
+        case 4: softmax_write_kernel<4, 8><<<grid, 64 * a.waves, 0, stream>>>(a); break;
+        case 2: softmax_write_kernel<2, 8><<<grid, 64 * a.waves, 0, stream>>>(a); break;
+        default: softmax_write_kernel<1, 8><<<grid, 64 * a.waves, 0, stream>>>(a); break;
+    }
+    GNNMP_LAUNCH_CHECK("softmax_write_kernel");
+    return GNNMP_OK;
 }
 
 // fold plan->ws ([n_chunks][D] partial sums written by another kernel in the same virtual-row layout) into out's long rows
