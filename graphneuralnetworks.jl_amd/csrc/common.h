@@ -36,6 +36,8 @@ enum Knob {
                               // at 2.4M x 100 => 100.  (A register prefetch of the next tile was tried and removed:
                               // 1.13 vs 0.82 ms.)
     KNOB_GAT_FAST_EXP = 8,   // 1 = v_exp_f32-based exp in the one-pass GAT kernel (experiment; default 0 = accurate expf)
+    KNOB_GRADW_SLABS = 9,    // ΔW kernel: slabs per CU (0 = auto)
+    KNOB_GRADW_RP = 10,      // ΔW kernel: row pairs loaded per batch (0 = auto, else 2|4|8)
     KNOB_COUNT = 12
 };
 int knob(int k);

@@ -43,13 +43,39 @@ __global__ void __launch_bounds__(256) colsum_partial_kernel(const float *x, int
         part[(int64_t)blockIdx.x * D + d] = acc;
     }
 }
-__global__ void __launch_bounds__(256) fold_partials_kernel(const float *part, int nparts, int64_t len,
+// out[g][i] = Σ_{p in group g} part[p][i], parts added in order, 8 loads in flight; blockIdx.y = group of `per` parts.
+// Called twice (slabs -> FOLD_GROUPS -> 1) when there are many slabs: a serial walk over 2048 partials cost 0.5 ms.
+constexpr int FOLD_GROUPS = 32;
+__global__ void __launch_bounds__(256) fold_partials_kernel(const float *part, int nparts, int per, int64_t len,
                                                             float *out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= len) return;
+    const int p0 = (int)blockIdx.y * per, p1 = min(nparts, p0 + per);
     float acc = 0.0f;
-    for (int p = 0; p < nparts; ++p) acc = acc + part[(int64_t)p * len + i];
-    out[i] = acc;
+    int p = p0;
+    for (; p + 8 <= p1; p += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = part[(int64_t)(p + u) * len + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = acc + v[u];
+    }
+    for (; p < p1; ++p) acc = acc + part[(int64_t)p * len + i];
+    out[(int64_t)blockIdx.y * len + i] = acc;
+}
+// folds part[nparts][len] into out[len]; `scratch` holds FOLD_GROUPS * len floats
+static int fold_partials(const float *part, int nparts, int64_t len, float *out, float *scratch, hipStream_t stream) {
+    const unsigned nb = (unsigned)((len + 255) / 256);
+    if (nparts <= 2 * FOLD_GROUPS) {
+        fold_partials_kernel<<<dim3(nb, 1), 256, 0, stream>>>(part, nparts, nparts, len, out);
+    } else {
+        const int per = (nparts + FOLD_GROUPS - 1) / FOLD_GROUPS;
+        const int groups = (nparts + per - 1) / per;
+        fold_partials_kernel<<<dim3(nb, (unsigned)groups), 256, 0, stream>>>(part, nparts, per, len, scratch);
+        fold_partials_kernel<<<dim3(nb, 1), 256, 0, stream>>>(scratch, groups, groups, len, out);
+    }
+    GNNMP_LAUNCH_CHECK("fold_partials_kernel");
+    return GNNMP_OK;
 }
 
 struct GradWArgs {
@@ -82,28 +108,65 @@ __global__ void __launch_bounds__(256) dense_gradw_kernel(const GradWArgs a) {
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
     const int64_t n0 = (int64_t)blockIdx.x * a.rows_per_slab;
     const int64_t n1 = min(a.N, n0 + a.rows_per_slab);
-    const float *dzp = a.dz + (o_ok ? o0 + li : 0);
-    const float *xp = a.x + k0 + li;
-    for (int64_t n = n0; n < n1; n += 2 * RP) {
+    // Lanes whose ΔW row / column does not exist read a clamped (valid) column instead: their accumulator rows /
+    // columns are never stored, so nothing needs masking in the main loop — and nothing may be masked there: a select on
+    // the loaded value makes hipcc sink the load under a branch with its own vmcnt(0) (seen in the ISA: 20 serialised
+    // round trips per batch, 3.8 ms; 4x slower than this form).
+    const float *pa = a.dz + (o_ok ? o0 + li : 0) + (n0 + half) * a.Dout;
+    const float *pb = a.x + k0 + (n0 + half) * a.K;
+    int koff[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) koff[t] = k_ok[t] ? t * 32 + li : 0;
+    const int64_t sa = 2 * (int64_t)a.Dout, sb = 2 * (int64_t)a.K;   // one row pair
+    int64_t n = n0;
+    if (n + 2 * RP <= n1) {
+        // software pipeline: the batch after the current one is in flight while the current one's 4*RP MFMAs issue
         float av[RP], bv[RP][4];
 #pragma unroll
-        for (int p = 0; p < RP; ++p) {                            // unconditional, clamped loads; masked afterwards
-            const int64_t row = n + 2 * p + half;
-            const int64_t rc = min(row, a.N - 1);
-            const bool r_ok = row < n1;
-            const float va = dzp[rc * a.Dout];
-            av[p] = (r_ok && o_ok) ? va : 0.0f;
+        for (int p = 0; p < RP; ++p) {
+            av[p] = pa[p * sa];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const float vb = xp[rc * a.K + (k_ok[t] ? t * 32 : 0)];
-                bv[p][t] = (r_ok && k_ok[t]) ? vb : 0.0f;
-            }
+            for (int t = 0; t < 4; ++t) bv[p][t] = pb[p * sb + koff[t]];
         }
+        for (; n + 2 * RP <= n1; n += 2 * RP) {
+            const bool more = n + 4 * RP <= n1;          // else re-read the current batch (harmless, discarded)
+            const float *qa = more ? pa + RP * sa : pa;
+            const float *qb = more ? pb + RP * sb : pb;
+            float an[RP], bn[RP][4];
 #pragma unroll
-        for (int p = 0; p < RP; ++p)
+            for (int p = 0; p < RP; ++p) {
+                an[p] = qa[p * sa];
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p], bv[p][t], acc[t], 0, 0, 0);
+                for (int t = 0; t < 4; ++t) bn[p][t] = qb[p * sb + koff[t]];
+            }
+#pragma unroll
+            for (int p = 0; p < RP; ++p)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p], bv[p][t], acc[t], 0, 0, 0);
+#pragma unroll
+            for (int p = 0; p < RP; ++p) {
+                av[p] = an[p];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) bv[p][t] = bn[p][t];
+            }
+            pa += RP * sa;
+            pb += RP * sb;
+        }
+    }
+    // tail of the slab: fewer than RP row pairs, the last one possibly half empty (N odd)
+    for (; n < n1; n += 2) {
+        const bool r_ok = n + half < n1;
+        const int64_t back = r_ok ? 0 : 1;               // the missing row re-reads the previous one, weight 0
+        const float va = pa[-back * (int64_t)a.Dout];
+        float vb[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) vb[t] = pb[-back * (int64_t)a.K + koff[t]];
+        const float am = r_ok ? 1.0f : 0.0f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(va * am, vb[t] * am, acc[t], 0, 0, 0);
+        pa += sa;
+        pb += sb;
     }
     // C/D layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     float *part = a.part + (int64_t)blockIdx.x * a.Dout * a.K;
@@ -124,7 +187,9 @@ static int gradw_slabs(int64_t N) {
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const int64_t by_rows = (N + 511) / 512;                      // at least 512 rows per slab
-    return (int)std::max<int64_t>(1, std::min<int64_t>(2 * (int64_t)cus, by_rows));
+    int per_cu = knob(KNOB_GRADW_SLABS);
+    if (per_cu <= 0) per_cu = 8;   // 2 -> 8 slabs per CU: 3.8 -> 2.4 ms at 2.4M x 100 x 100 (more waves to cover the load latency)
+    return (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)per_cu * cus, by_rows));
 }
 
 }  // namespace gnnmp
@@ -146,7 +211,7 @@ int gnnmp_act_grad_f32(const float *dy, const float *y, int act, float *dz, int6
 
 int64_t gnnmp_dense_grad_workspace(int64_t N, int64_t Dout, int64_t K) {
     if (N <= 0 || Dout <= 0 || K <= 0) return 0;
-    return (int64_t)gradw_slabs(N) * std::max(Dout * K, Dout);
+    return ((int64_t)gradw_slabs(N) + FOLD_GROUPS) * std::max(Dout * K, Dout);
 }
 
 int gnnmp_dense_grad_w_f32(const float *dz, const float *x, int64_t N, int64_t Dout, int64_t K, float *dW,
@@ -176,17 +241,19 @@ int gnnmp_dense_grad_w_f32(const float *dz, const float *x, int64_t N, int64_t D
         a.Dout = (int)Dout;
         a.K = (int)K;
         dim3 grid((unsigned)slabs, (unsigned)((Dout + 127) / 128), (unsigned)((K + 127) / 128));
-        dense_gradw_kernel<4><<<grid, 256, 0, stream>>>(a);
+        switch (knob(KNOB_GRADW_RP)) {
+            case 4: dense_gradw_kernel<4><<<grid, 256, 0, stream>>>(a); break;
+            case 8: dense_gradw_kernel<8><<<grid, 256, 0, stream>>>(a); break;
+            default: dense_gradw_kernel<2><<<grid, 256, 0, stream>>>(a); break;   // fewest registers, most waves: 1.55 ms
+        }
         GNNMP_LAUNCH_CHECK("dense_gradw_kernel");
         const int64_t len = Dout * K;
-        fold_partials_kernel<<<(unsigned)((len + 255) / 256), 256, 0, stream>>>(workspace, slabs, len, dW);
-        GNNMP_LAUNCH_CHECK("fold_partials_kernel");
+        if (int rc = fold_partials(workspace, slabs, len, dW, workspace + (int64_t)slabs * len, stream)) return rc;
     }
     if (db) {
         colsum_partial_kernel<<<(unsigned)slabs, 256, 0, stream>>>(dz, N, (int)Dout, rps, workspace);
         GNNMP_LAUNCH_CHECK("colsum_partial_kernel");
-        fold_partials_kernel<<<(unsigned)((Dout + 255) / 256), 256, 0, stream>>>(workspace, slabs, Dout, db);
-        GNNMP_LAUNCH_CHECK("fold_partials_kernel");
+        if (int rc = fold_partials(workspace, slabs, Dout, db, workspace + (int64_t)slabs * Dout, stream)) return rc;
     }
     return GNNMP_OK;
 }
