@@ -1,0 +1,288 @@
+// graphprep.hip — device-side graph preparation on either side of the path.  Integer work,
+// bit-exact by construction:
+//   sort_edge_index(u, v)       GNNGraphs/src/utils.jl:30-45     lexicographic sort of the (u_k, v_k) pairs
+//   is_bidirected(g)            GNNGraphs/src/query.jl:553-558   sort_edge_index(s, t) == sort_edge_index(t, s)
+//   has_self_loops(g)           GNNGraphs/src/query.jl:565-569   any(s .== t)
+//   sample_neighbors(g, nodes, K; dir, replace)   GNNGraphs/src/sampling.jl:68-119 (the edge-id selection; the reference
+//                               builds adjacency lists on the host and calls StatsBase.sample per node)
+// The CUDA extension of the reference round-trips sort_edge_index through the CPU (GNNGraphsCUDAExt.jl:24-30).
+#include <cstring>
+#include <algorithm>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include "common.h"
+
+namespace gnnmp {
+
+static inline unsigned nb(int64_t n, int bs = 256) { return (unsigned)((n + bs - 1) / bs); }
+
+// key = (u << 32) | v, both 0-based; bad[0] set if an index does not fit 32 bits or is negative
+__global__ void pack_pairs_kernel(const void *u, const void *v, int idx_bytes, int base, int64_t E, uint64_t *keys,
+                                  int *bad) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= E) return;
+    const int64_t a = load_index(u, k, idx_bytes, base), b = load_index(v, k, idx_bytes, base);
+    if (a < 0 || b < 0 || a > 0xffffffffLL || b > 0xffffffffLL) {
+        *bad = 1;
+        keys[k] = 0;
+        return;
+    }
+    keys[k] = ((uint64_t)a << 32) | (uint64_t)b;
+}
+__global__ void unpack_pairs_kernel(const uint64_t *keys, int idx_bytes, int base, int64_t E, void *u, void *v) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= E) return;
+    store_index(u, k, idx_bytes, (int64_t)(keys[k] >> 32) + base);
+    store_index(v, k, idx_bytes, (int64_t)(keys[k] & 0xffffffffULL) + base);
+}
+__global__ void keys_differ_kernel(const uint64_t *a, const uint64_t *b, int64_t E, int *flag) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < E && a[k] != b[k]) *flag = 1;
+}
+__global__ void self_loop_kernel(const void *u, const void *v, int idx_bytes, int64_t E, int *flag) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < E && load_index(u, k, idx_bytes, 0) == load_index(v, k, idx_bytes, 0)) *flag = 1;
+}
+
+#define PREP_HIP(expr)                                  \
+    do {                                                \
+        hipError_t e__ = (expr);                        \
+        if (e__ != hipSuccess) {                        \
+            rc = hip_fail(e__, #expr);                  \
+            goto done;                                  \
+        }                                               \
+    } while (0)
+
+// sorted keys of the pairs (first, second) into keys_out (device, E entries); scratch freed before returning
+static int sorted_pair_keys(const void *first, const void *second, int idx_bytes, int base, int64_t E, uint64_t *keys_out,
+                            hipStream_t stream) {
+    int rc = GNNMP_OK;
+    uint64_t *keys_in = nullptr;
+    void *tmp = nullptr;
+    int *flag = nullptr;
+    int hflag = 0;
+    size_t tmp_bytes = 0;
+    PREP_HIP(hipMalloc((void **)&keys_in, sizeof(uint64_t) * (size_t)std::max<int64_t>(E, 1)));
+    PREP_HIP(hipMalloc((void **)&flag, sizeof(int)));
+    PREP_HIP(hipMemsetAsync(flag, 0, sizeof(int), stream));
+    pack_pairs_kernel<<<nb(E), 256, 0, stream>>>(first, second, idx_bytes, base, E, keys_in, flag);
+    PREP_HIP(hipGetLastError());
+    PREP_HIP(rocprim::radix_sort_keys(nullptr, tmp_bytes, keys_in, keys_out, (size_t)E, 0, 64, stream));
+    PREP_HIP(hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 16)));
+    PREP_HIP(rocprim::radix_sort_keys(tmp, tmp_bytes, keys_in, keys_out, (size_t)E, 0, 64, stream));
+    PREP_HIP(hipMemcpyAsync(&hflag, flag, sizeof(int), hipMemcpyDeviceToHost, stream));
+    PREP_HIP(hipStreamSynchronize(stream));
+    if (hflag) rc = fail(GNNMP_EBOUNDS, "sort_edge_index: an index is negative or does not fit 32 bits");
+done:
+    if (keys_in) (void)hipFree(keys_in);
+    if (tmp) (void)hipFree(tmp);
+    if (flag) (void)hipFree(flag);
+    return rc;
+}
+
+// ---- neighbour sampling ---------------------------------------------------------------------------
+// counter-based generator: splitmix64 of (seed, seed node, draw index) -> 53 uniform bits
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z += 0x9e3779b97f4a7c15ULL;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ double uniform01(uint64_t seed, uint64_t node, uint64_t draw) {
+    const uint64_t r = mix64(mix64(seed ^ (node * 0xd1342543de82ef95ULL)) + draw);
+    return (double)(r >> 11) * (1.0 / 9007199254740992.0);
+}
+
+__global__ void sample_counts_kernel(const int32_t *rowptr, const void *nodes, int idx_bytes, int base, int64_t M,
+                                     int64_t n_rows, int64_t K, int replace, int64_t *counts, int *bad) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    const int64_t v = load_index(nodes, i, idx_bytes, base);
+    if (v < 0 || v >= n_rows) {
+        *bad = 1;
+        counts[i] = 0;
+        return;
+    }
+    const int64_t d = rowptr[v + 1] - rowptr[v];
+    // sampling.jl:73-78: replace ? (K > 0 ? K : d) : (K > 0 ? min(d, K) : d); nothing can be drawn from an empty list
+    counts[i] = d == 0 ? 0 : (K > 0 ? (replace ? K : (d < K ? d : K)) : d);
+}
+
+// one thread per seed node.  Without replacement: Knuth's selection sampling (Algorithm S) over the row — every k-subset
+// equally likely, chosen edges stay in original edge order.  With replacement: k independent uniform picks.
+__global__ void sample_fill_kernel(const int32_t *rowptr, const int32_t *eid, const void *nodes, int idx_bytes, int base,
+                                   int64_t M, int64_t K, int replace, uint64_t seed, const int64_t *offsets,
+                                   void *eids_out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    const int64_t v = load_index(nodes, i, idx_bytes, base);
+    const int beg = rowptr[v], d = rowptr[v + 1] - beg;
+    const int64_t o = offsets[i], k = offsets[i + 1] - o;
+    if (k == 0) return;
+    if (replace) {
+        for (int64_t j = 0; j < k; ++j) {
+            const int pick = min(d - 1, (int)(uniform01(seed, (uint64_t)i, (uint64_t)j) * d));
+            store_index(eids_out, o + j, idx_bytes, (int64_t)eid[beg + pick] + base);
+        }
+        return;
+    }
+    int64_t chosen = 0;
+    for (int p = 0; p < d && chosen < k; ++p) {
+        // take slot p with probability (k - chosen) / (d - p)
+        if (uniform01(seed, (uint64_t)i, (uint64_t)p) * (double)(d - p) < (double)(k - chosen)) {
+            store_index(eids_out, o + chosen, idx_bytes, (int64_t)eid[beg + p] + base);
+            ++chosen;
+        }
+    }
+}
+
+}  // namespace gnnmp
+
+using namespace gnnmp;
+
+extern "C" {
+
+int gnnmp_sort_edge_index(const void *u, const void *v, int idx_bytes, int index_base, int64_t n_edges, void *u_out,
+                          void *v_out, gnnmp_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (idx_bytes != 4 && idx_bytes != 8) return fail(GNNMP_EINVAL, "sort_edge_index: idx_bytes %d", idx_bytes);
+    if (index_base != 0 && index_base != 1) return fail(GNNMP_EINVAL, "sort_edge_index: index_base %d", index_base);
+    if (n_edges < 0) return fail(GNNMP_EINVAL, "sort_edge_index: negative size");
+    if (n_edges == 0) return GNNMP_OK;
+    if (!u || !v || !u_out || !v_out) return fail(GNNMP_EINVAL, "sort_edge_index: null pointer");
+    uint64_t *keys = nullptr;
+    if (hipMalloc((void **)&keys, sizeof(uint64_t) * (size_t)n_edges) != hipSuccess)
+        return fail(GNNMP_EALLOC, "sort_edge_index: hipMalloc");
+    int rc = sorted_pair_keys(u, v, idx_bytes, index_base, n_edges, keys, stream);
+    if (rc == GNNMP_OK) {
+        unpack_pairs_kernel<<<nb(n_edges), 256, 0, stream>>>(keys, idx_bytes, index_base, n_edges, u_out, v_out);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
+            rc = fail(GNNMP_ELAUNCH, "sort_edge_index: unpack");
+    }
+    (void)hipFree(keys);
+    return rc;
+}
+
+int gnnmp_is_bidirected(const void *s, const void *t, int idx_bytes, int index_base, int64_t n_edges, int *result,
+                        gnnmp_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (idx_bytes != 4 && idx_bytes != 8) return fail(GNNMP_EINVAL, "is_bidirected: idx_bytes %d", idx_bytes);
+    if (!result) return fail(GNNMP_EINVAL, "is_bidirected: null result");
+    *result = 1;
+    if (n_edges <= 0) return n_edges < 0 ? fail(GNNMP_EINVAL, "is_bidirected: negative size") : GNNMP_OK;
+    if (!s || !t) return fail(GNNMP_EINVAL, "is_bidirected: null pointer");
+    uint64_t *a = nullptr, *b = nullptr;
+    int *flag = nullptr;
+    int rc = GNNMP_OK, h = 0;
+    if (hipMalloc((void **)&a, sizeof(uint64_t) * (size_t)n_edges) != hipSuccess ||
+        hipMalloc((void **)&b, sizeof(uint64_t) * (size_t)n_edges) != hipSuccess ||
+        hipMalloc((void **)&flag, sizeof(int)) != hipSuccess) {
+        rc = fail(GNNMP_EALLOC, "is_bidirected: hipMalloc");
+    } else {
+        rc = sorted_pair_keys(s, t, idx_bytes, index_base, n_edges, a, stream);
+        if (rc == GNNMP_OK) rc = sorted_pair_keys(t, s, idx_bytes, index_base, n_edges, b, stream);
+        if (rc == GNNMP_OK) {
+            (void)hipMemsetAsync(flag, 0, sizeof(int), stream);
+            keys_differ_kernel<<<nb(n_edges), 256, 0, stream>>>(a, b, n_edges, flag);
+            if (hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+                hipStreamSynchronize(stream) != hipSuccess)
+                rc = fail(GNNMP_ELAUNCH, "is_bidirected: compare");
+            else
+                *result = h ? 0 : 1;
+        }
+    }
+    if (a) (void)hipFree(a);
+    if (b) (void)hipFree(b);
+    if (flag) (void)hipFree(flag);
+    return rc;
+}
+
+int gnnmp_has_self_loops(const void *s, const void *t, int idx_bytes, int64_t n_edges, int *result,
+                         gnnmp_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (idx_bytes != 4 && idx_bytes != 8) return fail(GNNMP_EINVAL, "has_self_loops: idx_bytes %d", idx_bytes);
+    if (!result) return fail(GNNMP_EINVAL, "has_self_loops: null result");
+    *result = 0;
+    if (n_edges <= 0) return n_edges < 0 ? fail(GNNMP_EINVAL, "has_self_loops: negative size") : GNNMP_OK;
+    if (!s || !t) return fail(GNNMP_EINVAL, "has_self_loops: null pointer");
+    int *flag = nullptr;
+    int h = 0;
+    if (hipMalloc((void **)&flag, sizeof(int)) != hipSuccess) return fail(GNNMP_EALLOC, "has_self_loops: hipMalloc");
+    (void)hipMemsetAsync(flag, 0, sizeof(int), stream);
+    self_loop_kernel<<<nb(n_edges), 256, 0, stream>>>(s, t, idx_bytes, n_edges, flag);
+    int rc = GNNMP_OK;
+    if (hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+        hipStreamSynchronize(stream) != hipSuccess)
+        rc = fail(GNNMP_ELAUNCH, "has_self_loops");
+    *result = h;
+    (void)hipFree(flag);
+    return rc;
+}
+
+int gnnmp_sample_neighbors(gnnmp_graph_t *plan, const void *nodes, int idx_bytes, int index_base, int64_t n_nodes,
+                           int64_t K, int replace, uint64_t seed, int64_t *offsets, void *eids_out, int64_t capacity,
+                           int64_t *total, gnnmp_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!plan) return fail(GNNMP_EINVAL, "sample_neighbors: null plan");
+    if (plan->self_loops) return fail(GNNMP_EINVAL, "sample_neighbors: the plan must not add self loops");
+    if (idx_bytes != 4 && idx_bytes != 8) return fail(GNNMP_EINVAL, "sample_neighbors: idx_bytes %d", idx_bytes);
+    if (index_base != 0 && index_base != 1) return fail(GNNMP_EINVAL, "sample_neighbors: index_base %d", index_base);
+    if (n_nodes < 0 || capacity < 0) return fail(GNNMP_EINVAL, "sample_neighbors: negative size");
+    if (!total || !offsets) return fail(GNNMP_EINVAL, "sample_neighbors: null offsets/total");
+    *total = 0;
+    if (n_nodes == 0) {
+        if (hipMemsetAsync(offsets, 0, sizeof(int64_t), stream) != hipSuccess) return fail(GNNMP_ELAUNCH, "sample_neighbors");
+        return GNNMP_OK;
+    }
+    if (!nodes) return fail(GNNMP_EINVAL, "sample_neighbors: null nodes");
+    int rc = GNNMP_OK;
+    int64_t *counts = nullptr;
+    void *tmp = nullptr;
+    int *flag = nullptr;
+    int hflag = 0;
+    size_t tmp_bytes = 0;
+    int64_t tot = 0;
+    PREP_HIP(hipMalloc((void **)&counts, sizeof(int64_t) * (size_t)(n_nodes + 1)));
+    PREP_HIP(hipMalloc((void **)&flag, sizeof(int)));
+    PREP_HIP(hipMemsetAsync(flag, 0, sizeof(int), stream));
+    PREP_HIP(hipMemsetAsync(counts + n_nodes, 0, sizeof(int64_t), stream));
+    sample_counts_kernel<<<nb(n_nodes), 256, 0, stream>>>(plan->rowptr, nodes, idx_bytes, index_base, n_nodes, plan->n_dst,
+                                                          K, replace ? 1 : 0, counts, flag);
+    PREP_HIP(hipGetLastError());
+    PREP_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, counts, offsets, (int64_t)0, (size_t)(n_nodes + 1),
+                                     rocprim::plus<int64_t>(), stream));
+    PREP_HIP(hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 16)));
+    PREP_HIP(rocprim::exclusive_scan(tmp, tmp_bytes, counts, offsets, (int64_t)0, (size_t)(n_nodes + 1),
+                                     rocprim::plus<int64_t>(), stream));
+    PREP_HIP(hipMemcpyAsync(&tot, offsets + n_nodes, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+    PREP_HIP(hipMemcpyAsync(&hflag, flag, sizeof(int), hipMemcpyDeviceToHost, stream));
+    PREP_HIP(hipStreamSynchronize(stream));
+    if (hflag) {
+        rc = fail(GNNMP_EBOUNDS, "sample_neighbors: a seed node is outside 1..%lld", (long long)plan->n_dst);
+        goto done;
+    }
+    *total = tot;
+    if (tot > capacity) {
+        rc = fail(GNNMP_EINVAL, "sample_neighbors: %lld edge ids do not fit the capacity %lld (offsets are valid: retry)",
+                  (long long)tot, (long long)capacity);
+        goto done;
+    }
+    if (tot > 0) {
+        if (!eids_out) {
+            rc = fail(GNNMP_EINVAL, "sample_neighbors: null eids_out");
+            goto done;
+        }
+        sample_fill_kernel<<<nb(n_nodes), 256, 0, stream>>>(plan->rowptr, plan->eid, nodes, idx_bytes, index_base, n_nodes, K,
+                                                            replace ? 1 : 0, seed, offsets, eids_out);
+        PREP_HIP(hipGetLastError());
+    }
+done:
+    if (counts) (void)hipFree(counts);
+    if (tmp) (void)hipFree(tmp);
+    if (flag) (void)hipFree(flag);
+    return rc;
+}
+
+}  // extern "C"

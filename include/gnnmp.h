@@ -129,6 +129,32 @@ int gnnmp_batch_coo(const void *src, const void *dst, int idx_bytes, int index_b
                     const int64_t *edge_ptr, const int64_t *node_ptr, int64_t n_graphs,
                     void *out_src, void *out_dst, void *graph_indicator, gnnmp_stream_t stream);
 
+/* sort_edge_index(u, v) — GNNGraphs/src/utils.jl:30-45: the pairs (u_k, v_k) sorted lexicographically (by u, then v),
+ * one common permutation.  64-bit radix sort of the packed pairs on the device (the reference's CUDA extension copies
+ * the index to the CPU for this, GNNGraphsCUDAExt.jl:24-30).  Indices must fit 32 bits (GNNMP_EBOUNDS otherwise).
+ * Synchronises the stream (graph prep). */
+int gnnmp_sort_edge_index(const void *u, const void *v, int idx_bytes, int index_base, int64_t n_edges,
+                          void *u_out, void *v_out, gnnmp_stream_t stream);
+/* is_bidirected(g) — GNNGraphs/src/query.jl:553-558: sort_edge_index(s, t) == sort_edge_index(t, s); *result = 0 | 1 (host). */
+int gnnmp_is_bidirected(const void *s, const void *t, int idx_bytes, int index_base, int64_t n_edges,
+                        int *result, gnnmp_stream_t stream);
+/* has_self_loops(g) — GNNGraphs/src/query.jl:565-569: any(s .== t); *result = 0 | 1 (host). */
+int gnnmp_has_self_loops(const void *s, const void *t, int idx_bytes, int64_t n_edges, int *result,
+                         gnnmp_stream_t stream);
+/* The edge selection of sample_neighbors(g, nodes, K; dir, replace) — GNNGraphs/src/sampling.jl:68-83.  For seed i
+ * (nodes[i], in the plan's destination numbering) with d incoming edges, draws k_i = (K > 0 ? (replace ? K : min(d, K))
+ * : d) of them (0 if d = 0): without replacement every k-subset is equally likely (selection sampling; the chosen edges
+ * keep their original order), with replacement k independent uniform picks.  dir = :in uses the graph's plan, dir = :out
+ * a plan of the reversed edge index.  Outputs: offsets[n_nodes + 1] (device, int64, exclusive prefix sums of k_i),
+ * eids_out[offsets[n_nodes]] = original edge positions (index width / base of `nodes`), *total (host).  capacity =
+ * entries available in eids_out; if too small GNNMP_EINVAL is returned with *total and offsets valid.  The generator is
+ * counter based (seed, seed-node position, draw index): the same call returns the same sample; it is NOT Julia's RNG
+ * stream, so parity with the reference is distributional (tests check membership, counts, uniqueness, uniformity).
+ * Synchronises the stream. */
+int gnnmp_sample_neighbors(gnnmp_graph_t *plan, const void *nodes, int idx_bytes, int index_base, int64_t n_nodes,
+                           int64_t K, int replace, uint64_t seed, int64_t *offsets, void *eids_out,
+                           int64_t capacity, int64_t *total, gnnmp_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Leaf ops: _gather / _scatter  (GNNGraphs/src/gatherscatter.jl:4,12-18)
  * ---------------------------------------------------------------------------------------------- */
