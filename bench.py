@@ -145,12 +145,84 @@ def run_batched(args, rank, world, dist, barrier):
         dist.destroy_process_group()
 
 
+def run_rowpart(args, rank, world, dist, barrier):
+    """One products-shaped graph partitioned by destination rows across the ranks (gnnmp.rowpart, SURVEY.md §8e "next"):
+    two GCNConv(100=>100, relu) layers per step, each followed by ONE all-gather of the (N, 100) layer output.  Total work
+    is fixed: strong scaling; communication-bound by design (§8e: 122 MB leave every rank per layer at world = 8)."""
+    import numpy as np
+    import torch
+    import gnnmp
+    from gnnmp import _lib as L, rowpart as RP, synth
+    from gnnmp.graph import Plan
+    N, E, D = synth.PRODUCTS["N"], synth.PRODUCTS["E"], synth.PRODUCTS["D"]
+    s, t = synth.products_like()
+    g = gnnmp.add_self_loops(gnnmp.GNNGraph(torch.from_numpy(s).cuda(), torch.from_numpy(t).cuda(), num_nodes=N,
+                                            _validated=True))
+    lib = L.load()
+    deg = torch.empty(N, dtype=torch.float32, device="cuda")
+    L.check(lib.gnnmp_degree_f32(g.plan(False).handle, None, L.ptr(deg), L.stream_ptr()))
+    c = torch.empty_like(deg)
+    L.check(lib.gnnmp_inv_sqrt_f32(L.ptr(deg), L.ptr(c), N, L.stream_ptr()))
+    bounds = RP.partition_rows_by_edges(g.t, N, world)
+    lo, hi = bounds[rank]
+    sl, tl, keep = RP.local_edges(g.s, g.t, lo, hi)
+    plan = Plan(sl, tl, N, hi - lo, 1, False, validate=False)
+    cl = c[lo:hi].contiguous()
+    del g
+    torch.cuda.empty_cache()
+    layers = [gnnmp.GCNConv((D, D), "relu", seed=31), gnnmp.GCNConv((D, D), "relu", seed=32)]
+    x = torch.from_numpy(synth.features(N, D, seed=1)).cuda()
+    agg = torch.empty((hi - lo, D), dtype=torch.float32, device="cuda")
+
+    def local_layer(l):
+        def f(h):
+            L.check(lib.gnnmp_propagate_f32(plan.handle, L.COPY_XJ, L.SUM, L.ptr(h), None, L.ptr(c), L.ptr(cl), L.ptr(agg), D,
+                                            L.stream_ptr()))
+            return gnnmp.dense(agg, l.weight, l.bias, "relu")
+        return f
+
+    fs = [local_layer(l) for l in layers]
+
+    def step():
+        return RP.row_parallel_forward(fs, x, bounds, rank, world, dist)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert out.shape == (N, D)
+    Ep = E + N
+    result = {
+        "metric": "edges/sec (fwd) 2 x GCNConv, ogbn-products-shape, one graph row-partitioned across the GPUs",
+        "value": 2 * Ep / (dt / args.steps), "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"products-shape N={N} E'={Ep} D={D}: 2 x GCNConv({D}=>{D},relu); rank rows {lo}..{hi} "
+                               f"({int(keep.numel())} edges on rank {rank})",
+                   "parallelism": f"row-partition x{world}: per-rank plan over its destination rows, one all-gather of the "
+                                  f"(N,{D}) output per layer ({4 * N * D / max(world, 1) / 1e6:.0f} MB per rank)"},
+    }
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="products", choices=["products", "arxiv", "batched"],
+    ap.add_argument("--workload", default="products", choices=["products", "arxiv", "batched", "rowpart"],
                     help="products (default, the BASELINE.json metric) | arxiv | batched (config 5: 8192 graphs sharded "
                          "by graph across the ranks, one RCCL all-gather of logits per step; strong scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -185,6 +257,8 @@ def main():
 
     if args.workload == "batched":
         return run_batched(args, rank, world, dist, barrier)
+    if args.workload == "rowpart":
+        return run_rowpart(args, rank, world, dist, barrier)
 
     # ---- workload -------------------------------------------------------------------------------------------
     if args.workload == "products":
