@@ -1,0 +1,27 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence committed under profiles/ (run on the GPU box through gpurun):
+#   tools/profile_round.sh <tag>      e.g. r01  ->  gpurun_out/<tag>_*.csv
+# One kernel-trace pass for durations, then one PMC pass per counter group (kernel-trace only, as the pool requires).
+set -u
+TAG=${1:-r01}
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$REPO/gpurun_out
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+BENCH="python $REPO/bench.py --no-cpu-baseline --no-extras"
+run() {  # name, rocprof args..., -- bench args
+    local name=$1; shift
+    rm -rf "/tmp/prof_$name"
+    timeout 600 rocprofv3 "$@" -d "/tmp/prof_$name" -- $BENCH_ARGS > "$OUT/${TAG}_$name.log" 2>&1
+    local db
+    db=$(find "/tmp/prof_$name" -name '*_results.db' | head -1)
+    if [ -n "$db" ]; then python "$REPO/tools/rocpd_summary.py" "$db" > "$OUT/${TAG}_$name.csv"; else echo "no db for $name" >&2; fi
+}
+BENCH_ARGS="$BENCH --steps 20 --warmup 5"
+run bench_products_kernel_stats --kernel-trace --stats
+BENCH_ARGS="$BENCH --steps 3 --warmup 1"
+run pmc_rd --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_32B_sum
+run pmc_wr --kernel-trace --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_HIT_sum TCC_MISS_sum
+run pmc_fs --kernel-trace --pmc FETCH_SIZE
+run pmc_ws --kernel-trace --pmc WRITE_SIZE
+ls -la "$OUT" | grep "$TAG"

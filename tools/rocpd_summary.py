@@ -8,12 +8,17 @@ import sqlite3
 import sys
 
 
+def short(name, n=140):
+    """library kernels (rocPRIM, ATen) carry kilobyte-long template names"""
+    return name if len(name) <= n else name[:n] + "..."
+
+
 def main(path):
     c = sqlite3.connect(path)
     print("# kernel stats (durations in us)")
     print("name,calls,total_us,avg_us,pct")
     for name, calls, total, avg, pct in c.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
-        print(f"\"{name}\",{calls},{total:.3f},{avg:.3f},{pct:.3f}")
+        print(f"\"{short(name)}\",{calls},{total:.3f},{avg:.3f},{pct:.3f}")
     try:
         rows = list(c.execute(
             "select k.name, p.counter_name, count(*), avg(p.value), sum(p.value) from counters_collection p "
@@ -33,7 +38,7 @@ def main(path):
         print("# PMC counters (per-dispatch average)")
         print("name,counter,dispatches,avg_value,sum_value")
         for name, cn, n, avg, tot in rows:
-            print(f"\"{name}\",{cn},{n},{avg:.3f},{tot:.3f}")
+            print(f"\"{short(name)}\",{cn},{n},{avg:.3f},{tot:.3f}")
 
 
 if __name__ == "__main__":
