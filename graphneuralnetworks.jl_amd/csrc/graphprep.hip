@@ -107,7 +107,8 @@ __global__ void sample_counts_kernel(const int32_t *rowptr, const void *nodes, i
     }
     const int64_t d = rowptr[v + 1] - rowptr[v];
     // sampling.jl:73-78: replace ? (K > 0 ? K : d) : (K > 0 ? min(d, K) : d); nothing can be drawn from an empty list
-    counts[i] = d == 0 ? 0 : (K > 0 ? (replace ? K : (d < K ? d : K)) : d);
+    // replace = 2: picks with replacement but only min(d, K) of them — NeighborLoader's rand(neighbors, min(K, d)), samplers.jl:60-61
+    counts[i] = d == 0 ? 0 : (K > 0 ? (replace == 1 ? K : (d < K ? d : K)) : d);
 }
 
 // one thread per seed node.  Without replacement: Knuth's selection sampling (Algorithm S) over the row — every k-subset
@@ -134,6 +135,81 @@ __global__ void sample_fill_kernel(const int32_t *rowptr, const int32_t *eid, co
         if (uniform01(seed, (uint64_t)i, (uint64_t)p) * (double)(d - p) < (double)(k - chosen)) {
             store_index(eids_out, o + chosen, idx_bytes, (int64_t)eid[beg + p] + base);
             ++chosen;
+        }
+    }
+}
+
+// ---- node sets and induced subgraphs --------------------------------------------------------------------
+// first[v] = smallest position k with cand[k] = v, for the candidates that are not in the set yet (map[v] == 0).
+// Three passes keep the result independent of thread scheduling: reset, atomicMin, claim.
+__global__ void unique_reset_kernel(const void *cand, int idx_bytes, int base, int64_t M, int64_t n_nodes, int32_t *first,
+                                    int *bad) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= M) return;
+    const int64_t v = load_index(cand, k, idx_bytes, base);
+    if (v < 0 || v >= n_nodes) {
+        *bad = 1;
+        return;
+    }
+    first[v] = 0x7fffffff;
+}
+__global__ void unique_min_kernel(const void *cand, int idx_bytes, int base, int64_t M, int64_t n_nodes,
+                                  const int32_t *map, int32_t *first) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= M) return;
+    const int64_t v = load_index(cand, k, idx_bytes, base);
+    if (v < 0 || v >= n_nodes || map[v] != 0) return;
+    atomicMin(&first[v], (int32_t)k);
+}
+__global__ void unique_flag_kernel(const void *cand, int idx_bytes, int base, int64_t M, int64_t n_nodes,
+                                   const int32_t *map, const int32_t *first, int64_t *flags) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > M) return;
+    if (k == M) {
+        flags[k] = 0;
+        return;
+    }
+    const int64_t v = load_index(cand, k, idx_bytes, base);
+    flags[k] = (v >= 0 && v < n_nodes && map[v] == 0 && first[v] == (int32_t)k) ? 1 : 0;
+}
+__global__ void unique_write_kernel(const void *cand, int idx_bytes, int base, int64_t M, const int64_t *flags,
+                                    const int64_t *pos, int64_t set_size, int32_t *map, void *list_out) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= M || !flags[k]) return;
+    const int64_t v = load_index(cand, k, idx_bytes, base);
+    map[v] = (int32_t)(set_size + pos[k] + 1);
+    store_index(list_out, pos[k], idx_bytes, v + base);
+}
+
+// induced_subgraph(graph, nodes) — GNNGraphs/src/sampling.jl:173-203: for every listed node (in list order) its incoming
+// edges (in edge order) whose source is listed too, relabelled by list position.
+__global__ void induced_count_kernel(const int32_t *rowptr, const int32_t *col, const int32_t *map, const void *nodes,
+                                     int idx_bytes, int base, int64_t M, int64_t *counts) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > M) return;
+    if (i == M) {
+        counts[i] = 0;
+        return;
+    }
+    const int64_t v = load_index(nodes, i, idx_bytes, base);
+    int64_t c = 0;
+    for (int p = rowptr[v]; p < rowptr[v + 1]; ++p) c += map[col[p]] != 0;
+    counts[i] = c;
+}
+__global__ void induced_fill_kernel(const int32_t *rowptr, const int32_t *col, const int32_t *eid, const int32_t *map,
+                                    const void *nodes, int idx_bytes, int base, int64_t M, const int64_t *offsets,
+                                    void *s_out, void *t_out, void *eid_out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    const int64_t v = load_index(nodes, i, idx_bytes, base);
+    int64_t o = offsets[i];
+    for (int p = rowptr[v]; p < rowptr[v + 1]; ++p) {
+        const int32_t m = map[col[p]];
+        if (m != 0) {
+            store_index(s_out, o, idx_bytes, (int64_t)m - 1 + base);
+            store_index(t_out, o, idx_bytes, i + base);
+            store_index(eid_out, o, idx_bytes, (int64_t)eid[p] + base);
+            ++o;
         }
     }
 }
@@ -249,7 +325,7 @@ int gnnmp_sample_neighbors(gnnmp_graph_t *plan, const void *nodes, int idx_bytes
     PREP_HIP(hipMemsetAsync(flag, 0, sizeof(int), stream));
     PREP_HIP(hipMemsetAsync(counts + n_nodes, 0, sizeof(int64_t), stream));
     sample_counts_kernel<<<nb(n_nodes), 256, 0, stream>>>(plan->rowptr, nodes, idx_bytes, index_base, n_nodes, plan->n_dst,
-                                                          K, replace ? 1 : 0, counts, flag);
+                                                          K, replace, counts, flag);
     PREP_HIP(hipGetLastError());
     PREP_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, counts, offsets, (int64_t)0, (size_t)(n_nodes + 1),
                                      rocprim::plus<int64_t>(), stream));
@@ -282,6 +358,104 @@ done:
     if (counts) (void)hipFree(counts);
     if (tmp) (void)hipFree(tmp);
     if (flag) (void)hipFree(flag);
+    return rc;
+}
+
+int gnnmp_unique_append(int32_t *map, int32_t *first, int64_t n_nodes, const void *cand, int idx_bytes, int index_base,
+                        int64_t n_cand, int64_t set_size, void *list_out, int64_t *n_new, gnnmp_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (idx_bytes != 4 && idx_bytes != 8) return fail(GNNMP_EINVAL, "unique_append: idx_bytes %d", idx_bytes);
+    if (index_base != 0 && index_base != 1) return fail(GNNMP_EINVAL, "unique_append: index_base %d", index_base);
+    if (n_cand < 0 || n_nodes < 0 || set_size < 0 || n_nodes > 0x7fffffff || n_cand > 0x7fffffff)
+        return fail(GNNMP_EINVAL, "unique_append: bad size");
+    if (!n_new) return fail(GNNMP_EINVAL, "unique_append: null n_new");
+    *n_new = 0;
+    if (n_cand == 0) return GNNMP_OK;
+    if (!map || !first || !cand || !list_out) return fail(GNNMP_EINVAL, "unique_append: null pointer");
+    int rc = GNNMP_OK;
+    int64_t *flags = nullptr, *pos = nullptr;
+    void *tmp = nullptr;
+    int *bad = nullptr;
+    int hbad = 0;
+    size_t tmp_bytes = 0;
+    int64_t tot = 0;
+    PREP_HIP(hipMalloc((void **)&flags, sizeof(int64_t) * (size_t)(n_cand + 1)));
+    PREP_HIP(hipMalloc((void **)&pos, sizeof(int64_t) * (size_t)(n_cand + 1)));
+    PREP_HIP(hipMalloc((void **)&bad, sizeof(int)));
+    PREP_HIP(hipMemsetAsync(bad, 0, sizeof(int), stream));
+    unique_reset_kernel<<<nb(n_cand), 256, 0, stream>>>(cand, idx_bytes, index_base, n_cand, n_nodes, first, bad);
+    unique_min_kernel<<<nb(n_cand), 256, 0, stream>>>(cand, idx_bytes, index_base, n_cand, n_nodes, map, first);
+    unique_flag_kernel<<<nb(n_cand + 1), 256, 0, stream>>>(cand, idx_bytes, index_base, n_cand, n_nodes, map, first, flags);
+    PREP_HIP(hipGetLastError());
+    PREP_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, flags, pos, (int64_t)0, (size_t)(n_cand + 1),
+                                     rocprim::plus<int64_t>(), stream));
+    PREP_HIP(hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 16)));
+    PREP_HIP(rocprim::exclusive_scan(tmp, tmp_bytes, flags, pos, (int64_t)0, (size_t)(n_cand + 1),
+                                     rocprim::plus<int64_t>(), stream));
+    unique_write_kernel<<<nb(n_cand), 256, 0, stream>>>(cand, idx_bytes, index_base, n_cand, flags, pos, set_size, map,
+                                                        list_out);
+    PREP_HIP(hipGetLastError());
+    PREP_HIP(hipMemcpyAsync(&tot, pos + n_cand, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+    PREP_HIP(hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, stream));
+    PREP_HIP(hipStreamSynchronize(stream));
+    if (hbad) rc = fail(GNNMP_EBOUNDS, "unique_append: a node is outside 1..%lld", (long long)n_nodes);
+    *n_new = tot;
+done:
+    if (flags) (void)hipFree(flags);
+    if (pos) (void)hipFree(pos);
+    if (tmp) (void)hipFree(tmp);
+    if (bad) (void)hipFree(bad);
+    return rc;
+}
+
+int gnnmp_induced_subgraph(gnnmp_graph_t *plan, const int32_t *map, const void *nodes, int idx_bytes, int index_base,
+                           int64_t n_nodes, int64_t *offsets, void *s_out, void *t_out, void *eid_out, int64_t capacity,
+                           int64_t *total, gnnmp_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!plan) return fail(GNNMP_EINVAL, "induced_subgraph: null plan");
+    if (plan->self_loops) return fail(GNNMP_EINVAL, "induced_subgraph: the plan must not add self loops");
+    if (idx_bytes != 4 && idx_bytes != 8) return fail(GNNMP_EINVAL, "induced_subgraph: idx_bytes %d", idx_bytes);
+    if (index_base != 0 && index_base != 1) return fail(GNNMP_EINVAL, "induced_subgraph: index_base %d", index_base);
+    if (n_nodes < 0 || capacity < 0) return fail(GNNMP_EINVAL, "induced_subgraph: negative size");
+    if (!total || !offsets) return fail(GNNMP_EINVAL, "induced_subgraph: null offsets/total");
+    *total = 0;
+    if (n_nodes == 0) return GNNMP_OK;
+    if (!map || !nodes) return fail(GNNMP_EINVAL, "induced_subgraph: null pointer");
+    int rc = GNNMP_OK;
+    int64_t *counts = nullptr;
+    void *tmp = nullptr;
+    size_t tmp_bytes = 0;
+    int64_t tot = 0;
+    PREP_HIP(hipMalloc((void **)&counts, sizeof(int64_t) * (size_t)(n_nodes + 1)));
+    induced_count_kernel<<<nb(n_nodes + 1), 256, 0, stream>>>(plan->rowptr, plan->col, map, nodes, idx_bytes, index_base,
+                                                              n_nodes, counts);
+    PREP_HIP(hipGetLastError());
+    PREP_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, counts, offsets, (int64_t)0, (size_t)(n_nodes + 1),
+                                     rocprim::plus<int64_t>(), stream));
+    PREP_HIP(hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 16)));
+    PREP_HIP(rocprim::exclusive_scan(tmp, tmp_bytes, counts, offsets, (int64_t)0, (size_t)(n_nodes + 1),
+                                     rocprim::plus<int64_t>(), stream));
+    PREP_HIP(hipMemcpyAsync(&tot, offsets + n_nodes, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+    PREP_HIP(hipStreamSynchronize(stream));
+    *total = tot;
+    if (capacity == 0 && !s_out && !t_out && !eid_out) goto done;   // count-only call: offsets and *total are the result
+    if (tot > capacity) {
+        rc = fail(GNNMP_EINVAL, "induced_subgraph: %lld edges do not fit the capacity %lld (offsets are valid: retry)",
+                  (long long)tot, (long long)capacity);
+        goto done;
+    }
+    if (tot > 0) {
+        if (!s_out || !t_out || !eid_out) {
+            rc = fail(GNNMP_EINVAL, "induced_subgraph: null output");
+            goto done;
+        }
+        induced_fill_kernel<<<nb(n_nodes), 256, 0, stream>>>(plan->rowptr, plan->col, plan->eid, map, nodes, idx_bytes,
+                                                             index_base, n_nodes, offsets, s_out, t_out, eid_out);
+        PREP_HIP(hipGetLastError());
+    }
+done:
+    if (counts) (void)hipFree(counts);
+    if (tmp) (void)hipFree(tmp);
     return rc;
 }
 

@@ -23,6 +23,7 @@ SYMBOLS = (
     "gnnmp_plan_create", "gnnmp_plan_destroy", "gnnmp_plan_info", "gnnmp_plan_export",
     "gnnmp_add_self_loops", "gnnmp_batch_coo",
     "gnnmp_sort_edge_index", "gnnmp_is_bidirected", "gnnmp_has_self_loops", "gnnmp_sample_neighbors",
+    "gnnmp_unique_append", "gnnmp_induced_subgraph",
     "gnnmp_gather_f32", "gnnmp_edge_sub_f32", "gnnmp_scatter_f32", "gnnmp_scatter_atomic_f32",
     "gnnmp_propagate_f32", "gnnmp_propagate_emul_f32", "gnnmp_propagate_slots_f32", "gnnmp_plan_slot_gather_f32",
     "gnnmp_degree_f32", "gnnmp_inv_sqrt_f32",
@@ -69,6 +70,8 @@ def load():
         "gnnmp_is_bidirected": [vp, vp, i, i, i64, ctypes.POINTER(i), vp],
         "gnnmp_has_self_loops": [vp, vp, i, i64, ctypes.POINTER(i), vp],
         "gnnmp_sample_neighbors": [vp, vp, i, i, i64, i64, i, ctypes.c_uint64, vp, vp, i64, ctypes.POINTER(i64), vp],
+        "gnnmp_unique_append": [vp, vp, i64, vp, i, i, i64, i64, vp, ctypes.POINTER(i64), vp],
+        "gnnmp_induced_subgraph": [vp, vp, vp, i, i, i64, vp, vp, vp, vp, i64, ctypes.POINTER(i64), vp],
         "gnnmp_gather_f32": [vp, vp, i, i, i64, vp, i64, vp],
         "gnnmp_edge_sub_f32": [vp, vp, vp, vp, i, i, i64, i, vp, i64, vp],
         "gnnmp_scatter_f32": [vp, i, vp, vp, i64, vp],

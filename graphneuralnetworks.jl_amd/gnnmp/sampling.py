@@ -97,3 +97,117 @@ def sample_neighbors(g: GNNGraph, nodes, K: int = -1, dir: str = "in", replace: 
     gnew.eid = eids
     gnew.sample_offsets = offsets
     return gnew
+
+
+class NodeSet:
+    """An ordered set of nodes on the device: `nodes` (list, discovery order) + map[N] (0 = absent, else 1-based position)."""
+
+    def __init__(self, g: GNNGraph):
+        self.g = g
+        self.map = torch.zeros(g.num_nodes, dtype=torch.int32, device=g.device)
+        self._first = torch.empty(g.num_nodes, dtype=torch.int32, device=g.device)
+        self.nodes = torch.empty(0, dtype=g.s.dtype, device=g.device)
+
+    def add(self, cand):
+        """append the not-yet-present nodes of `cand` (each once, first occurrence first); returns them"""
+        g = self.g
+        cand = cand.to(device=g.device, dtype=g.s.dtype).contiguous()
+        if cand.numel() == 0:
+            return cand
+        new = torch.empty(cand.numel(), dtype=g.s.dtype, device=g.device)
+        n_new = ctypes.c_int64(0)
+        L.check(L.load().gnnmp_unique_append(L.ptr(self.map), L.ptr(self._first), g.num_nodes, L.ptr(cand), g.idx_bytes,
+                                             g.index_base, cand.numel(), self.nodes.numel(), L.ptr(new),
+                                             ctypes.byref(n_new), L.stream_ptr()))
+        new = new[: n_new.value]
+        self.nodes = torch.cat([self.nodes, new])
+        return new
+
+
+def induced_subgraph(g: GNNGraph, nodes):
+    """Graphs.induced_subgraph(g, nodes) — sampling.jl:173-203: the listed nodes (relabelled by list position) and every
+    edge of g between two of them, grouped by target in list order, in-edge order inside a target.  `.nid` / `.eid` of
+    the result are the reference's node list / edata indices; node features follow the nodes."""
+    ns = nodes if isinstance(nodes, NodeSet) else None
+    if ns is None:
+        ns = NodeSet(g)
+        given = nodes.to(device=g.device, dtype=g.s.dtype).contiguous()
+        ns.add(given)
+        assert ns.nodes.numel() == given.numel(), "induced_subgraph: the node list must not repeat a node"
+    M = ns.nodes.numel()
+    lib = L.load()
+    offsets = torch.empty(M + 1, dtype=torch.int64, device=g.device)
+    total = ctypes.c_int64(0)
+    plan = g.plan(False)
+    # count-only call first (capacity 0, no outputs), then exactly-sized outputs
+    L.check(lib.gnnmp_induced_subgraph(plan.handle, L.ptr(ns.map), L.ptr(ns.nodes), g.idx_bytes, g.index_base, M,
+                                       L.ptr(offsets), None, None, None, 0, ctypes.byref(total), L.stream_ptr()))
+    E = total.value
+    s = torch.empty(E, dtype=g.s.dtype, device=g.device)
+    t = torch.empty_like(s)
+    eid = torch.empty_like(s)
+    if E > 0:
+        L.check(lib.gnnmp_induced_subgraph(plan.handle, L.ptr(ns.map), L.ptr(ns.nodes), g.idx_bytes, g.index_base, M,
+                                           L.ptr(offsets), L.ptr(s), L.ptr(t), L.ptr(eid), E, ctypes.byref(total),
+                                           L.stream_ptr()))
+    x = None
+    if g.x is not None:
+        from .msgpass import _gather
+        x = _gather(g.x, ns.nodes, g.index_base)
+    w = None
+    if g.w is not None and E > 0:
+        w = torch.empty(E, dtype=torch.float32, device=g.device)
+        L.check(lib.gnnmp_gather_f32(L.ptr(g.w), L.ptr(eid), g.idx_bytes, g.index_base, E, L.ptr(w), 1, L.stream_ptr()))
+    sub = GNNGraph(s, t, w, num_nodes=M, x=x, index_base=g.index_base, device=g.device, _validated=True)
+    sub.nid, sub.eid = ns.nodes, eid
+    return sub
+
+
+class NeighborLoader:
+    """NeighborLoader(graph; num_neighbors, input_nodes, num_layers, batch_size) — GNNGraphs/src/samplers.jl:27-101: for
+    every batch of input nodes, `num_layers` rounds of "sample num_neighbors[l] in-neighbours of every frontier node (with
+    replacement, as `rand(neighbors, k)` does), the sampled nodes become the next frontier", then the induced subgraph of
+    everything reached.  All steps run on the device (sample -> set union -> induced subgraph).  Deviation, documented:
+    the reference expands each input node's neighbourhood separately (a node reached from two input nodes is expanded
+    twice, independently); here the batch shares one frontier per layer.  Node order inside a mini-batch is discovery
+    order (the reference's is the iteration order of a Julia `Set`, i.e. unspecified)."""
+
+    def __init__(self, graph: GNNGraph, num_neighbors, num_layers, input_nodes=None, batch_size=None, seed=0):
+        assert len(num_neighbors) >= num_layers
+        self.graph, self.num_neighbors, self.num_layers, self.seed = graph, list(num_neighbors), int(num_layers), int(seed)
+        if input_nodes is None:
+            input_nodes = torch.arange(graph.index_base, graph.num_nodes + graph.index_base, dtype=graph.s.dtype,
+                                       device=graph.device)
+        self.input_nodes = input_nodes.to(device=graph.device, dtype=graph.s.dtype).contiguous()
+        self.batch_size = int(batch_size) if batch_size is not None else max(1, self.input_nodes.numel())
+
+    def __len__(self):
+        return (self.input_nodes.numel() + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        g = self.graph
+        lib = L.load()
+        for b, start in enumerate(range(0, self.input_nodes.numel(), self.batch_size)):
+            batch = self.input_nodes[start:start + self.batch_size]
+            sub_nodes = NodeSet(g)
+            frontier = sub_nodes.add(batch)
+            frontier = sub_nodes.nodes                      # a repeated input node is one node
+            for layer in range(self.num_layers):
+                K = self.num_neighbors[layer]
+                if K <= 0 or frontier.numel() == 0:
+                    frontier = frontier[:0]
+                    continue
+                # rand(neighbors, min(K, d)): d picks at most, drawn with replacement
+                plan = g.plan(False)
+                M = frontier.numel()
+                offsets = torch.empty(M + 1, dtype=torch.int64, device=g.device)
+                eids = torch.empty(M * K, dtype=g.s.dtype, device=g.device)
+                total = ctypes.c_int64(0)
+                L.check(lib.gnnmp_sample_neighbors(plan.handle, L.ptr(frontier), g.idx_bytes, g.index_base, M, K, 2,
+                                                   ctypes.c_uint64((self.seed * 1000003 + b * 101 + layer) & (2**64 - 1)),
+                                                   L.ptr(offsets), L.ptr(eids), M * K, ctypes.byref(total), L.stream_ptr()))
+                cand = _take_index(g.s, eids[: total.value], g.index_base)
+                layer_set = NodeSet(g)                      # the sampled nodes, each once: the next frontier
+                frontier = layer_set.add(cand)
+                sub_nodes.add(frontier)
+            yield induced_subgraph(g, sub_nodes)

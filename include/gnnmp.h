@@ -144,7 +144,8 @@ int gnnmp_has_self_loops(const void *s, const void *t, int idx_bytes, int64_t n_
 /* The edge selection of sample_neighbors(g, nodes, K; dir, replace) — GNNGraphs/src/sampling.jl:68-83.  For seed i
  * (nodes[i], in the plan's destination numbering) with d incoming edges, draws k_i = (K > 0 ? (replace ? K : min(d, K))
  * : d) of them (0 if d = 0): without replacement every k-subset is equally likely (selection sampling; the chosen edges
- * keep their original order), with replacement k independent uniform picks.  dir = :in uses the graph's plan, dir = :out
+ * keep their original order), with replacement k independent uniform picks (replace = 2: min(d, K) picks with
+ * replacement, what NeighborLoader's `rand(neighbors, min(K, d))` draws, samplers.jl:56-62).  dir = :in uses the graph's plan, dir = :out
  * a plan of the reversed edge index.  Outputs: offsets[n_nodes + 1] (device, int64, exclusive prefix sums of k_i),
  * eids_out[offsets[n_nodes]] = original edge positions (index width / base of `nodes`), *total (host).  capacity =
  * entries available in eids_out; if too small GNNMP_EINVAL is returned with *total and offsets valid.  The generator is
@@ -154,6 +155,24 @@ int gnnmp_has_self_loops(const void *s, const void *t, int idx_bytes, int64_t n_
 int gnnmp_sample_neighbors(gnnmp_graph_t *plan, const void *nodes, int idx_bytes, int index_base, int64_t n_nodes,
                            int64_t K, int replace, uint64_t seed, int64_t *offsets, void *eids_out,
                            int64_t capacity, int64_t *total, gnnmp_stream_t stream);
+
+/* Ordered node sets on the device (the `Set` / `Dict(node => i)` bookkeeping of NeighborLoader, samplers.jl:78-99, and of
+ * induced_subgraph, sampling.jl:178).  map[n_nodes] (int32, zero-initialised by the caller) holds 0 for "absent" and the
+ * 1-based list position otherwise; first[n_nodes] is int32 scratch.  Appends to the set the candidates that are not in
+ * it yet, each once, in order of first occurrence: writes them to list_out[0 .. *n_new) (index width / base of `cand`)
+ * and map[v] = set_size + position + 1.  Deterministic (no dependence on thread scheduling).  Synchronises the stream. */
+int gnnmp_unique_append(int32_t *map, int32_t *first, int64_t n_nodes, const void *cand, int idx_bytes,
+                        int index_base, int64_t n_cand, int64_t set_size, void *list_out, int64_t *n_new,
+                        gnnmp_stream_t stream);
+/* induced_subgraph(graph, nodes) — GNNGraphs/src/sampling.jl:173-203: for every listed node i (in list order) its incoming
+ * edges (in edge order) whose source is listed too, relabelled by list position: s_out = map[source], t_out = position of
+ * i, eid_out = the edge's position in g.  `map` as built by gnnmp_unique_append from the same list (nodes must be valid
+ * and distinct).  offsets[n_nodes + 1] (device int64) = first output edge of every listed node; *total (host) = edge
+ * count; capacity as in gnnmp_sample_neighbors (capacity = 0 with NULL outputs = count-only call).  NB the reference records `findfirst` of the (source, target) pair as the
+ * edge index, i.e. the FIRST parallel edge for all copies of a multi-edge; this returns each copy's own position. */
+int gnnmp_induced_subgraph(gnnmp_graph_t *plan, const int32_t *map, const void *nodes, int idx_bytes,
+                           int index_base, int64_t n_nodes, int64_t *offsets, void *s_out, void *t_out,
+                           void *eid_out, int64_t capacity, int64_t *total, gnnmp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Leaf ops: _gather / _scatter  (GNNGraphs/src/gatherscatter.jl:4,12-18)
