@@ -148,6 +148,29 @@ end
 # NOTE on `a`: Julia stores l.a of size (2C, H) column-major = C row-major [H][2C]: exactly the layout gnnmp.h asks for,
 # so `l.a` itself is passed — no permutedims.
 
+# ---- the other attention layers on the same one-pass kernel (gnnmp_attn_conv_f32) -----------------------------------------
+# mode 1: gatv2_conv (conv.jl:171-214; Q = Wxi, K = Wxj, a = l.a (C, H) as stored)   mode 2: transformer_conv attention
+# (conv.jl:553-616; Q = W3x, K = W4x, V = W2x, scale = l.sqrt_out)   mode 3: agnn_conv (conv.jl:337-352; K = x, scale = l.β[1])
+function attention(g::GNNGraph{<:COO_T}, mode::Int, K::AnyROCMatrix{Float32}; Q = nothing, V = nothing, a = nothing,
+                   slope = 0.2f0, scale = 1f0, bias = nothing, relu = false, heads::Int = 1, self_loops::Bool)
+    out = similar(K)
+    check(@ccall libgnnmp.gnnmp_attn_conv_f32(plan(g; self_loops).handle::Ptr{Cvoid}, mode::Cint, devptr(Q)::Ptr{Cvoid},
+                                              devptr(K)::Ptr{Cvoid}, devptr(V)::Ptr{Cvoid}, devptr(a)::Ptr{Cvoid},
+                                              Float32(slope)::Cfloat, Float32(scale)::Cfloat, devptr(bias)::Ptr{Cvoid},
+                                              Cint(relu)::Cint, devptr(out)::Ptr{Cvoid}, C_NULL::Ptr{Cvoid},
+                                              heads::Int64, (size(K, 1) ÷ heads)::Int64, stream_ptr()::Ptr{Cvoid})::Cint)
+    return out
+end
+
+# ---- graph prep that the CUDA extension sends to the CPU (GNNGraphs/ext/GNNGraphsCUDAExt.jl:24-30) ---------------------------
+function GNNGraphs.sort_edge_index(u::ROCVector{I}, v::ROCVector{I}) where {I <: Union{Int32, Int64}}
+    uo, vo = similar(u), similar(v)
+    check(@ccall libgnnmp.gnnmp_sort_edge_index(devptr(u)::Ptr{Cvoid}, devptr(v)::Ptr{Cvoid}, sizeof(I)::Cint, 1::Cint,
+                                                length(u)::Int64, devptr(uo)::Ptr{Cvoid}, devptr(vo)::Ptr{Cvoid},
+                                                stream_ptr()::Ptr{Cvoid})::Cint)
+    return uo, vo
+end
+
 # ---- adjoints (needs ChainRulesCore as a further weakdep) ---------------------------------------------------------------
 # Zygote reaches the methods above only if they carry rrules.  The pullback of the fused propagate w.r.t. xj is the same
 # kernel on the plan of the reversed edge index; w.r.t. the edge weights it is one dot product per edge; max / min have
