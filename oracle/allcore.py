@@ -18,7 +18,8 @@ def lib(rebuild: bool = False):
     if _lib is None or rebuild:
         src = os.path.join(_HERE, "cpu_allcore.c")
         if rebuild or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
-            subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libgnn_allcore.so"])
+            subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libgnn_allcore.so"] +
+                                  (["ALLCORE_ARCH=-march=native"] if rebuild else []))
         _lib = ctypes.CDLL(_LIB_PATH)
         _lib.ac_threads.restype = ctypes.c_int
     return _lib
