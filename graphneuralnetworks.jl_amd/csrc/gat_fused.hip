@@ -315,6 +315,10 @@ static void launch_rows_lph(const GatFusedArgs &a, dim3 grid, int blk, hipStream
         gat_fused_rows_kernel<VEC, U, 8, MODE><<<grid, blk, 0, stream>>>(a);
     else if (VEC == 4 && a.lph == 16)
         gat_fused_rows_kernel<VEC, U, 16, MODE><<<grid, blk, 0, stream>>>(a);
+    else if (VEC == 4 && a.lph == 32)
+        gat_fused_rows_kernel<VEC, U, 32, MODE><<<grid, blk, 0, stream>>>(a);
+    else if (VEC == 4 && a.lph == 64)
+        gat_fused_rows_kernel<VEC, U, 64, MODE><<<grid, blk, 0, stream>>>(a);
     else
         gat_fused_rows_kernel<VEC, U, 0, MODE><<<grid, blk, 0, stream>>>(a);
 }
