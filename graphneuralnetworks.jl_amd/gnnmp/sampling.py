@@ -46,6 +46,8 @@ def has_self_loops(g: GNNGraph) -> bool:
 
 def _take_index(v, pos, index_base):
     """v[pos] for an index vector v (bit copy through the float gather: one or two 32-bit words per element)"""
+    if pos.numel() == 0 or v.numel() == 0:
+        return torch.empty(0, dtype=v.dtype, device=v.device)
     words = 2 if v.dtype == torch.int64 else 1
     src = v.contiguous().view(torch.float32).view(v.numel(), words)
     out = torch.empty((pos.numel(), words), dtype=torch.float32, device=v.device)
