@@ -1,0 +1,126 @@
+"""k-hop layers that are repeated applications of the GCN-normalised propagate: SGConv and TAGConv.
+GNNlib/src/layers/conv.jl  sg_conv :501-542, tag_conv :634-685; constructors GraphNeuralNetworks/src/layers/conv.jl
+(SGConv(in => out, k = 1; bias, add_self_loops = true, use_edge_weight = false), TAGConv(in => out, k = 3; ...)).
+Every hop is ONE fused kernel launch (both `x .* c'` scalings folded into the aggregation, per-edge coefficients cached in
+plan order on the graph); nothing is computed on the host.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib as L
+from .graph import GNNGraph, check_num_nodes
+from .layers import dense, glorot_uniform
+
+
+def _norm_slots(g: GNNGraph, loops: bool, w):
+    """(c, ss_slot, w_slot): c = 1 ./ sqrt.(degree(g; dir = :in, edge_weight)), the source factor and the edge weight in plan
+    slot order — constants of the graph, cached on it like gcn_conv's"""
+    from .layers import _inv_sqrt
+    key = ("gcn_norm", bool(loops), w is not None, None if w is None else (w.data_ptr(), w._version))
+    hit = g._cache.get(key)
+    if hit is not None:
+        return hit
+    lib = L.load()
+    plan = g.plan(loops)
+    N = g.num_nodes
+    d = torch.empty(N, dtype=torch.float32, device=g.device)
+    L.check(lib.gnnmp_degree_f32(plan.handle, L.ptr(w), L.ptr(d), L.stream_ptr()))
+    c = _inv_sqrt(d)
+    ss = torch.empty(plan.n_total, dtype=torch.float32, device=g.device)
+    L.check(lib.gnnmp_plan_slot_gather_f32(plan.handle, 0, L.ptr(c), L.ptr(ss), L.stream_ptr()))
+    ws = None
+    if w is not None:
+        ws = torch.empty(plan.n_total, dtype=torch.float32, device=g.device)
+        L.check(lib.gnnmp_plan_slot_gather_f32(plan.handle, 1, L.ptr(w), L.ptr(ws), L.stream_ptr()))
+    g._cache[key] = (c, ss, ws)
+    return c, ss, ws
+
+
+def _hop(g: GNNGraph, loops: bool, x, c, ss, ws):
+    """x .* c' -> propagate(copy_xj | w_mul_xj, g, +) -> .* c'   (conv.jl:528-536)"""
+    plan = g.plan(loops)
+    out = torch.empty((plan.n_dst, x.shape[1]), dtype=torch.float32, device=x.device)
+    L.check(L.load().gnnmp_propagate_slots_f32(plan.handle, L.SUM, L.ptr(x), L.ptr(ws), L.ptr(ss), L.ptr(c), L.ptr(out),
+                                               x.shape[1], L.stream_ptr()))
+    return out
+
+
+def _edge_weights(l, g: GNNGraph, edge_weight):
+    if edge_weight is not None:
+        assert edge_weight.numel() == g.num_edges, \
+            f"Wrong number of edge weights (expected {g.num_edges} but given {edge_weight.numel()})"
+        return edge_weight.to(torch.float32).contiguous()
+    return g.w if (l.use_edge_weight and g.w is not None) else None
+
+
+def sg_conv(l, g: GNNGraph, x, edge_weight=None):
+    """conv.jl:501-542: W applied first if it shrinks the features, k normalised hops, W last otherwise, + bias"""
+    check_num_nodes(g, x)
+    w = _edge_weights(l, g, edge_weight)
+    loops = bool(l.add_self_loops)
+    c, ss, ws = _norm_slots(g, loops, w)
+    Dout, Din = l.weight.shape
+    x = x.contiguous()
+    if Dout < Din:
+        x = dense(x, l.weight)
+    for _ in range(l.k):
+        x = _hop(g, loops, x, c, ss, ws)
+    if Dout >= Din:
+        return dense(x, l.weight, l.bias)
+    from .layers import bias_act
+    return bias_act(x, l.bias, None)
+
+
+def tag_conv(l, g: GNNGraph, x, edge_weight=None):
+    """conv.jl:634-685: sum_total = Σ_{iter} W * (Σ_{j <= iter} Ã^j x), accumulated in the reference's order, + bias"""
+    check_num_nodes(g, x)
+    w = _edge_weights(l, g, edge_weight)
+    loops = bool(l.add_self_loops)
+    c, ss, ws = _norm_slots(g, loops, w)
+    lib = L.load()
+    x = x.contiguous()
+    sum_pow = sum_total = None
+    for it in range(l.k):
+        x = _hop(g, loops, x, c, ss, ws)
+        if it == 0:
+            sum_pow = x
+            sum_total = dense(sum_pow, l.weight)
+        else:
+            nxt = torch.empty_like(sum_pow)
+            L.check(lib.gnnmp_add_f32(L.ptr(sum_pow), L.ptr(x), L.ptr(nxt), nxt.numel(), L.stream_ptr()))
+            sum_pow = nxt
+            term = dense(sum_pow, l.weight)
+            L.check(lib.gnnmp_add_f32(L.ptr(sum_total), L.ptr(term), L.ptr(sum_total), term.numel(), L.stream_ptr()))
+    from .layers import bias_act
+    return bias_act(sum_total, l.bias, None)
+
+
+class _KHop:
+    takes_graph = True
+
+    def __init__(self, ch, k, bias=True, add_self_loops=True, use_edge_weight=False, device="cuda", seed=None):
+        cin, cout = ch
+        self.weight = glorot_uniform(cout, cin, device=device, seed=seed)
+        self.bias = torch.zeros(cout, dtype=torch.float32, device=device) if bias else None
+        self.k, self.add_self_loops, self.use_edge_weight = int(k), add_self_loops, use_edge_weight
+
+
+class SGConv(_KHop):
+    """SGConv(in => out, k = 1; bias = true, add_self_loops = true, use_edge_weight = false)"""
+
+    def __init__(self, ch, k=1, **kw):
+        super().__init__(ch, k, **kw)
+
+    def __call__(self, g, x, edge_weight=None):
+        return sg_conv(self, g, x, edge_weight)
+
+
+class TAGConv(_KHop):
+    """TAGConv(in => out, k = 3; bias = true, add_self_loops = true, use_edge_weight = false)"""
+
+    def __init__(self, ch, k=3, **kw):
+        super().__init__(ch, k, **kw)
+
+    def __call__(self, g, x, edge_weight=None):
+        return tag_conv(self, g, x, edge_weight)
