@@ -29,6 +29,7 @@ struct ReduceArgs {
     const float *rowsub;     // [n_dst][D]: the message is exp(x - rowsub[row]) (softmax numerator, utils.jl:94)
     const float *rowden;     // [n_dst][D]: softmax_write_kernel divides by it
     float den_add;           // softmax_edges adds eps(T) to the denominator (utils.jl:71)
+    const float *gate_i;     // [n_dst][D] GATED: message = sigmoid(gate_i[row] + x[j][0:D]) .* x[j][D:2D]  (x rows are 2D wide)
     const float *ss;         // [n_src] nullable
     const float *w_slot;     // [E'] slot order, nullable (takes precedence over w)
     const float *ss_slot;    // [E'] slot order, nullable (takes precedence over ss)
@@ -51,7 +52,13 @@ struct ReduceArgs {
 };
 
 // reduce slots [beg, end) of one destination into acc[VEC]; all lanes of the group call this together.
-template <int VEC, int OP, bool SCALED, int U, bool EMAT = false, bool EXPSUB = false>
+// NNlib.sigmoid: t = exp(-abs(x)); ifelse(x >= 0, inv(1 + t), t / (1 + t))
+__device__ __forceinline__ float nn_sigmoid(float x) {
+    const float t = expf(-fabsf(x));
+    return x >= 0.0f ? 1.0f / (1.0f + t) : t / (1.0f + t);
+}
+
+template <int VEC, int OP, bool SCALED, int U, bool EMAT = false, bool EXPSUB = false, bool GATED = false>
 __device__ __forceinline__ void reduce_range(const ReduceArgs &a, int beg, int end, int lig,
                                              int gbase, int G, int f0, bool active,
                                              float acc[VEC], int row = 0) {
@@ -59,6 +66,8 @@ __device__ __forceinline__ void reduce_range(const ReduceArgs &a, int beg, int e
 #pragma unroll
     for (int q = 0; q < VEC; ++q) sub[q] = 0.0f;
     if (EXPSUB && active) Vec<VEC>::load(a.rowsub + (int64_t)row * a.D + f0, sub);
+    if (GATED && active) Vec<VEC>::load(a.gate_i + (int64_t)row * a.D + f0, sub);   // Ax_i slice
+    const int64_t ldx = GATED ? 2 * (int64_t)a.D : (int64_t)a.D;
     for (int base = beg; base < end; base += G) {
         const int p = base + lig;
         int c = 0, ev = 0;
@@ -82,6 +91,7 @@ __device__ __forceinline__ void reduce_range(const ReduceArgs &a, int beg, int e
         const int n = min(G, end - base);
         for (int j = 0; j < n; j += U) {
             float v[U][VEC];
+            float gb[GATED ? U : 1][VEC];
             float em[EMAT ? U : 1][VEC];
             float wj[U], sj[U];
 #pragma unroll
@@ -104,7 +114,12 @@ __device__ __forceinline__ void reduce_range(const ReduceArgs &a, int beg, int e
                     sj[u] = __shfl(sv, gbase + jj, 64);
                 }
                 if (active && (j + u < n)) {
-                    Vec<VEC>::load(a.x + (int64_t)cj * a.D + f0, v[u]);
+                    if (GATED) {
+                        Vec<VEC>::load(a.x + (int64_t)cj * ldx + f0, gb[GATED ? u : 0]);          // Bx_j
+                        Vec<VEC>::load(a.x + (int64_t)cj * ldx + a.D + f0, v[u]);                 // Vx_j
+                    } else {
+                        Vec<VEC>::load(a.x + (int64_t)cj * ldx + f0, v[u]);
+                    }
                 } else {
 #pragma unroll
                     for (int q = 0; q < VEC; ++q) v[u][q] = 0.0f;
@@ -122,6 +137,7 @@ __device__ __forceinline__ void reduce_range(const ReduceArgs &a, int beg, int e
                         }
                         if (EMAT) t = em[EMAT ? u : 0][q] * t;  // e .* xj (GNNlib/src/msgpass.jl:187-191)
                         if (EXPSUB) t = expf(t - sub[q]);        // num = exp.(e .- max_) (GNNlib/src/utils.jl:94)
+                        if (GATED) t = nn_sigmoid(sub[q] + gb[GATED ? u : 0][q]) * t;   // sigmoid.(Ax_i .+ Bx_j) .* Vx_j (conv.jl:291)
                         acc[q] = op_apply<OP>(acc[q], t);
                     }
                 }
@@ -148,7 +164,7 @@ __device__ __forceinline__ void finalize_store(const ReduceArgs &a, int row, int
 }
 
 // virtual rows: [0, n_chunks) are chunks of long rows (raw partials), [n_chunks, n_chunks + n_rows) ordinary rows.
-template <int VEC, int OP, bool SCALED, int U, bool EMAT = false, bool EXPSUB = false>
+template <int VEC, int OP, bool SCALED, int U, bool EMAT = false, bool EXPSUB = false, bool GATED = false>
 __global__ void __launch_bounds__(256) csr_rows_kernel(const ReduceArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -167,8 +183,8 @@ __global__ void __launch_bounds__(256) csr_rows_kernel(const ReduceArgs a) {
 #pragma unroll
     for (int q = 0; q < VEC; ++q) acc[q] = op_identity<OP>();
     if (v < a.n_chunks) {
-        reduce_range<VEC, OP, SCALED, U, EMAT, EXPSUB>(a, a.chunk_beg[v], a.chunk_end[v], lig, gbase, G, f0, active, acc,
-                                                       EXPSUB ? a.chunk_row[v] : 0);
+        reduce_range<VEC, OP, SCALED, U, EMAT, EXPSUB, GATED>(a, a.chunk_beg[v], a.chunk_end[v], lig, gbase, G, f0, active, acc,
+                                                              (EXPSUB || GATED) ? a.chunk_row[v] : 0);
         if (active) Vec<VEC>::store(a.partial + (int64_t)v * a.D + f0, acc);
         return;
     }
@@ -176,7 +192,7 @@ __global__ void __launch_bounds__(256) csr_rows_kernel(const ReduceArgs a) {
     const int beg = a.rowptr[row];
     const int end = a.rowptr[row + 1];
     if (end - beg > a.long_thresh) return;  // split row: its chunks are virtual rows, folded by csr_combine_kernel
-    reduce_range<VEC, OP, SCALED, U, EMAT, EXPSUB>(a, beg, end, lig, gbase, G, f0, active, acc, row);
+    reduce_range<VEC, OP, SCALED, U, EMAT, EXPSUB, GATED>(a, beg, end, lig, gbase, G, f0, active, acc, row);
     finalize_store<VEC, OP>(a, row, end - beg, f0, active, acc);
 }
 
@@ -277,7 +293,7 @@ __global__ void __launch_bounds__(256) csr_combine_kernel(const ReduceArgs a) {
     finalize_store<VEC, OP>(a, row, a.rowptr[row + 1] - a.rowptr[row], f0, active, acc);
 }
 
-template <int VEC, int OP, bool SCALED, int U, bool EMAT = false, bool EXPSUB = false>
+template <int VEC, int OP, bool SCALED, int U, bool EMAT = false, bool EXPSUB = false, bool GATED = false>
 static int launch_reduce(const ReduceArgs &a0, hipStream_t stream) {
     ReduceArgs a = a0;
     const int G = 1 << a.log2g;
@@ -298,7 +314,7 @@ static int launch_reduce(const ReduceArgs &a0, hipStream_t stream) {
             gx = (int64_t)a.cpx * 8;
         }
         dim3 grid((unsigned)gx, (unsigned)tiles);
-        csr_rows_kernel<VEC, OP, SCALED, U, EMAT, EXPSUB><<<grid, 64 * waves, 0, stream>>>(a);
+        csr_rows_kernel<VEC, OP, SCALED, U, EMAT, EXPSUB, GATED><<<grid, 64 * waves, 0, stream>>>(a);
         GNNMP_LAUNCH_CHECK("csr_rows_kernel");
     }
     if (a.n_long > 0) {
@@ -325,6 +341,13 @@ static int dispatch_scaled(const ReduceArgs &a, bool scaled, hipStream_t s) {
 template <int VEC>
 static int dispatch_op(const ReduceArgs &a, int op, bool scaled, hipStream_t s) {
     if (a.rowsub) return launch_reduce<VEC, OP_SUM, false, 8, false, true>(a, s);   // softmax denominator
+    if (a.gate_i) {   // two rows per edge in flight: half the batch
+        switch (op) {
+            case OP_SUM: return launch_reduce<VEC, OP_SUM, false, 4, false, false, true>(a, s);
+            case OP_MAX: return launch_reduce<VEC, OP_MAX, false, 4, false, false, true>(a, s);
+            default: return launch_reduce<VEC, OP_MIN, false, 4, false, false, true>(a, s);
+        }
+    }
     if (a.emat) {   // two rows per edge in flight: half the batch
         switch (op) {
             case OP_SUM: return launch_reduce<VEC, OP_SUM, false, 4, true>(a, s);
@@ -342,7 +365,8 @@ static int dispatch_op(const ReduceArgs &a, int op, bool scaled, hipStream_t s) 
 // shared by propagate (idx = col) and scatter (idx = eid)
 int run_reduce(gnnmp_graph_t *p, const int32_t *idx, int aggr, const float *x, const float *w,
                const float *ss, const float *w_slot, const float *ss_slot, const float *sd, float *out,
-               int64_t D, hipStream_t stream, const float *emat = nullptr, const float *rowsub = nullptr) {
+               int64_t D, hipStream_t stream, const float *emat = nullptr, const float *rowsub = nullptr,
+               const float *gate_i = nullptr) {
     if (p->n_dst == 0 || D == 0) return GNNMP_OK;
     if (p->n_chunks > 0) {
         if (int rc = ensure_workspace(p, (size_t)p->n_chunks * (size_t)D)) return rc;
@@ -357,6 +381,7 @@ int run_reduce(gnnmp_graph_t *p, const int32_t *idx, int aggr, const float *x, c
     a.rowsub = rowsub;
     a.rowden = nullptr;
     a.den_add = 0.0f;
+    a.gate_i = gate_i;
     a.ss = ss;
     a.w_slot = w_slot;
     a.ss_slot = ss_slot;
@@ -380,6 +405,7 @@ int run_reduce(gnnmp_graph_t *p, const int32_t *idx, int aggr, const float *x, c
     a.waves = 4;
     int vec = pick_vec(D, x, out);
     if (emat && (reinterpret_cast<uintptr_t>(emat) & (4 * vec - 1)) != 0) vec = 1;
+    if (gate_i && (reinterpret_cast<uintptr_t>(gate_i) & (4 * vec - 1)) != 0) vec = 1;
     a.log2g = pick_log2g((D + vec - 1) / vec);
     const int op = (aggr == GNNMP_MAX) ? OP_MAX : (aggr == GNNMP_MIN ? OP_MIN : OP_SUM);
     const bool scaled = w || ss || w_slot || ss_slot;
@@ -532,6 +558,17 @@ int gnnmp_propagate_emul_f32(gnnmp_graph_t *plan, int aggr, const float *xj, con
         return fail(GNNMP_EINVAL, "propagate_emul: null xj/e/out");
     if (!e) return run_reduce(plan, plan->col, aggr, xj, nullptr, nullptr, nullptr, nullptr, nullptr, out, D, (hipStream_t)stream);
     return run_reduce(plan, plan->col, aggr, xj, nullptr, nullptr, nullptr, nullptr, nullptr, out, D, (hipStream_t)stream, e);
+}
+
+int gnnmp_propagate_gated_f32(gnnmp_graph_t *plan, int aggr, const float *gate_i, const float *bv_j, float *out, int64_t D,
+                              gnnmp_stream_t stream) {
+    if (!plan) return fail(GNNMP_EINVAL, "propagate_gated: null plan");
+    if (int rc = check_aggr(aggr, "propagate_gated")) return rc;
+    if (D < 0 || D > (1 << 19)) return fail(GNNMP_EINVAL, "propagate_gated: bad D %lld", (long long)D);
+    if (plan->n_dst > 0 && D > 0 && (!out || !gate_i || (!bv_j && plan->n_total > 0)))
+        return fail(GNNMP_EINVAL, "propagate_gated: null pointer");
+    return run_reduce(plan, plan->col, aggr, bv_j, nullptr, nullptr, nullptr, nullptr, nullptr, out, D, (hipStream_t)stream,
+                      nullptr, nullptr, gate_i);
 }
 
 int gnnmp_propagate_slots_f32(gnnmp_graph_t *plan, int aggr, const float *xj, const float *w_slot,

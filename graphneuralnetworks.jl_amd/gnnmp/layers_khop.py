@@ -124,3 +124,52 @@ class TAGConv(_KHop):
 
     def __call__(self, g, x, edge_weight=None):
         return tag_conv(self, g, x, edge_weight)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# ResGatedGraphConv: the gated message  sigmoid.(A*xi .+ B*xj) .* (V*xj)  as a functor of the fused propagate
+# ---------------------------------------------------------------------------------------------------------
+def res_gated_graph_conv(l, g: GNNGraph, x):
+    """GNNlib/src/layers/conv.jl:287-300: σ.(U*xi .+ Σ_j sigmoid.(A*xi .+ B*xj) .* V*xj .+ bias).  B and V are applied by
+    ONE dense call on the stacked weight, so that an edge reads its source's (Bx, Vx) as one contiguous row."""
+    from .layers import bias_act
+    check_num_nodes(g, x)
+    x = x.contiguous()
+    lib = L.load()
+    plan = g.plan(False)
+    D = l.A.shape[0]
+    Ax = dense(x, l.A)
+    BVx = dense(x, l.BV)                                              # [N][2D] = [Bx | Vx]
+    m = torch.empty((plan.n_dst, D), dtype=torch.float32, device=x.device)
+    L.check(lib.gnnmp_propagate_gated_f32(plan.handle, L.SUM, L.ptr(Ax), L.ptr(BVx), L.ptr(m), D, L.stream_ptr()))
+    Ux = dense(x, l.U)
+    L.check(lib.gnnmp_add_f32(L.ptr(Ux), L.ptr(m), L.ptr(Ux), Ux.numel(), L.stream_ptr()))     # (U*xi .+ m)
+    return bias_act(Ux, l.bias, l.sigma)
+
+
+class ResGatedGraphConv:
+    """ResGatedGraphConv(in => out, σ = identity; bias = true) — GraphNeuralNetworks/src/layers/conv.jl:849-858"""
+
+    takes_graph = True
+
+    def __init__(self, ch, sigma=None, bias=True, device="cuda", seed=None):
+        cin, cout = ch
+        sd = (lambda k: None if seed is None else seed + k)
+        self.A = glorot_uniform(cout, cin, device=device, seed=sd(0))
+        self.B = glorot_uniform(cout, cin, device=device, seed=sd(1))
+        self.U = glorot_uniform(cout, cin, device=device, seed=sd(2))
+        self.V = glorot_uniform(cout, cin, device=device, seed=sd(3))
+        self.bias = torch.zeros(cout, dtype=torch.float32, device=device) if bias else None
+        self.sigma = sigma
+
+    @property
+    def BV(self):
+        """[B; V] stacked (2*out, in); rebuilt only when B or V change"""
+        key = (self.B.data_ptr(), self.B._version, self.V.data_ptr(), self.V._version)
+        if getattr(self, "_bv_key", None) != key:
+            self._bv = torch.cat([self.B, self.V], 0).contiguous()
+            self._bv_key = key
+        return self._bv
+
+    def __call__(self, g, x):
+        return res_gated_graph_conv(self, g, x)

@@ -218,6 +218,14 @@ int gnnmp_propagate_f32(gnnmp_graph_t *plan, int msg, int aggr, const float *xj,
 int gnnmp_propagate_emul_f32(gnnmp_graph_t *plan, int aggr, const float *xj, const float *e, float *out, int64_t D,
                              gnnmp_stream_t stream);
 
+/* The gated message of res_gated_graph_conv (GNNlib/src/layers/conv.jl:287-300):
+ *   out[i] = aggr_{k: t_k = i} sigmoid.(gate_i[i] .+ Bx[s_k]) .* Vx[s_k]
+ * gate_i = A*x [n_dst][D]; bv_j [n_src][2D] holds every source's Bx (first D) and Vx (last D) side by side — one dense
+ * call with the stacked weight [B; V] produces it, and one contiguous 8D-byte gather per edge reads it.  sigmoid is
+ * NNlib's formulation (exp(-|x|) based).  The (D, E) gate and message arrays are never written. */
+int gnnmp_propagate_gated_f32(gnnmp_graph_t *plan, int aggr, const float *gate_i, const float *bv_j, float *out,
+                              int64_t D, gnnmp_stream_t stream);
+
 /* The same fused propagate with the per-edge factors already laid out in the plan's slot order:
  *   w_slot[p]   = w[eid_p]          (1 for plan-added self loops)      — gnnmp_plan_slot_gather_f32(plan, 1, w, ...)
  *   ss_slot[p]  = scale_src[col_p]                                    — gnnmp_plan_slot_gather_f32(plan, 0, scale_src, ...)

@@ -54,3 +54,24 @@ def tag_conv(s, t, n, x, weight, bias=None, k=3, add_self_loops_=True, edge_weig
             sum_pow = (sum_pow + x).astype(f32)
             sum_total = (sum_total + O.matmul(weight, sum_pow, blas)).astype(f32)
     return sum_total if bias is None else (sum_total + O._f32(bias)[None, :]).astype(f32)
+
+
+def _nn_sigmoid(x):
+    """NNlib.sigmoid: t = exp(-abs(x)); ifelse(x >= 0, inv(1 + t), t / (1 + t)), float32"""
+    x = O._f32(x)
+    t = np.exp(-np.abs(x)).astype(f32)
+    return np.where(x >= 0, (f32(1) / (f32(1) + t)).astype(f32), (t / (f32(1) + t)).astype(f32)).astype(f32)
+
+
+def res_gated_graph_conv(s, t, n, x, A, B, U, V, bias=None, sigma=None, blas=True):
+    """GNNlib/src/layers/conv.jl:287-300 through the generic path: gather Ax by t, (Bx, Vx) by s, the (D, E) gated
+    message, scatter(+), then σ.(U*xi .+ m .+ bias)"""
+    s, t = O._i64(s), O._i64(t)
+    x = O._f32(x)
+    Ax, Bx, Vx, Ux = (O.matmul(W, x, blas) for W in (A, B, V, U))
+    msg = (_nn_sigmoid((O.gather(Ax, t) + O.gather(Bx, s)).astype(f32)) * O.gather(Vx, s)).astype(f32)
+    m = O.scatter(O.SUM, msg, t, n)
+    y = (Ux + m).astype(f32)
+    if bias is not None:
+        y = (y + O._f32(bias)[None, :]).astype(f32)
+    return O._act(sigma, y)

@@ -114,3 +114,42 @@ def test_hip_sg_and_tag_vs_oracle(gm, KH, Din, Dout, k, weighted, loops):
         y = l(gw, dev(x)).cpu().numpy()
         ref = KH.sg_conv(s, t, n, x, l.weight.cpu().numpy(), l.bias.cpu().numpy(), k=k, add_self_loops_=loops, edge_weight=w)
         assert rel(y, ref.astype(np.float64)) <= 1e-5
+
+
+def test_oracle_res_gated_vs_dense_float64(oracle, KH):
+    rng = np.random.default_rng(8)
+    n, Din, Dout = 40, 5, 6
+    s, t = simple(rng, n, 300)
+    x = rng.standard_normal((n, Din)).astype(np.float32)
+    A, B, U, V = ((rng.standard_normal((Dout, Din)) * 0.5).astype(np.float32) for _ in range(4))
+    b = (rng.standard_normal(Dout) * 0.1).astype(np.float32)
+    y = KH.res_gated_graph_conv(s, t, n, x, A, B, U, V, b, "relu")
+    x64 = x.astype(np.float64)
+    Ax, Bx, Ux, Vx = (x64 @ W.T.astype(np.float64) for W in (A, B, U, V))
+    adj = np.zeros((n, n))
+    adj[t - 1, s - 1] = 1
+    gate = 1 / (1 + np.exp(-(Ax[:, None, :] + Bx[None, :, :])))           # [i, j, d]
+    m = (adj[..., None] * gate * Vx[None]).sum(1)
+    assert rel(y, np.maximum(Ux + m + b, 0)) < 5e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Din,Dout", [(16, 32), (100, 100), (7, 5), (64, 1)])
+def test_hip_res_gated_vs_oracle(gm, KH, Din, Dout):
+    from gnnmp.layers_khop import ResGatedGraphConv
+    rng = np.random.default_rng(Din * 3 + Dout)
+    n, E = 1300, 18000
+    s = rng.integers(1, n + 1, E)
+    t = rng.integers(1, n - 5, E)                          # a few empty destinations
+    t[:2000] = 6                                           # hub: split row
+    p = rng.permutation(E)
+    s, t = s[p], t[p]
+    x = rng.standard_normal((n, Din)).astype(np.float32)
+    g = gm.GNNGraph(dev(s), dev(t), num_nodes=n)
+    l = ResGatedGraphConv((Din, Dout), "relu", seed=9)
+    l.bias = dev((rng.standard_normal(Dout) * 0.1).astype(np.float32))
+    y = l(g, dev(x)).cpu().numpy()
+    c = lambda v: v.cpu().numpy()
+    ref = KH.res_gated_graph_conv(s, t, n, x, c(l.A), c(l.B), c(l.U), c(l.V), c(l.bias), "relu")
+    assert y.shape == ref.shape
+    assert rel(y, ref.astype(np.float64)) <= 1e-5
