@@ -29,6 +29,7 @@ SYMBOLS = (
     "gnnmp_degree_f32", "gnnmp_inv_sqrt_f32",
     "gnnmp_edge_softmax_f32", "gnnmp_segment_softmax_f32", "gnnmp_gat_node_scores_f32", "gnnmp_gat_aggregate_f32", "gnnmp_gat_conv_f32",
     "gnnmp_gat_conv_stats_f32", "gnnmp_gat_conv_grad_f32", "gnnmp_attn_conv_f32",
+    "gnnmp_attn_conv_grad_f32",
     "gnnmp_bias_act_f32",
     "gnnmp_segment_pool_f32", "gnnmp_dense_f32",
     "gnnmp_edge_dot_f32", "gnnmp_edge_dot_plan_f32", "gnnmp_propagate_maxmin_grad_f32",
@@ -84,6 +85,7 @@ def load():
         "gnnmp_gat_conv_f32": [vp, vp, vp, vp, f, vp, i, vp, i64, i64, vp],
         "gnnmp_gat_conv_stats_f32": [vp, vp, vp, vp, f, vp, i, vp, vp, i64, i64, vp],
         "gnnmp_attn_conv_f32": [vp, i, vp, vp, vp, vp, f, f, vp, i, vp, vp, i64, i64, vp],
+        "gnnmp_attn_conv_grad_f32": [vp, vp, i, vp, vp, vp, vp, f, f, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, vp],
         "gnnmp_gat_conv_grad_f32": [vp, vp, vp, vp, vp, f, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, vp],
         "gnnmp_degree_f32": [vp, vp, vp, vp],
         "gnnmp_inv_sqrt_f32": [vp, vp, i64, vp],

@@ -1,0 +1,132 @@
+"""Differentiable GATv2Conv and TransformerConv (attention core + root weight + skip connection) — forward AND backward on
+the HIP kernels (csrc/gat_fused.hip, csrc/attn_backward.hip), wrapped as torch.autograd.Functions like gnnmp/backward.py.
+The forward keeps 8 bytes of softmax statistics per destination and head; the pullback is two edge passes that rebuild α in
+registers, then the dense adjoints.  concat = true; no edge features / dropout (as in the forward)."""
+from __future__ import annotations
+
+import torch
+
+from . import _lib as L
+from .backward import _act_code, act_grad, dense_grad_w, dense_grad_x, plan_transposed
+from .graph import GNNGraph, check_num_nodes
+from .layers import dense
+from .layers_attn import ATTN_DOT, ATTN_GATV2
+
+
+def _attn_forward(plan, mode, Q, K, V, a, slope, scale, bias, act, H, C):
+    N = plan.n_dst
+    out = torch.empty((N, H * C), dtype=torch.float32, device=K.device)
+    stats = torch.empty((N, H, 2), dtype=torch.float32, device=K.device)
+    L.check(L.load().gnnmp_attn_conv_f32(plan.handle, mode, L.ptr(Q), L.ptr(K), L.ptr(V), L.ptr(a), float(slope), float(scale),
+                                         L.ptr(bias), act, L.ptr(out), L.ptr(stats), H, C, L.stream_ptr()))
+    return out, stats
+
+
+def _attn_backward(g, loops, mode, Q, K, V, a, slope, scale, stats, dz, H, C):
+    plan, plan_t = g.plan(loops), plan_transposed(g, loops)
+    N = g.num_nodes
+    f32 = dict(dtype=torch.float32, device=dz.device)
+    line = torch.empty((N, H, 4), **f32)
+    dQ = torch.empty((N, H * C), **f32)
+    dK = torch.empty((N, H * C), **f32)
+    dV = torch.empty((N, H * C), **f32) if mode == ATTN_DOT else None
+    dA = torch.empty((N, H * C), **f32) if mode == ATTN_GATV2 else None
+    da = torch.empty((H, C), **f32) if mode == ATTN_GATV2 else None
+    L.check(L.load().gnnmp_attn_conv_grad_f32(plan.handle, plan_t.handle, mode, L.ptr(Q), L.ptr(K), L.ptr(V), L.ptr(a),
+                                              float(slope), float(scale), L.ptr(stats), L.ptr(dz), L.ptr(line), L.ptr(dQ),
+                                              L.ptr(dK), L.ptr(dV), L.ptr(dA), L.ptr(da), H, C, L.stream_ptr()))
+    return dQ, dK, dV, da
+
+
+def _add_(a, b):
+    L.check(L.load().gnnmp_add_f32(L.ptr(a), L.ptr(b), L.ptr(a), a.numel(), L.stream_ptr()))
+    return a
+
+
+class _GATv2ConvFn(torch.autograd.Function):
+    """gatv2_conv (GNNlib/src/layers/conv.jl:171-214), concat = true, e === nothing"""
+
+    @staticmethod
+    def forward(ctx, x, Wi, bi, Wj, a, bias, g, sigma, heads, slope, loops):
+        H, C = heads, Wi.shape[0] // heads
+        x = x.contiguous()
+        Q = dense(x, Wi, bi)
+        K = dense(x, Wj)
+        a_hc = a.t().contiguous()                                   # (C, H) as Julia stores it -> [H][C]
+        out, stats = _attn_forward(g.plan(loops), ATTN_GATV2, Q, K, None, a_hc, slope, 1.0, bias, _act_code(sigma), H, C)
+        ctx.save_for_backward(x, Wi, Wj, Q, K, a_hc, stats, out)
+        ctx.g, ctx.sigma, ctx.H, ctx.C, ctx.slope, ctx.loops = g, sigma, H, C, slope, loops
+        ctx.has_bi, ctx.has_b = bi is not None, bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, Wi, Wj, Q, K, a_hc, stats, y = ctx.saved_tensors
+        dz = act_grad(dy.contiguous(), y, ctx.sigma)
+        db = dense_grad_w(dz, dz, need_w=False)[1] if ctx.has_b else None
+        dQ, dK, _, da = _attn_backward(ctx.g, ctx.loops, ATTN_GATV2, Q, K, None, a_hc, ctx.slope, 1.0, stats, dz, ctx.H, ctx.C)
+        dWi, dbi = dense_grad_w(dQ, x, need_b=ctx.has_bi)
+        dWj, _ = dense_grad_w(dK, x, need_b=False)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _add_(dense_grad_x(dQ, Wi), dense_grad_x(dK, Wj))
+        return dx, dWi, dbi, dWj, da.t(), db, None, None, None, None, None
+
+
+def gatv2_conv_ad(l, g: GNNGraph, x):
+    """differentiable GATv2Conv forward: gradients w.r.t. x, dense_i (weight, bias), dense_j weight, a, bias"""
+    check_num_nodes(g, x)
+    assert l.concat and l.dense_e is None, "the HIP adjoint covers concat = true without edge features"
+    return _GATv2ConvFn.apply(x, l.dense_i_weight, l.dense_i_bias, l.dense_j_weight, l.a, l.bias, g, l.sigma, l.heads,
+                              l.negative_slope, bool(l.add_self_loops))
+
+
+class _TransformerConvFn(torch.autograd.Function):
+    """transformer_conv (conv.jl:553-629): attention core, + W1 x (root weight), + x (skip connection); concat = true"""
+
+    @staticmethod
+    def forward(ctx, x, W1, b1, W2, b2, W3, b3, W4, b4, g, heads, sqrt_out, loops, skip):
+        H, C = heads, W2.shape[0] // heads
+        x = x.contiguous()
+        V, Q, K = dense(x, W2, b2), dense(x, W3, b3), dense(x, W4, b4)
+        h, stats = _attn_forward(g.plan(loops), ATTN_DOT, Q, K, V, None, 0.0, sqrt_out, None, L.ACT_IDENTITY, H, C)
+        if W1 is not None:
+            _add_(h, dense(x, W1, b1))
+        if skip:
+            _add_(h, x)
+        ctx.save_for_backward(x, Q, K, V, stats, W2, W3, W4, *([W1] if W1 is not None else []))
+        ctx.g, ctx.H, ctx.C, ctx.scale, ctx.loops, ctx.skip = g, H, C, sqrt_out, loops, skip
+        ctx.has = (W1 is not None, b1 is not None, b2 is not None, b3 is not None, b4 is not None)
+        return h
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, Q, K, V, stats, W2, W3, W4, *rest = ctx.saved_tensors
+        W1 = rest[0] if rest else None
+        dh = dy.contiguous()
+        dQ, dK, dV, _ = _attn_backward(ctx.g, ctx.loops, ATTN_DOT, Q, K, V, None, 0.0, ctx.scale, stats, dh, ctx.H, ctx.C)
+        has_w1, hb1, hb2, hb3, hb4 = ctx.has
+        dW2, db2 = dense_grad_w(dV, x, need_b=hb2)
+        dW3, db3 = dense_grad_w(dQ, x, need_b=hb3)
+        dW4, db4 = dense_grad_w(dK, x, need_b=hb4)
+        dW1 = db1 = None
+        if has_w1:
+            dW1, db1 = dense_grad_w(dh, x, need_b=hb1)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = dense_grad_x(dV, W2)
+            _add_(dx, dense_grad_x(dQ, W3))
+            _add_(dx, dense_grad_x(dK, W4))
+            if has_w1:
+                _add_(dx, dense_grad_x(dh, W1))
+            if ctx.skip:
+                _add_(dx, dh)
+        return dx, dW1, db1, dW2, db2, dW3, db3, dW4, db4, None, None, None, None, None
+
+
+def transformer_conv_ad(l, g: GNNGraph, x):
+    """differentiable TransformerConv forward (concat = true): gradients w.r.t. x and W1..W4 (+ their biases)"""
+    check_num_nodes(g, x)
+    assert l.concat, "the HIP adjoint covers concat = true"
+    return _TransformerConvFn.apply(x, l.W1_weight, l.W1_bias, l.W2_weight, l.W2_bias, l.W3_weight, l.W3_bias, l.W4_weight,
+                                    l.W4_bias, g, l.heads, l.sqrt_out, bool(l.add_self_loops), bool(l.skip_connection))

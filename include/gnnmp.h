@@ -328,6 +328,17 @@ int gnnmp_gat_conv_grad_f32(gnnmp_graph_t *plan, gnnmp_graph_t *plan_t, const fl
                             float *line, float *dsd, float *dss, float *dWx_src, float *dWx_dst, float *da,
                             int64_t H, int64_t C, gnnmp_stream_t stream);
 
+/* Pullback of gnnmp_attn_conv_f32 for the GATV2 and DOT logits (the GAT logit has the cheaper dedicated entry above; the
+ * cosine logit has none yet: GNNMP_EUNSUPPORTED).  dout = Δ w.r.t. the aggregated (pre-bias, pre-σ) output; stats from the
+ * forward; plan_t = plan of the reversed edge index.  Caller-supplied: line [n_dst][H][4] (16-byte aligned scratch),
+ * dQ [n_dst][H*C], dK [n_src][H*C]; DOT also dV [n_src][H*C]; GATV2 also dA [n_dst][H*C] (scratch: per-destination terms
+ * of Δa) and da [H][C] (may be NULL).  With GATV2, V is K and dK holds the whole gradient of K.  Two edge passes, no
+ * atomics, run-to-run identical. */
+int gnnmp_attn_conv_grad_f32(gnnmp_graph_t *plan, gnnmp_graph_t *plan_t, int mode, const float *Q, const float *K,
+                             const float *V, const float *a, float negative_slope, float scale, const float *stats,
+                             const float *dout, float *line, float *dQ, float *dK, float *dV, float *dA, float *da,
+                             int64_t H, int64_t C, gnnmp_stream_t stream);
+
 /* out[n][c] = act( mean_h y[n][h][c] + bias[c] ) — the concat = false tail of gat_conv (`mean(x, dims = 2)`,
  * GNNlib/src/layers/conv.jl:143-147): heads added in order, one division by H, then σ.(x .+ bias). */
 int gnnmp_head_mean_f32(const float *y, const float *bias, int act, float *out, int64_t N, int64_t H,
