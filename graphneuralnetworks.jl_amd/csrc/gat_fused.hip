@@ -245,45 +245,50 @@ __global__ void __launch_bounds__(256) gat_fused_rows_kernel(const GatFusedArgs 
     gat_fused_store<VEC>(a, row, f0, active, acc);
 }
 
+// one BLOCK per long row (see csr_combine_kernel): every lane group merges a contiguous slice of the row's chunk partials
+// (acc, m, den) with the log-sum-exp rescale, the slice results meet in LDS, group 0 merges them in slice order.
 template <int VEC>
 __global__ void __launch_bounds__(256) gat_fused_combine_kernel(const GatFusedArgs a) {
+    __shared__ float red[256 * (VEC + 2)];
     const int G = 1 << a.log2g;
     const int lig = threadIdx.x & (G - 1);
-    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> a.log2g;
-    if (r >= a.n_long) return;
-    const int f0 = ((int)blockIdx.y * G + lig) * VEC;
-    if (f0 >= a.D) return;
+    const int grp = threadIdx.x >> a.log2g;
+    const int NG = 256 >> a.log2g;
+    const int r = blockIdx.x;
+    const int f0 = lig * VEC;
+    const bool active = f0 < a.D;
+    const int fc = active ? f0 : 0;
     const int row = a.long_rows[r];
     const int c0 = a.long_cptr[r], c1 = a.long_cptr[r + 1];
+    const int per = (c1 - c0 + NG - 1) / NG;
+    const int s0 = min(c1, c0 + grp * per), s1 = min(c1, s0 + per);
     const int LN = a.D / VEC;
     const int64_t S = a.D + 2 * LN;
-    // loads in batches of CB (independent, clamped), folded in chunk order: a hub with 200 chunks otherwise costs one
-    // dependent L2 round trip per chunk, twice (86 us on the arxiv shape)
     constexpr int CB = 8;
-    const int li = f0 / VEC;
+    const int li = fc / VEC;
     float M = -__builtin_inff();
-    for (int c = c0; c < c1; c += CB) {
+    for (int c = s0; c < s1; c += CB) {
         float mv[CB];
 #pragma unroll
-        for (int u = 0; u < CB; ++u) mv[u] = a.partial[(int64_t)min(c + u, c1 - 1) * S + a.D + li];
+        for (int u = 0; u < CB; ++u) mv[u] = a.partial[(int64_t)min(c + u, s1 - 1) * S + a.D + li];
 #pragma unroll
         for (int u = 0; u < CB; ++u) M = fmaxf(M, mv[u]);
     }
     float den = 0.0f, acc[VEC];
 #pragma unroll
     for (int q = 0; q < VEC; ++q) acc[q] = 0.0f;
-    for (int c = c0; c < c1; c += CB) {
+    for (int c = s0; c < s1; c += CB) {
         float mv[CB], dv[CB], v[CB][VEC];
 #pragma unroll
         for (int u = 0; u < CB; ++u) {
-            const float *pc = a.partial + (int64_t)min(c + u, c1 - 1) * S;
+            const float *pc = a.partial + (int64_t)min(c + u, s1 - 1) * S;
             mv[u] = pc[a.D + li];
             dv[u] = pc[a.D + LN + li];
-            Vec<VEC>::load(pc + f0, v[u]);
+            Vec<VEC>::load(pc + fc, v[u]);
         }
 #pragma unroll
         for (int u = 0; u < CB; ++u) {
-            if (c + u < c1) {
+            if (c + u < s1) {
                 const float sc = expf(mv[u] - M);
                 den = fmaf(dv[u], sc, den);
 #pragma unroll
@@ -291,11 +296,37 @@ __global__ void __launch_bounds__(256) gat_fused_combine_kernel(const GatFusedAr
             }
         }
     }
+    float *mine = red + threadIdx.x * (VEC + 2);
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) mine[q] = acc[q];
+    mine[VEC] = M;
+    mine[VEC + 1] = den;
+    __syncthreads();
+    if (grp != 0 || !active) return;
+    float Mt = M;
+    for (int k = 1; k < NG; ++k) {
+        if (c0 + k * per >= c1) break;
+        Mt = fmaxf(Mt, red[((k << a.log2g) + lig) * (VEC + 2) + VEC]);
+    }
+    {
+        const float sc = expf(M - Mt);
+        den *= sc;
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) acc[q] *= sc;
+    }
+    for (int k = 1; k < NG; ++k) {
+        if (c0 + k * per >= c1) break;
+        const float *o = red + ((k << a.log2g) + lig) * (VEC + 2);
+        const float sc = expf(o[VEC] - Mt);
+        den = fmaf(o[VEC + 1], sc, den);
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) acc[q] = fmaf(o[q], sc, acc[q]);
+    }
 #pragma unroll
     for (int q = 0; q < VEC; ++q) acc[q] = acc[q] / den;
     if (a.stats && (f0 % a.C) == 0) {
         float *st = a.stats + ((int64_t)row * a.H + f0 / a.C) * 2;
-        st[0] = M;
+        st[0] = Mt;
         st[1] = den;
     }
     gat_fused_store<VEC>(a, row, f0, true, acc);
@@ -356,8 +387,7 @@ static int launch_gat_fused(GatFusedArgs a, hipStream_t stream) {
         GNNMP_LAUNCH_CHECK("gat_fused_rows_kernel");
     }
     if (a.n_long > 0) {
-        const int64_t threads = (int64_t)a.n_long << a.log2g;
-        gat_fused_combine_kernel<VEC><<<(unsigned)((threads + 255) / 256), 256, 0, stream>>>(a);
+        gat_fused_combine_kernel<VEC><<<(unsigned)a.n_long, 256, 0, stream>>>(a);
         GNNMP_LAUNCH_CHECK("gat_fused_combine_kernel");
     }
     return GNNMP_OK;

@@ -259,36 +259,49 @@ __global__ void __launch_bounds__(256) softmax_write_kernel(const ReduceArgs a) 
     }
 }
 
-// one lane group per long row: fold its chunk partials in chunk order, then the usual epilogue.
+// one BLOCK per long row: its 256 / G lane groups fold contiguous slices of the row's chunk partials (in chunk order, 8
+// loads in flight), the slice results meet in LDS and group 0 folds them in slice order, then the usual epilogue.  (One
+// lane group per row walked a 12 800-edge hub's 200 chunks alone: 14-40 us of a 250 us arxiv layer.)
 template <int VEC, int OP>
 __global__ void __launch_bounds__(256) csr_combine_kernel(const ReduceArgs a) {
+    __shared__ float red[256 * VEC];
     const int G = 1 << a.log2g;
     const int lig = threadIdx.x & (G - 1);
-    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> a.log2g;
-    if (r >= a.n_long) return;
+    const int grp = threadIdx.x >> a.log2g;
+    const int NG = 256 >> a.log2g;
+    const int r = blockIdx.x;
     const int f0 = ((int)blockIdx.y * G + lig) * VEC;
     const bool active = f0 < a.D;
     const int row = a.long_rows[r];
     const int c0 = a.long_cptr[r], c1 = a.long_cptr[r + 1];
+    const int per = (c1 - c0 + NG - 1) / NG;
+    const int s0 = min(c1, c0 + grp * per), s1 = min(c1, s0 + per);
     float acc[VEC];
 #pragma unroll
     for (int q = 0; q < VEC; ++q) acc[q] = op_identity<OP>();
     if (active) {
-        // 8 partial loads in flight, folded in chunk order (a 12 800-edge row has 200 chunks: one dependent L2 round
-        // trip per chunk made this kernel 51 us on the arxiv shape)
         constexpr int CB = 8;
-        for (int c = c0; c < c1; c += CB) {
+        for (int c = s0; c < s1; c += CB) {
             float v[CB][VEC];
 #pragma unroll
-            for (int u = 0; u < CB; ++u) Vec<VEC>::load(a.partial + (int64_t)min(c + u, c1 - 1) * a.D + f0, v[u]);
+            for (int u = 0; u < CB; ++u) Vec<VEC>::load(a.partial + (int64_t)min(c + u, s1 - 1) * a.D + f0, v[u]);
 #pragma unroll
             for (int u = 0; u < CB; ++u) {
-                if (c + u < c1) {
+                if (c + u < s1) {
 #pragma unroll
                     for (int q = 0; q < VEC; ++q) acc[q] = op_apply<OP>(acc[q], v[u][q]);
                 }
             }
         }
+    }
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) red[threadIdx.x * VEC + q] = acc[q];
+    __syncthreads();
+    if (grp != 0) return;
+    for (int k = 1; k < NG; ++k) {
+        if (c0 + k * per >= c1) break;               // empty slices hold the identity: nothing to fold
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) acc[q] = op_apply<OP>(acc[q], red[((k << a.log2g) + lig) * VEC + q]);
     }
     finalize_store<VEC, OP>(a, row, a.rowptr[row + 1] - a.rowptr[row], f0, active, acc);
 }
@@ -318,8 +331,7 @@ static int launch_reduce(const ReduceArgs &a0, hipStream_t stream) {
         GNNMP_LAUNCH_CHECK("csr_rows_kernel");
     }
     if (a.n_long > 0) {
-        const int64_t threads = (int64_t)a.n_long << a.log2g;
-        dim3 grid((unsigned)((threads + 255) / 256), (unsigned)tiles);
+        dim3 grid((unsigned)a.n_long, (unsigned)tiles);
         csr_combine_kernel<VEC, OP><<<grid, 256, 0, stream>>>(a);
         GNNMP_LAUNCH_CHECK("csr_combine_kernel");
     }
@@ -474,8 +486,7 @@ int run_combine_sum(gnnmp_graph_t *p, float *out, int64_t D, hipStream_t stream)
     a.log2g = pick_log2g((D + vec - 1) / vec);
     const int G = 1 << a.log2g;
     const int tiles = (int)(((D + vec - 1) / vec + G - 1) / G);
-    const int64_t threads = (int64_t)a.n_long << a.log2g;
-    dim3 grid((unsigned)((threads + 255) / 256), (unsigned)tiles);
+    dim3 grid((unsigned)a.n_long, (unsigned)tiles);
     switch (vec) {
         case 4: csr_combine_kernel<4, OP_SUM><<<grid, 256, 0, stream>>>(a); break;
         case 2: csr_combine_kernel<2, OP_SUM><<<grid, 256, 0, stream>>>(a); break;
