@@ -53,6 +53,7 @@ struct GatFusedArgs {
     float scale;          // DOT: divisor (sqrt(out)); COS: multiplier (β)
     int long_thresh;
     int cpx;
+    int nbc;              // leading blocks (chunk virtual rows) that are not remapped
     int waves;
 };
 
@@ -161,7 +162,7 @@ __global__ void __launch_bounds__(256) gat_fused_rows_kernel(const GatFusedArgs 
     const int grp = lane >> a.log2g;
     const int gbase = lane - lig;
     const int rpw = 64 >> a.log2g;
-    const int chunk = a.cpx ? xcd_remap(blockIdx.x, a.cpx, 1) : (int)blockIdx.x;
+    const int chunk = a.cpx ? xcd_remap_after(blockIdx.x, a.nbc, a.cpx) : (int)blockIdx.x;
     const int64_t v64 = ((int64_t)chunk * a.waves + wave) * rpw + grp;
     if (v64 >= (int64_t)a.n_rows + a.n_chunks) return;
     const int v = (int)v64;
@@ -369,8 +370,9 @@ static int launch_gat_fused(GatFusedArgs a, hipStream_t stream) {
         int64_t gx = chunks;
         a.cpx = 0;
         if (use_xcd_remap(a.n_src, a.D, chunks)) {
-            a.cpx = (int)((chunks + 7) / 8);
-            gx = (int64_t)a.cpx * 8;
+            a.nbc = (int)std::min<int64_t>(chunks, (a.n_chunks + rows_per_block - 1) / rows_per_block);
+            a.cpx = (int)((chunks - a.nbc + 7) / 8);
+            gx = (int64_t)a.nbc + (int64_t)a.cpx * 8;
         }
         dim3 grid((unsigned)gx, 1);
         const int U = knob(KNOB_UNROLL);
@@ -480,6 +482,7 @@ static int attn_conv_impl(gnnmp_graph_t *plan, int mode, const float *Q, const f
     g.scale = scale;
     g.long_thresh = plan->long_thresh;
     g.cpx = 0;
+    g.nbc = 0;
     g.waves = 4;
     switch (mode) {
         case GNNMP_ATTN_GATV2: return launch_mode<GNNMP_ATTN_GATV2>(g, vec, stream);

@@ -47,7 +47,8 @@ struct ReduceArgs {
     int log2g;
     int mean;
     int long_thresh;
-    int cpx;                 // chunks per XCD (grid.x = 8*cpx) ; 0 = no remap
+    int cpx;                 // logical blocks per XCD (grid.x = nbc + 8*cpx) ; 0 = no remap
+    int nbc;                 // leading blocks (chunk virtual rows) that are not remapped
     int waves;               // waves per block
 };
 
@@ -173,7 +174,7 @@ __global__ void __launch_bounds__(256) csr_rows_kernel(const ReduceArgs a) {
     const int grp = lane >> a.log2g;
     const int gbase = lane - lig;
     const int rpw = 64 >> a.log2g;
-    const int chunk = a.cpx ? xcd_remap(blockIdx.x, a.cpx, 1) : (int)blockIdx.x;
+    const int chunk = a.cpx ? xcd_remap_after(blockIdx.x, a.nbc, a.cpx) : (int)blockIdx.x;
     const int64_t v64 = ((int64_t)chunk * a.waves + wave) * rpw + grp;
     if (v64 >= (int64_t)a.n_rows + a.n_chunks) return;
     const int v = (int)v64;
@@ -323,8 +324,9 @@ static int launch_reduce(const ReduceArgs &a0, hipStream_t stream) {
         int64_t gx = chunks;
         a.cpx = 0;
         if (use_xcd_remap(a.n_src, a.D, chunks)) {
-            a.cpx = (int)((chunks + 7) / 8);
-            gx = (int64_t)a.cpx * 8;
+            a.nbc = (int)std::min<int64_t>(chunks, (a.n_chunks + rows_per_block - 1) / rows_per_block);
+            a.cpx = (int)((chunks - a.nbc + 7) / 8);
+            gx = (int64_t)a.nbc + (int64_t)a.cpx * 8;
         }
         dim3 grid((unsigned)gx, (unsigned)tiles);
         csr_rows_kernel<VEC, OP, SCALED, U, EMAT, EXPSUB, GATED><<<grid, 64 * waves, 0, stream>>>(a);
@@ -414,6 +416,7 @@ int run_reduce(gnnmp_graph_t *p, const int32_t *idx, int aggr, const float *x, c
     a.mean = (aggr == GNNMP_MEAN);
     a.long_thresh = p->long_thresh;
     a.cpx = 0;
+    a.nbc = 0;
     a.waves = 4;
     int vec = pick_vec(D, x, out);
     if (emat && (reinterpret_cast<uintptr_t>(emat) & (4 * vec - 1)) != 0) vec = 1;
