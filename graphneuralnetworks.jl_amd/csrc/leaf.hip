@@ -170,6 +170,14 @@ __global__ void __launch_bounds__(256) head_mean_kernel(const float *y, const fl
     if (act == GNNMP_ACT_RELU) v = v < 0.0f ? 0.0f : v;
     out[i] = v;
 }
+// pullback of `mean(x, dims = 2)`: dy[n][h][c] = dz[n][c] / H for every head
+__global__ void __launch_bounds__(256) head_mean_grad_kernel(const float *dz, float *dy, int64_t N, int H, int C) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * H * C) return;
+    const int64_t n = i / ((int64_t)H * C);
+    const int c = (int)(i % C);
+    dy[i] = dz[n * C + c] / (float)H;
+}
 // flag[0] = 1 if idx[k] > idx[k+1] for some k
 __global__ void __launch_bounds__(256) unsorted_kernel(const void *idx, int idx_bytes, int64_t n, int *flag) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -278,6 +286,16 @@ int gnnmp_head_mean_f32(const float *y, const float *bias, int act, float *out, 
     if (!y || !out) return fail(GNNMP_EINVAL, "head_mean: null pointer");
     head_mean_kernel<<<(unsigned)((N * C + 255) / 256), 256, 0, stream>>>(y, bias, act, out, N, (int)H, (int)C);
     GNNMP_LAUNCH_CHECK("head_mean_kernel");
+    return GNNMP_OK;
+}
+
+int gnnmp_head_mean_grad_f32(const float *dz, float *dy, int64_t N, int64_t H, int64_t C, gnnmp_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (N < 0 || H <= 0 || C <= 0) return fail(GNNMP_EINVAL, "head_mean_grad: bad size");
+    if (N == 0) return GNNMP_OK;
+    if (!dz || !dy) return fail(GNNMP_EINVAL, "head_mean_grad: null pointer");
+    head_mean_grad_kernel<<<(unsigned)((N * H * C + 255) / 256), 256, 0, stream>>>(dz, dy, N, (int)H, (int)C);
+    GNNMP_LAUNCH_CHECK("head_mean_grad_kernel");
     return GNNMP_OK;
 }
 

@@ -283,7 +283,7 @@ class _GATConvFn(torch.autograd.Function):
     (csrc/gat_backward.hip) + the dense adjoints."""
 
     @staticmethod
-    def forward(ctx, x, weight, a, bias, g, sigma, heads, slope, add_self_loops):
+    def forward(ctx, x, weight, a, bias, g, sigma, heads, slope, add_self_loops, concat=True):
         from .layers import dense
         lib = L.load()
         plan = g.plan(add_self_loops)
@@ -295,10 +295,17 @@ class _GATConvFn(torch.autograd.Function):
         a_hc = a.t().contiguous()                                   # [H][2C]
         out = torch.empty((N, H * C), dtype=torch.float32, device=x.device)
         stats = torch.empty((N, H, 2), dtype=torch.float32, device=x.device)
-        L.check(lib.gnnmp_gat_conv_stats_f32(plan.handle, L.ptr(Wx), None, L.ptr(a_hc), float(slope), L.ptr(bias),
-                                             _act_code(sigma), L.ptr(out), L.ptr(stats), H, C, L.stream_ptr()))
+        # concat = false: the heads are averaged BEFORE bias and σ (conv.jl:143-147), so the kernel's fused tail is off
+        L.check(lib.gnnmp_gat_conv_stats_f32(plan.handle, L.ptr(Wx), None, L.ptr(a_hc), float(slope),
+                                             L.ptr(bias) if concat else None, _act_code(sigma) if concat else L.ACT_IDENTITY,
+                                             L.ptr(out), L.ptr(stats), H, C, L.stream_ptr()))
+        if not concat:
+            y = torch.empty((N, C), dtype=torch.float32, device=x.device)
+            L.check(lib.gnnmp_head_mean_f32(L.ptr(out), L.ptr(bias), _act_code(sigma), L.ptr(y), N, H, C, L.stream_ptr()))
+            out = y
         ctx.save_for_backward(x, weight, Wx, a_hc, stats, out)
         ctx.g, ctx.sigma, ctx.H, ctx.C, ctx.slope, ctx.loops, ctx.has_bias = g, sigma, H, C, slope, add_self_loops, bias is not None
+        ctx.concat = concat
         return out
 
     @staticmethod
@@ -311,6 +318,10 @@ class _GATConvFn(torch.autograd.Function):
         db = None
         if ctx.has_bias and ctx.needs_input_grad[3]:
             _, db = dense_grad_w(dz, dz, need_w=False, need_b=True)
+        if not ctx.concat:                       # pullback of mean(x, dims = 2): every head receives Δ / H
+            dzh = torch.empty((N, H * C), dtype=torch.float32, device=dz.device)
+            L.check(lib.gnnmp_head_mean_grad_f32(L.ptr(dz), L.ptr(dzh), N, H, C, L.stream_ptr()))
+            dz = dzh
         plan, plan_t = g.plan(ctx.loops), plan_transposed(g, ctx.loops)
         f32 = dict(dtype=torch.float32, device=dz.device)
         line = torch.empty((N, H, 4), **f32)
@@ -323,12 +334,12 @@ class _GATConvFn(torch.autograd.Function):
                                             L.ptr(da_hc), H, C, L.stream_ptr()))
         dW = dense_grad_w(dWx, x, need_b=False)[0] if ctx.needs_input_grad[1] else None
         dx = dense_grad_x(dWx, weight) if ctx.needs_input_grad[0] else None
-        return dx, dW, da_hc.t(), db, None, None, None, None, None
+        return dx, dW, da_hc.t(), db, None, None, None, None, None, None
 
 
 def gat_conv_ad(l, g: GNNGraph, x):
-    """differentiable GATConv forward (concat = true, no edge features): gradients w.r.t. x, l.dense_x_weight, l.a, l.bias"""
+    """differentiable GATConv forward (no edge features; concat = true or false): gradients w.r.t. x, l.dense_x_weight,
+    l.a, l.bias"""
     check_num_nodes(g, x)
-    assert l.concat, "the HIP adjoint covers concat = true"
     return _GATConvFn.apply(x, l.dense_x_weight, l.a, l.bias, g, l.sigma, l.heads, l.negative_slope,
-                            bool(l.add_self_loops))
+                            bool(l.add_self_loops), bool(l.concat))

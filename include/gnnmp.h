@@ -343,6 +343,8 @@ int gnnmp_attn_conv_grad_f32(gnnmp_graph_t *plan, gnnmp_graph_t *plan_t, int mod
  * GNNlib/src/layers/conv.jl:143-147): heads added in order, one division by H, then σ.(x .+ bias). */
 int gnnmp_head_mean_f32(const float *y, const float *bias, int act, float *out, int64_t N, int64_t H,
                         int64_t C, gnnmp_stream_t stream);
+/* its pullback: dy[n][h][c] = dz[n][c] / H (the heads' gradient of `mean(x, dims = 2)`) */
+int gnnmp_head_mean_grad_f32(const float *dz, float *dy, int64_t N, int64_t H, int64_t C, gnnmp_stream_t stream);
 /* out = a + b (n floats) — degree(g; dir = :both) = out-degree + in-degree (GNNGraphs/src/query.jl:362-367). */
 int gnnmp_add_f32(const float *a, const float *b, float *out, int64_t n, gnnmp_stream_t stream);
 /* out = alpha .* x .+ y (out may alias x or y) — `(1 .+ ϵ) .* xi .+ m` of gin_conv, GNNlib/src/layers/conv.jl:250-256 */

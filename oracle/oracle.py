@@ -393,7 +393,8 @@ def grad_gcn_conv(s, t, n, x, weight, bias, sigma, dy, add_self_loops_=True):
     return dx, dW, db
 
 
-def grad_gat_conv(s, t, n, x, dense_x_weight, a, bias, sigma, dy, heads=1, negative_slope=0.2, add_self_loops_=True):
+def grad_gat_conv(s, t, n, x, dense_x_weight, a, bias, sigma, dy, heads=1, negative_slope=0.2, add_self_loops_=True,
+                  concat=True):
     """(Δx, ΔW, Δa, Δb) of gat_conv (concat = true, no edge features; conv.jl:112-167), composed rule by rule in the order
     Zygote walks the forward backwards: σ, bias, ∇scatter(+) (Δβ = Δ[t]), β = α .* Wxj, the softmax_edge_neighbors
     pullback  Δl = α .* (Δα - Σ_{N(i)} α Δα)  (utils.jl:84-97 is exp / scatter / gather / division, this is what their
@@ -422,10 +423,10 @@ def grad_gat_conv(s, t, n, x, dense_x_weight, a, bias, sigma, dy, heads=1, negat
     alpha = p / den[ti]
     o = np.zeros((n, H, C))
     np.add.at(o, ti, alpha[..., None] * Wxj)
-    y = o.reshape(n, H * C) + (0 if bias is None else np.asarray(bias, np.float64)[None, :])
+    y = (o.reshape(n, H * C) if concat else o.mean(axis=1)) + (0 if bias is None else np.asarray(bias, np.float64)[None, :])
     dz = np.asarray(dy, np.float64) * (y > 0) if sigma == "relu" else np.asarray(dy, np.float64)
     db = dz.sum(0)
-    delta = dz.reshape(n, H, C)
+    delta = dz.reshape(n, H, C) if concat else np.repeat(dz[:, None, :] / H, H, axis=1)   # ∇mean(x, dims = 2)
     dbeta = delta[ti]                                             # ∇scatter(+)
     dalpha = (dbeta * Wxj).sum(-1)
     dWxj = alpha[..., None] * dbeta
