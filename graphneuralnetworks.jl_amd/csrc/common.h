@@ -41,6 +41,7 @@ enum Knob {
     KNOB_COUNT = 12
 };
 int knob(int k);
+int device_cus();   // compute units of the current device, queried once (hipDeviceGetAttribute costs microseconds per call)
 
 // ---- device helpers ---------------------------------------------------------------------------
 // index element load: idx_bytes in {4, 8}; returns 0-based int64

@@ -420,9 +420,7 @@ static int launch_wlds(const DenseWArgs &w, size_t lds_bytes, int col_tiles, int
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(dense_wlds_kernel)");
         attr_set = true;
     }
-    int dev = 0, cus = 256;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int cus = device_cus();
     int64_t gx = (n_row_tiles + w.waves - 1) / w.waves;
     if (gx > cus) gx = cus;  // one persistent block per CU (the LDS image allows no more)
     dim3 grid((unsigned)gx, (unsigned)col_tiles);

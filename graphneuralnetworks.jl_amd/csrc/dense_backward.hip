@@ -183,9 +183,7 @@ __global__ void __launch_bounds__(256) dense_gradw_kernel(const GradWArgs a) {
 }
 
 static int gradw_slabs(int64_t N) {
-    int dev = 0, cus = 256;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int cus = device_cus();
     const int64_t by_rows = (N + 511) / 512;                      // at least 512 rows per slab
     int per_cu = knob(KNOB_GRADW_SLABS);
     if (per_cu <= 0) per_cu = 8;   // 2 -> 8 slabs per CU: 3.8 -> 2.4 ms at 2.4M x 100 x 100 (more waves to cover the load latency)

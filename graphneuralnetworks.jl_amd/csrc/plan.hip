@@ -29,6 +29,17 @@ int hip_fail(hipError_t e, const char *what) {
     return e == hipErrorOutOfMemory ? GNNMP_EALLOC : GNNMP_ELAUNCH;
 }
 int knob(int k) { return (k >= 0 && k < KNOB_COUNT) ? g_knobs[k] : 0; }
+int device_cus() {
+    static int cached[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    if (cached[dev] == 0) {
+        int cus = 256;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        cached[dev] = cus;
+    }
+    return cached[dev];
+}
 
 int ensure_workspace(gnnmp_graph *p, size_t floats) {
     if (floats <= p->ws_floats) return GNNMP_OK;
