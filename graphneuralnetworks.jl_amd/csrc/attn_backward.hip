@@ -509,8 +509,8 @@ extern "C" int gnnmp_attn_conv_grad_f32(gnnmp_graph_t *plan, gnnmp_graph_t *plan
     int log2g = 0;
     while ((1 << log2g) < lanes) ++log2g;
     if (H == 1 && lanes <= 64) lph = 1 << log2g;
-    if ((lph & (lph - 1)) != 0 || lanes > 64)
-        return fail(GNNMP_EUNSUPPORTED, "attn_conv_grad: needs H*C <= 256 and a power-of-two lane count per head (C = %lld)", (long long)C);
+    if (lanes > 64)
+        return fail(GNNMP_EUNSUPPORTED, "attn_conv_grad: the feature row must fit one wave (H*C = %lld)", (long long)(H * C));
     const int NA = mode == GNNMP_ATTN_GATV2 ? 4 : 2;
     const int64_t R = std::max<int64_t>(256, (plan->n_dst + 2047) / 2048);
     const size_t colsum_need = (size_t)((plan->n_dst + R - 1) / R) * (size_t)D;
@@ -533,7 +533,7 @@ extern "C" int gnnmp_attn_conv_grad_f32(gnnmp_graph_t *plan, gnnmp_graph_t *plan
     g.C = (int)C;
     g.D = D;
     g.log2g = log2g;
-    g.lph = lph;
+    g.lph = lph_code(lph, log2g);
     g.waves = 1;
     g.slope = negative_slope;
     g.scale = scale;

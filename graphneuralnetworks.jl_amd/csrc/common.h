@@ -130,6 +130,16 @@ __device__ __forceinline__ float dpp_mov(float v) {
 template <int LPH>
 __device__ __forceinline__ float group_sum(float d, int lph) {
     if (LPH == 0) {
+        if (lph & 0x10000) {
+            // a head of n lanes, n NOT a power of two (lph_code below): every lane reads its head's n lanes in order —
+            // n ds_bpermutes instead of log2(n) DPP steps, the price of odd head widths (e.g. C = 7 classes)
+            const int n = lph & 0xff, G = 1 << ((lph >> 8) & 0xff);
+            const int lane = (int)__lane_id(), lig = lane & (G - 1);
+            const int hb = lane - lig + (lig / n) * n;
+            float s = 0.0f;
+            for (int k = 0; k < n; ++k) s += __shfl(d, hb + k, 64);
+            return s;
+        }
         for (int o = 1; o < lph; o <<= 1) d += __shfl_xor(d, o, 64);
         return d;
     }
@@ -140,6 +150,11 @@ __device__ __forceinline__ float group_sum(float d, int lph) {
     if (LPH >= 32) d += __shfl_xor(d, 16, 64);
     if (LPH >= 64) d += __shfl_xor(d, 32, 64);
     return d;
+}
+
+// what the kernels get as `lph`: the lane count itself when it is a power of two, otherwise a code group_sum<0> decodes
+inline int lph_code(int lph, int log2g) {
+    return (lph & (lph - 1)) == 0 ? lph : (0x10000 | (log2g << 8) | lph);
 }
 
 // block -> logical chunk remap so that each XCD (block b runs on XCD b % 8) walks a contiguous range of

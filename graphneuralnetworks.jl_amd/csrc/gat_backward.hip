@@ -500,8 +500,8 @@ extern "C" int gnnmp_gat_conv_grad_f32(gnnmp_graph_t *plan, gnnmp_graph_t *plan_
         lph = 1;
         while (lph < lanes) lph <<= 1;
     }
-    if ((lph & (lph - 1)) != 0 || lanes > 64)
-        return fail(GNNMP_EUNSUPPORTED, "gat_conv_grad: needs a power-of-two lane count per head and H*C <= 256 (C = %lld)", (long long)C);
+    if (lanes > 64)
+        return fail(GNNMP_EUNSUPPORTED, "gat_conv_grad: the feature row must fit one wave (H*C = %lld)", (long long)(H * C));
     // workspaces: chunk partials of each pass in that plan's workspace; the da partials reuse the forward plan's
     const int64_t Rd = std::max<int64_t>(256, (plan->n_dst + 2047) / 2048), Rs = std::max<int64_t>(256, (plan->n_src + 2047) / 2048);
     const size_t colsum_need = (size_t)std::max((plan->n_dst + Rd - 1) / Rd, (plan->n_src + Rs - 1) / Rs) * (size_t)D;
@@ -524,7 +524,7 @@ extern "C" int gnnmp_gat_conv_grad_f32(gnnmp_graph_t *plan, gnnmp_graph_t *plan_
     g.D = D;
     g.log2g = 0;
     while ((1 << g.log2g) < lanes) ++g.log2g;
-    g.lph = lph;
+    g.lph = lph_code(lph, g.log2g);   // odd head widths sum their lanes one by one (common.h group_sum<0>)
     g.waves = 1;
     g.slope = negative_slope;
     if (vec == 4) {   // the usual case (C a multiple of 4): compile-time lane count per head -> DPP butterflies

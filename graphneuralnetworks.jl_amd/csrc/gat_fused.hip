@@ -433,14 +433,12 @@ static int attn_conv_impl(gnnmp_graph_t *plan, int mode, const float *Q, const f
     int log2g = 0;
     while ((1 << log2g) < lanes) ++log2g;   // one feature tile: the head butterfly needs the whole row in one group
     if (H == 1 && lanes <= 64) lph = 1 << log2g;   // a single head may spill over idle lanes: they carry zeros
-    const bool pow2 = (lph & (lph - 1)) == 0;
-    if (!pow2 || lanes > 64) {
+    if (lanes > 64) {
         if (mode != GNNMP_ATTN_GAT || stats)
             return fail(GNNMP_EUNSUPPORTED,
-                        "attn_conv: the one-pass kernel needs H*C <= 256 and a power-of-two lane count per head (C = %lld)",
-                        (long long)C);
-        // GAT with a head width that is not a power-of-two lane count (or wider than a wave): three-pass kernels on
-        // node scores
+                        "attn_conv: the one-pass kernel needs a feature row that fits one wave (H*C = %lld lanes %d > 64)",
+                        (long long)(H * C), lanes);
+        // GAT rows wider than a wave: three-pass kernels on node scores
         const size_t need = (size_t)(plan->n_dst + plan->n_src) * (size_t)H;
         if (int rc = ensure_workspace(plan, need)) return rc;
         float *sdst = plan->ws, *ssrc = plan->ws + (size_t)plan->n_dst * (size_t)H;
@@ -475,7 +473,7 @@ static int attn_conv_impl(gnnmp_graph_t *plan, int mode, const float *Q, const f
     g.n_rows = (int)plan->n_dst;
     g.n_src = (int)plan->n_src;
     g.log2g = log2g;
-    g.lph = lph;
+    g.lph = lph_code(lph, log2g);   // odd head widths (C = 7 classes, ...) sum their lanes one by one
     g.act = act;
     g.fast_exp = knob(KNOB_GAT_FAST_EXP);
     g.slope = negative_slope;

@@ -165,6 +165,32 @@ def dense_grad_x(dz, W):
     return dx
 
 
+class _DenseFn(torch.autograd.Function):
+    """σ.(W * x .+ b) — Flux.Dense acting on [N, in] rows, forward and backward on the MFMA kernels"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, sigma):
+        from .layers import dense
+        x = x.contiguous()
+        y = dense(x, weight, bias, sigma)
+        ctx.save_for_backward(x, weight, y)
+        ctx.sigma, ctx.has_bias = sigma, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        dz = act_grad(dy.contiguous(), y, ctx.sigma)
+        dW, db = dense_grad_w(dz, x, need_w=ctx.needs_input_grad[1], need_b=ctx.has_bias and ctx.needs_input_grad[2])
+        dx = dense_grad_x(dz, weight) if ctx.needs_input_grad[0] else None
+        return dx, dW, db, None
+
+
+def dense_ad(l, x):
+    """differentiable gnnmp.Dense forward: gradients w.r.t. x, l.weight, l.bias"""
+    return _DenseFn.apply(x, l.weight, l.bias, l.sigma)
+
+
 class _GCNConvFn(torch.autograd.Function):
     """gcn_conv (GNNlib/src/layers/conv.jl:14-72, default norm, no edge weights) with HIP forward AND backward"""
 

@@ -297,8 +297,10 @@ int gnnmp_gat_conv_f32(gnnmp_graph_t *plan, const float *Wx_src, const float *Wx
 
 /* Training forward of the same path: as gnnmp_gat_conv_f32, and additionally saves the neighbourhood-softmax statistics
  * stats[i][h] = (m_i, den_i) — the running maximum of the logits and Σ_j exp(l_ij - m_i) — 8 bytes per destination and
- * head instead of the reference's (H, E') α array that Zygote keeps alive for the pullback.  Needs a power-of-two lane
- * count per head and H*C <= 256 (GNNMP_EUNSUPPORTED otherwise). */
+ * head instead of the reference's (H, E') α array that Zygote keeps alive for the pullback.  The feature row must fit one
+ * wave (H*C / v lanes <= 64 with v = 4, 2 or 1 floats per lane as C's divisibility allows; GNNMP_EUNSUPPORTED otherwise).
+ * Head widths whose lane count is a power of two reduce with DPP butterflies; any other width (C = 7 classes, ...) is
+ * supported too, summing the head's lanes one by one. */
 int gnnmp_gat_conv_stats_f32(gnnmp_graph_t *plan, const float *Wx_src, const float *Wx_dst, const float *a,
                              float negative_slope, const float *bias, int act, float *out, float *stats,
                              int64_t H, int64_t C, gnnmp_stream_t stream);
@@ -310,8 +312,8 @@ int gnnmp_gat_conv_stats_f32(gnnmp_graph_t *plan, const float *Wx_src, const flo
  *   a: GAT [H][2C], GATV2 [H][C] (Julia (C, H) as stored), otherwise ignored
  *   scale: DOT divides the dot product by it (l.sqrt_out); COS multiplies the cosine by it (l.β); else ignored
  *   stats: optional [n_dst][H][2] softmax statistics as in gnnmp_gat_conv_stats_f32
- * Needs H*C <= 256 and either H == 1 or a power-of-two lane count per head (C in {1,2,4,8,16,32,64} with 16-byte rows);
- * GNNMP_EUNSUPPORTED otherwise (mode GAT falls back to the three-pass kernels instead). */
+ * The feature row must fit one wave (see gnnmp_gat_conv_stats_f32); GNNMP_EUNSUPPORTED otherwise (mode GAT without stats
+ * falls back to the three-pass kernels instead). */
 int gnnmp_attn_conv_f32(gnnmp_graph_t *plan, int mode, const float *Q, const float *K, const float *V,
                         const float *a, float negative_slope, float scale, const float *bias, int act,
                         float *out, float *stats, int64_t H, int64_t C, gnnmp_stream_t stream);

@@ -131,7 +131,8 @@ def hub_graph(rng, n, E):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("H,C,concat,Din", [(8, 16, True, 100), (4, 8, False, 20), (1, 64, True, 32), (2, 4, True, 6),
-                                           (1, 25, True, 10), (1, 3, False, 4), (16, 4, True, 12)])
+                                           (1, 25, True, 10), (1, 3, False, 4), (16, 4, True, 12),
+                                           (4, 7, False, 10), (2, 12, True, 9), (5, 3, True, 7)])   # odd head widths
 def test_hip_gatv2_vs_oracle(gm, AL, H, C, concat, Din):
     from gnnmp.layers_attn import GATv2Conv
     rng = np.random.default_rng(H * 100 + C)
@@ -216,11 +217,11 @@ def test_attn_conv_rejects_what_it_cannot_do(gm):
     from gnnmp.layers_attn import ATTN_COS, ATTN_GATV2, attn_conv
     g = gm.GNNGraph(dev(np.array([1, 2, 3])), dev(np.array([2, 3, 1])), num_nodes=3)
     plan = g.plan(True)
-    K = torch.randn((3, 24), device="cuda")
-    a = torch.randn((2, 12), device="cuda")
-    with pytest.raises(L.GnnmpError) as ei:                    # C = 12: 3 lanes per head
-        attn_conv(plan, ATTN_GATV2, K, a=a, H=2, C=12)
+    K = torch.randn((3, 2 * 130), device="cuda")
+    a = torch.randn((2, 130), device="cuda")
+    with pytest.raises(L.GnnmpError) as ei:                    # 260 features = 130 float2 lanes: wider than a wave
+        attn_conv(plan, ATTN_GATV2, K, a=a, H=2, C=130)
     assert ei.value.status == L.EUNSUPPORTED
     with pytest.raises(L.GnnmpError) as ei:                    # cosine logit is single-head
-        attn_conv(plan, ATTN_COS, K, H=2, C=12)
+        attn_conv(plan, ATTN_COS, K[:, :24].contiguous(), H=2, C=12)
     assert ei.value.status == L.EINVAL

@@ -240,7 +240,7 @@ def test_oracle_gat_adjoint_matches_finite_differences(oracle, sigma):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("H,C,Din,sigma", [(2, 4, 6, "relu"), (8, 16, 100, "relu"), (1, 64, 32, None), (4, 8, 20, None),
-                                          (3, 2, 5, "relu"), (1, 1, 3, None)])
+                                          (3, 2, 5, "relu"), (1, 1, 3, None), (4, 7, 12, "relu"), (2, 12, 9, None)])
 def test_gat_layer_backward_vs_oracle(gm, oracle, H, C, Din, sigma):
     import torch
     from gnnmp.backward import gat_conv_ad

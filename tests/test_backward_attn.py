@@ -118,7 +118,8 @@ def close(got, ref, tol=3e-5):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("H,C,Din,sigma", [(2, 4, 6, "relu"), (8, 16, 100, "relu"), (1, 64, 32, None), (4, 8, 20, None), (1, 3, 5, None)])
+@pytest.mark.parametrize("H,C,Din,sigma", [(2, 4, 6, "relu"), (8, 16, 100, "relu"), (1, 64, 32, None), (4, 8, 20, None), (1, 3, 5, None),
+                                          (4, 7, 12, "relu"), (3, 5, 6, None)])
 def test_hip_gatv2_backward_vs_oracle(gm, AL, AG, H, C, Din, sigma):
     from gnnmp.backward_attn import gatv2_conv_ad
     from gnnmp.layers_attn import GATv2Conv

@@ -1,0 +1,74 @@
+"""End-to-end training on the HIP kernels, forward and backward (SURVEY.md §8f rank 1 made usable): the reference's Cora
+example model — GNNChain(GCNConv(in => 64, relu), GCNConv(64 => 64, relu), Dense(64 => 7))
+(GraphNeuralNetworks/test/examples/node_classification_cora.jl:51-54) — on a Cora-sized planted-partition graph, full
+batch, and a GAT variant.  torch supplies the loss and the optimiser (plumbing); every layer's forward and pullback is a
+libgnnmp call.  The test asserts what the reference's example asserts: the model learns (accuracy well above chance)."""
+import numpy as np
+import pytest
+
+
+def planted_partition(seed=0, n=2708, classes=7, deg_in=3.2, deg_out=0.7, D=64):
+    rng = np.random.default_rng(seed)
+    y = rng.integers(0, classes, n)
+    m_in, m_out = int(n * deg_in / 2), int(n * deg_out / 2)
+    # within-community pairs: draw a node, then a partner of the same class
+    order = np.argsort(y, kind="stable")
+    starts = np.searchsorted(y[order], np.arange(classes))
+    ends = np.append(starts[1:], n)
+    a = rng.integers(0, n, m_in)
+    b = order[starts[y[a]] + (rng.random(m_in) * (ends[y[a]] - starts[y[a]])).astype(np.int64)]
+    c = rng.integers(0, n, m_out)
+    d = rng.integers(0, n, m_out)
+    u, v = np.concatenate([a, c]), np.concatenate([b, d])
+    keep = u != v
+    u, v = u[keep], v[keep]
+    s = np.concatenate([u, v]) + 1
+    t = np.concatenate([v, u]) + 1
+    x = (rng.standard_normal((n, D)) * 1.0).astype(np.float32)
+    x[np.arange(n), y] += 0.6                      # a weak class signal in the features: the graph has to help
+    return s, t, x, y
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["gcn", "gat"])
+def test_full_batch_training_learns(kind):
+    import torch
+    import torch.nn.functional as F
+    import gnnmp
+    from gnnmp.backward import dense_ad, gat_conv_ad, gcn_conv_ad
+    gnnmp.load()
+    s, t, x, y = planted_partition()
+    n, D = x.shape
+    dev = lambda v: torch.from_numpy(np.ascontiguousarray(v)).cuda()
+    g = gnnmp.GNNGraph(dev(s), dev(t), num_nodes=n)
+    X, Y = dev(x), dev(y)
+    rng = np.random.default_rng(1)
+    train = torch.from_numpy(rng.permutation(n)[:1400]).cuda()
+    test = torch.from_numpy(np.setdiff1d(np.arange(n), train.cpu().numpy())).cuda()
+    if kind == "gcn":
+        l1, l2, head = gnnmp.GCNConv((D, 64), "relu", seed=1), gnnmp.GCNConv((64, 64), "relu", seed=2), gnnmp.Dense((64, 7), seed=3)
+        params = [l1.weight, l1.bias, l2.weight, l2.bias, head.weight, head.bias]
+        fwd = lambda: dense_ad(head, gcn_conv_ad(l2, g, gcn_conv_ad(l1, g, X)))
+    else:
+        l1, head = gnnmp.GATConv((D, 8), "relu", heads=8, seed=1), gnnmp.GATConv((64, 7), None, heads=4, concat=False, seed=2)
+        params = [l1.dense_x_weight, l1.a, l1.bias, head.dense_x_weight, head.a, head.bias]
+        fwd = lambda: gat_conv_ad(head, g, gat_conv_ad(l1, g, X))
+    for p in params:
+        p.requires_grad_(True)
+    opt = torch.optim.Adam(params, lr=1e-2)
+    losses = []
+    for epoch in range(60):
+        opt.zero_grad()
+        logits = fwd()
+        loss = F.cross_entropy(logits[train], Y[train])
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    with torch.no_grad():
+        logits = fwd()
+        acc_test = float((logits[test].argmax(1) == Y[test]).float().mean())
+        # the same features without the graph: a logistic-regression-strength baseline the GNN has to beat
+        acc_feat = float((X[test][:, :7].argmax(1) == Y[test]).float().mean())
+    assert np.isfinite(losses).all()
+    assert losses[-1] < 0.5 * losses[0], (losses[0], losses[-1])
+    assert acc_test > 0.6 and acc_test > acc_feat + 0.1, (acc_test, acc_feat)
