@@ -63,7 +63,7 @@ def test_full_batch_training_learns(kind):
         loss = F.cross_entropy(logits[train], Y[train])
         loss.backward()
         opt.step()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
     with torch.no_grad():
         logits = fwd()
         acc_test = float((logits[test].argmax(1) == Y[test]).float().mean())
@@ -72,3 +72,49 @@ def test_full_batch_training_learns(kind):
     assert np.isfinite(losses).all()
     assert losses[-1] < 0.5 * losses[0], (losses[0], losses[-1])
     assert acc_test > 0.6 and acc_test > acc_feat + 0.1, (acc_test, acc_feat)
+
+
+@pytest.mark.gpu
+def test_mini_batch_training_with_neighbor_loader_learns():
+    """the same model trained on NeighborLoader mini-batches (device-side sampling -> induced subgraph -> HIP forward and
+    backward on the mini-batch graph), evaluated full batch"""
+    import torch
+    import torch.nn.functional as F
+    import gnnmp
+    from gnnmp import sampling as S
+    from gnnmp.backward import dense_ad, gcn_conv_ad
+    gnnmp.load()
+    s, t, x, y = planted_partition(seed=4)
+    n, D = x.shape
+    dev = lambda v: torch.from_numpy(np.ascontiguousarray(v)).cuda()
+    X, Y = dev(x), dev(y)
+    g = gnnmp.GNNGraph(dev(s), dev(t), num_nodes=n, x=X)
+    rng = np.random.default_rng(2)
+    perm = rng.permutation(n)
+    train, test = perm[:1400], torch.from_numpy(perm[1400:]).cuda()
+    l1, l2, head = gnnmp.GCNConv((D, 64), "relu", seed=1), gnnmp.GCNConv((64, 64), "relu", seed=2), gnnmp.Dense((64, 7), seed=3)
+    params = [l1.weight, l1.bias, l2.weight, l2.bias, head.weight, head.bias]
+    for p in params:
+        p.requires_grad_(True)
+    opt = torch.optim.Adam(params, lr=1e-2)
+    first = last = None
+    for epoch in range(8):
+        loader = S.NeighborLoader(g, num_neighbors=[8, 8], num_layers=2, input_nodes=dev(train[rng.permutation(len(train))] + 1),
+                                  batch_size=200, seed=epoch)
+        tot = 0.0
+        for mb in loader:
+            k = min(200, mb.num_nodes)                       # the batch's input nodes come first in a mini-batch
+            opt.zero_grad()
+            logits = dense_ad(head, gcn_conv_ad(l2, mb, gcn_conv_ad(l1, mb, mb.x)))
+            seeds = mb.nid[:k] - 1
+            loss = F.cross_entropy(logits[:k], Y[seeds])
+            loss.backward()
+            opt.step()
+            tot += float(loss.detach())
+        first = tot if first is None else first
+        last = tot
+    with torch.no_grad():
+        logits = dense_ad(head, gcn_conv_ad(l2, g, gcn_conv_ad(l1, g, X)))
+        acc = float((logits[test].argmax(1) == Y[test]).float().mean())
+    assert last < 0.6 * first, (first, last)
+    assert acc > 0.6, acc
