@@ -453,64 +453,79 @@ extern "C" int gnnmp_dense_f32(const float *x1, const float *W1, int64_t D1, int
     a.out = out;
     a.N = N;
     a.Dout = (int)Dout;
-    // W-resident kernel when W^T (for one 128-column tile) plus at least one wave region fits the 160 KB LDS
+    // W-resident kernel when W^T (for one column tile) plus the wave regions fit the 160 KB LDS.  The column tile is 128
+    // wide unless that leaves room for only 4 waves (K1 + K2 around 256): then 64-wide tiles — x is staged twice, but 8
+    // waves (two per SIMD) overlap one wave's staging with the other's MFMAs (GraphConv 128 => 128: see DESIGN.md).
     {
         const int k0p = ((int)D1 + 1) & ~1, k1p = ((int)D2 + 1) & ~1;
         const int ktot = k0p + (D2 > 0 ? k1p : 0);
         const int kmax = std::max(k0p, k1p);
-        const int full = (int)(Dout / 128), rem = (int)(Dout % 128);
-        const int nt_max = full > 0 ? 4 : (rem + 31) / 32;
-        const int ncols_max = full > 0 ? 128 : rem;
-        const size_t wbytes = (size_t)ktot * (size_t)(nt_max * 32 + 1) * sizeof(float);
         const size_t budget = 160 * 1024 - 64;   // 4 pipe tokens live after the wave regions
-        // Wave regions: prefer 8 waves per CU (two per SIMD: one wave's staging hides under the other's MFMAs).  If the
-        // whole 32 x K image does not leave room for 8 regions, stage x in k-chunks (ks columns at a time); only if even
-        // 64-column chunks do not fit, fall back to 4 waves with the largest chunk that fits.
-        int waves = 0, ks = 0;
-        for (int wv : {8, 4}) {  // fewer than one wave per SIMD cannot feed the matrix pipe: K-chunked kernel instead
-            if (wbytes >= budget) break;
-            const int cols_fit = (int)((budget - wbytes) / ((size_t)wv * 32 * sizeof(float)));  // floats per region row
-            int kfit = ((cols_fit - 1) & ~3);               // leave the +1 (odd leading dimension)
-            kfit = std::min(kfit, (kmax + 3) & ~3);
-            kfit = std::min(kfit, 128);                      // <= 32 float4 per staged row (shift-mapped staging)
-            if (kfit >= ((kmax + 3) & ~3) || kfit >= 48) {   // (24-column chunks measured slower than 4 waves x 44)
-                const int nkc = (kmax + kfit - 1) / kfit;     // balanced chunks, multiple of 4
-                ks = (((kmax + nkc - 1) / nkc) + 3) & ~3;
-                waves = wv;
-                break;
+        struct Cfg { int tw, waves, ks, xld, old_, tp; size_t wbytes, region; };
+        auto size_for = [&](int tw) -> Cfg {
+            Cfg c{};
+            c.tw = tw;
+            const int full = (int)(Dout / tw), rem = (int)(Dout % tw);
+            const int nt_max = full > 0 ? tw / 32 : (rem + 31) / 32;
+            const int ncols_max = full > 0 ? tw : rem;
+            c.wbytes = (size_t)ktot * (size_t)(nt_max * 32 + 1) * sizeof(float);
+            // Wave regions: prefer 8 waves per CU.  If the whole 32 x K image does not leave room for 8 regions, stage x
+            // in k-chunks (ks columns at a time); only if even 48-column chunks do not fit, fall back to 4 waves.
+            for (int wv : {8, 4}) {  // fewer than one wave per SIMD cannot feed the matrix pipe: K-chunked kernel instead
+                if (c.wbytes >= budget) break;
+                const int cols_fit = (int)((budget - c.wbytes) / ((size_t)wv * 32 * sizeof(float)));  // floats per region row
+                int kfit = ((cols_fit - 1) & ~3);               // leave the +1 (odd leading dimension)
+                kfit = std::min(kfit, (kmax + 3) & ~3);
+                kfit = std::min(kfit, 128);                      // <= 32 float4 per staged row (shift-mapped staging)
+                if (kfit >= ((kmax + 3) & ~3) || kfit >= 48) {   // (24-column chunks measured slower than 4 waves x 44)
+                    const int nkc = (kmax + kfit - 1) / kfit;     // balanced chunks, multiple of 4
+                    c.ks = (((kmax + nkc - 1) / nkc) + 3) & ~3;
+                    c.waves = wv;
+                    break;
+                }
             }
+            c.xld = c.ks + 1;                                   // odd: conflict-free A-operand reads
+            // the wave region is sized for the x image (>= one 32-column output tile); the output tile passes through it
+            // whole if it fits, else tp column tiles at a time
+            const int region_cols = (std::max(c.xld, 32) + 3) & ~3;
+            c.tp = 4;
+            c.old_ = (ncols_max + 3) & ~3;
+            if (c.old_ > region_cols) {
+                c.tp = region_cols / 32;
+                c.old_ = c.tp * 32;
+            }
+            c.region = (size_t)32 * (size_t)region_cols;
+            if (c.waves > 0 && c.wbytes + (size_t)c.waves * c.region * sizeof(float) > budget) c.waves = 0;
+            return c;
+        };
+        Cfg c = size_for(128);
+        if (c.waves < 8 && Dout >= 128) {
+            const Cfg c64 = size_for(64);
+            if (c64.waves == 8) c = c64;
         }
-        const int xld = ks + 1;                                 // odd: conflict-free A-operand reads
-        // the wave region is sized for the x image (>= one 32-column output tile); the output tile passes through it
-        // whole if it fits, else w.tp column tiles at a time
-        const int region_cols = (std::max(xld, 32) + 3) & ~3;
-        int tp = 4, old_ = (ncols_max + 3) & ~3;
-        if (old_ > region_cols) {
-            tp = region_cols / 32;
-            old_ = tp * 32;
-        }
-        const size_t region = (size_t)32 * (size_t)region_cols;
-        if (waves > 0 && wbytes + (size_t)waves * region * sizeof(float) > budget) waves = 0;
-        if (waves > 0 && N >= 256 && knob(KNOB_DENSE_GENERIC) == 0) {
+        if (c.waves > 0 && N >= 256 && knob(KNOB_DENSE_GENERIC) == 0) {
             DenseWArgs w;
             w.d = a;
-            w.waves = waves;
-            w.xld = xld;
-            w.old_ = old_;
-            w.tp = tp;
-            w.ks = ks;
+            w.waves = c.waves;
+            w.xld = c.xld;
+            w.old_ = c.old_;
+            w.tp = c.tp;
+            w.ks = c.ks;
             w.skew = knob(KNOB_DENSE_PREFETCH) & 15;          // experiment knob (slot 7): low 4 bits = s_sleep(127) count,
             w.token = (knob(KNOB_DENSE_PREFETCH) >> 4) & 1;   //                           bit 4 = matrix-pipe token
-            w.region = (int)region;
+            w.region = (int)c.region;
             w.ktot_pad = ktot;
             const int64_t n_row_tiles = (N + 31) / 32;
-            const size_t lds_bytes = wbytes + (size_t)waves * region * sizeof(float) + 16;   // + 4 pipe tokens
+            const size_t lds_bytes = c.wbytes + (size_t)c.waves * c.region * sizeof(float) + 16;   // + 4 pipe tokens
+            const int full = (int)(Dout / c.tw), rem = (int)(Dout % c.tw);
             if (full > 0) {
                 w.n0 = 0;
-                if (int rc = launch_wlds<4>(w, lds_bytes, full, n_row_tiles, stream)) return rc;
+                int rc = c.tw == 128 ? launch_wlds<4>(w, lds_bytes, full, n_row_tiles, stream)
+                                     : launch_wlds<2>(w, lds_bytes, full, n_row_tiles, stream);
+                if (rc) return rc;
             }
             if (rem > 0) {
-                w.n0 = full * 128;
+                w.n0 = full * c.tw;
                 const int nt = (rem + 31) / 32;
                 int rc = GNNMP_OK;
                 switch (nt) {
