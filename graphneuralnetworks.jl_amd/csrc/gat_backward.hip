@@ -43,16 +43,6 @@ struct GatBwdArgs {
 
 __device__ __forceinline__ float lrelu_b(float x, float slope) { return x > 0.0f ? x : x * slope; }
 
-template <int VEC>
-__device__ __forceinline__ void load_or_zero(const float *p, bool ok, float v[VEC]) {
-    if (ok) {
-        Vec<VEC>::load(p, v);
-    } else {
-#pragma unroll
-        for (int q = 0; q < VEC; ++q) v[q] = 0.0f;
-    }
-}
-
 // decode the virtual row of this lane group; false = nothing to do
 __device__ __forceinline__ bool virtual_row(const GatBwdArgs &a, int &v, bool &is_chunk, int &row, int &beg, int &end,
                                             int &lig, int &gbase, int &G) {
