@@ -82,6 +82,42 @@ done:
     return rc;
 }
 
+// Scratch for the per-mini-batch entry points (sample_neighbors, unique_append, induced_subgraph): hipMalloc / hipFree cost
+// ~0.1-1 ms each and a NeighborLoader batch made ~50 of them.  Freed blocks are parked in a small per-thread cache and
+// handed out again (every entry point synchronises its stream before returning, so a parked block is idle).
+struct PrepBlock { void *p; size_t cap; };
+static thread_local PrepBlock g_prep_cache[8] = {};
+static hipError_t prep_alloc(void **out, size_t bytes) {
+    bytes = std::max<size_t>(bytes, 256);
+    int best = -1;
+    for (int i = 0; i < 8; ++i)
+        if (g_prep_cache[i].p && g_prep_cache[i].cap >= bytes && (best < 0 || g_prep_cache[i].cap < g_prep_cache[best].cap)) best = i;
+    if (best >= 0 && g_prep_cache[best].cap <= 4 * bytes + (1 << 20)) {
+        *out = g_prep_cache[best].p;
+        g_prep_cache[best] = PrepBlock{nullptr, 0};
+        return hipSuccess;
+    }
+    return hipMalloc(out, bytes);
+}
+static void prep_free(void *p, size_t bytes) {
+    if (!p) return;
+    bytes = std::max<size_t>(bytes, 256);
+    int slot = -1;
+    for (int i = 0; i < 8; ++i)
+        if (!g_prep_cache[i].p) { slot = i; break; }
+    if (slot < 0) {   // cache full: evict the smallest block
+        slot = 0;
+        for (int i = 1; i < 8; ++i)
+            if (g_prep_cache[i].cap < g_prep_cache[slot].cap) slot = i;
+        if (g_prep_cache[slot].cap >= bytes) {
+            (void)hipFree(p);
+            return;
+        }
+        (void)hipFree(g_prep_cache[slot].p);
+    }
+    g_prep_cache[slot] = PrepBlock{p, bytes};
+}
+
 // ---- neighbour sampling ---------------------------------------------------------------------------
 // counter-based generator: splitmix64 of (seed, seed node, draw index) -> 53 uniform bits
 __device__ __forceinline__ uint64_t mix64(uint64_t z) {
@@ -185,32 +221,49 @@ __global__ void unique_write_kernel(const void *cand, int idx_bytes, int base, i
 // edges (in edge order) whose source is listed too, relabelled by list position.
 __global__ void induced_count_kernel(const int32_t *rowptr, const int32_t *col, const int32_t *map, const void *nodes,
                                      int idx_bytes, int base, int64_t M, int64_t *counts) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // one WAVE per listed node, 64 slots of its row at a time (a thread per node walked a 17 000-edge hub alone: tens of
+    // milliseconds per mini-batch); the kept slots are counted with a ballot
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
     if (i > M) return;
     if (i == M) {
-        counts[i] = 0;
+        if (lane == 0) counts[i] = 0;
         return;
     }
     const int64_t v = load_index(nodes, i, idx_bytes, base);
+    const int beg = rowptr[v], end = rowptr[v + 1];
     int64_t c = 0;
-    for (int p = rowptr[v]; p < rowptr[v + 1]; ++p) c += map[col[p]] != 0;
-    counts[i] = c;
+    for (int p0 = beg; p0 < end; p0 += 64) {
+        const int p = p0 + lane;
+        const bool keep = p < end && map[col[min(p, end - 1)]] != 0;
+        c += __popcll(__ballot(keep));
+    }
+    if (lane == 0) counts[i] = c;
 }
 __global__ void induced_fill_kernel(const int32_t *rowptr, const int32_t *col, const int32_t *eid, const int32_t *map,
                                     const void *nodes, int idx_bytes, int base, int64_t M, const int64_t *offsets,
                                     void *s_out, void *t_out, void *eid_out) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // one wave per listed node; a kept slot's output position = edges kept before it in the row (ballot prefix): in-edge
+    // order is preserved
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
     if (i >= M) return;
     const int64_t v = load_index(nodes, i, idx_bytes, base);
+    const int beg = rowptr[v], end = rowptr[v + 1];
     int64_t o = offsets[i];
-    for (int p = rowptr[v]; p < rowptr[v + 1]; ++p) {
-        const int32_t m = map[col[p]];
-        if (m != 0) {
-            store_index(s_out, o, idx_bytes, (int64_t)m - 1 + base);
-            store_index(t_out, o, idx_bytes, i + base);
-            store_index(eid_out, o, idx_bytes, (int64_t)eid[p] + base);
-            ++o;
+    for (int p0 = beg; p0 < end; p0 += 64) {
+        const int p = p0 + lane;
+        const int pc = min(p, end - 1);
+        const int32_t m = map[col[pc]];
+        const bool keep = p < end && m != 0;
+        const unsigned long long mask = __ballot(keep);
+        if (keep) {
+            const int64_t at = o + __popcll(mask & ((1ull << lane) - 1ull));
+            store_index(s_out, at, idx_bytes, (int64_t)m - 1 + base);
+            store_index(t_out, at, idx_bytes, i + base);
+            store_index(eid_out, at, idx_bytes, (int64_t)eid[pc] + base);
         }
+        o += __popcll(mask);
     }
 }
 
@@ -320,8 +373,8 @@ int gnnmp_sample_neighbors(gnnmp_graph_t *plan, const void *nodes, int idx_bytes
     int hflag = 0;
     size_t tmp_bytes = 0;
     int64_t tot = 0;
-    PREP_HIP(hipMalloc((void **)&counts, sizeof(int64_t) * (size_t)(n_nodes + 1)));
-    PREP_HIP(hipMalloc((void **)&flag, sizeof(int)));
+    PREP_HIP(prep_alloc((void **)&counts, sizeof(int64_t) * (size_t)(n_nodes + 1)));
+    PREP_HIP(prep_alloc((void **)&flag, sizeof(int)));
     PREP_HIP(hipMemsetAsync(flag, 0, sizeof(int), stream));
     PREP_HIP(hipMemsetAsync(counts + n_nodes, 0, sizeof(int64_t), stream));
     sample_counts_kernel<<<nb(n_nodes), 256, 0, stream>>>(plan->rowptr, nodes, idx_bytes, index_base, n_nodes, plan->n_dst,
@@ -329,7 +382,7 @@ int gnnmp_sample_neighbors(gnnmp_graph_t *plan, const void *nodes, int idx_bytes
     PREP_HIP(hipGetLastError());
     PREP_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, counts, offsets, (int64_t)0, (size_t)(n_nodes + 1),
                                      rocprim::plus<int64_t>(), stream));
-    PREP_HIP(hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 16)));
+    PREP_HIP(prep_alloc(&tmp, tmp_bytes));
     PREP_HIP(rocprim::exclusive_scan(tmp, tmp_bytes, counts, offsets, (int64_t)0, (size_t)(n_nodes + 1),
                                      rocprim::plus<int64_t>(), stream));
     PREP_HIP(hipMemcpyAsync(&tot, offsets + n_nodes, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
@@ -355,9 +408,9 @@ int gnnmp_sample_neighbors(gnnmp_graph_t *plan, const void *nodes, int idx_bytes
         PREP_HIP(hipGetLastError());
     }
 done:
-    if (counts) (void)hipFree(counts);
-    if (tmp) (void)hipFree(tmp);
-    if (flag) (void)hipFree(flag);
+    prep_free(counts, sizeof(int64_t) * (size_t)(n_nodes + 1));
+    prep_free(tmp, tmp_bytes);
+    prep_free(flag, sizeof(int));
     return rc;
 }
 
@@ -379,9 +432,9 @@ int gnnmp_unique_append(int32_t *map, int32_t *first, int64_t n_nodes, const voi
     int hbad = 0;
     size_t tmp_bytes = 0;
     int64_t tot = 0;
-    PREP_HIP(hipMalloc((void **)&flags, sizeof(int64_t) * (size_t)(n_cand + 1)));
-    PREP_HIP(hipMalloc((void **)&pos, sizeof(int64_t) * (size_t)(n_cand + 1)));
-    PREP_HIP(hipMalloc((void **)&bad, sizeof(int)));
+    PREP_HIP(prep_alloc((void **)&flags, sizeof(int64_t) * (size_t)(n_cand + 1)));
+    PREP_HIP(prep_alloc((void **)&pos, sizeof(int64_t) * (size_t)(n_cand + 1)));
+    PREP_HIP(prep_alloc((void **)&bad, sizeof(int)));
     PREP_HIP(hipMemsetAsync(bad, 0, sizeof(int), stream));
     unique_reset_kernel<<<nb(n_cand), 256, 0, stream>>>(cand, idx_bytes, index_base, n_cand, n_nodes, first, bad);
     unique_min_kernel<<<nb(n_cand), 256, 0, stream>>>(cand, idx_bytes, index_base, n_cand, n_nodes, map, first);
@@ -389,7 +442,7 @@ int gnnmp_unique_append(int32_t *map, int32_t *first, int64_t n_nodes, const voi
     PREP_HIP(hipGetLastError());
     PREP_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, flags, pos, (int64_t)0, (size_t)(n_cand + 1),
                                      rocprim::plus<int64_t>(), stream));
-    PREP_HIP(hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 16)));
+    PREP_HIP(prep_alloc(&tmp, tmp_bytes));
     PREP_HIP(rocprim::exclusive_scan(tmp, tmp_bytes, flags, pos, (int64_t)0, (size_t)(n_cand + 1),
                                      rocprim::plus<int64_t>(), stream));
     unique_write_kernel<<<nb(n_cand), 256, 0, stream>>>(cand, idx_bytes, index_base, n_cand, flags, pos, set_size, map,
@@ -401,10 +454,10 @@ int gnnmp_unique_append(int32_t *map, int32_t *first, int64_t n_nodes, const voi
     if (hbad) rc = fail(GNNMP_EBOUNDS, "unique_append: a node is outside 1..%lld", (long long)n_nodes);
     *n_new = tot;
 done:
-    if (flags) (void)hipFree(flags);
-    if (pos) (void)hipFree(pos);
-    if (tmp) (void)hipFree(tmp);
-    if (bad) (void)hipFree(bad);
+    prep_free(flags, sizeof(int64_t) * (size_t)(n_cand + 1));
+    prep_free(pos, sizeof(int64_t) * (size_t)(n_cand + 1));
+    prep_free(tmp, tmp_bytes);
+    prep_free(bad, sizeof(int));
     return rc;
 }
 
@@ -426,13 +479,13 @@ int gnnmp_induced_subgraph(gnnmp_graph_t *plan, const int32_t *map, const void *
     void *tmp = nullptr;
     size_t tmp_bytes = 0;
     int64_t tot = 0;
-    PREP_HIP(hipMalloc((void **)&counts, sizeof(int64_t) * (size_t)(n_nodes + 1)));
-    induced_count_kernel<<<nb(n_nodes + 1), 256, 0, stream>>>(plan->rowptr, plan->col, map, nodes, idx_bytes, index_base,
+    PREP_HIP(prep_alloc((void **)&counts, sizeof(int64_t) * (size_t)(n_nodes + 1)));
+    induced_count_kernel<<<nb((n_nodes + 1) * 64), 256, 0, stream>>>(plan->rowptr, plan->col, map, nodes, idx_bytes, index_base,
                                                               n_nodes, counts);
     PREP_HIP(hipGetLastError());
     PREP_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, counts, offsets, (int64_t)0, (size_t)(n_nodes + 1),
                                      rocprim::plus<int64_t>(), stream));
-    PREP_HIP(hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 16)));
+    PREP_HIP(prep_alloc(&tmp, tmp_bytes));
     PREP_HIP(rocprim::exclusive_scan(tmp, tmp_bytes, counts, offsets, (int64_t)0, (size_t)(n_nodes + 1),
                                      rocprim::plus<int64_t>(), stream));
     PREP_HIP(hipMemcpyAsync(&tot, offsets + n_nodes, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
@@ -449,13 +502,13 @@ int gnnmp_induced_subgraph(gnnmp_graph_t *plan, const int32_t *map, const void *
             rc = fail(GNNMP_EINVAL, "induced_subgraph: null output");
             goto done;
         }
-        induced_fill_kernel<<<nb(n_nodes), 256, 0, stream>>>(plan->rowptr, plan->col, plan->eid, map, nodes, idx_bytes,
+        induced_fill_kernel<<<nb(n_nodes * 64), 256, 0, stream>>>(plan->rowptr, plan->col, plan->eid, map, nodes, idx_bytes,
                                                              index_base, n_nodes, offsets, s_out, t_out, eid_out);
         PREP_HIP(hipGetLastError());
     }
 done:
-    if (counts) (void)hipFree(counts);
-    if (tmp) (void)hipFree(tmp);
+    prep_free(counts, sizeof(int64_t) * (size_t)(n_nodes + 1));
+    prep_free(tmp, tmp_bytes);
     return rc;
 }
 
