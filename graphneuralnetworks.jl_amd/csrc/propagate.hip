@@ -507,10 +507,11 @@ __global__ void degree_count_kernel(const int32_t *rowptr, int64_t n, float *deg
 // weighted in-degree: one thread per destination, weights added in original edge order
 // (zeros(T,N) .+ scatter(+, w, t) — GNNGraphs/src/query.jl:359-369)
 __global__ void degree_weighted_kernel(const int32_t *rowptr, const int32_t *eid, const float *w,
-                                       int64_t n, int n_edges, float *deg) {
+                                       int64_t n, int n_edges, float *deg, int long_thresh) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int beg = rowptr[i], end = rowptr[i + 1];
+    if (end - beg > long_thresh) return;   // split rows: degree_long_kernel (a 17 000-edge hub made this thread a 5.6 ms tail)
     float acc = 0.0f;
     int p = beg;
     for (; p + 8 <= end; p += 8) {
@@ -528,6 +529,25 @@ __global__ void degree_weighted_kernel(const int32_t *rowptr, const int32_t *eid
         acc = acc + (e < n_edges ? w[e] : 1.0f);
     }
     deg[i] = 0.0f + acc;
+}
+// weighted in-degree of the split rows: one block per long row, threads stride over its slots, fixed-shape LDS tree
+__global__ void __launch_bounds__(256) degree_long_kernel(const int32_t *rowptr, const int32_t *eid, const float *w,
+                                                          const int32_t *long_rows, int n_edges, float *deg) {
+    __shared__ float red[256];
+    const int row = long_rows[blockIdx.x];
+    const int beg = rowptr[row], end = rowptr[row + 1];
+    float acc = 0.0f;
+    for (int p = beg + (int)threadIdx.x; p < end; p += 256) {
+        const int e = eid[p];
+        acc = acc + (e < n_edges ? w[e] : 1.0f);
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] = red[threadIdx.x] + red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) deg[row] = 0.0f + red[0];
 }
 __global__ void inv_sqrt_kernel(const float *deg, float *out, int64_t n) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -614,10 +634,13 @@ int gnnmp_degree_f32(gnnmp_graph_t *plan, const float *w, float *deg, gnnmp_stre
     if (plan->n_dst == 0) return GNNMP_OK;
     if (!deg) return fail(GNNMP_EINVAL, "degree: null output");
     const unsigned nb = (unsigned)((plan->n_dst + 255) / 256);
-    if (w)
+    if (w) {
         degree_weighted_kernel<<<nb, 256, 0, stream>>>(plan->rowptr, plan->eid, w, plan->n_dst,
-                                                        (int)plan->n_edges, deg);
-    else
+                                                        (int)plan->n_edges, deg, plan->long_thresh);
+        if (plan->n_long > 0)
+            degree_long_kernel<<<(unsigned)plan->n_long, 256, 0, stream>>>(plan->rowptr, plan->eid, w, plan->long_rows,
+                                                                            (int)plan->n_edges, deg);
+    } else
         degree_count_kernel<<<nb, 256, 0, stream>>>(plan->rowptr, plan->n_dst, deg);
     GNNMP_LAUNCH_CHECK("degree kernel");
     return GNNMP_OK;

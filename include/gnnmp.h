@@ -364,7 +364,10 @@ int gnnmp_bias_act_f32(const float *x, const float *bias, int act, float *out, i
  * reduce_nodes(aggr, g, x) / global_pool — GNNlib/src/utils.jl:12-16, GNNlib/src/layers/pool.jl:3-5,
  * for a SORTED graph_indicator (what MLUtils.batch builds, transform.jl:691-699): contiguous segments.
  * seg_ids[N] has values index_base .. index_base+G-1, non-decreasing.  out is [G][D].
- * (An unsorted indicator goes through gnnmp_plan_create(src = 1..N, dst = indicator) + gnnmp_propagate_f32.)
+ * (An unsorted indicator goes through gnnmp_plan_create(src = 1..N, dst = indicator) + gnnmp_scatter_f32.)
+ * One lane group reduces one graph: right for a batch of many small graphs.  For FEW LARGE graphs (a whole-graph
+ * readout is G = 1) use the same plan route — it cuts large segments into balanced chunks (N = 2.4 M, G = 1: 283 ms
+ * here against 0.3 ms through the plan); the host mirror switches at N > 256 * G.
  * ---------------------------------------------------------------------------------------------- */
 int gnnmp_segment_pool_f32(int aggr, const float *x, const void *seg_ids, int idx_bytes,
                            int index_base, float *out, int64_t D, int64_t N, int64_t G,

@@ -166,7 +166,8 @@ def test_degree_and_norm_bit_exact(gm, gold, oracle):
         s, t, n = c["s"], c["t"], int(c["n"])
         g = graph(gm, s, t, n, c["w"])
         np.testing.assert_array_equal(host(gm.degree(g, dir="in", edge_weight=False)), c["deg_in"])
-        np.testing.assert_array_equal(host(gm.degree(g, dir="in", edge_weight=True)), c["deg_in_w"])
+        # weighted: bit-exact where the row is not split; a split row's weights are summed by a block (fixed tree)
+        assert_rows_equal_or_close(host(gm.degree(g, dir="in", edge_weight=True)), c["deg_in_w"], indeg_of(t, n))
         np.testing.assert_array_equal(host(gm.degree(g, dir="out", edge_weight=False)), oracle.degree(s, n))
         both = host(gm.degree(g, dir="both", edge_weight=False))
         np.testing.assert_array_equal(both, oracle.degree(s, n) + oracle.degree(t, n))
