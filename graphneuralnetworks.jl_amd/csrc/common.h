@@ -38,6 +38,7 @@ enum Knob {
     KNOB_GAT_FAST_EXP = 8,   // 1 = v_exp_f32-based exp in the one-pass GAT kernel (experiment; default 0 = accurate expf)
     KNOB_GRADW_SLABS = 9,    // ΔW kernel: slabs per CU (0 = auto)
     KNOB_GRADW_RP = 10,      // ΔW kernel: row pairs loaded per batch (0 = auto, else 2|4|8)
+    KNOB_GRADW_MIN_ROWS = 11,  // ΔW kernel: rows-per-slab floor (0 = auto: ~3 slabs per CU on small inputs, 512 on large)
     KNOB_COUNT = 12
 };
 int knob(int k);

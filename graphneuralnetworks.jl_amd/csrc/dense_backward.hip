@@ -184,7 +184,14 @@ __global__ void __launch_bounds__(256) dense_gradw_kernel(const GradWArgs a) {
 
 static int gradw_slabs(int64_t N) {
     const int cus = device_cus();
-    const int64_t by_rows = (N + 511) / 512;                      // at least 512 rows per slab
+    // rows per slab floor: about three slabs per CU on small inputs (169 343 x 128 x 128: 166 -> 114 us with 256 instead
+    // of 512; 20 000 rows: 67 -> 24 us with 64), 512 once there are plenty of rows.  knob 11 overrides (experiments).
+    int min_rows = knob(KNOB_GRADW_MIN_ROWS);
+    if (min_rows <= 0) {
+        min_rows = 64;
+        while (min_rows < 512 && (int64_t)min_rows * 3 * cus < N) min_rows <<= 1;
+    }
+    const int64_t by_rows = (N + min_rows - 1) / min_rows;        // at least min_rows rows per slab
     int per_cu = knob(KNOB_GRADW_SLABS);
     if (per_cu <= 0) per_cu = 8;   // 2 -> 8 slabs per CU: 3.8 -> 2.4 ms at 2.4M x 100 x 100 (more waves to cover the load latency)
     return (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)per_cu * cus, by_rows));
