@@ -184,12 +184,14 @@ __global__ void __launch_bounds__(256) dense_gradw_kernel(const GradWArgs a) {
 
 static int gradw_slabs(int64_t N) {
     const int cus = device_cus();
-    // rows per slab floor: about three slabs per CU on small inputs (169 343 x 128 x 128: 166 -> 114 us with 256 instead
-    // of 512; 20 000 rows: 67 -> 24 us with 64), 512 once there are plenty of rows.  knob 11 overrides (experiments).
+    // rows per slab floor.  A wave is latency-bound per batch of row pairs (~1.2 us), so a block's time is proportional to
+    // its slab length: about three slabs per CU on small inputs (169 343 x 128 x 128: 166 -> 114 us with 256 rows instead
+    // of 512; 20 000 rows: 67 -> 24 us with 64), never more than 256 rows (400 000 rows: 426 -> 340 us, 800 000: 651 -> 565
+    // us; no difference at 2.4 M, where the slab count is capped by slabs-per-CU anyway).  knob 11 overrides.
     int min_rows = knob(KNOB_GRADW_MIN_ROWS);
     if (min_rows <= 0) {
         min_rows = 64;
-        while (min_rows < 512 && (int64_t)min_rows * 3 * cus < N) min_rows <<= 1;
+        while (min_rows < 256 && (int64_t)min_rows * 3 * cus < N) min_rows <<= 1;
     }
     const int64_t by_rows = (N + min_rows - 1) / min_rows;        // at least min_rows rows per slab
     int per_cu = knob(KNOB_GRADW_SLABS);
@@ -236,6 +238,10 @@ int gnnmp_dense_grad_w_f32(const float *dz, const float *x, int64_t N, int64_t D
                     (long long)gnnmp_dense_grad_workspace(N, Dout, K));
     int64_t rps = (N + slabs - 1) / slabs;
     rps = (rps + 1) & ~(int64_t)1;                               // even: row pairs never straddle slabs
+    // a slab length that is a multiple of 64 rows puts every slab's stream at the same offset of the HBM channel
+    // interleave when the row size is a power of two too (245 760 x 128: all blocks camp on two channels, 221 us for a
+    // job that takes 118 us at 169 343 rows): de-tune it.  Slabs past the end of the input are empty (n0 >= N).
+    if ((rps & 63) == 0) rps += 2;
     if (dW) {
         GradWArgs a;
         a.dz = dz;
