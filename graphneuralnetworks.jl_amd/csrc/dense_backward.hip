@@ -119,40 +119,43 @@ __global__ void __launch_bounds__(256) dense_gradw_kernel(const GradWArgs a) {
     for (int t = 0; t < 4; ++t) koff[t] = k_ok[t] ? t * 32 + li : 0;
     const int64_t sa = 2 * (int64_t)a.Dout, sb = 2 * (int64_t)a.K;   // one row pair
     int64_t n = n0;
-    if (n + 2 * RP <= n1) {
-        // software pipeline: the batch after the current one is in flight while the current one's 4*RP MFMAs issue
-        float av[RP], bv[RP][4];
-#pragma unroll
-        for (int p = 0; p < RP; ++p) {
-            av[p] = pa[p * sa];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) bv[p][t] = pb[p * sb + koff[t]];
-        }
-        for (; n + 2 * RP <= n1; n += 2 * RP) {
-            const bool more = n + 4 * RP <= n1;          // else re-read the current batch (harmless, discarded)
-            const float *qa = more ? pa + RP * sa : pa;
-            const float *qb = more ? pb + RP * sb : pb;
-            float an[RP], bn[RP][4];
+    // Software pipeline, NB batches deep: a wave is latency-bound per batch (~1.2 us from load to MFMA) while a batch's
+    // 4*RP MFMAs take 0.1-0.2 us, so NB - 1 further batches are in flight while one is consumed.  The ring lives in
+    // registers: the slot index is a compile-time constant in the unrolled loop.  Batches past the end re-read the last
+    // full batch (harmless, never consumed).
+    constexpr int NB = 4;
+    const int64_t nfull = n1 > n0 ? (n1 - n0) / (2 * RP) : 0;     // full batches of RP row pairs in this slab
+    if (nfull > 0) {
+        float av[NB][RP], bv[NB][RP][4];
+        auto load_batch = [&](int slot, int64_t b) {
+            const int64_t bc = b < nfull ? b : nfull - 1;
+            const float *qa = pa + bc * RP * sa;
+            const float *qb = pb + bc * RP * sb;
 #pragma unroll
             for (int p = 0; p < RP; ++p) {
-                an[p] = qa[p * sa];
+                av[slot][p] = qa[p * sa];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) bn[p][t] = qb[p * sb + koff[t]];
+                for (int t = 0; t < 4; ++t) bv[slot][p][t] = qb[p * sb + koff[t]];
             }
+        };
 #pragma unroll
-            for (int p = 0; p < RP; ++p)
+        for (int s = 0; s < NB - 1; ++s) load_batch(s, s);
+        for (int64_t b0 = 0; b0 < nfull; b0 += NB) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p], bv[p][t], acc[t], 0, 0, 0);
+            for (int s = 0; s < NB; ++s) {
+                load_batch((s + NB - 1) % NB, b0 + s + NB - 1);
+                if (b0 + s < nfull) {
 #pragma unroll
-            for (int p = 0; p < RP; ++p) {
-                av[p] = an[p];
+                    for (int p = 0; p < RP; ++p)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) bv[p][t] = bn[p][t];
+                        for (int t = 0; t < 4; ++t)
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][p], bv[s][p][t], acc[t], 0, 0, 0);
+                }
             }
-            pa += RP * sa;
-            pb += RP * sb;
         }
+        n += nfull * 2 * RP;
+        pa += nfull * RP * sa;
+        pb += nfull * RP * sb;
     }
     // tail of the slab: fewer than RP row pairs, the last one possibly half empty (N odd)
     for (; n < n1; n += 2) {
@@ -195,7 +198,8 @@ static int gradw_slabs(int64_t N) {
     }
     const int64_t by_rows = (N + min_rows - 1) / min_rows;        // at least min_rows rows per slab
     int per_cu = knob(KNOB_GRADW_SLABS);
-    if (per_cu <= 0) per_cu = 8;   // 2 -> 8 slabs per CU: 3.8 -> 2.4 ms at 2.4M x 100 x 100 (more waves to cover the load latency)
+    if (per_cu <= 0) per_cu = 4;   // with the 4-deep register pipeline 4 slabs per CU are enough (1.05 vs 1.09 ms with 8 at
+                                   // 2.4M x 128 x 128; before the pipeline it took 8 to cover the load latency)
     return (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)per_cu * cus, by_rows));
 }
 
