@@ -149,6 +149,15 @@ __global__ void __launch_bounds__(256) add_kernel(const float *a, const float *b
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = a[i] + b[i];
 }
+// out[n][d] = a[n][d * (Da > 1)] * b[n][d]   — `α .* feats` of global_attention_pool (GNNlib/src/layers/pool.jl:6-10) with a
+// gate of one channel (broadcast over the features) or of D channels
+__global__ void __launch_bounds__(256) mul_rows_kernel(const float *a, int Da, const float *b, float *out, int64_t N, int D) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * D) return;
+    const int64_t n = i / D;
+    const int d = (int)(i - n * D);
+    out[i] = a[n * Da + (Da > 1 ? d : 0)] * b[i];
+}
 // out = alpha .* x .+ y   — gin_conv's `(1 .+ ϵ) .* xi .+ m` (GNNlib/src/layers/conv.jl:250-256): product rounded, then sum
 __global__ void __launch_bounds__(256) axpy_kernel(float alpha, const float *x, const float *y, float *out, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -264,6 +273,16 @@ int gnnmp_add_f32(const float *a, const float *b, float *out, int64_t n, gnnmp_s
     if (!a || !b || !out) return fail(GNNMP_EINVAL, "add: null pointer");
     add_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(a, b, out, n);
     GNNMP_LAUNCH_CHECK("add_kernel");
+    return GNNMP_OK;
+}
+
+int gnnmp_mul_rows_f32(const float *a, int64_t Da, const float *b, float *out, int64_t N, int64_t D, gnnmp_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (N < 0 || D <= 0 || (Da != 1 && Da != D)) return fail(GNNMP_EINVAL, "mul_rows: a must have 1 or D channels");
+    if (N == 0) return GNNMP_OK;
+    if (!a || !b || !out) return fail(GNNMP_EINVAL, "mul_rows: null pointer");
+    mul_rows_kernel<<<(unsigned)((N * D + 255) / 256), 256, 0, stream>>>(a, (int)Da, b, out, N, (int)D);
+    GNNMP_LAUNCH_CHECK("mul_rows_kernel");
     return GNNMP_OK;
 }
 

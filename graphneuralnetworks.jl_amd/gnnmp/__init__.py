@@ -12,7 +12,8 @@ from .msgpass import (aggregate_neighbors, apply_edges, copy_xi, copy_xj, e_mul_
                       xi_dot_xj, xi_sub_xj, xj_sub_xi)
 from .layers_attn import (AGNNConv, GATv2Conv, GINConv, TransformerConv, agnn_conv, gatv2_conv, gin_conv,  # noqa: F401
                           transformer_conv)
-from .layers_khop import ResGatedGraphConv, SGConv, TAGConv, res_gated_graph_conv, sg_conv, tag_conv  # noqa: F401
+from .layers_khop import (GlobalAttentionPool, ResGatedGraphConv, SGConv, TAGConv, global_attention_pool,  # noqa: F401
+                          res_gated_graph_conv, sg_conv, tag_conv)
 from .sampling import (NeighborLoader, NodeSet, has_self_loops, induced_subgraph, is_bidirected, sample_neighbors,  # noqa: F401
                        sort_edge_index)
 from .utils import (broadcast_edges, broadcast_nodes, expand_srcdst, reduce_edges, reduce_nodes,  # noqa: F401

@@ -33,7 +33,7 @@ SYMBOLS = (
     "gnnmp_bias_act_f32",
     "gnnmp_segment_pool_f32", "gnnmp_dense_f32",
     "gnnmp_edge_dot_f32", "gnnmp_edge_dot_plan_f32", "gnnmp_propagate_maxmin_grad_f32",
-    "gnnmp_head_mean_f32", "gnnmp_head_mean_grad_f32", "gnnmp_add_f32", "gnnmp_axpy_f32", "gnnmp_is_sorted",
+    "gnnmp_head_mean_f32", "gnnmp_head_mean_grad_f32", "gnnmp_add_f32", "gnnmp_axpy_f32", "gnnmp_mul_rows_f32", "gnnmp_is_sorted",
     "gnnmp_act_grad_f32", "gnnmp_dense_grad_workspace", "gnnmp_dense_grad_w_f32",
 )
 
@@ -102,6 +102,7 @@ def load():
         "gnnmp_head_mean_grad_f32": [vp, vp, i64, i64, i64, vp],
         "gnnmp_add_f32": [vp, vp, vp, i64, vp],
         "gnnmp_axpy_f32": [f, vp, vp, vp, i64, vp],
+        "gnnmp_mul_rows_f32": [vp, i64, vp, vp, i64, i64, vp],
         "gnnmp_is_sorted": [vp, i, i64, ctypes.POINTER(i), vp],
         "gnnmp_propagate_maxmin_grad_f32": [vp, vp, vp, vp, vp, i64, vp],
         "gnnmp_act_grad_f32": [vp, vp, i, vp, i64, vp],

@@ -173,3 +173,31 @@ class ResGatedGraphConv:
 
     def __call__(self, g, x):
         return res_gated_graph_conv(self, g, x)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# GlobalAttentionPool: softmax_nodes(g, fgate(x)) .* ffeat(x), summed per graph
+# ---------------------------------------------------------------------------------------------------------
+def global_attention_pool(l, g: GNNGraph, x):
+    """GNNlib/src/layers/pool.jl:6-10.  fgate maps [N, D] -> [N, 1] (or [N, D']); ffeat -> [N, D'] (identity if None)."""
+    from .utils import reduce_nodes, softmax_nodes
+    check_num_nodes(g, x)
+    alpha = softmax_nodes(g, l.fgate(x)).contiguous()
+    feats = (x if l.ffeat is None else l.ffeat(x)).contiguous()
+    assert alpha.shape[1] in (1, feats.shape[1]), "the gate must have one channel or as many as the features"
+    out = torch.empty_like(feats)
+    L.check(L.load().gnnmp_mul_rows_f32(L.ptr(alpha), alpha.shape[1], L.ptr(feats), L.ptr(out), feats.shape[0], feats.shape[1],
+                                        L.stream_ptr()))
+    return reduce_nodes("+", g, out)
+
+
+class GlobalAttentionPool:
+    """GlobalAttentionPool(fgate, ffeat = identity) — GraphNeuralNetworks/src/layers/pool.jl"""
+
+    takes_graph = True
+
+    def __init__(self, fgate, ffeat=None):
+        self.fgate, self.ffeat = fgate, ffeat
+
+    def __call__(self, g, x):
+        return global_attention_pool(self, g, x)

@@ -349,6 +349,10 @@ int gnnmp_head_mean_f32(const float *y, const float *bias, int act, float *out, 
 int gnnmp_head_mean_grad_f32(const float *dz, float *dy, int64_t N, int64_t H, int64_t C, gnnmp_stream_t stream);
 /* out = a + b (n floats) — degree(g; dir = :both) = out-degree + in-degree (GNNGraphs/src/query.jl:362-367). */
 int gnnmp_add_f32(const float *a, const float *b, float *out, int64_t n, gnnmp_stream_t stream);
+/* out[n][:] = a[n][:] .* b[n][:] with a of 1 channel (broadcast) or D channels — `α .* l.ffeat(x)` of
+ * global_attention_pool, GNNlib/src/layers/pool.jl:6-10 (out may alias b) */
+int gnnmp_mul_rows_f32(const float *a, int64_t Da, const float *b, float *out, int64_t N, int64_t D,
+                       gnnmp_stream_t stream);
 /* out = alpha .* x .+ y (out may alias x or y) — `(1 .+ ϵ) .* xi .+ m` of gin_conv, GNNlib/src/layers/conv.jl:250-256 */
 int gnnmp_axpy_f32(float alpha, const float *x, const float *y, float *out, int64_t n, gnnmp_stream_t stream);
 /* *result_host = 1 iff idx[0..n) is non-decreasing (is a graph_indicator one that `batch` could have built?).
