@@ -35,6 +35,8 @@ struct GatFusedArgs {
     const float *Wx_val;  // V [n_src][D] (== Wx_src unless MODE = DOT)
     const float *Wx_dst;  // Q [n_dst][D]
     const float *a;       // GAT [H][2C], GATV2 [H][C], else unused
+    const float *escore;  // GAT with edge features: [n_edges][H] = a_e . We_k, original edge order; else null
+    const int32_t *eid;   // plan slot -> original edge position (escore lookup)
     const float *bias;    // [D] or null
     float *out;           // [n_dst][D]
     float *partial;       // [n_chunks][D + 2*D/VEC]
@@ -67,6 +69,7 @@ struct LaneRow {
     float vi[VEC];  // Q_i slice (GATV2, DOT, COS)
     float s0;       // GAT: a_d . Q_i;  COS: |x_i|
     float am;       // 1 for lanes that own features, 0 for idle lanes
+    int h;          // this lane's head
 };
 
 // One batch = U edges: U independent row loads, U dot products, their butterflies (DPP when the lane count per head LPH
@@ -80,15 +83,25 @@ __device__ __forceinline__ void gat_online_range(const GatFusedArgs &a, int beg,
     for (int base = beg; base < end; base += G) {
         const int p = base + lig;
         const int c = p < end ? a.col[p] : 0;
+        // edge features (gat_conv with dense_e): the edge's share of the logit, a_e . We_k, precomputed per edge and head,
+        // is fetched by original edge position (uniform branch: absent for the headline layer)
+        const bool edge_term = MODE == GNNMP_ATTN_GAT && a.escore != nullptr;
+        const int ev = (edge_term && p < end) ? a.eid[p] : 0;
         const int n = min(G, end - base);
         for (int j = 0; j < n; j += U) {
             float v[U][VEC];                                  // K_j
             float w[MODE == GNNMP_ATTN_DOT ? U : 1][VEC];     // V_j when it is a different array
+            float es[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int cj = __shfl(c, gbase + min(j + u, n - 1), 64);
                 Vec<VEC>::load(a.Wx_src + (int64_t)cj * a.D + fc, v[u]);
                 if (MODE == GNNMP_ATTN_DOT) Vec<VEC>::load(a.Wx_val + (int64_t)cj * a.D + fc, w[MODE == GNNMP_ATTN_DOT ? u : 0]);
+                es[u] = 0.0f;
+                if (edge_term) {
+                    const int ej = __shfl(ev, gbase + min(j + u, n - 1), 64);
+                    es[u] = a.escore[(int64_t)ej * a.H + r.h];
+                }
             }
             float l[U], nn[U];
 #pragma unroll
@@ -115,7 +128,7 @@ __device__ __forceinline__ void gat_online_range(const GatFusedArgs &a, int beg,
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 float lu = l[u];
-                if (MODE == GNNMP_ATTN_GAT) lu = lrelu(r.s0 + lu, a.slope);
+                if (MODE == GNNMP_ATTN_GAT) lu = lrelu(edge_term ? (r.s0 + lu) + es[u] : r.s0 + lu, a.slope);
                 if (MODE == GNNMP_ATTN_DOT) lu = lu / a.scale;
                 if (MODE == GNNMP_ATTN_COS) lu = a.scale * (lu / (r.s0 * sqrtf(nn[u])));
                 l[u] = (j + u < n) ? lu : -__builtin_inff();
@@ -186,6 +199,7 @@ __global__ void __launch_bounds__(256) gat_fused_rows_kernel(const GatFusedArgs 
     LaneRow<VEC> r;
     r.am = active ? 1.0f : 0.0f;
     r.s0 = 0.0f;
+    r.h = fc / a.C;
     {
         const int h = fc / a.C, c0 = fc - h * a.C;
         float qi[VEC];
@@ -410,9 +424,11 @@ using namespace gnnmp;
 
 static int attn_conv_impl(gnnmp_graph_t *plan, int mode, const float *Q, const float *K, const float *V, const float *a,
                           float negative_slope, float scale, const float *bias, int act, float *out, float *stats,
-                          int64_t H, int64_t C, gnnmp_stream_t stream_) {
+                          int64_t H, int64_t C, gnnmp_stream_t stream_, const float *escore = nullptr) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!plan) return fail(GNNMP_EINVAL, "attn_conv: null plan");
+    if (escore && plan->self_loops)
+        return fail(GNNMP_EINVAL, "gat_conv: edge features and add_self_loops cannot be combined (GNNlib/src/layers/conv.jl:120)");
     if (mode < GNNMP_ATTN_GAT || mode > GNNMP_ATTN_COS) return fail(GNNMP_EINVAL, "attn_conv: bad mode %d", mode);
     if (H <= 0 || C <= 0 || H * C > (1 << 20)) return fail(GNNMP_EINVAL, "attn_conv: bad H/C");
     if (mode == GNNMP_ATTN_COS && H != 1) return fail(GNNMP_EINVAL, "attn_conv: the cosine logit is single-head");
@@ -434,7 +450,7 @@ static int attn_conv_impl(gnnmp_graph_t *plan, int mode, const float *Q, const f
     while ((1 << log2g) < lanes) ++log2g;   // one feature tile: the head butterfly needs the whole row in one group
     if (H == 1 && lanes <= 64) lph = 1 << log2g;   // a single head may spill over idle lanes: they carry zeros
     if (lanes > 64) {
-        if (mode != GNNMP_ATTN_GAT || stats)
+        if (mode != GNNMP_ATTN_GAT || stats || escore)
             return fail(GNNMP_EUNSUPPORTED,
                         "attn_conv: the one-pass kernel needs a feature row that fits one wave (H*C = %lld lanes %d > 64)",
                         (long long)(H * C), lanes);
@@ -456,6 +472,8 @@ static int attn_conv_impl(gnnmp_graph_t *plan, int mode, const float *Q, const f
     g.Wx_val = V;
     g.Wx_dst = Q;
     g.a = a;
+    g.escore = escore;
+    g.eid = plan->eid;
     g.bias = bias;
     g.out = out;
     g.partial = plan->ws;
@@ -502,6 +520,13 @@ extern "C" int gnnmp_gat_conv_stats_f32(gnnmp_graph_t *plan, const float *Wx_src
     if (!stats) return fail(GNNMP_EINVAL, "gat_conv_stats: null stats");
     return attn_conv_impl(plan, GNNMP_ATTN_GAT, Wx_dst, Wx_src, nullptr, a, negative_slope, 1.0f, bias, act, out, stats, H,
                           C, stream);
+}
+extern "C" int gnnmp_gat_conv_edge_f32(gnnmp_graph_t *plan, const float *Wx_src, const float *Wx_dst, const float *a,
+                                       const float *edge_score, float negative_slope, const float *bias, int act,
+                                       float *out, int64_t H, int64_t C, gnnmp_stream_t stream) {
+    if (!edge_score && plan && plan->n_edges > 0) return fail(GNNMP_EINVAL, "gat_conv_edge: null edge_score");
+    return attn_conv_impl(plan, GNNMP_ATTN_GAT, Wx_dst, Wx_src, nullptr, a, negative_slope, 1.0f, bias, act, out, nullptr,
+                          H, C, stream, edge_score);
 }
 extern "C" int gnnmp_attn_conv_f32(gnnmp_graph_t *plan, int mode, const float *Q, const float *K, const float *V,
                                    const float *a, float negative_slope, float scale, const float *bias, int act,

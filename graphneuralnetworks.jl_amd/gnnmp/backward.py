@@ -367,5 +367,6 @@ def gat_conv_ad(l, g: GNNGraph, x):
     """differentiable GATConv forward (no edge features; concat = true or false): gradients w.r.t. x, l.dense_x_weight,
     l.a, l.bias"""
     check_num_nodes(g, x)
+    assert getattr(l, "dense_e_weight", None) is None, "the HIP adjoint does not cover edge features"
     return _GATConvFn.apply(x, l.dense_x_weight, l.a, l.bias, g, l.sigma, l.heads, l.negative_slope,
                             bool(l.add_self_loops), bool(l.concat))

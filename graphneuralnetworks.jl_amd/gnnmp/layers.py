@@ -216,21 +216,36 @@ def gat_conv(l, g: GNNGraph, x, e=None, return_alpha=False, exact_order=False):
     """GNNlib/src/layers/conv.jl:112-167 (no edge features: dense_e === nothing).  dense_x GEMM -> node scores ->
     one fused edge-softmax + weighted aggregate over the (self-looped) plan."""
     check_num_nodes(g, x)
-    assert e is None, "edge features (dense_e) are outside the hot path"
+    dense_e = getattr(l, "dense_e_weight", None)
+    assert not (e is None and dense_e is not None), "Input edge features required for this layer"
+    assert not (e is not None and dense_e is None), "Input edge features were not specified in the layer constructor"
     loops = bool(l.add_self_loops)
+    if loops:
+        assert e is None, "Using edge features and setting add_self_loops=true at the same time is not yet supported."
     plan = g.plan(loops)
     H = l.heads
     C = l.channel[1]
     N = g.num_nodes
     Wx = dense(x, l.dense_x_weight)                        # reshape(dense_x(x), C, H, N)
-    a_hc = l.a_hc                                          # [H][2C]
+    a_hc = l.a_hc                                          # [H][2C] (node part)
     lib = L.load()
     out = torch.empty((N, H * C), dtype=torch.float32, device=x.device)
     code, post = _act_code(l.sigma)
     fuse_tail = bool(l.concat)
     b = l.bias if (fuse_tail and l.bias is not None) else None
     alpha = None
-    if return_alpha or exact_order:
+    if e is not None:
+        # edge features (conv.jl:152-167): We = dense_e(e); the edge's share of the logit a[2C:3C, h] . We_k[:, h] is one
+        # scalar per edge and head, added inside the one-pass kernel
+        assert not (return_alpha or exact_order), "alpha output / reference order: not with edge features"
+        from .graph import check_num_edges
+        check_num_edges(g, e)
+        We = dense(e, dense_e)
+        es = torch.empty((g.num_edges, H), dtype=torch.float32, device=x.device)
+        L.check(lib.gnnmp_gat_node_scores_f32(L.ptr(We), L.ptr(l.a_edge_hc), L.ptr(es), None, g.num_edges, H, C, L.stream_ptr()))
+        L.check(lib.gnnmp_gat_conv_edge_f32(plan.handle, L.ptr(Wx), None, L.ptr(a_hc), L.ptr(es), float(l.negative_slope),
+                                            L.ptr(b), code if fuse_tail else L.ACT_IDENTITY, L.ptr(out), H, C, L.stream_ptr()))
+    elif return_alpha or exact_order:
         # the reference's operation order (max pass, denominator pass, α = num/den, β = α .* Wxj) and the α output
         sd = torch.empty((N, H), dtype=torch.float32, device=x.device)
         ss = torch.empty((N, H), dtype=torch.float32, device=x.device)
@@ -261,14 +276,21 @@ class GATConv:
     def __init__(self, ch, sigma=None, heads=1, concat=True, negative_slope=0.2, bias=True, add_self_loops=True,
                  dropout=0.0, device="cuda", seed=None):
         cin, cout = ch
+        ein = 0
+        if isinstance(cin, tuple):                         # GATConv((in, ein) => out, ...): edge features of size ein
+            cin, ein = cin
         assert dropout == 0.0, "dropout is identity in the forward/test mode this engine covers"
+        if add_self_loops:
+            assert ein == 0, "Using edge features and setting add_self_loops=true at the same time is not yet supported."
         self.channel = (cin, cout)
         self.heads = heads
         self.concat = concat
         self.negative_slope = float(negative_slope)
         self.add_self_loops = add_self_loops
         self.dense_x_weight = glorot_uniform(cout * heads, cin, device=device, seed=seed)
-        self.a = glorot_uniform(2 * cout, heads, device=device, seed=None if seed is None else seed + 1)
+        self.dense_e_weight = glorot_uniform(cout * heads, ein, device=device, seed=None if seed is None else seed + 2) \
+            if ein > 0 else None
+        self.a = glorot_uniform((3 if ein > 0 else 2) * cout, heads, device=device, seed=None if seed is None else seed + 1)
         nb = cout * heads if concat else cout
         self.bias = torch.zeros(nb, dtype=torch.float32, device=device) if bias else None
         self.sigma = sigma
@@ -278,9 +300,19 @@ class GATConv:
         """[H][2C] row-major image of `a` (a[h][0:C] targets, a[h][C:2C] sources); rebuilt only when `a` changes"""
         key = (self.a.data_ptr(), self.a._version)
         if getattr(self, "_a_hc_key", None) != key:
-            self._a_hc = self.a.t().contiguous()
+            C = self.channel[1]
+            at = self.a.t()                                             # [H][2C] or [H][3C]
+            self._a_hc = at[:, :2 * C].contiguous()
+            # the edge part a[2C:3C, :] in the [H][2C] image gnnmp_gat_node_scores_f32 reads (its first half)
+            self._a_edge_hc = torch.cat([at[:, 2 * C:], torch.zeros_like(at[:, 2 * C:])], 1).contiguous() \
+                if at.shape[1] == 3 * C else None
             self._a_hc_key = key
         return self._a_hc
+
+    @property
+    def a_edge_hc(self):
+        self.a_hc
+        return self._a_edge_hc
 
     def __call__(self, g, x, e=None):
         return gat_conv(self, g, x, e)

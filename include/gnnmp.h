@@ -295,6 +295,14 @@ int gnnmp_gat_conv_f32(gnnmp_graph_t *plan, const float *Wx_src, const float *Wx
                        float negative_slope, const float *bias, int act, float *out, int64_t H,
                        int64_t C, gnnmp_stream_t stream);
 
+/* gat_conv with edge features (l.dense_e, conv.jl:152-167: `Wxx = vcat(Wxi, Wxj, We)`): the edge's share of the logit,
+ * edge_score[k][h] = a[2C:3C, h] . We_k[:, h] with We = dense_e(e), is a per-edge scalar per head — compute it with
+ * gnnmp_gat_node_scores_f32 on the (E, H*C) matrix We — and is added inside the one-pass kernel, fetched by original edge
+ * position.  `a` is the node part [H][2C].  The plan must not add self loops (conv.jl:119-121 forbids the combination). */
+int gnnmp_gat_conv_edge_f32(gnnmp_graph_t *plan, const float *Wx_src, const float *Wx_dst, const float *a,
+                            const float *edge_score, float negative_slope, const float *bias, int act, float *out,
+                            int64_t H, int64_t C, gnnmp_stream_t stream);
+
 /* Training forward of the same path: as gnnmp_gat_conv_f32, and additionally saves the neighbourhood-softmax statistics
  * stats[i][h] = (m_i, den_i) — the running maximum of the logits and Σ_j exp(l_ij - m_i) — 8 bytes per destination and
  * head instead of the reference's (H, E') α array that Zygote keeps alive for the pullback.  The feature row must fit one

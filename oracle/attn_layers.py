@@ -124,6 +124,25 @@ def gin_conv(s, t, n, x, eps, aggr=O.SUM):
     return (((f32(1) + f32(eps)) * x).astype(f32) + m).astype(f32)
 
 
+def gat_conv_edge(s, t, n, x, e, dense_x_weight, dense_e_weight, a, bias=None, sigma=None, heads=1, concat=True,
+                  negative_slope=0.2):
+    """gat_conv with edge features (conv.jl:112-167, l.dense_e !== nothing, add_self_loops = false):
+    Wxx = vcat(Wxi, Wxj, We); aWW = sum(l.a .* Wxx, dims = 1); logα = leakyrelu.(aWW).  a: Julia shape (3C, H)."""
+    s, t = O._i64(s), O._i64(t)
+    H = heads
+    C = dense_x_weight.shape[0] // H
+    Wx = O.matmul(dense_x_weight, x).reshape(n, H, C)
+    We = O.matmul(dense_e_weight, O._f32(e)).reshape(len(s), H, C)
+    Wxi, Wxj = O.gather(Wx, t), O.gather(Wx, s)
+    Wxx = np.concatenate([Wxi, Wxj, We], axis=2)                       # [E, H, 3C]
+    a_h = O._f32(np.asarray(a).T)                                      # [H, 3C]
+    logit = _lrelu(_sum_dim1((a_h[None] * Wxx).astype(f32)), negative_slope)
+    alpha = O.softmax_edge_neighbors(t, n, logit)
+    beta = (alpha[..., None] * Wxj).astype(f32)
+    y = O.scatter(O.SUM, beta.reshape(len(s), H * C), t, n).reshape(n, H, C)
+    return _heads_tail(y, n, H, C, concat, bias, sigma)
+
+
 # ---------------------------------------------------------------------------------------------------------
 # independent float64 formulation: dense masked attention on the adjacency matrix (simple graphs only)
 # ---------------------------------------------------------------------------------------------------------
