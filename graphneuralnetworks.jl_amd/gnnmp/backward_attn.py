@@ -1,7 +1,8 @@
 """Differentiable GATv2Conv and TransformerConv (attention core + root weight + skip connection) — forward AND backward on
 the HIP kernels (csrc/gat_fused.hip, csrc/attn_backward.hip), wrapped as torch.autograd.Functions like gnnmp/backward.py.
 The forward keeps 8 bytes of softmax statistics per destination and head; the pullback is two edge passes that rebuild α in
-registers, then the dense adjoints.  concat = true; no edge features / dropout (as in the forward)."""
+registers, then the dense adjoints.  concat = true or false (mean over heads and its pullback as two leaf kernels); no
+edge features / dropout (as in the forward)."""
 from __future__ import annotations
 
 import torch
@@ -44,18 +45,25 @@ def _add_(a, b):
 
 
 class _GATv2ConvFn(torch.autograd.Function):
-    """gatv2_conv (GNNlib/src/layers/conv.jl:171-214), concat = true, e === nothing"""
+    """gatv2_conv (GNNlib/src/layers/conv.jl:171-214), e === nothing; concat = true or false"""
 
     @staticmethod
-    def forward(ctx, x, Wi, bi, Wj, a, bias, g, sigma, heads, slope, loops):
+    def forward(ctx, x, Wi, bi, Wj, a, bias, g, sigma, heads, slope, loops, concat=True):
         H, C = heads, Wi.shape[0] // heads
         x = x.contiguous()
         Q = dense(x, Wi, bi)
         K = dense(x, Wj)
         a_hc = a.t().contiguous()                                   # (C, H) as Julia stores it -> [H][C]
-        out, stats = _attn_forward(g.plan(loops), ATTN_GATV2, Q, K, None, a_hc, slope, 1.0, bias, _act_code(sigma), H, C)
+        # concat = false: heads averaged before bias and σ (conv.jl:196-200): the kernel's fused tail is off
+        out, stats = _attn_forward(g.plan(loops), ATTN_GATV2, Q, K, None, a_hc, slope, 1.0, bias if concat else None,
+                                   _act_code(sigma) if concat else L.ACT_IDENTITY, H, C)
+        if not concat:
+            y = torch.empty((out.shape[0], C), dtype=torch.float32, device=x.device)
+            L.check(L.load().gnnmp_head_mean_f32(L.ptr(out), L.ptr(bias), _act_code(sigma), L.ptr(y), out.shape[0], H, C,
+                                                 L.stream_ptr()))
+            out = y
         ctx.save_for_backward(x, Wi, Wj, Q, K, a_hc, stats, out)
-        ctx.g, ctx.sigma, ctx.H, ctx.C, ctx.slope, ctx.loops = g, sigma, H, C, slope, loops
+        ctx.g, ctx.sigma, ctx.H, ctx.C, ctx.slope, ctx.loops, ctx.concat = g, sigma, H, C, slope, loops, concat
         ctx.has_bi, ctx.has_b = bi is not None, bias is not None
         return out
 
@@ -64,32 +72,41 @@ class _GATv2ConvFn(torch.autograd.Function):
         x, Wi, Wj, Q, K, a_hc, stats, y = ctx.saved_tensors
         dz = act_grad(dy.contiguous(), y, ctx.sigma)
         db = dense_grad_w(dz, dz, need_w=False)[1] if ctx.has_b else None
+        if not ctx.concat:                       # pullback of mean(x, dims = 2): every head receives Δ / H
+            dzh = torch.empty((dz.shape[0], ctx.H * ctx.C), dtype=torch.float32, device=dz.device)
+            L.check(L.load().gnnmp_head_mean_grad_f32(L.ptr(dz), L.ptr(dzh), dz.shape[0], ctx.H, ctx.C, L.stream_ptr()))
+            dz = dzh
         dQ, dK, _, da = _attn_backward(ctx.g, ctx.loops, ATTN_GATV2, Q, K, None, a_hc, ctx.slope, 1.0, stats, dz, ctx.H, ctx.C)
         dWi, dbi = dense_grad_w(dQ, x, need_b=ctx.has_bi)
         dWj, _ = dense_grad_w(dK, x, need_b=False)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = _add_(dense_grad_x(dQ, Wi), dense_grad_x(dK, Wj))
-        return dx, dWi, dbi, dWj, da.t(), db, None, None, None, None, None
+        return dx, dWi, dbi, dWj, da.t(), db, None, None, None, None, None, None
 
 
 def gatv2_conv_ad(l, g: GNNGraph, x):
     """differentiable GATv2Conv forward: gradients w.r.t. x, dense_i (weight, bias), dense_j weight, a, bias"""
     check_num_nodes(g, x)
-    assert l.concat and l.dense_e is None, "the HIP adjoint covers concat = true without edge features"
+    assert l.dense_e is None, "the HIP adjoint does not cover edge features"
     return _GATv2ConvFn.apply(x, l.dense_i_weight, l.dense_i_bias, l.dense_j_weight, l.a, l.bias, g, l.sigma, l.heads,
-                              l.negative_slope, bool(l.add_self_loops))
+                              l.negative_slope, bool(l.add_self_loops), bool(l.concat))
 
 
 class _TransformerConvFn(torch.autograd.Function):
     """transformer_conv (conv.jl:553-629): attention core, + W1 x (root weight), + x (skip connection); concat = true"""
 
     @staticmethod
-    def forward(ctx, x, W1, b1, W2, b2, W3, b3, W4, b4, g, heads, sqrt_out, loops, skip):
+    def forward(ctx, x, W1, b1, W2, b2, W3, b3, W4, b4, g, heads, sqrt_out, loops, skip, concat=True):
         H, C = heads, W2.shape[0] // heads
         x = x.contiguous()
         V, Q, K = dense(x, W2, b2), dense(x, W3, b3), dense(x, W4, b4)
         h, stats = _attn_forward(g.plan(loops), ATTN_DOT, Q, K, V, None, 0.0, sqrt_out, None, L.ACT_IDENTITY, H, C)
+        if not concat:                                              # mean over heads before the root weight (conv.jl:600-603)
+            y = torch.empty((h.shape[0], C), dtype=torch.float32, device=x.device)
+            L.check(L.load().gnnmp_head_mean_f32(L.ptr(h), None, L.ACT_IDENTITY, L.ptr(y), h.shape[0], H, C, L.stream_ptr()))
+            h = y
+        ctx.concat = concat
         if W1 is not None:
             _add_(h, dense(x, W1, b1))
         if skip:
@@ -104,7 +121,11 @@ class _TransformerConvFn(torch.autograd.Function):
         x, Q, K, V, stats, W2, W3, W4, *rest = ctx.saved_tensors
         W1 = rest[0] if rest else None
         dh = dy.contiguous()
-        dQ, dK, dV, _ = _attn_backward(ctx.g, ctx.loops, ATTN_DOT, Q, K, V, None, 0.0, ctx.scale, stats, dh, ctx.H, ctx.C)
+        dha = dh
+        if not ctx.concat:
+            dha = torch.empty((dh.shape[0], ctx.H * ctx.C), dtype=torch.float32, device=dh.device)
+            L.check(L.load().gnnmp_head_mean_grad_f32(L.ptr(dh), L.ptr(dha), dh.shape[0], ctx.H, ctx.C, L.stream_ptr()))
+        dQ, dK, dV, _ = _attn_backward(ctx.g, ctx.loops, ATTN_DOT, Q, K, V, None, 0.0, ctx.scale, stats, dha, ctx.H, ctx.C)
         has_w1, hb1, hb2, hb3, hb4 = ctx.has
         dW2, db2 = dense_grad_w(dV, x, need_b=hb2)
         dW3, db3 = dense_grad_w(dQ, x, need_b=hb3)
@@ -121,12 +142,12 @@ class _TransformerConvFn(torch.autograd.Function):
                 _add_(dx, dense_grad_x(dh, W1))
             if ctx.skip:
                 _add_(dx, dh)
-        return dx, dW1, db1, dW2, db2, dW3, db3, dW4, db4, None, None, None, None, None
+        return dx, dW1, db1, dW2, db2, dW3, db3, dW4, db4, None, None, None, None, None, None
 
 
 def transformer_conv_ad(l, g: GNNGraph, x):
-    """differentiable TransformerConv forward (concat = true): gradients w.r.t. x and W1..W4 (+ their biases)"""
+    """differentiable TransformerConv forward (concat = true or false): gradients w.r.t. x and W1..W4 (+ their biases)"""
     check_num_nodes(g, x)
-    assert l.concat, "the HIP adjoint covers concat = true"
     return _TransformerConvFn.apply(x, l.W1_weight, l.W1_bias, l.W2_weight, l.W2_bias, l.W3_weight, l.W3_bias, l.W4_weight,
-                                    l.W4_bias, g, l.heads, l.sqrt_out, bool(l.add_self_loops), bool(l.skip_connection))
+                                    l.W4_bias, g, l.heads, l.sqrt_out, bool(l.add_self_loops), bool(l.skip_connection),
+                                    bool(l.concat))

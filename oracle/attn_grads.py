@@ -24,7 +24,8 @@ def _softmax_pullback(alpha, dalpha, ti, n, H):
     return alpha * (dalpha - sa[ti])
 
 
-def grad_gatv2_conv(s, t, n, x, Wi, bi, Wj, a, bias, sigma, dy, heads=1, negative_slope=0.2, add_self_loops_=True):
+def grad_gatv2_conv(s, t, n, x, Wi, bi, Wj, a, bias, sigma, dy, heads=1, negative_slope=0.2, add_self_loops_=True,
+                    concat=True):
     """(Δx, ΔWi, Δbi, ΔWj, Δa, Δb); a: Julia shape (C, H)"""
     s, t = O._i64(s), O._i64(t)
     if add_self_loops_:
@@ -42,10 +43,11 @@ def grad_gatv2_conv(s, t, n, x, Wi, bi, Wj, a, bias, sigma, dy, heads=1, negativ
     alpha = _softmax_agg(l, ti, n, H)
     o = np.zeros((n, H, C))
     np.add.at(o, ti, alpha[..., None] * K[si])
-    y = o.reshape(n, H * C) + (0 if bias is None else np.asarray(bias, np.float64)[None, :])
+    y = (o.reshape(n, H * C) if concat else o.mean(axis=1)) + (0 if bias is None else np.asarray(bias, np.float64)[None, :])
     dz = np.asarray(dy, np.float64) * (y > 0) if sigma == "relu" else np.asarray(dy, np.float64)
     db = dz.sum(0)
-    delta = dz.reshape(n, H, C)[ti]                                 # Δβ = Δ[t]
+    dzh = dz.reshape(n, H, C) if concat else np.repeat(dz[:, None, :] / H, H, axis=1)   # ∇mean(x, dims = 2)
+    delta = dzh[ti]                                                 # Δβ = Δ[t]
     dalpha = (delta * K[si]).sum(-1)
     dKj = alpha[..., None] * delta
     dl = _softmax_pullback(alpha, dalpha, ti, n, H)
@@ -63,8 +65,8 @@ def grad_gatv2_conv(s, t, n, x, Wi, bi, Wj, a, bias, sigma, dy, heads=1, negativ
 
 
 def grad_transformer_conv(s, t, n, x, W1, b1, W2, b2, W3, b3, W4, b4, dy, heads=1, add_self_loops_=False,
-                          skip_connection=False):
-    """(Δx, {name: ΔW / Δb}) for the configuration transformer_conv of oracle/attn_layers.py covers (concat = true)"""
+                          skip_connection=False, concat=True):
+    """(Δx, {name: ΔW / Δb}) for the configuration transformer_conv of oracle/attn_layers.py covers"""
     s, t = O._i64(s), O._i64(t)
     if add_self_loops_:
         s, t, _ = O.add_self_loops(s, t, n)
@@ -78,7 +80,7 @@ def grad_transformer_conv(s, t, n, x, W1, b1, W2, b2, W3, b3, W4, b4, dy, heads=
     l = (Q[ti] * K[si]).sum(-1) / sc
     alpha = _softmax_agg(l, ti, n, H)
     dh = np.asarray(dy, np.float64)
-    delta = dh.reshape(n, H, C)[ti]
+    delta = (dh.reshape(n, H, C) if concat else np.repeat(dh[:, None, :] / H, H, axis=1))[ti]   # ∇mean(x, dims = 2)
     dalpha = (delta * V[si]).sum(-1)
     dV = np.zeros((n, H, C))
     np.add.at(dV, si, alpha[..., None] * delta)

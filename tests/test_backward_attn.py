@@ -61,23 +61,24 @@ def test_oracle_gatv2_adjoint_vs_finite_differences(oracle, AL, AG, sigma):
     _fd_check(loss, [x, Wi, bi, Wj, a, b], list(enumerate(g)), np.random.default_rng(1), per=8, need=35)
 
 
-def test_oracle_transformer_adjoint_vs_finite_differences(oracle, AL, AG):
+@pytest.mark.parametrize("concat", [True, False])
+def test_oracle_transformer_adjoint_vs_finite_differences(oracle, AL, AG, concat):
     rng = np.random.default_rng(32)
     n, H, C = 36, 2, 3
-    Din = H * C
+    Din = Dout = H * C if concat else C
     s, t = _graph(rng, n, 220)
     x = rng.standard_normal((n, Din)).astype(np.float32)
     mk = lambda rr: ((rng.standard_normal((rr, Din)) * 0.5).astype(np.float32), (rng.standard_normal(rr) * 0.1).astype(np.float32))
-    (W1, b1), (W2, b2), (W3, b3), (W4, b4) = mk(H * C), mk(H * C), mk(H * C), mk(H * C)
-    r = rng.standard_normal((n, H * C)).astype(np.float32)
+    (W1, b1), (W2, b2), (W3, b3), (W4, b4) = mk(Dout), mk(H * C), mk(H * C), mk(H * C)
+    r = rng.standard_normal((n, Dout)).astype(np.float32)
 
     def loss(xv, W1v, b1v, W2v, b2v, W3v, b3v, W4v, b4v):
-        y = AL.transformer_conv(s, t, n, xv, W1v, b1v, W2v, b2v, W3v, b3v, W4v, b4v, heads=H, add_self_loops_=True,
-                                skip_connection=True)
+        y = AL.transformer_conv(s, t, n, xv, W1v, b1v, W2v, b2v, W3v, b3v, W4v, b4v, heads=H, concat=concat,
+                                add_self_loops_=True, skip_connection=True)
         return float((y.astype(np.float64) * r).sum())
 
     dx, gw = AG.grad_transformer_conv(s, t, n, x, W1, b1, W2, b2, W3, b3, W4, b4, r, heads=H, add_self_loops_=True,
-                                      skip_connection=True)
+                                      skip_connection=True, concat=concat)
     grads = [(0, dx)] + [(1 + 2 * k, gw[f"W{k + 1}"]) for k in range(4)] + [(2 + 2 * k, gw[f"b{k + 1}"]) for k in range(4)]
     _fd_check(loss, [x, W1, b1, W2, b2, W3, b3, W4, b4], grads, np.random.default_rng(2), per=6, need=40)
 
@@ -152,19 +153,21 @@ def test_hip_gatv2_backward_vs_oracle(gm, AL, AG, H, C, Din, sigma):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("H,C,root,skip,loops", [(2, 4, True, True, True), (8, 16, True, False, False), (1, 32, False, True, True),
-                                                (4, 8, True, False, True)])
-def test_hip_transformer_backward_vs_oracle(gm, AL, AG, H, C, root, skip, loops):
+@pytest.mark.parametrize("H,C,root,skip,loops,concat", [(2, 4, True, True, True, True), (8, 16, True, False, False, True),
+                                                       (1, 32, False, True, True, True), (4, 8, True, False, True, True),
+                                                       (4, 8, True, True, True, False), (3, 5, False, False, False, False)])
+def test_hip_transformer_backward_vs_oracle(gm, AL, AG, H, C, root, skip, loops, concat):
     from gnnmp.backward_attn import transformer_conv_ad
     from gnnmp.layers_attn import TransformerConv
     rng = np.random.default_rng(H * 9 + C)
     n, E = 1400, 22000
     s, t = hub_graph(rng, n, E)
-    Din = H * C if skip else 20
+    Dout = H * C if concat else C
+    Din = Dout if skip else 20
     x = rng.standard_normal((n, Din)).astype(np.float32)
-    r = rng.standard_normal((n, H * C)).astype(np.float32)
+    r = rng.standard_normal((n, Dout)).astype(np.float32)
     g = gm.GNNGraph(dev(s), dev(t), num_nodes=n)
-    l = TransformerConv((Din, C), heads=H, add_self_loops=loops, root_weight=root, skip_connection=skip, seed=6)
+    l = TransformerConv((Din, C), heads=H, concat=concat, add_self_loops=loops, root_weight=root, skip_connection=skip, seed=6)
     names = ["W1", "W2", "W3", "W4"] if root else ["W2", "W3", "W4"]
     for nm in names:
         setattr(l, f"{nm}_bias", dev((rng.standard_normal(getattr(l, f"{nm}_bias").numel()) * 0.1).astype(np.float32)))
@@ -175,9 +178,9 @@ def test_hip_transformer_backward_vs_oracle(gm, AL, AG, H, C, root, skip, loops)
     xt = dev(x).requires_grad_(True)
     y = transformer_conv_ad(l, g, xt)
     args = (w["W1"][0], w["W1"][1], w["W2"][0], w["W2"][1], w["W3"][0], w["W3"][1], w["W4"][0], w["W4"][1])
-    close(y, AL.transformer_conv(s, t, n, x, *args, heads=H, add_self_loops_=loops, skip_connection=skip), 1e-5)
+    close(y, AL.transformer_conv(s, t, n, x, *args, heads=H, concat=concat, add_self_loops_=loops, skip_connection=skip), 1e-5)
     (y * dev(r)).sum().backward()
-    dx, gw = AG.grad_transformer_conv(s, t, n, x, *args, r, heads=H, add_self_loops_=loops, skip_connection=skip)
+    dx, gw = AG.grad_transformer_conv(s, t, n, x, *args, r, heads=H, add_self_loops_=loops, skip_connection=skip, concat=concat)
     close(xt.grad, dx)
     for nm in names:
         k = nm[1]

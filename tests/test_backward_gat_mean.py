@@ -76,3 +76,44 @@ def test_hip_gat_mean_heads_backward_vs_oracle(oracle, H, C, Din):
         gn = got.cpu().numpy()
         assert gn.shape == want.shape
         assert np.linalg.norm(gn - want) <= 3e-5 * np.linalg.norm(want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,C,Din", [(4, 8, 20), (3, 7, 9)])
+def test_hip_gatv2_mean_heads_backward_vs_oracle(oracle, H, C, Din):
+    import torch
+    import gnnmp
+    from gnnmp.backward_attn import gatv2_conv_ad
+    from gnnmp.layers_attn import GATv2Conv
+    from oracle import attn_grads as AG, attn_layers as AL
+    gnnmp.load()
+    rng = np.random.default_rng(H + C)
+    n, E = 1400, 22000
+    s = rng.integers(1, n + 1, E)
+    t = rng.integers(1, n + 1, E)
+    t[:2500] = 7
+    s[3000:5500] = 11
+    p = rng.permutation(E)
+    s, t = s[p], t[p]
+    x = rng.standard_normal((n, Din)).astype(np.float32)
+    r = rng.standard_normal((n, C)).astype(np.float32)
+    dev = lambda v: torch.from_numpy(np.ascontiguousarray(v)).cuda()
+    g = gnnmp.GNNGraph(dev(s), dev(t), num_nodes=n)
+    l = GATv2Conv((Din, C), "relu", heads=H, concat=False, seed=2)
+    l.dense_i_bias = dev((rng.standard_normal(H * C) * 0.1).astype(np.float32))
+    l.bias = dev((rng.standard_normal(C) * 0.1).astype(np.float32))
+    prm = [l.dense_i_weight, l.dense_i_bias, l.dense_j_weight, l.a, l.bias]
+    ref_in = [q.cpu().numpy() for q in prm]
+    for q in prm:
+        q.requires_grad_(True)
+    xt = dev(x).requires_grad_(True)
+    y = gatv2_conv_ad(l, g, xt)
+    ref = AL.gatv2_conv(s, t, n, x, *ref_in, "relu", heads=H, concat=False)
+    assert y.shape == ref.shape == (n, C)
+    assert np.linalg.norm(y.detach().cpu().numpy() - ref) <= 1e-5 * np.linalg.norm(ref)
+    (y * dev(r)).sum().backward()
+    grads = AG.grad_gatv2_conv(s, t, n, x, *ref_in, "relu", r, heads=H, concat=False)
+    for got, want in zip([xt.grad] + [q.grad for q in prm], grads):
+        gn = got.cpu().numpy()
+        assert gn.shape == want.shape
+        assert np.linalg.norm(gn - want) <= 3e-5 * np.linalg.norm(want)
