@@ -1,0 +1,149 @@
+"""Maximum-size cases: feature matrices with more than 2^31 elements (N . D > 2 147 483 647), i.e. every row address of the
+gather / reduce kernels needs 64-bit arithmetic.  The CPU oracle cannot finish these sizes, so parity is checked through
+size-independent properties with an exact expected value:
+
+  * all D columns of a row carry the same small integer -> every column of propagate(copy_xj, +) is the SAME exactly
+    representable integer sum, which torch's int64 index_add_ over (s mod 1024) gives independently;
+  * attention over neighbours that all carry the same value v returns v (softmax weights sum to one), whatever the logits.
+
+The plan itself is int32 by design: a graph with 2^31 or more edges / nodes must be REFUSED, not wrapped."""
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def gm():
+    import torch
+    assert torch.cuda.is_available()
+    import gnnmp
+    gnnmp.load()
+    return gnnmp
+
+
+def _big_graph(torch, n, E, seed):
+    gen = torch.Generator(device="cuda").manual_seed(seed)
+    s = torch.randint(1, n + 1, (E,), device="cuda", generator=gen, dtype=torch.int64)
+    t = torch.randint(1, n + 1, (E,), device="cuda", generator=gen, dtype=torch.int64)
+    # make sure the LAST rows (addresses beyond 2^31 elements / 2^33 bytes) are sources AND destinations
+    s[:4096] = torch.arange(n - 4095, n + 1, device="cuda")
+    t[4096:8192] = torch.arange(n - 4095, n + 1, device="cuda")
+    return s, t
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("aggr", ["+", "max"])
+def test_propagate_beyond_2_pow_31_elements(gm, aggr):
+    import torch
+    n, D, E = 17_000_000, 128, 30_000_000                 # N . D = 2.18e9 > 2^31
+    assert n * D > 2**31
+    s, t = _big_graph(torch, n, E, 1)
+    g = gm.GNNGraph(s, t, num_nodes=n)
+    val = (torch.arange(n, device="cuda", dtype=torch.int64) % 1024)
+    x = val.to(torch.float32)[:, None].expand(n, D).contiguous()
+    out = gm.propagate(gm.copy_xj, g, aggr, xj=x)
+    assert out.shape == (n, D)
+    if aggr == "+":
+        want = torch.zeros(n, dtype=torch.int64, device="cuda").index_add_(0, t - 1, val[s - 1])
+    else:
+        want = torch.full((n,), -1, dtype=torch.int64, device="cuda").scatter_reduce_(0, t - 1, val[s - 1], "amax")
+    assert int(want.max()) < 2**24
+    empty = want < 0 if aggr == "max" else None
+    want = want.to(torch.float32)
+    if empty is not None:
+        want[empty] = float("-inf")                       # empty destinations keep NNlib's identity fill (typemin)
+    for c in (0, 1, 63, D - 1):
+        assert bool((out[:, c] == want).all()), f"column {c}"
+    assert bool((out[n - 4096:] == want[n - 4096:, None]).all())             # the rows past 2^31 elements, every column
+    del out, x
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.gpu
+def test_gather_scatter_beyond_2_pow_31_elements(gm):
+    import torch
+    from gnnmp.msgpass import _gather
+    n, D, K = 17_000_000, 128, 6_000_000
+    val = (torch.arange(n, device="cuda", dtype=torch.int64) % 4096)
+    x = val.to(torch.float32)[:, None].expand(n, D).contiguous()
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    idx = torch.randint(n - 2_000_000, n + 1, (K,), device="cuda", generator=gen, dtype=torch.int64)   # rows past 2^31 elements
+    y = _gather(x, idx)
+    assert y.shape == (K, D)
+    want = val[idx - 1].to(torch.float32)
+    assert bool((y[:, 0] == want).all()) and bool((y[:, D - 1] == want).all()) and bool((y[:, 77] == want).all())
+
+
+@pytest.mark.gpu
+def test_attention_beyond_2_pow_31_elements(gm):
+    import torch
+    n, H, C, E = 17_000_000, 8, 16, 24_000_000            # N . H . C = 2.18e9 > 2^31
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    t = torch.randint(1, n + 1, (E,), device="cuda", generator=gen, dtype=torch.int64)
+    t[:4096] = torch.arange(n - 4095, n + 1, device="cuda")
+    # sources congruent to the destination mod 7: every neighbour of t (and t itself through its self loop) carries t mod 7
+    k = torch.randint(0, (n // 7) - 1, (E,), device="cuda", generator=gen, dtype=torch.int64)
+    s = ((t - 1) % 7) + 7 * k + 1
+    assert int(s.max()) <= n and int(s.min()) >= 1
+    g = gm.GNNGraph(s, t, num_nodes=n)
+    val = ((torch.arange(n, device="cuda", dtype=torch.int64) % 7) + 1).to(torch.float32)
+    Wx = val[:, None].expand(n, H * C).contiguous()
+    # logits that differ per edge (random a): the weights are non-trivial, their sum is still one
+    a = torch.randn((2 * C, H), device="cuda", generator=gen) * 0.3
+    l = gm.GATConv((4, C), None, heads=H, bias=False, seed=1)
+    l.a = a
+    from gnnmp import _lib as L
+    out = torch.empty((n, H * C), dtype=torch.float32, device="cuda")
+    L.check(L.load().gnnmp_gat_conv_f32(g.plan(True).handle, L.ptr(Wx), None, L.ptr(l.a_hc), 0.2, None, L.ACT_IDENTITY,
+                                        L.ptr(out), H, C, L.stream_ptr()))
+    torch.cuda.synchronize()
+    err = (out - val[:, None]).abs().amax(dim=1)
+    assert float(err.max()) <= 1e-5 * 7, float(err.max())
+    assert float(err[n - 4096:].max()) <= 1e-5 * 7
+
+
+@pytest.mark.gpu
+def test_dense_and_its_adjoints_beyond_2_pow_31_elements(gm):
+    import torch
+    from gnnmp.backward import dense_grad_w, dense_grad_x
+    n, Din, Dout = 17_000_000, 128, 128
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn((n, Din), device="cuda", generator=gen)
+    W = torch.randn((Dout, Din), device="cuda", generator=gen) / Din ** 0.5
+    b = torch.randn((Dout,), device="cuda", generator=gen) * 0.1
+    y = gm.dense(x, W, b, "relu")
+    tail = slice(n - 8192, n)                              # rows whose addresses lie past 2^31 elements
+    ref = torch.relu(x[tail].double() @ W.double().t() + b.double())
+    assert float((y[tail].double() - ref).norm()) <= 1e-5 * float(ref.norm())
+    head = torch.relu(x[:8192].double() @ W.double().t() + b.double())
+    assert float((y[:8192].double() - head).norm()) <= 1e-5 * float(head.norm())
+    dx = dense_grad_x(y, W)
+    ref = y[tail].double() @ W.double()
+    assert float((dx[tail].double() - ref).norm()) <= 1e-5 * float(ref.norm())
+    del dx
+    # dW = y' x sums over all 17M rows: a miss of the rows past 2^31 elements is an O(1) relative error.  Reference in
+    # float64 over row blocks (keeps the float64 copies small).
+    dW, db = dense_grad_w(y, x)
+    refW = torch.zeros((Dout, Din), dtype=torch.float64, device="cuda")
+    refb = torch.zeros((Dout,), dtype=torch.float64, device="cuda")
+    for r0 in range(0, n, 1_000_000):
+        yb = y[r0:r0 + 1_000_000].double()
+        refW += yb.t() @ x[r0:r0 + 1_000_000].double()
+        refb += yb.sum(0)
+    assert float((dW.double() - refW).norm()) <= 2e-5 * float(refW.norm())
+    assert float((db.double() - refb).norm()) <= 2e-5 * float(refb.norm())
+
+
+@pytest.mark.gpu
+def test_plan_refuses_what_int32_cannot_index(gm):
+    import torch
+    from gnnmp import _lib as L
+    lib = L.load()
+    s = torch.ones(4, dtype=torch.int64, device="cuda")
+    import ctypes
+    h = ctypes.c_void_p()
+    rc = lib.gnnmp_plan_create(ctypes.byref(h), L.ptr(s), L.ptr(s), 8, 1, 2**31, 2**31, 4, 0, 0, L.stream_ptr())
+    assert rc != 0 and not h.value
+    rc = lib.gnnmp_plan_create(ctypes.byref(h), L.ptr(s), L.ptr(s), 8, 1, 4, 4, 2**31 + 5, 0, 0, L.stream_ptr())
+    assert rc != 0 and not h.value
+    rc = lib.gnnmp_plan_create(ctypes.byref(h), L.ptr(s), L.ptr(s), 8, 1, 2**31 - 2, 2**31 - 2, 4, 1, 0, L.stream_ptr())
+    assert rc != 0 and not h.value                        # E + n self loops does not fit either
