@@ -187,6 +187,58 @@ __global__ void __launch_bounds__(256) head_mean_grad_kernel(const float *dz, fl
     const int c = (int)(i % C);
     dy[i] = dz[n * C + c] / (float)H;
 }
+// sum over the G lanes (a power of two <= 64) that share a row
+template <int G>
+__device__ __forceinline__ float lanes_sum(float v) {
+#pragma unroll
+    for (int o = G >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+// xn = x ./ sqrt.(sum(x .^ 2, dims = 1))  (agnn_conv, GNNlib/src/layers/conv.jl:341-342): G lanes per row, the norm kept
+template <int G>
+__global__ void __launch_bounds__(256) row_normalize_kernel(const float *__restrict__ x, float *__restrict__ xn,
+                                                            float *__restrict__ rnorm, int64_t N, int D) {
+    const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
+    const int l = threadIdx.x & (G - 1);
+    const int64_t rc = min(row, N - 1);
+    const float *xr = x + rc * D;
+    float ss = 0.0f;
+    for (int k = l; k < D; k += G) { const float v = xr[k]; ss += v * v; }
+    const float r = sqrtf(lanes_sum<G>(ss));
+    if (row >= N) return;
+    for (int k = l; k < D; k += G) xn[rc * D + k] = xr[k] / r;
+    if (l == 0 && rnorm) rnorm[rc] = r;
+}
+// pullback of the row normalisation with two cotangents of xn (as query and as key of the attention):
+//   dn = dq + dk,  dx = base + (dn - xn (xn . dn)) / r,   qdot[row] = qscale (xn . dq)  (the share that carries d/dβ)
+template <int G>
+__global__ void __launch_bounds__(256) row_normalize_grad_kernel(const float *__restrict__ dq, const float *__restrict__ dk,
+                                                                 const float *__restrict__ xn, const float *__restrict__ rnorm,
+                                                                 const float *__restrict__ base, float *__restrict__ dx,
+                                                                 float *__restrict__ qdot, float qscale, int64_t N, int D) {
+    const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
+    const int l = threadIdx.x & (G - 1);
+    const int64_t rc = min(row, N - 1);
+    const int64_t o = rc * D;
+    float p = 0.0f, q = 0.0f;
+    for (int k = l; k < D; k += G) {
+        const float n = xn[o + k];
+        const float a = dq ? dq[o + k] : 0.0f, b = dk ? dk[o + k] : 0.0f;
+        p += n * (a + b);
+        q += n * a;
+    }
+    p = lanes_sum<G>(p);
+    q = lanes_sum<G>(q);
+    if (row >= N) return;
+    const float r = rnorm[rc];
+    for (int k = l; k < D; k += G) {
+        const float n = xn[o + k];
+        const float dn = (dq ? dq[o + k] : 0.0f) + (dk ? dk[o + k] : 0.0f);
+        const float v = (dn - n * p) / r;
+        dx[o + k] = base ? base[o + k] + v : v;
+    }
+    if (l == 0 && qdot) qdot[rc] = qscale * q;
+}
 // flag[0] = 1 if idx[k] > idx[k+1] for some k
 __global__ void __launch_bounds__(256) unsorted_kernel(const void *idx, int idx_bytes, int64_t n, int *flag) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -315,6 +367,49 @@ int gnnmp_head_mean_grad_f32(const float *dz, float *dy, int64_t N, int64_t H, i
     if (!dz || !dy) return fail(GNNMP_EINVAL, "head_mean_grad: null pointer");
     head_mean_grad_kernel<<<(unsigned)((N * H * C + 255) / 256), 256, 0, stream>>>(dz, dy, N, (int)H, (int)C);
     GNNMP_LAUNCH_CHECK("head_mean_grad_kernel");
+    return GNNMP_OK;
+}
+
+static int row_group(int64_t D) {   // lanes per row: the power of two >= D, clamped to [4, 64]
+    int g = 4;
+    while (g < 64 && g < D) g <<= 1;
+    return g;
+}
+
+int gnnmp_row_normalize_f32(const float *x, float *xn, float *rnorm, int64_t N, int64_t D, gnnmp_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (N < 0 || D <= 0 || D > (1 << 20)) return fail(GNNMP_EINVAL, "row_normalize: bad size");
+    if (N == 0) return GNNMP_OK;
+    if (!x || !xn) return fail(GNNMP_EINVAL, "row_normalize: null pointer");
+    const int g = row_group(D);
+    const unsigned grid = (unsigned)((N * g + 255) / 256);
+    switch (g) {
+        case 4: row_normalize_kernel<4><<<grid, 256, 0, stream>>>(x, xn, rnorm, N, (int)D); break;
+        case 8: row_normalize_kernel<8><<<grid, 256, 0, stream>>>(x, xn, rnorm, N, (int)D); break;
+        case 16: row_normalize_kernel<16><<<grid, 256, 0, stream>>>(x, xn, rnorm, N, (int)D); break;
+        case 32: row_normalize_kernel<32><<<grid, 256, 0, stream>>>(x, xn, rnorm, N, (int)D); break;
+        default: row_normalize_kernel<64><<<grid, 256, 0, stream>>>(x, xn, rnorm, N, (int)D); break;
+    }
+    GNNMP_LAUNCH_CHECK("row_normalize_kernel");
+    return GNNMP_OK;
+}
+
+int gnnmp_row_normalize_grad_f32(const float *dq, const float *dk, const float *xn, const float *rnorm, const float *base,
+                                 float *dx, float *qdot, float qscale, int64_t N, int64_t D, gnnmp_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (N < 0 || D <= 0 || D > (1 << 20)) return fail(GNNMP_EINVAL, "row_normalize_grad: bad size");
+    if (N == 0) return GNNMP_OK;
+    if (!xn || !rnorm || !dx || (!dq && !dk)) return fail(GNNMP_EINVAL, "row_normalize_grad: null pointer");
+    const int g = row_group(D);
+    const unsigned grid = (unsigned)((N * g + 255) / 256);
+    switch (g) {
+        case 4: row_normalize_grad_kernel<4><<<grid, 256, 0, stream>>>(dq, dk, xn, rnorm, base, dx, qdot, qscale, N, (int)D); break;
+        case 8: row_normalize_grad_kernel<8><<<grid, 256, 0, stream>>>(dq, dk, xn, rnorm, base, dx, qdot, qscale, N, (int)D); break;
+        case 16: row_normalize_grad_kernel<16><<<grid, 256, 0, stream>>>(dq, dk, xn, rnorm, base, dx, qdot, qscale, N, (int)D); break;
+        case 32: row_normalize_grad_kernel<32><<<grid, 256, 0, stream>>>(dq, dk, xn, rnorm, base, dx, qdot, qscale, N, (int)D); break;
+        default: row_normalize_grad_kernel<64><<<grid, 256, 0, stream>>>(dq, dk, xn, rnorm, base, dx, qdot, qscale, N, (int)D); break;
+    }
+    GNNMP_LAUNCH_CHECK("row_normalize_grad_kernel");
     return GNNMP_OK;
 }
 

@@ -145,6 +145,48 @@ class _TransformerConvFn(torch.autograd.Function):
         return dx, dW1, db1, dW2, db2, dW3, db3, dW4, db4, None, None, None, None, None, None
 
 
+class _AGNNConvFn(torch.autograd.Function):
+    """agnn_conv (conv.jl:337-352) as the reference writes it — xn = x ./ norm, α = softmax(β (xn_i . xn_j)), Σ α x_j — so
+    that the pullback is the dot-product attention pullback on (Q, K, V) = (xn, xn, x) plus the row normalisation's:
+      Δx = ΔV + ∇normalise(ΔQ + ΔK),   Δβ = Σ_e Δlogit_e cos_e = (1 / β) Σ_i xn_i . ΔQ_i   (ΔQ_i = β Σ_e Δlogit_e xn_j)"""
+
+    @staticmethod
+    def forward(ctx, x, beta, g, loops):
+        x = x.contiguous()
+        N, D = x.shape
+        b = float(beta)
+        assert b != 0.0, "β = 0 makes every logit zero: Δβ is not recoverable from ΔQ (use a non-zero init_beta)"
+        lib = L.load()
+        xn = torch.empty_like(x)
+        rn = torch.empty(N, dtype=torch.float32, device=x.device)
+        L.check(lib.gnnmp_row_normalize_f32(L.ptr(x), L.ptr(xn), L.ptr(rn), N, D, L.stream_ptr()))
+        out, stats = _attn_forward(g.plan(loops), ATTN_DOT, xn, xn, x, None, 0.0, 1.0 / b, None, L.ACT_IDENTITY, 1, D)
+        ctx.save_for_backward(x, xn, rn, stats)
+        ctx.g, ctx.loops, ctx.b = g, loops, b
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, xn, rn, stats = ctx.saved_tensors
+        N, D = x.shape
+        dQ, dK, dV, _ = _attn_backward(ctx.g, ctx.loops, ATTN_DOT, xn, xn, x, None, 0.0, 1.0 / ctx.b, stats, dy.contiguous(), 1, D)
+        dx = torch.empty_like(x)
+        qdot = torch.empty((N, 1), dtype=torch.float32, device=x.device)
+        L.check(L.load().gnnmp_row_normalize_grad_f32(L.ptr(dQ), L.ptr(dK), L.ptr(xn), L.ptr(rn), L.ptr(dV), L.ptr(dx),
+                                                      L.ptr(qdot), 1.0 / ctx.b, N, D, L.stream_ptr()))
+        dbeta = None
+        if ctx.needs_input_grad[1]:
+            dbeta = dense_grad_w(qdot, qdot, need_w=False)[1]                   # deterministic column sum of (N, 1)
+        return dx, dbeta, None, None
+
+
+def agnn_conv_ad(l, g: GNNGraph, x):
+    """differentiable AGNNConv forward: gradients w.r.t. x and β (when `l.beta` is a 1-element tensor that requires grad)"""
+    check_num_nodes(g, x)
+    beta = l.beta if torch.is_tensor(l.beta) else torch.tensor([float(l.beta)], dtype=torch.float32, device=x.device)
+    return _AGNNConvFn.apply(x, beta, g, bool(l.add_self_loops))
+
+
 def transformer_conv_ad(l, g: GNNGraph, x):
     """differentiable TransformerConv forward (concat = true or false): gradients w.r.t. x and W1..W4 (+ their biases)"""
     check_num_nodes(g, x)

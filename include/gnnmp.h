@@ -355,6 +355,16 @@ int gnnmp_head_mean_f32(const float *y, const float *bias, int act, float *out, 
                         int64_t C, gnnmp_stream_t stream);
 /* its pullback: dy[n][h][c] = dz[n][c] / H (the heads' gradient of `mean(x, dims = 2)`) */
 int gnnmp_head_mean_grad_f32(const float *dz, float *dy, int64_t N, int64_t H, int64_t C, gnnmp_stream_t stream);
+/* xn[n][:] = x[n][:] / sqrt(sum(x[n][:]^2)) — `xn = x ./ sqrt.(sum(x .^ 2, dims = 1))` of agnn_conv
+ * (GNNlib/src/layers/conv.jl:341-342); rnorm (optional) keeps the norms for the pullback.  A zero row gives NaN like the
+ * reference's 0 / 0. */
+int gnnmp_row_normalize_f32(const float *x, float *xn, float *rnorm, int64_t N, int64_t D, gnnmp_stream_t stream);
+/* its pullback for the two uses of xn in the attention (query and key cotangents dq, dk; either may be NULL):
+ *   dn = dq + dk;  dx = base + (dn - xn (xn . dn)) / rnorm   (base optional: another cotangent of x, e.g. the value's);
+ *   qdot[n] = qscale (xn[n] . dq[n]) (optional): with logit = β (xn_i . xn_j) and qscale = 1 / β, Σ_n qdot[n] = dL/dβ. */
+int gnnmp_row_normalize_grad_f32(const float *dq, const float *dk, const float *xn, const float *rnorm,
+                                 const float *base, float *dx, float *qdot, float qscale, int64_t N, int64_t D,
+                                 gnnmp_stream_t stream);
 /* out = a + b (n floats) — degree(g; dir = :both) = out-degree + in-degree (GNNGraphs/src/query.jl:362-367). */
 int gnnmp_add_f32(const float *a, const float *b, float *out, int64_t n, gnnmp_stream_t stream);
 /* out[n][:] = a[n][:] .* b[n][:] with a of 1 channel (broadcast) or D channels — `α .* l.ffeat(x)` of

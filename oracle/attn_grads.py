@@ -64,6 +64,32 @@ def grad_gatv2_conv(s, t, n, x, Wi, bi, Wj, a, bias, sigma, dy, heads=1, negativ
             da.T.astype(f), db.astype(f))
 
 
+def grad_agnn_conv(s, t, n, x, beta, dy, add_self_loops_=True):
+    """(Δx, Δβ) of agnn_conv (GNNlib/src/layers/conv.jl:337-352): xn = x ./ norm, α = softmax(β cos), out = Σ α x_j"""
+    s, t = O._i64(s), O._i64(t)
+    if add_self_loops_:
+        s, t, _ = O.add_self_loops(s, t, n)
+    si, ti = s - 1, t - 1
+    x64 = np.asarray(x, np.float64)
+    b = float(beta)
+    r = np.sqrt((x64 * x64).sum(1))
+    xn = x64 / r[:, None]
+    cos = (xn[ti] * xn[si]).sum(1)[:, None]                          # [E', 1]
+    alpha = _softmax_agg(b * cos, ti, n, 1)
+    delta = np.asarray(dy, np.float64)[ti]
+    dalpha = (delta * x64[si]).sum(1)[:, None]
+    dx = np.zeros_like(x64)
+    np.add.at(dx, si, alpha * delta)                                # through the message α .* xj
+    dl = _softmax_pullback(alpha, dalpha, ti, n, 1)
+    dbeta = float((dl * cos).sum())
+    dcos = dl * b
+    dxn = np.zeros_like(x64)
+    np.add.at(dxn, ti, dcos * xn[si])
+    np.add.at(dxn, si, dcos * xn[ti])
+    dx += (dxn - xn * (xn * dxn).sum(1)[:, None]) / r[:, None]      # through x ./ sqrt.(sum(x .^ 2, dims = 1))
+    return dx.astype(np.float32), np.float32(dbeta)
+
+
 def grad_transformer_conv(s, t, n, x, W1, b1, W2, b2, W3, b3, W4, b4, dy, heads=1, add_self_loops_=False,
                           skip_connection=False, concat=True):
     """(Δx, {name: ΔW / Δb}) for the configuration transformer_conv of oracle/attn_layers.py covers"""

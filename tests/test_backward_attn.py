@@ -83,6 +83,21 @@ def test_oracle_transformer_adjoint_vs_finite_differences(oracle, AL, AG, concat
     _fd_check(loss, [x, W1, b1, W2, b2, W3, b3, W4, b4], grads, np.random.default_rng(2), per=6, need=40)
 
 
+def test_oracle_agnn_adjoint_vs_finite_differences(oracle, AL, AG):
+    rng = np.random.default_rng(41)
+    n, D = 30, 5
+    s, t = _graph(rng, n, 180)
+    x = rng.standard_normal((n, D)).astype(np.float32)
+    r = rng.standard_normal((n, D)).astype(np.float32)
+    beta = np.array([1.7], np.float32)
+
+    def loss(xv, bv):
+        return float((AL.agnn_conv(s, t, n, xv, float(bv[0])).astype(np.float64) * r).sum())
+
+    dx, db = AG.grad_agnn_conv(s, t, n, x, float(beta[0]), r)
+    _fd_check(loss, [x, beta], [(0, dx), (1, np.array([db], np.float32))], np.random.default_rng(4), per=20, need=15)
+
+
 # ------------------------------------------------------------------------------------------------- GPU
 @pytest.fixture(scope="module")
 def gm():
@@ -186,6 +201,38 @@ def test_hip_transformer_backward_vs_oracle(gm, AL, AG, H, C, root, skip, loops,
         k = nm[1]
         close(getattr(l, f"{nm}_weight").grad, gw[f"W{k}"])
         close(getattr(l, f"{nm}_bias").grad, gw[f"b{k}"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,beta,loops", [(16, 1.0, True), (100, 2.5, True), (7, 0.6, False), (64, -1.3, True)])
+def test_hip_agnn_backward_vs_oracle(gm, AL, AG, D, beta, loops):
+    import torch
+    from gnnmp.backward_attn import agnn_conv_ad
+    from gnnmp.layers_attn import AGNNConv
+    rng = np.random.default_rng(D)
+    n, E = 1500, 24000
+    s, t = hub_graph(rng, n, E)
+    if not loops:                                          # every node needs an in-edge (softmax over an empty set otherwise)
+        s = np.concatenate([s, np.roll(np.arange(1, n + 1), 1)])
+        t = np.concatenate([t, np.arange(1, n + 1)])
+    x = rng.standard_normal((n, D)).astype(np.float32)
+    r = rng.standard_normal((n, D)).astype(np.float32)
+    g = gm.GNNGraph(dev(s), dev(t), num_nodes=n)
+    l = AGNNConv(init_beta=beta, add_self_loops=loops)
+    l.beta = torch.tensor([beta], dtype=torch.float32, device="cuda", requires_grad=True)
+    xt = dev(x).requires_grad_(True)
+    y = agnn_conv_ad(l, g, xt)
+    ref = AL.agnn_conv(s, t, n, x, beta, add_self_loops_=loops)
+    close(y, ref, 1e-5)
+    plain = AGNNConv(init_beta=beta, add_self_loops=loops)(g, dev(x))       # the one-pass cosine kernel: same layer
+    close(plain, ref, 1e-5)
+    (y * dev(r)).sum().backward()
+    dx, db = AG.grad_agnn_conv(s, t, n, x, beta, r, add_self_loops_=loops)
+    close(xt.grad, dx)
+    assert abs(float(l.beta.grad[0]) - float(db)) <= 1e-4 * max(1.0, abs(float(db)))
+    xt2 = dev(x).requires_grad_(True)
+    (agnn_conv_ad(l, g, xt2) * dev(r)).sum().backward()
+    assert bool((xt2.grad == xt.grad).all())
 
 
 @pytest.mark.gpu
