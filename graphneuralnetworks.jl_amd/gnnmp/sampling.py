@@ -67,14 +67,12 @@ def _out_plan(g: GNNGraph) -> Plan:
 
 def sample_neighbors(g: GNNGraph, nodes, K: int = -1, dir: str = "in", replace: bool = False, dropnodes: bool = False,
                      seed: int = 0):
-    """sample_neighbors(g, nodes, K; dir, replace) — sampling.jl:68-119 with dropnodes = false: a graph on the same
-    node set holding, for every seed node, K of its incoming (dir = "in") or outgoing ("out") edges drawn uniformly
-    (all of them if K <= 0 or, without replacement, if it has fewer).  `.eid` of the result holds the positions of the
-    kept edges in g (the reference's edata.EID).  The draw is reproducible in `seed`; it is not Julia's RNG stream."""
+    """sample_neighbors(g, nodes, K; dir, replace, dropnodes) — sampling.jl:68-119: a graph holding, for every seed
+    node, K of its incoming (dir = "in") or outgoing ("out") edges drawn uniformly (all of them if K <= 0 or, without
+    replacement, if it has fewer) — on the same node set, or with dropnodes = true on the seeds followed by the sampled
+    neighbours in first-appearance order (`.nid` = the reference's ndata.NID).  `.eid` of the result holds the
+    positions of the kept edges in g (edata.EID).  The draw is reproducible in `seed`; it is not Julia's RNG stream."""
     assert dir in ("in", "out")
-    if dropnodes:
-        raise NotImplementedError("sample_neighbors(dropnodes = true) relabels nodes on the host in the reference; "
-                                  "not on the device path yet")
     nodes = nodes.to(device=g.device, dtype=g.s.dtype).contiguous()
     plan = g.plan(False) if dir == "in" else _out_plan(g)
     M = nodes.numel()
@@ -94,8 +92,24 @@ def sample_neighbors(g: GNNGraph, nodes, K: int = -1, dir: str = "in", replace: 
         w = torch.empty(eids.numel(), dtype=torch.float32, device=g.device)
         L.check(lib.gnnmp_gather_f32(L.ptr(g.w), L.ptr(eids), g.idx_bytes, g.index_base, eids.numel(), L.ptr(w), 1,
                                      L.stream_ptr()))
-    gnew = GNNGraph(s, t, w, num_nodes=g.num_nodes, graph_indicator=g.graph_indicator, num_graphs=g.num_graphs, x=g.x,
-                    index_base=g.index_base, device=g.device, _validated=True)
+    if not dropnodes:
+        gnew = GNNGraph(s, t, w, num_nodes=g.num_nodes, graph_indicator=g.graph_indicator, num_graphs=g.num_graphs, x=g.x,
+                        index_base=g.index_base, device=g.device, _validated=True)
+    else:
+        # sampling.jl:100-116: nodes_all = [nodes; setdiff(s | t, nodes)] (first-appearance order), edges relabelled by
+        # position in nodes_all, node data restricted to nodes_all, ndata.NID = nodes_all.  The ordered device set gives
+        # exactly that list and its inverse map (1-based positions, 0 = absent).
+        ns = NodeSet(g)
+        ns.add(nodes)
+        assert ns.nodes.numel() == nodes.numel(), "sample_neighbors(dropnodes = true): `nodes` must not repeat a node"
+        ns.add(s if dir == "in" else t)
+        relabel = lambda v: _take_index(ns.map, v, g.index_base).to(g.s.dtype) - (1 - g.index_base)   # index plumbing
+        from .msgpass import _gather
+        gi = None if g.graph_indicator is None else _take_index(g.graph_indicator, ns.nodes, g.index_base)
+        x = None if g.x is None else _gather(g.x, ns.nodes, g.index_base)
+        gnew = GNNGraph(relabel(s), relabel(t), w, num_nodes=ns.nodes.numel(), graph_indicator=gi, num_graphs=g.num_graphs,
+                        x=x, index_base=g.index_base, device=g.device, _validated=True)
+        gnew.nid = ns.nodes
     gnew.eid = eids
     gnew.sample_offsets = offsets
     return gnew

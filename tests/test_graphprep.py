@@ -121,6 +121,56 @@ def test_sample_neighbors_reference_properties(gm, idx):
         assert set(eid[ss == i]) <= set(adjo[i - 1])
 
 
+def _ref_dropnodes(s, t, nodes, eids, dir):
+    """sampling.jl:100-116 restated: nodes_all = [nodes; setdiff(s | t, nodes)], edges relabelled by position"""
+    ss, tt = s[eids - 1], t[eids - 1]
+    other = []
+    seen = set(int(v) for v in nodes)
+    for v in (ss if dir == "in" else tt):                            # setdiff keeps first-appearance order
+        if int(v) not in seen:
+            seen.add(int(v))
+            other.append(int(v))
+    nodes_all = np.array([int(v) for v in nodes] + other)
+    pos = {v: i + 1 for i, v in enumerate(nodes_all)}
+    return nodes_all, np.array([pos[int(v)] for v in ss]), np.array([pos[int(v)] for v in tt])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dir,K,idx", [("in", -1, "int64"), ("out", -1, "int32"), ("in", 3, "int64"), ("out", 2, "int64")])
+def test_sample_neighbors_dropnodes_relabels_like_the_reference(gm, dir, K, idx):
+    from gnnmp import sampling as S
+    rng = np.random.default_rng(12)
+    n, E, D = 60, 500, 5
+    s = rng.integers(1, n + 1, E).astype(idx)
+    t = rng.integers(1, n + 1, E).astype(idx)
+    x = rng.standard_normal((n, D)).astype(np.float32)
+    w = rng.random(E).astype(np.float32)
+    g = gm.GNNGraph(dev(s), dev(t), dev(w), num_nodes=n, x=dev(x))
+    nodes = np.array([7, 2, 31, 40])
+    sg = S.sample_neighbors(g, dev(nodes), K, dir=dir, dropnodes=True, seed=3)
+    eid = sg.eid.cpu().numpy()
+    nid = sg.nid.cpu().numpy()
+    nodes_all, rs, rt = _ref_dropnodes(s, t, nodes, eid, dir)       # the relabelling is deterministic given the draw
+    np.testing.assert_array_equal(nid, nodes_all)
+    np.testing.assert_array_equal(sg.s.cpu().numpy(), rs)
+    np.testing.assert_array_equal(sg.t.cpu().numpy(), rt)
+    assert sg.s.dtype == g.s.dtype and sg.num_nodes == len(nodes_all)
+    # test/sampling.jl:35-46
+    if K < 0:
+        key = t if dir == "in" else s
+        assert sg.num_edges == sum(int((key == i).sum()) for i in nodes)
+    assert eid.shape == (sg.num_edges,) and nid.shape == (sg.num_nodes,)
+    np.testing.assert_array_equal(sg.w.cpu().numpy(), w[eid - 1])
+    np.testing.assert_array_equal(sg.x.cpu().numpy(), x[nid - 1])
+    assert len(np.unique(nid)) == len(nid)
+    # the relabelled graph is usable on the path: propagate over it equals the oracle on the relabelled COO
+    out = gm.propagate(gm.copy_xj, sg, "+", xj=sg.x).cpu().numpy()
+    want = np.zeros((len(nid), D), np.float32)
+    for a, b in zip(rs, rt):
+        want[b - 1] += x[nid[a - 1] - 1]
+    np.testing.assert_allclose(out, want, rtol=1e-5, atol=1e-6)
+
+
 @pytest.mark.gpu
 def test_sample_neighbors_large_counts_uniqueness_uniformity(gm):
     from gnnmp import sampling as S
