@@ -165,6 +165,34 @@ __global__ void sample_fill_kernel(const int32_t *rowptr, const int32_t *eid, co
         }
         return;
     }
+    if ((int64_t)d > 2 * k * k) {
+        // Hub seed, few picks: Floyd's algorithm — a uniformly random k-subset of the d slots in k draws (not d): for
+        // j = d-k .. d-1 draw r in [0, j]; take r unless it is already chosen, then take j (never chosen before).  The
+        // chosen slots are kept sorted in the output (insertion, O(k) each), so the result is in original edge order like
+        // the selection sampling below; O(k^2) instead of O(d) keeps a 17 000-edge seed from being the kernel.
+        for (int64_t c = 0; c < k; ++c) {
+            const int j = d - (int)k + (int)c;
+            const int r = min(j, (int)(uniform01(seed, (uint64_t)i, (uint64_t)c) * (double)(j + 1)));
+            int64_t lo = 0, hi = c;                    // first position with slot >= r among the c sorted picks
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (load_index(eids_out, o + mid, idx_bytes, 0) < r) lo = mid + 1; else hi = mid;
+            }
+            const bool taken = lo < c && load_index(eids_out, o + lo, idx_bytes, 0) == r;
+            if (taken) {
+                store_index(eids_out, o + c, idx_bytes, (int64_t)j);        // j exceeds every earlier pick: append
+            } else {
+                for (int64_t q = c; q > lo; --q)
+                    store_index(eids_out, o + q, idx_bytes, load_index(eids_out, o + q - 1, idx_bytes, 0));
+                store_index(eids_out, o + lo, idx_bytes, (int64_t)r);
+            }
+        }
+        for (int64_t c = 0; c < k; ++c) {
+            const int p = (int)load_index(eids_out, o + c, idx_bytes, 0);
+            store_index(eids_out, o + c, idx_bytes, (int64_t)eid[beg + p] + base);
+        }
+        return;
+    }
     int64_t chosen = 0;
     for (int p = 0; p < d && chosen < k; ++p) {
         // take slot p with probability (k - chosen) / (d - p)

@@ -207,6 +207,20 @@ def test_sample_neighbors_large_counts_uniqueness_uniformity(gm):
     p = 200 / d
     z = (h - R * p) / np.sqrt(R * p * (1 - p))
     assert abs(z.mean()) < 0.15 and 0.85 < z.std() < 1.15 and np.abs(z).max() < 5.5
+    # few picks from the hub (d > 2 K^2: the kernel's Floyd branch instead of the O(d) selection scan): same properties
+    hits[:] = 0
+    R, Kf = 3000, 8
+    hub_pos = np.nonzero(t == 9)[0] + 1
+    for r in range(R):
+        e = S.sample_neighbors(g, dev(hub), Kf, seed=50000 + r).eid.cpu().numpy()
+        assert len(e) == Kf and len(np.unique(e)) == Kf
+        assert (np.diff(np.searchsorted(hub_pos, e)) > 0).all()     # kept in original edge order
+        hits[e] += 1
+    h = hits[hub_pos]
+    assert h.sum() == Kf * R and hits.sum() == h.sum()
+    p = Kf / d
+    z = (h - R * p) / np.sqrt(R * p * (1 - p))
+    assert abs(z.mean()) < 0.15 and 0.85 < z.std() < 1.15 and np.abs(z).max() < 6.0
     # with replacement: k independent uniform picks
     e = S.sample_neighbors(g, dev(hub), 20000, replace=True, seed=2).eid.cpu().numpy()
     assert len(e) == 20000 and set(e) <= set(np.nonzero(t == 9)[0] + 1)
