@@ -239,6 +239,25 @@ __global__ void __launch_bounds__(256) row_normalize_grad_kernel(const float *__
     }
     if (l == 0 && qdot) qdot[rc] = qscale * q;
 }
+// Flux.GRUCell's pointwise part (the cell of gated_graph_conv, GNNlib/src/layers/conv.jl:228-232; Flux 0.16, un-vendored):
+// gx = Wi m, gh = Wh h, both [N][3D] with the gates in the order r, z, candidate, b [3D] (nullable):
+//   r = σ(gx_r + gh_r + b_r),  z = σ(gx_z + gh_z + b_z),  h~ = tanh(gx_n + r .* gh_n + b_n),  h' = (1 - z) .* h~ + z .* h
+__global__ void __launch_bounds__(256) gru_pointwise_kernel(const float *__restrict__ gx, const float *__restrict__ gh,
+                                                            const float *__restrict__ b, const float *__restrict__ h,
+                                                            float *__restrict__ out, int64_t N, int D) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * D) return;
+    const int64_t n = i / D;
+    const int d = (int)(i - n * D);
+    const int64_t o = n * 3 * D + d;
+    const float br = b ? b[d] : 0.0f, bz = b ? b[D + d] : 0.0f, bn = b ? b[2 * D + d] : 0.0f;
+    const float xr = gx[o] + gh[o] + br, xz = gx[o + D] + gh[o + D] + bz;
+    const float tr = expf(-fabsf(xr)), tz = expf(-fabsf(xz));
+    const float r = xr >= 0.0f ? 1.0f / (1.0f + tr) : tr / (1.0f + tr);
+    const float z = xz >= 0.0f ? 1.0f / (1.0f + tz) : tz / (1.0f + tz);
+    const float c = tanhf(gx[o + 2 * D] + r * gh[o + 2 * D] + bn);
+    out[i] = (1.0f - z) * c + z * h[i];
+}
 // flag[0] = 1 if idx[k] > idx[k+1] for some k
 __global__ void __launch_bounds__(256) unsorted_kernel(const void *idx, int idx_bytes, int64_t n, int *flag) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -367,6 +386,17 @@ int gnnmp_head_mean_grad_f32(const float *dz, float *dy, int64_t N, int64_t H, i
     if (!dz || !dy) return fail(GNNMP_EINVAL, "head_mean_grad: null pointer");
     head_mean_grad_kernel<<<(unsigned)((N * H * C + 255) / 256), 256, 0, stream>>>(dz, dy, N, (int)H, (int)C);
     GNNMP_LAUNCH_CHECK("head_mean_grad_kernel");
+    return GNNMP_OK;
+}
+
+int gnnmp_gru_pointwise_f32(const float *gx, const float *gh, const float *b, const float *h, float *out, int64_t N, int64_t D,
+                            gnnmp_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (N < 0 || D <= 0 || D > (1 << 20)) return fail(GNNMP_EINVAL, "gru_pointwise: bad size");
+    if (N == 0) return GNNMP_OK;
+    if (!gx || !gh || !h || !out) return fail(GNNMP_EINVAL, "gru_pointwise: null pointer");
+    gru_pointwise_kernel<<<(unsigned)((N * D + 255) / 256), 256, 0, stream>>>(gx, gh, b, h, out, N, (int)D);
+    GNNMP_LAUNCH_CHECK("gru_pointwise_kernel");
     return GNNMP_OK;
 }
 

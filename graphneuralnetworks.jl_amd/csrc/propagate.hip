@@ -29,7 +29,11 @@ struct ReduceArgs {
     const float *rowsub;     // [n_dst][D]: the message is exp(x - rowsub[row]) (softmax numerator, utils.jl:94)
     const float *rowden;     // [n_dst][D]: softmax_write_kernel divides by it
     float den_add;           // softmax_edges adds eps(T) to the denominator (utils.jl:71)
-    const float *gate_i;     // [n_dst][D] GATED: message = sigmoid(gate_i[row] + x[j][0:D]) .* x[j][D:2D]  (x rows are 2D wide)
+    const float *gate_i;     // [n_dst][D] GATED = 1: message = sigmoid(gate_i[row] + x[j][0:D]) .* x[j][D:2D]  (x rows are 2D wide)
+                             // [n_dst][2D] GATED = 2 (cg_message, conv.jl:326-333): sigmoid(gate_i[row][0:D] + x[j][0:D] + e[0:D]) .*
+                             //   act(gate_i[row][D:2D] + x[j][D:2D] + e[D:2D]), e = emat row (2D wide) of the edge, optional
+    int gated;               // 0 | 1 | 2
+    int act;                 // GATED = 2: dense_s's activation (gnnmp_act)
     const float *ss;         // [n_src] nullable
     const float *w_slot;     // [E'] slot order, nullable (takes precedence over w)
     const float *ss_slot;    // [E'] slot order, nullable (takes precedence over ss)
@@ -52,14 +56,28 @@ struct ReduceArgs {
     int waves;               // waves per block
 };
 
-// reduce slots [beg, end) of one destination into acc[VEC]; all lanes of the group call this together.
 // NNlib.sigmoid: t = exp(-abs(x)); ifelse(x >= 0, inv(1 + t), t / (1 + t))
 __device__ __forceinline__ float nn_sigmoid(float x) {
     const float t = expf(-fabsf(x));
     return x >= 0.0f ? 1.0f / (1.0f + t) : t / (1.0f + t);
 }
+// NNlib.softplus: log1p(exp(-abs(x))) + relu(x)
+__device__ __forceinline__ float nn_softplus(float x) {
+    return log1pf(expf(-fabsf(x))) + (x < 0.0f ? 0.0f : x);
+}
 
-template <int VEC, int OP, bool SCALED, int U, bool EMAT = false, bool EXPSUB = false, bool GATED = false>
+// dense_s's σ of CGConv (constructor argument `act`, GraphNeuralNetworks/src/layers/conv.jl:925-930)
+__device__ __forceinline__ float cg_act(float x, int act) {
+    switch (act) {
+        case GNNMP_ACT_RELU: return x < 0.0f ? 0.0f : x;
+        case GNNMP_ACT_SOFTPLUS: return nn_softplus(x);
+        case GNNMP_ACT_TANH: return tanhf(x);
+        default: return x;
+    }
+}
+
+// reduce slots [beg, end) of one destination into acc[VEC]; all lanes of the group call this together.
+template <int VEC, int OP, bool SCALED, int U, bool EMAT = false, bool EXPSUB = false, int GATED = 0>
 __device__ __forceinline__ void reduce_range(const ReduceArgs &a, int beg, int end, int lig,
                                              int gbase, int G, int f0, bool active,
                                              float acc[VEC], int row = 0) {
@@ -67,7 +85,14 @@ __device__ __forceinline__ void reduce_range(const ReduceArgs &a, int beg, int e
 #pragma unroll
     for (int q = 0; q < VEC; ++q) sub[q] = 0.0f;
     if (EXPSUB && active) Vec<VEC>::load(a.rowsub + (int64_t)row * a.D + f0, sub);
-    if (GATED && active) Vec<VEC>::load(a.gate_i + (int64_t)row * a.D + f0, sub);   // Ax_i slice
+    float sub2[VEC];
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) sub2[q] = 0.0f;
+    if (GATED == 1 && active) Vec<VEC>::load(a.gate_i + (int64_t)row * a.D + f0, sub);   // Ax_i slice
+    if (GATED == 2 && active) {
+        Vec<VEC>::load(a.gate_i + (int64_t)row * 2 * a.D + f0, sub);                     // dense_f's share of x_i
+        Vec<VEC>::load(a.gate_i + (int64_t)row * 2 * a.D + a.D + f0, sub2);              // dense_s's share of x_i
+    }
     const int64_t ldx = GATED ? 2 * (int64_t)a.D : (int64_t)a.D;
     for (int base = beg; base < end; base += G) {
         const int p = base + lig;
@@ -94,6 +119,7 @@ __device__ __forceinline__ void reduce_range(const ReduceArgs &a, int beg, int e
             float v[U][VEC];
             float gb[GATED ? U : 1][VEC];
             float em[EMAT ? U : 1][VEC];
+            float em2[(EMAT && GATED == 2) ? U : 1][VEC];
             float wj[U], sj[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -103,7 +129,15 @@ __device__ __forceinline__ void reduce_range(const ReduceArgs &a, int beg, int e
                     // e .* xj with e (D, E'): the edge's own row of factors, by original edge position; self loops the
                     // plan added carry no features and weigh 1
                     const int ej = __shfl(ev, gbase + jj, 64);
-                    if (active && (j + u < n) && ej < a.n_edges) {
+                    if (GATED == 2) {   // the edge's share of both pre-activations (additive: absent = 0)
+                        if (active && (j + u < n) && ej < a.n_edges) {
+                            Vec<VEC>::load(a.emat + (int64_t)ej * 2 * a.D + f0, em[EMAT ? u : 0]);
+                            Vec<VEC>::load(a.emat + (int64_t)ej * 2 * a.D + a.D + f0, em2[(EMAT && GATED == 2) ? u : 0]);
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < VEC; ++q) em[EMAT ? u : 0][q] = em2[(EMAT && GATED == 2) ? u : 0][q] = 0.0f;
+                        }
+                    } else if (active && (j + u < n) && ej < a.n_edges) {
                         Vec<VEC>::load(a.emat + (int64_t)ej * a.D + f0, em[EMAT ? u : 0]);
                     } else {
 #pragma unroll
@@ -136,9 +170,17 @@ __device__ __forceinline__ void reduce_range(const ReduceArgs &a, int beg, int e
                             t = t * sj[u];  // xj .* cout'   (GNNlib/src/layers/conv.jl:59), rounded
                             t = wj[u] * t;  // w .* xj        (GNNlib/src/msgpass.jl:203-208), rounded
                         }
-                        if (EMAT) t = em[EMAT ? u : 0][q] * t;  // e .* xj (GNNlib/src/msgpass.jl:187-191)
+                        if (EMAT && GATED != 2) t = em[EMAT ? u : 0][q] * t;  // e .* xj (GNNlib/src/msgpass.jl:187-191)
                         if (EXPSUB) t = expf(t - sub[q]);        // num = exp.(e .- max_) (GNNlib/src/utils.jl:94)
-                        if (GATED) t = nn_sigmoid(sub[q] + gb[GATED ? u : 0][q]) * t;   // sigmoid.(Ax_i .+ Bx_j) .* Vx_j (conv.jl:291)
+                        if (GATED == 1) t = nn_sigmoid(sub[q] + gb[GATED ? u : 0][q]) * t;   // sigmoid.(Ax_i .+ Bx_j) .* Vx_j (conv.jl:291)
+                        if (GATED == 2) {   // dense_f(z) .* dense_s(z), z = vcat(xi, xj, e): the K-sum in z's order (conv.jl:326-333)
+                            float f = sub[q] + gb[GATED ? u : 0][q], g = sub2[q] + t;
+                            if (EMAT) {
+                                f = f + em[EMAT ? u : 0][q];
+                                g = g + em2[(EMAT && GATED == 2) ? u : 0][q];
+                            }
+                            t = nn_sigmoid(f) * cg_act(g, a.act);
+                        }
                         acc[q] = op_apply<OP>(acc[q], t);
                     }
                 }
@@ -165,7 +207,7 @@ __device__ __forceinline__ void finalize_store(const ReduceArgs &a, int row, int
 }
 
 // virtual rows: [0, n_chunks) are chunks of long rows (raw partials), [n_chunks, n_chunks + n_rows) ordinary rows.
-template <int VEC, int OP, bool SCALED, int U, bool EMAT = false, bool EXPSUB = false, bool GATED = false>
+template <int VEC, int OP, bool SCALED, int U, bool EMAT = false, bool EXPSUB = false, int GATED = 0>
 __global__ void __launch_bounds__(256) csr_rows_kernel(const ReduceArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -307,7 +349,7 @@ __global__ void __launch_bounds__(256) csr_combine_kernel(const ReduceArgs a) {
     finalize_store<VEC, OP>(a, row, a.rowptr[row + 1] - a.rowptr[row], f0, active, acc);
 }
 
-template <int VEC, int OP, bool SCALED, int U, bool EMAT = false, bool EXPSUB = false, bool GATED = false>
+template <int VEC, int OP, bool SCALED, int U, bool EMAT = false, bool EXPSUB = false, int GATED = 0>
 static int launch_reduce(const ReduceArgs &a0, hipStream_t stream) {
     ReduceArgs a = a0;
     const int G = 1 << a.log2g;
@@ -355,11 +397,15 @@ static int dispatch_scaled(const ReduceArgs &a, bool scaled, hipStream_t s) {
 template <int VEC>
 static int dispatch_op(const ReduceArgs &a, int op, bool scaled, hipStream_t s) {
     if (a.rowsub) return launch_reduce<VEC, OP_SUM, false, 8, false, true>(a, s);   // softmax denominator
+    if (a.gate_i && a.gated == 2) {   // cg_conv aggregates with + (conv.jl:313)
+        return a.emat ? launch_reduce<VEC, OP_SUM, false, 2, true, false, 2>(a, s)
+                      : launch_reduce<VEC, OP_SUM, false, 4, false, false, 2>(a, s);
+    }
     if (a.gate_i) {   // two rows per edge in flight: half the batch
         switch (op) {
-            case OP_SUM: return launch_reduce<VEC, OP_SUM, false, 4, false, false, true>(a, s);
-            case OP_MAX: return launch_reduce<VEC, OP_MAX, false, 4, false, false, true>(a, s);
-            default: return launch_reduce<VEC, OP_MIN, false, 4, false, false, true>(a, s);
+            case OP_SUM: return launch_reduce<VEC, OP_SUM, false, 4, false, false, 1>(a, s);
+            case OP_MAX: return launch_reduce<VEC, OP_MAX, false, 4, false, false, 1>(a, s);
+            default: return launch_reduce<VEC, OP_MIN, false, 4, false, false, 1>(a, s);
         }
     }
     if (a.emat) {   // two rows per edge in flight: half the batch
@@ -380,7 +426,7 @@ static int dispatch_op(const ReduceArgs &a, int op, bool scaled, hipStream_t s) 
 int run_reduce(gnnmp_graph_t *p, const int32_t *idx, int aggr, const float *x, const float *w,
                const float *ss, const float *w_slot, const float *ss_slot, const float *sd, float *out,
                int64_t D, hipStream_t stream, const float *emat = nullptr, const float *rowsub = nullptr,
-               const float *gate_i = nullptr) {
+               const float *gate_i = nullptr, int gated = 1, int act = 0) {
     if (p->n_dst == 0 || D == 0) return GNNMP_OK;
     if (p->n_chunks > 0) {
         if (int rc = ensure_workspace(p, (size_t)p->n_chunks * (size_t)D)) return rc;
@@ -396,6 +442,8 @@ int run_reduce(gnnmp_graph_t *p, const int32_t *idx, int aggr, const float *x, c
     a.rowden = nullptr;
     a.den_add = 0.0f;
     a.gate_i = gate_i;
+    a.gated = gate_i ? gated : 0;
+    a.act = act;
     a.ss = ss;
     a.w_slot = w_slot;
     a.ss_slot = ss_slot;
@@ -603,6 +651,17 @@ int gnnmp_propagate_gated_f32(gnnmp_graph_t *plan, int aggr, const float *gate_i
         return fail(GNNMP_EINVAL, "propagate_gated: null pointer");
     return run_reduce(plan, plan->col, aggr, bv_j, nullptr, nullptr, nullptr, nullptr, nullptr, out, D, (hipStream_t)stream,
                       nullptr, nullptr, gate_i);
+}
+
+int gnnmp_propagate_cg_f32(gnnmp_graph_t *plan, const float *fs_i, const float *fs_j, const float *fs_e, int act, float *out,
+                           int64_t D, gnnmp_stream_t stream) {
+    if (!plan) return fail(GNNMP_EINVAL, "propagate_cg: null plan");
+    if (act < GNNMP_ACT_IDENTITY || act > GNNMP_ACT_TANH) return fail(GNNMP_EINVAL, "propagate_cg: bad act %d", act);
+    if (D < 0 || D > (1 << 19)) return fail(GNNMP_EINVAL, "propagate_cg: bad D %lld", (long long)D);
+    if (plan->n_dst > 0 && D > 0 && (!out || !fs_i || (!fs_j && plan->n_total > 0)))
+        return fail(GNNMP_EINVAL, "propagate_cg: null pointer");
+    return run_reduce(plan, plan->col, GNNMP_SUM, fs_j, nullptr, nullptr, nullptr, nullptr, nullptr, out, D, (hipStream_t)stream,
+                      fs_e, nullptr, fs_i, 2, act);
 }
 
 int gnnmp_propagate_slots_f32(gnnmp_graph_t *plan, int aggr, const float *xj, const float *w_slot,

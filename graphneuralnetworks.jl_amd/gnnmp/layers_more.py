@@ -1,0 +1,238 @@
+"""More layers of the reference's zoo that run on the same kernels: CGConv, EdgeConv, GatedGraphConv, DConv.
+GNNlib/src/layers/conv.jl  cg_conv :304-333, edge_conv :237-246, gated_graph_conv :218-233, d_conv :696-725;
+constructors GraphNeuralNetworks/src/layers/conv.jl :925-931 (CGConv), :582 (EdgeConv), :525-530 (GatedGraphConv),
+:1584-1589 (DConv).
+
+  * CGConv: `dense_f(z) .* dense_s(z)` with z = vcat(xi, xj, e) is split by the column blocks of the two weight matrices
+    into node-level contractions (x_i share, x_j share) and one edge-level contraction (e share); the per-edge sum,
+    sigmoid, activation, product and the aggregation are ONE pass of the row kernel (gnnmp_propagate_cg_f32).  The
+    (2 nin + ein, E) concatenation and the two (out, E) dense outputs of the reference are never built.
+  * EdgeConv: a general `nn` sees per-edge inputs, so the reference's composition is kept — but `vcat(xi, xj .- xi)` is
+    never materialised: the first Dense takes the two halves as the two segments of the MFMA kernel.
+  * GatedGraphConv: W_l h on the MFMA kernel, propagate(copy_xj), the GRU cell = two contractions + one pointwise kernel.
+  * DConv: every diffusion step `propagate(w_mul_xj, g | gᵀ, +; xj = T * deg)` is ONE launch (the degree scaling is the
+    kernel's per-source factor); the two weight products of a step are the two segments of one dense call.
+torch allocates; every arithmetic step is a libgnnmp call.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib as L
+from .graph import GNNGraph, check_num_edges, check_num_nodes, degree
+from .layers import Dense, dense, glorot_uniform
+from .msgpass import _gather, _scatter_plan, aggr_code
+
+_CG_ACT = {None: L.ACT_IDENTITY, "identity": L.ACT_IDENTITY, "relu": L.ACT_RELU, "softplus": L.ACT_SOFTPLUS,
+           "tanh": L.ACT_TANH}
+
+
+def _add(a, b):
+    out = torch.empty_like(a)
+    L.check(L.load().gnnmp_add_f32(L.ptr(a), L.ptr(b), L.ptr(out), a.numel(), L.stream_ptr()))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# CGConv
+# ---------------------------------------------------------------------------------------------------------
+def cg_conv(l, g: GNNGraph, x, e=None):
+    check_num_nodes(g, x)
+    nin, ein = l.ch[0]
+    out = l.ch[1]
+    if e is not None:
+        check_num_edges(g, e)
+        assert e.shape[1] == ein
+    else:
+        assert ein == 0, "CGConv was built with edge features"
+    x = x.contiguous()
+    Wi, Wj, We, b = l.split_weights()
+    fs_i = dense(x, Wi, b)                                  # [N][2 out]: (dense_f | dense_s) share of x_i, biases folded in
+    fs_j = dense(x, Wj)
+    fs_e = dense(e.contiguous(), We) if e is not None else None
+    plan = g.plan(False)
+    m = torch.empty((g.num_nodes, out), dtype=torch.float32, device=x.device)
+    L.check(L.load().gnnmp_propagate_cg_f32(plan.handle, L.ptr(fs_i), L.ptr(fs_j), L.ptr(fs_e), _CG_ACT[l.act], L.ptr(m), out,
+                                            L.stream_ptr()))
+    if l.residual:
+        if x.shape[1] == out:
+            m = _add(m, x)
+        else:
+            import warnings
+            warnings.warn("number of output features different from number of input features, residual not applied.")
+    return m
+
+
+class CGConv:
+    """CGConv((in, ein) => out, act = identity; residual = false, bias = true): `ch` is `(in, out)` or `((in, ein), out)`"""
+
+    takes_graph = True
+
+    def __init__(self, ch, act=None, residual=False, bias=True, device="cuda", seed=None):
+        cin, out = ch
+        nin, ein = cin if isinstance(cin, (tuple, list)) else (cin, 0)
+        assert act in _CG_ACT, f"unsupported activation {act!r}"
+        self.ch, self.act, self.residual = ((nin, ein), out), act, bool(residual)
+        sd = (lambda k: None if seed is None else seed + k)
+        self.dense_f_weight = glorot_uniform(out, 2 * nin + ein, device=device, seed=sd(0))
+        self.dense_s_weight = glorot_uniform(out, 2 * nin + ein, device=device, seed=sd(1))
+        self.dense_f_bias = torch.zeros(out, dtype=torch.float32, device=device) if bias else None
+        self.dense_s_bias = torch.zeros(out, dtype=torch.float32, device=device) if bias else None
+
+    def split_weights(self):
+        """([Wf_i; Ws_i], [Wf_j; Ws_j], [Wf_e; Ws_e] | None, [bf; bs] | None): the column blocks of dense_f / dense_s
+        stacked so that one contraction gives both pre-activation shares (memory plumbing, cached per parameter version)"""
+        ps = (self.dense_f_weight, self.dense_s_weight, self.dense_f_bias, self.dense_s_bias)
+        key = tuple((p.data_ptr(), p._version) for p in ps if p is not None)
+        if getattr(self, "_split_key", None) != key:
+            (nin, ein), _ = self.ch
+            Wf, Ws = self.dense_f_weight, self.dense_s_weight
+            blk = lambda a, b: torch.cat([Wf[:, a:b], Ws[:, a:b]], dim=0).contiguous()
+            bias = None if self.dense_f_bias is None else torch.cat([self.dense_f_bias, self.dense_s_bias]).contiguous()
+            self._split = (blk(0, nin), blk(nin, 2 * nin), blk(2 * nin, 2 * nin + ein) if ein > 0 else None, bias)
+            self._split_key = key
+        return self._split
+
+    def __call__(self, g, x, e=None):
+        return cg_conv(self, g, x, e)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# EdgeConv
+# ---------------------------------------------------------------------------------------------------------
+def edge_conv(l, g: GNNGraph, x):
+    """propagate(edge_conv_message, g, aggr): l.nn(vcat(xi, xj .- xi)) per edge, then the aggregation"""
+    check_num_nodes(g, x)
+    x = x.contiguous()
+    D = x.shape[1]
+    xi = _gather(x, g.t, g.index_base)                      # (D, E) as the reference forms it
+    dj = torch.empty((g.num_edges, D), dtype=torch.float32, device=x.device)
+    L.check(L.load().gnnmp_edge_sub_f32(L.ptr(x), L.ptr(x), L.ptr(g.s), L.ptr(g.t), g.idx_bytes, g.index_base, g.num_edges,
+                                        1, L.ptr(dj), D, L.stream_ptr()))                       # xj .- xi
+    layers = l.nn if isinstance(l.nn, (list, tuple)) else [l.nn]
+    first = layers[0]
+    assert isinstance(first, Dense) and first.weight.shape[1] == 2 * D, "EdgeConv: nn must start with Dense(2 in => ...)"
+    W = first.weight
+    m = dense(xi, W[:, :D], first.bias, first.sigma, x2=dj, W2=W[:, D:])                       # nn's first layer on the vcat
+    for layer in layers[1:]:
+        m = layer(m)
+    return _scatter_plan(l.aggr, m, g.plan(False))
+
+
+class EdgeConv:
+    """EdgeConv(nn; aggr = max) — `nn` a gnnmp Dense or a list of layers starting with Dense(2 in => ...)"""
+
+    takes_graph = True
+
+    def __init__(self, nn, aggr="max"):
+        self.nn, self.aggr = nn, aggr
+
+    def __call__(self, g, x):
+        return edge_conv(self, g, x)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# GatedGraphConv
+# ---------------------------------------------------------------------------------------------------------
+def gru_cell(m, h, Wi, Wh, b):
+    """Flux.GRUCell: gates r, z, candidate from Wi m and Wh h (+ b), h' = (1 - z) h~ + z h"""
+    gx, gh = dense(m, Wi), dense(h, Wh)
+    out = torch.empty_like(h)
+    L.check(L.load().gnnmp_gru_pointwise_f32(L.ptr(gx), L.ptr(gh), L.ptr(b), L.ptr(h), L.ptr(out), h.shape[0], h.shape[1],
+                                             L.stream_ptr()))
+    return out
+
+
+def gated_graph_conv(l, g: GNNGraph, x):
+    check_num_nodes(g, x)
+    N, m = x.shape
+    assert m <= l.dims, "number of input features must be less or equal to output features."
+    if m < l.dims:
+        h = torch.zeros((N, l.dims), dtype=torch.float32, device=x.device)      # vcat(x, zeros): a copy, no arithmetic
+        h[:, :m] = x
+    else:
+        h = x.contiguous()
+    plan = g.plan(False)
+    lib = L.load()
+    for i in range(l.num_layers):
+        mm = dense(h, l.weight[i])
+        agg = torch.empty_like(mm)
+        L.check(lib.gnnmp_propagate_f32(plan.handle, L.COPY_XJ, aggr_code(l.aggr), L.ptr(mm), None, None, None, L.ptr(agg),
+                                        l.dims, L.stream_ptr()))
+        h = gru_cell(agg, h, l.gru_Wi, l.gru_Wh, l.gru_b)
+    return h
+
+
+class GatedGraphConv:
+    """GatedGraphConv(out, num_layers; aggr = +): weight [num_layers][out][out]; the GRU cell's Wi, Wh [3 out][out], b [3 out]"""
+
+    takes_graph = True
+
+    def __init__(self, dims, num_layers, aggr="+", device="cuda", seed=None):
+        sd = (lambda k: None if seed is None else seed + k)
+        self.dims, self.num_layers, self.aggr = int(dims), int(num_layers), aggr
+        self.weight = torch.stack([glorot_uniform(dims, dims, device=device, seed=sd(i)) for i in range(num_layers)]).contiguous()
+        self.gru_Wi = glorot_uniform(3 * dims, dims, device=device, seed=sd(100))
+        self.gru_Wh = glorot_uniform(3 * dims, dims, device=device, seed=sd(101))
+        self.gru_b = torch.zeros(3 * dims, dtype=torch.float32, device=device)
+
+    def __call__(self, g, x):
+        return gated_graph_conv(self, g, x)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# DConv
+# ---------------------------------------------------------------------------------------------------------
+def d_conv(l, g: GNNGraph, x):
+    check_num_nodes(g, x)
+    from .backward import plan_transposed
+    x = x.contiguous()
+    lib = L.load()
+    deg_out, deg_in = degree(g, dir="out"), degree(g, dir="in")
+    fplan, bplan = g.plan(False), plan_transposed(g, False)
+    msg = L.COPY_XJ if g.w is None else L.W_MUL_XJ
+    D = x.shape[1]
+
+    def step(plan, T, deg):          # propagate(w_mul_xj, g | gt, +; xj = T * Diagonal(deg)): the scaling is the source factor
+        out = torch.empty_like(T)
+        L.check(lib.gnnmp_propagate_f32(plan.handle, msg, L.SUM, L.ptr(T), L.ptr(g.w), L.ptr(deg), None, L.ptr(out), D,
+                                        L.stream_ptr()))
+        return out
+
+    def cheb(P, T0):                 # 2 * P - T0: the doubling is exact, so (P + P) - T0 rounds once like the reference
+        out = torch.empty_like(P)
+        L.check(lib.gnnmp_axpy_f32(-1.0, L.ptr(T0), L.ptr(_add(P, P)), L.ptr(out), P.numel(), L.stream_ptr()))
+        return out
+
+    W = l.weights
+    h = dense(x, W[0, 0], None, None, x2=x, W2=W[1, 0])
+    T0 = x
+    T1_in = T1_out = None
+    if l.k > 1:
+        T1_out, T1_in = step(fplan, T0, deg_out), step(bplan, T0, deg_in)
+        h = _add(h, dense(T1_in, W[0, 1], None, None, x2=T1_out, W2=W[1, 1]))
+    for i in range(1, l.k):          # the reference's `for i in 2:l.k` reads weight slice i (1-based): slice 2 twice
+        T2_in, T2_out = cheb(step(bplan, T1_in, deg_in), T0), cheb(step(fplan, T1_out, deg_out), T0)
+        h = _add(h, dense(T2_in, W[0, i], None, None, x2=T2_out, W2=W[1, i]))
+        T1_in, T1_out = T2_in, T2_out
+    if l.bias is not None:
+        from .layers import bias_act
+        h = bias_act(h, l.bias, None)
+    return h
+
+
+class DConv:
+    """DConv(in => out, k; bias = true): weights [2][k][out][in] (Julia (2, k, out, in))"""
+
+    takes_graph = True
+
+    def __init__(self, ch, k, bias=True, device="cuda", seed=None):
+        cin, out = ch
+        self.cin, self.out, self.k = cin, out, int(k)
+        sd = (lambda j: None if seed is None else seed + j)
+        self.weights = torch.stack([torch.stack([glorot_uniform(out, cin, device=device, seed=sd(a * 64 + i))
+                                                 for i in range(k)]) for a in range(2)]).contiguous()
+        self.bias = torch.zeros(out, dtype=torch.float32, device=device) if bias else None
+
+    def __call__(self, g, x):
+        return d_conv(self, g, x)

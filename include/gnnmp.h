@@ -61,8 +61,9 @@ typedef enum { GNNMP_SUM = 0, GNNMP_MEAN = 1, GNNMP_MAX = 2, GNNMP_MIN = 3 } gnn
  * E_MUL_XJ with a vector `e` is W_MUL_XJ with w = e (msgpass.jl:223-228). */
 typedef enum { GNNMP_COPY_XJ = 0, GNNMP_W_MUL_XJ = 1 } gnnmp_msg;
 
-/* activation fused into gnnmp_dense_f32's epilogue (the layers' `σ`). */
-typedef enum { GNNMP_ACT_IDENTITY = 0, GNNMP_ACT_RELU = 1 } gnnmp_act;
+/* activation fused into gnnmp_dense_f32's epilogue (the layers' `σ`): IDENTITY and RELU everywhere an `act` is taken;
+ * SOFTPLUS (NNlib.softplus = log1p(exp(-|x|)) + relu(x)) and TANH only as the second factor of gnnmp_propagate_cg_f32. */
+typedef enum { GNNMP_ACT_IDENTITY = 0, GNNMP_ACT_RELU = 1, GNNMP_ACT_SOFTPLUS = 2, GNNMP_ACT_TANH = 3 } gnnmp_act;
 /* per-edge attention logit of gnnmp_attn_conv_f32 (Q_i = row i of the target array, K_j = row j of the source array) */
 typedef enum {
     GNNMP_ATTN_GAT = 0,   /* leakyrelu(a[h][0:C] . Q_i + a[h][C:2C] . K_j)      gat_message   conv.jl:152-167 */
@@ -233,6 +234,13 @@ int gnnmp_propagate_gated_f32(gnnmp_graph_t *plan, int aggr, const float *gate_i
  * what changes is the traffic: a coalesced 4 B read per edge instead of a random 4 B gather (one 64 B sector) per
  * edge.  The factors depend only on the graph (GCN's 1/sqrt(deg), the graph's own weights), so a caller computes them
  * once per graph where the reference recomputes `xj .* cout'` on every call (GNNlib/src/layers/conv.jl:57-59). */
+/* cg_conv's propagate (GNNlib/src/layers/conv.jl:304-333): out[i] = Σ_{j -> i} sigmoid(f_ij) .* act(s_ij) with
+ *   z = vcat(x_i, x_j, e_ij),  f = l.dense_f's W z + b,  s = l.dense_s's W z + b  (act = dense_s's σ, any gnnmp_act)
+ * split by the blocks of the two weight matrices: fs_i [n_dst][2D] = the x_i share of (f | s) with the biases folded in,
+ * fs_j [n_src][2D] the x_j share, fs_e [n_edges][2D] the edge share in original edge order (NULL without edge features).
+ * One pass over the edges; the (2D, E) pre-activations of the reference are never built. */
+int gnnmp_propagate_cg_f32(gnnmp_graph_t *plan, const float *fs_i, const float *fs_j, const float *fs_e, int act,
+                           float *out, int64_t D, gnnmp_stream_t stream);
 int gnnmp_propagate_slots_f32(gnnmp_graph_t *plan, int aggr, const float *xj, const float *w_slot,
                               const float *ss_slot, const float *scale_dst, float *out, int64_t D,
                               gnnmp_stream_t stream);
@@ -355,6 +363,11 @@ int gnnmp_head_mean_f32(const float *y, const float *bias, int act, float *out, 
                         int64_t C, gnnmp_stream_t stream);
 /* its pullback: dy[n][h][c] = dz[n][c] / H (the heads' gradient of `mean(x, dims = 2)`) */
 int gnnmp_head_mean_grad_f32(const float *dz, float *dy, int64_t N, int64_t H, int64_t C, gnnmp_stream_t stream);
+/* Flux.GRUCell's pointwise part — the cell of gated_graph_conv (GNNlib/src/layers/conv.jl:228-232): gx = Wi m and
+ * gh = Wh h are [N][3D] (gates r, z, candidate), b [3D] or NULL:
+ *   r = σ(gx_r + gh_r + b_r), z = σ(gx_z + gh_z + b_z), h~ = tanh(gx_n + r .* gh_n + b_n), out = (1 - z) .* h~ + z .* h */
+int gnnmp_gru_pointwise_f32(const float *gx, const float *gh, const float *b, const float *h, float *out, int64_t N,
+                            int64_t D, gnnmp_stream_t stream);
 /* xn[n][:] = x[n][:] / sqrt(sum(x[n][:]^2)) — `xn = x ./ sqrt.(sum(x .^ 2, dims = 1))` of agnn_conv
  * (GNNlib/src/layers/conv.jl:341-342); rnorm (optional) keeps the norms for the pullback.  A zero row gives NaN like the
  * reference's 0 / 0. */

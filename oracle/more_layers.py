@@ -1,0 +1,114 @@
+"""CPU restatement of CGConv, EdgeConv, GatedGraphConv and DConv (GNNlib/src/layers/conv.jl cg_conv :304-333, edge_conv
+:237-246, gated_graph_conv :218-233, d_conv :696-725) — TEST INFRASTRUCTURE ONLY (same rules as oracle.py).  Statement by
+statement on the pinned primitives (gather, scatter, propagate, degree, matmul), float32, in the reference's order: the
+per-edge `vcat`s and the (2nin + ein, E) / (2D, E) arrays ARE materialised here, as the reference does.
+
+No known-answer vectors exist in the reference for these layers (test/layers/conv.jl checks sizes and gradients) and the
+GRU cell lives in un-vendored Flux 0.16 (restated from its published definition: Wi, Wh without bias, one bias vector b,
+gates in the order r, z, candidate; sigmoid_fast / tanh_fast are restated as the exact functions) — parity unpinned beyond
+the float64 identities tests/test_more_layers.py checks (dense-adjacency formulations)."""
+from __future__ import annotations
+
+import numpy as np
+
+from . import oracle as O
+
+f32 = np.float32
+
+
+def sigmoid(x):
+    x = np.asarray(x, f32)
+    t = np.exp(-np.abs(x)).astype(f32)
+    return np.where(x >= 0, f32(1) / (f32(1) + t), t / (f32(1) + t)).astype(f32)
+
+
+def softplus(x):
+    x = np.asarray(x, f32)
+    return (np.log1p(np.exp(-np.abs(x)).astype(f32)).astype(f32) + np.maximum(x, f32(0))).astype(f32)
+
+
+ACT = {None: lambda v: v, "identity": lambda v: v, "relu": lambda v: np.where(v < 0, f32(0), v).astype(f32),
+       "softplus": softplus, "tanh": lambda v: np.tanh(v).astype(f32), "sigmoid": sigmoid}
+
+
+def _dense(z, W, b, act, blas=True):
+    y = O.matmul(O._f32(W), O._f32(z), blas)
+    if b is not None:
+        y = (y + O._f32(b)[None, :]).astype(f32)
+    return ACT[act](y)
+
+
+def cg_conv(s, t, n, x, e, Wf, bf, Ws, bs, act=None, residual=False):
+    """m = propagate(cg_message, g, +): dense_f(z) .* dense_s(z), z = vcat(xi, xj, e); dense_f's σ is sigmoid"""
+    s, t = O._i64(s), O._i64(t)
+    x = O._f32(x)
+    xi, xj = O.gather(x, t), O.gather(x, s)
+    z = np.concatenate([xi, xj] + ([] if e is None else [O._f32(e)]), axis=1)
+    msg = (_dense(z, Wf, bf, "sigmoid") * _dense(z, Ws, bs, act)).astype(f32)
+    m = O.scatter(O.SUM, msg, t, n)
+    if residual and m.shape[1] == x.shape[1]:
+        m = (m + x).astype(f32)
+    return m
+
+
+def edge_conv(s, t, n, x, nn, aggr="max"):
+    """propagate(edge_conv_message, g, aggr): l.nn(vcat(xi, xj .- xi)); nn = [(W, b, act), ...] a chain of Dense layers"""
+    s, t = O._i64(s), O._i64(t)
+    x = O._f32(x)
+    xi, xj = O.gather(x, t), O.gather(x, s)
+    z = np.concatenate([xi, (xj - xi).astype(f32)], axis=1)
+    for W, b, act in nn:
+        z = _dense(z, W, b, act)
+    return O.scatter({"max": O.MAX, "+": O.SUM, "mean": O.MEAN, "min": O.MIN}[aggr], z, t, n)
+
+
+def gru_cell(m, h, Wi, Wh, b):
+    """Flux.GRUCell(x = m, h): gxs = chunk(Wi x, 3), ghs = chunk(Wh h, 3), bs = chunk(b, 3)"""
+    D = h.shape[1]
+    gx, gh = O.matmul(O._f32(Wi), m, True), O.matmul(O._f32(Wh), h, True)
+    bb = np.zeros(3 * D, f32) if b is None else O._f32(b)
+    r = sigmoid(((gx[:, :D] + gh[:, :D]).astype(f32) + bb[None, :D]).astype(f32))
+    z = sigmoid(((gx[:, D:2 * D] + gh[:, D:2 * D]).astype(f32) + bb[None, D:2 * D]).astype(f32))
+    c = np.tanh((((gx[:, 2 * D:] + (r * gh[:, 2 * D:]).astype(f32)).astype(f32)) + bb[None, 2 * D:]).astype(f32)).astype(f32)
+    return (((f32(1) - z) * c).astype(f32) + (z * h).astype(f32)).astype(f32)
+
+
+def gated_graph_conv(s, t, n, x, weight, Wi, Wh, b, aggr="+"):
+    """weight: [num_layers][dims][dims] (Julia (dims, dims, num_layers) read layer by layer)"""
+    s, t = O._i64(s), O._i64(t)
+    x = O._f32(x)
+    dims = weight.shape[1]
+    assert x.shape[1] <= dims
+    if x.shape[1] < dims:
+        x = np.concatenate([x, np.zeros((n, dims - x.shape[1]), f32)], axis=1)
+    h = x
+    op = {"+": O.SUM, "mean": O.MEAN, "max": O.MAX, "min": O.MIN}[aggr]
+    for i in range(weight.shape[0]):
+        m = O.matmul(O._f32(weight[i]), h, True)
+        m = O.propagate(op, s, t, n, m, None)
+        h = gru_cell(m, h, Wi, Wh, b)
+    return h
+
+
+def d_conv(s, t, n, x, weights, bias, k, edge_weight=None):
+    """weights: [2][k][out][in] (Julia (2, k, out, in)); degree(g) is the weighted degree when g has edge weights"""
+    s, t = O._i64(s), O._i64(t)
+    x = O._f32(x)
+    w = None if edge_weight is None else O._f32(edge_weight)
+    deg_out, deg_in = O.degree(s, n, w), O.degree(t, n, w)
+    W = lambda a, i: O._f32(weights[a][i])
+    mm = lambda Wm, v: O.matmul(Wm, v, True)
+    fwd = lambda v: O.propagate(O.SUM, s, t, n, O.scale_rows(v, deg_out), w)     # propagate(w_mul_xj, g,  +; xj = T * deg_out')
+    bwd = lambda v: O.propagate(O.SUM, t, s, n, O.scale_rows(v, deg_in), w)      # propagate(w_mul_xj, gt, +; xj = T * deg_in)
+    h = (mm(W(0, 0), x) + mm(W(1, 0), x)).astype(f32)
+    T0 = x
+    T1_in = T1_out = None
+    if k > 1:
+        T1_out, T1_in = fwd(T0), bwd(T0)
+        h = ((h + mm(W(0, 1), T1_in)).astype(f32) + mm(W(1, 1), T1_out)).astype(f32)
+    for i in range(1, k):       # Julia `for i in 2:l.k` reads l.weights[:, i, :, :] 1-based: slice 2 is used twice (as written)
+        T2_in = ((f32(2) * bwd(T1_in)).astype(f32) - T0).astype(f32)
+        T2_out = ((f32(2) * fwd(T1_out)).astype(f32) - T0).astype(f32)
+        h = ((h + mm(W(0, i), T2_in)).astype(f32) + mm(W(1, i), T2_out)).astype(f32)
+        T1_in, T1_out = T2_in, T2_out
+    return h if bias is None else (h + O._f32(bias)[None, :]).astype(f32)

@@ -1,0 +1,252 @@
+"""CGConv, EdgeConv, GatedGraphConv, DConv.  CPU: the oracle restatements (oracle/more_layers.py, float32, the reference's
+statement order with every per-edge array materialised) against independent float64 formulations (per-edge loops / dense
+adjacency algebra).  GPU: the HIP compositions (gnnmp/layers_more.py) against the oracle on graphs with hub rows."""
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def ML(oracle):
+    from oracle import more_layers
+    return more_layers
+
+
+def graph(rng, n, E, hubs=False):
+    s = rng.integers(1, n + 1, E)
+    t = rng.integers(1, n + 1, E)
+    if hubs:
+        t[: E // 8] = 7
+        s[E // 4: E // 4 + E // 10] = 11
+        p = rng.permutation(E)
+        s, t = s[p], t[p]
+    return s, t
+
+
+def rel(a, b):
+    return np.linalg.norm(np.asarray(a, np.float64) - b) / max(np.linalg.norm(b), 1e-30)
+
+
+def sig64(v):
+    return 1 / (1 + np.exp(-v))
+
+
+ACT64 = {None: lambda v: v, "relu": lambda v: np.maximum(v, 0), "softplus": lambda v: np.logaddexp(0, v), "tanh": np.tanh}
+
+
+def cg_ref64(s, t, n, x, e, Wf, bf, Ws, bs, act, residual):
+    x, Wf, Ws = (v.astype(np.float64) for v in (x, Wf, Ws))
+    out = np.zeros((n, Wf.shape[0]))
+    for k in range(len(s)):
+        z = np.concatenate([x[t[k] - 1], x[s[k] - 1]] + ([] if e is None else [e[k].astype(np.float64)]))
+        out[t[k] - 1] += sig64(Wf @ z + (0 if bf is None else bf)) * ACT64[act](Ws @ z + (0 if bs is None else bs))
+    return out + x if residual and out.shape[1] == x.shape[1] else out
+
+
+def cg_params(rng, nin, ein, out, bias=True):
+    K = 2 * nin + ein
+    Wf = (rng.standard_normal((out, K)) * 0.4).astype(np.float32)
+    Ws = (rng.standard_normal((out, K)) * 0.4).astype(np.float32)
+    bf = (rng.standard_normal(out) * 0.2).astype(np.float32) if bias else None
+    bs = (rng.standard_normal(out) * 0.2).astype(np.float32) if bias else None
+    return Wf, bf, Ws, bs
+
+
+@pytest.mark.parametrize("nin,ein,out,act,residual", [(5, 3, 4, "tanh", False), (6, 0, 6, "softplus", True), (4, 2, 4, None, True),
+                                                     (3, 0, 7, "relu", False)])
+def test_oracle_cg_conv_vs_float64_edge_loop(oracle, ML, nin, ein, out, act, residual):
+    rng = np.random.default_rng(nin * 7 + out)
+    n = 30
+    s, t = graph(rng, n, 200)
+    x = rng.standard_normal((n, nin)).astype(np.float32)
+    e = rng.standard_normal((len(s), ein)).astype(np.float32) if ein else None
+    Wf, bf, Ws, bs = cg_params(rng, nin, ein, out)
+    y = ML.cg_conv(s, t, n, x, e, Wf, bf, Ws, bs, act, residual)
+    assert rel(y, cg_ref64(s, t, n, x, e, Wf, bf, Ws, bs, act, residual)) < 5e-6
+
+
+def test_oracle_edge_conv_vs_float64_edge_loop(oracle, ML):
+    rng = np.random.default_rng(3)
+    n, D = 30, 5
+    s, t = graph(rng, n, 220)
+    x = rng.standard_normal((n, D)).astype(np.float32)
+    W1, b1 = (rng.standard_normal((8, 2 * D)) * 0.4).astype(np.float32), (rng.standard_normal(8) * 0.1).astype(np.float32)
+    W2, b2 = (rng.standard_normal((6, 8)) * 0.4).astype(np.float32), (rng.standard_normal(6) * 0.1).astype(np.float32)
+    for aggr in ("max", "+", "mean"):
+        y = ML.edge_conv(s, t, n, x, [(W1, b1, "relu"), (W2, b2, None)], aggr)
+        x64 = x.astype(np.float64)
+        msgs = [[] for _ in range(n)]
+        for k in range(len(s)):
+            z = np.concatenate([x64[t[k] - 1], x64[s[k] - 1] - x64[t[k] - 1]])
+            msgs[t[k] - 1].append(W2.astype(np.float64) @ np.maximum(W1.astype(np.float64) @ z + b1, 0) + b2)
+        has = np.array([len(m) > 0 for m in msgs])
+        red = {"max": lambda m: np.max(m, 0), "+": lambda m: np.sum(m, 0), "mean": lambda m: np.mean(m, 0)}[aggr]
+        want = np.stack([red(np.stack(m)) if m else np.zeros(6) for m in msgs])
+        assert rel(y[has], want[has]) < 5e-6
+        if aggr == "max":
+            assert np.isneginf(y[~has]).all()               # NNlib's identity fill for empty destinations
+        else:
+            assert (y[~has] == 0).all()
+
+
+def gru64(m, h, Wi, Wh, b):
+    D = h.shape[1]
+    gx, gh = m @ Wi.T.astype(np.float64), h @ Wh.T.astype(np.float64)
+    r = sig64(gx[:, :D] + gh[:, :D] + b[:D])
+    z = sig64(gx[:, D:2 * D] + gh[:, D:2 * D] + b[D:2 * D])
+    c = np.tanh(gx[:, 2 * D:] + r * gh[:, 2 * D:] + b[2 * D:])
+    return (1 - z) * c + z * h
+
+
+def ggc_params(rng, dims, layers):
+    w = (rng.standard_normal((layers, dims, dims)) * 0.3).astype(np.float32)
+    Wi = (rng.standard_normal((3 * dims, dims)) * 0.3).astype(np.float32)
+    Wh = (rng.standard_normal((3 * dims, dims)) * 0.3).astype(np.float32)
+    b = (rng.standard_normal(3 * dims) * 0.1).astype(np.float32)
+    return w, Wi, Wh, b
+
+
+@pytest.mark.parametrize("aggr", ["+", "mean"])
+def test_oracle_gated_graph_conv_vs_dense_float64(oracle, ML, aggr):
+    rng = np.random.default_rng(8)
+    n, Din, dims, layers = 35, 4, 6, 3
+    s, t = graph(rng, n, 240)
+    x = rng.standard_normal((n, Din)).astype(np.float32)
+    w, Wi, Wh, b = ggc_params(rng, dims, layers)
+    y = ML.gated_graph_conv(s, t, n, x, w, Wi, Wh, b, aggr)
+    A = np.zeros((n, n))
+    np.add.at(A, (t - 1, s - 1), 1.0)
+    if aggr == "mean":
+        A = A / np.maximum(A.sum(1, keepdims=True), 1)
+    h = np.concatenate([x.astype(np.float64), np.zeros((n, dims - Din))], axis=1)
+    for i in range(layers):
+        h = gru64(A @ (h @ w[i].T.astype(np.float64)), h, Wi, Wh, b.astype(np.float64))
+    assert rel(y, h) < 1e-5
+
+
+@pytest.mark.parametrize("k,weighted", [(1, False), (2, False), (3, True), (4, False)])
+def test_oracle_d_conv_vs_dense_float64(oracle, ML, k, weighted):
+    rng = np.random.default_rng(k)
+    n, Din, Dout = 30, 5, 4
+    s, t = graph(rng, n, 150)
+    x = rng.standard_normal((n, Din)).astype(np.float32)
+    ew = (rng.random(len(s)) * 0.2 + 0.05).astype(np.float32) if weighted else None
+    W = (rng.standard_normal((2, k, Dout, Din)) * 0.1).astype(np.float32)
+    b = (rng.standard_normal(Dout) * 0.1).astype(np.float32)
+    if not weighted:                                       # keep the degree-scaled powers O(1): a sparse graph
+        s, t = s[:60], t[:60]
+    y = ML.d_conv(s, t, n, x, W, b, k, ew)
+    A = np.zeros((n, n))                                    # A[s, t]
+    np.add.at(A, (s - 1, t - 1), 1.0 if ew is None else ew.astype(np.float64))
+    dout, din = A.sum(1), A.sum(0)
+    x64, W64 = x.astype(np.float64), W.astype(np.float64)
+    fwd = lambda T: A.T @ (dout[:, None] * T)
+    bwd = lambda T: A @ (din[:, None] * T)
+    h = x64 @ W64[0, 0].T + x64 @ W64[1, 0].T
+    if k > 1:
+        Tout, Tin = fwd(x64), bwd(x64)
+        h = h + Tin @ W64[0, 1].T + Tout @ W64[1, 1].T
+    for i in range(1, k):
+        Tin2, Tout2 = 2 * bwd(Tin) - x64, 2 * fwd(Tout) - x64
+        h = h + Tin2 @ W64[0, i].T + Tout2 @ W64[1, i].T
+        Tin, Tout = Tin2, Tout2
+    assert rel(y, h + b) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------- GPU
+@pytest.fixture(scope="module")
+def gm():
+    import torch
+    assert torch.cuda.is_available()
+    import gnnmp
+    gnnmp.load()
+    return gnnmp
+
+
+def dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nin,ein,out,act,residual", [(16, 8, 16, "tanh", True), (20, 0, 32, "softplus", False), (7, 3, 5, None, False),
+                                                     (64, 10, 64, "relu", True), (100, 0, 100, "softplus", True)])
+def test_hip_cg_conv_vs_oracle(gm, ML, nin, ein, out, act, residual):
+    rng = np.random.default_rng(nin + out)
+    n, E = 1500, 24000
+    s, t = graph(rng, n, E, hubs=True)
+    x = rng.standard_normal((n, nin)).astype(np.float32)
+    e = rng.standard_normal((E, ein)).astype(np.float32) if ein else None
+    Wf, bf, Ws, bs = cg_params(rng, nin, ein, out)
+    Wf *= 0.3
+    Ws *= 0.3
+    g = gm.GNNGraph(dev(s), dev(t), num_nodes=n)
+    l = gm.CGConv(((nin, ein), out), act, residual=residual)
+    l.dense_f_weight, l.dense_f_bias, l.dense_s_weight, l.dense_s_bias = dev(Wf), dev(bf), dev(Ws), dev(bs)
+    y = l(g, dev(x), None if e is None else dev(e)).cpu().numpy()
+    ref = ML.cg_conv(s, t, n, x, e, Wf, bf, Ws, bs, act, residual)
+    assert y.shape == ref.shape
+    assert rel(y, ref.astype(np.float64)) < 1e-5
+    y2 = l(g, dev(x), None if e is None else dev(e)).cpu().numpy()
+    np.testing.assert_array_equal(y, y2)                    # no atomics
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("aggr", ["max", "+", "mean"])
+def test_hip_edge_conv_vs_oracle(gm, ML, aggr):
+    rng = np.random.default_rng(5)
+    n, E, D = 1200, 20000, 12
+    s, t = graph(rng, n, E, hubs=True)
+    x = rng.standard_normal((n, D)).astype(np.float32)
+    g = gm.GNNGraph(dev(s), dev(t), num_nodes=n)
+    l1 = gm.Dense((2 * D, 32), "relu", seed=1)
+    l2 = gm.Dense((32, 16), None, seed=2)
+    l1.bias = dev((rng.standard_normal(32) * 0.1).astype(np.float32))
+    nn = [(l1.weight.cpu().numpy(), l1.bias.cpu().numpy(), "relu"), (l2.weight.cpu().numpy(), l2.bias.cpu().numpy(), None)]
+    y = gm.EdgeConv([l1, l2], aggr=aggr)(g, dev(x)).cpu().numpy()
+    ref = ML.edge_conv(s, t, n, x, nn, aggr)
+    fin = np.isfinite(ref)
+    np.testing.assert_array_equal(np.isfinite(y), fin)
+    assert rel(y[fin], ref[fin].astype(np.float64)) < 1e-5
+    # a single Dense as nn (the reference's own test configuration, test/layers/conv.jl:260)
+    y1 = gm.EdgeConv(l1, aggr=aggr)(g, dev(x)).cpu().numpy()
+    r1 = ML.edge_conv(s, t, n, x, nn[:1], aggr)
+    fin = np.isfinite(r1)
+    assert rel(y1[fin], r1[fin].astype(np.float64)) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Din,dims,layers,aggr", [(8, 16, 3, "+"), (16, 16, 2, "mean"), (5, 33, 2, "max")])
+def test_hip_gated_graph_conv_vs_oracle(gm, ML, Din, dims, layers, aggr):
+    rng = np.random.default_rng(dims)
+    n, E = 1200, 9000
+    s, t = graph(rng, n, E, hubs=(aggr != "+"))
+    s = np.concatenate([s, np.roll(np.arange(1, n + 1), 1)])            # every node has an in-edge (max over an empty set: -Inf)
+    t = np.concatenate([t, np.arange(1, n + 1)])
+    x = (rng.standard_normal((n, Din)) * 0.5).astype(np.float32)
+    w, Wi, Wh, b = ggc_params(rng, dims, layers)
+    w *= 0.3
+    g = gm.GNNGraph(dev(s), dev(t), num_nodes=n)
+    l = gm.GatedGraphConv(dims, layers, aggr=aggr)
+    l.weight, l.gru_Wi, l.gru_Wh, l.gru_b = dev(w), dev(Wi), dev(Wh), dev(b)
+    y = l(g, dev(x)).cpu().numpy()
+    ref = ML.gated_graph_conv(s, t, n, x, w, Wi, Wh, b, aggr)
+    assert y.shape == ref.shape == (n, dims)
+    assert rel(y, ref.astype(np.float64)) < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Din,Dout,k,weighted", [(16, 8, 1, False), (12, 12, 2, False), (20, 16, 3, True), (7, 5, 4, True)])
+def test_hip_d_conv_vs_oracle(gm, ML, Din, Dout, k, weighted):
+    rng = np.random.default_rng(Din + k)
+    n, E = 1500, 6000
+    s, t = graph(rng, n, E)
+    x = rng.standard_normal((n, Din)).astype(np.float32)
+    ew = (rng.random(E) * 0.2 + 0.05).astype(np.float32) if weighted else None
+    W = (rng.standard_normal((2, k, Dout, Din)) * 0.1).astype(np.float32)
+    b = (rng.standard_normal(Dout) * 0.1).astype(np.float32)
+    g = gm.GNNGraph(dev(s), dev(t), None if ew is None else dev(ew), num_nodes=n)
+    l = gm.DConv((Din, Dout), k)
+    l.weights, l.bias = dev(W), dev(b)
+    y = l(g, dev(x)).cpu().numpy()
+    ref = ML.d_conv(s, t, n, x, W, b, k, ew)
+    assert rel(y, ref.astype(np.float64)) < 2e-5
