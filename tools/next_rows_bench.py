@@ -63,6 +63,18 @@ del e
 row("apply_edges(xi_dot_xj)", t(lambda: gnnmp.apply_edges(gnnmp.xi_dot_xj, g, xi=x, xj=x)), E * (8 * D + 16 + 4))
 if not quick:
     row("apply_edges(xi_sub_xj) (writes (D, E))", t(lambda: gnnmp.apply_edges(gnnmp.xi_sub_xj, g, xi=x, xj=x), it=3), E * (12 * D + 16))
+lc = gnnmp.CGConv((D, D), "softplus", residual=True, seed=1)
+row("CGConv(100=>100, softplus, residual) layer", t(lambda: lc(g, x)))
+fs = torch.randn((N, 2 * D), device="cuda") * 0.3
+oc = torch.empty((N, D), device="cuda")
+from gnnmp import _lib as L
+row("  its one-pass kernel (sigmoid(f) .* softplus(s), +)", t(lambda: L.check(L.load().gnnmp_propagate_cg_f32(
+    g.plan(False).handle, L.ptr(fs), L.ptr(fs), None, L.ACT_SOFTPLUS, L.ptr(oc), D, L.stream_ptr()))), E * (8 * D + 4) + N * (12 * D + 8))
+del fs, oc
+lg = gnnmp.GatedGraphConv(D, 2, seed=1); row("GatedGraphConv(100, 2 layers) layer", t(lambda: lg(g, x)))
+ld = gnnmp.DConv((D, D), 2, seed=1); row("DConv(100=>100, k=2) layer", t(lambda: ld(g, x)))
+del lc, lg, ld
+torch.cuda.empty_cache()
 eh = torch.randn((E, H), device="cuda")
 row("softmax_edge_neighbors, H=8", t(lambda: gnnmp.softmax_edge_neighbors(g, eh)), E * (8 * H + 4))
 del eh
