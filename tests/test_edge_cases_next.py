@@ -127,3 +127,66 @@ def test_row_partition_with_more_ranks_than_rows_with_edges(gm):
     b = RP.partition_rows_by_edges(t, 5, 4)
     assert b[0][0] == 0 and b[-1][1] == 5 and all(lo <= hi for lo, hi in b)
     assert sum(int(((t - 1 >= lo) & (t - 1 < hi)).sum()) for lo, hi in b) == 4
+
+
+@pytest.mark.gpu
+def test_more_layers_on_degenerate_graphs(gm):
+    """CGConv / EdgeConv / GatedGraphConv / DConv with no edges, a single node, a single edge"""
+    import torch
+    from oracle import more_layers as ML
+    rng = np.random.default_rng(2)
+    for n, s, t in ((9, E0, E0), (1, E0, E0), (1, np.array([1]), np.array([1])), (4, np.array([2]), np.array([3]))):
+        g = gm.GNNGraph(dev(s), dev(t), num_nodes=n)
+        x = rng.standard_normal((n, 6)).astype(np.float32)
+        E = len(s)
+        # CGConv with edge features
+        e = rng.standard_normal((E, 3)).astype(np.float32)
+        l = gm.CGConv(((6, 3), 6), "softplus", residual=True, seed=1)
+        y = l(g, dev(x), dev(e) if E else torch.empty((0, 3), device="cuda")).cpu().numpy()
+        ref = ML.cg_conv(s, t, n, x, e, l.dense_f_weight.cpu().numpy(), l.dense_f_bias.cpu().numpy(),
+                         l.dense_s_weight.cpu().numpy(), l.dense_s_bias.cpu().numpy(), "softplus", True)
+        np.testing.assert_allclose(y, ref, rtol=1e-5, atol=1e-6)
+        # EdgeConv: empty destinations keep the identity of the aggregation (-Inf for max, 0 for +)
+        d1 = gm.Dense((12, 5), "relu", seed=2)
+        nn = [(d1.weight.cpu().numpy(), d1.bias.cpu().numpy(), "relu")]
+        for aggr in ("max", "+"):
+            y = gm.EdgeConv(d1, aggr=aggr)(g, dev(x)).cpu().numpy()
+            ref = ML.edge_conv(s, t, n, x, nn, aggr)
+            assert y.shape == ref.shape == (n, 5)
+            np.testing.assert_array_equal(np.isfinite(y), np.isfinite(ref))
+            fin = np.isfinite(ref)
+            np.testing.assert_allclose(y[fin], ref[fin], rtol=1e-5, atol=1e-6)
+        # GatedGraphConv (input padded from 6 to 8 features), DConv
+        lg = gm.GatedGraphConv(8, 2, seed=3)
+        y = lg(g, dev(x)).cpu().numpy()
+        ref = ML.gated_graph_conv(s, t, n, x, lg.weight.cpu().numpy(), lg.gru_Wi.cpu().numpy(), lg.gru_Wh.cpu().numpy(),
+                                  lg.gru_b.cpu().numpy(), "+")
+        np.testing.assert_allclose(y, ref, rtol=1e-5, atol=1e-6)
+        ld = gm.DConv((6, 4), 3, seed=4)
+        y = ld(g, dev(x)).cpu().numpy()
+        ref = ML.d_conv(s, t, n, x, ld.weights.cpu().numpy(), ld.bias.cpu().numpy(), 3)
+        np.testing.assert_allclose(y, ref, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_agnn_adjoint_without_edges_and_layer_argument_checks(gm):
+    import torch
+    from gnnmp.backward_attn import agnn_conv_ad
+    from gnnmp.layers_attn import AGNNConv
+    n = 11
+    g = gm.GNNGraph(dev(E0), dev(E0), num_nodes=n)
+    x = torch.randn((n, 5), device="cuda", requires_grad=True)
+    l = AGNNConv()
+    l.beta = torch.tensor([1.5], device="cuda", requires_grad=True)
+    y = agnn_conv_ad(l, g, x)                              # only self loops: out = x, dL/dx = r, dL/dβ = 0
+    r = torch.randn((n, 5), device="cuda")
+    (y * r).sum().backward()
+    assert torch.allclose(y, x, rtol=1e-6, atol=1e-7)
+    assert torch.allclose(x.grad, r, rtol=1e-5, atol=1e-6)
+    assert abs(float(l.beta.grad[0])) < 1e-5
+    with pytest.raises(AssertionError):
+        gm.GatedGraphConv(4, 1)(g, torch.randn((n, 5), device="cuda"))      # more input than output features
+    with pytest.raises(AssertionError):
+        gm.CGConv((5, 5))(g, torch.randn((n + 1, 5), device="cuda"))        # wrong number of nodes
+    with pytest.raises(AssertionError):
+        gm.CGConv(((5, 2), 5))(g, torch.randn((n, 5), device="cuda"))       # built with edge features, none given
