@@ -165,6 +165,7 @@ struct DenseWArgs {
     int old_;      // leading dimension of the wave-private output image (multiple of 4)
     int skew;      // s_sleep(127) repetitions for waves 4-7 before their first tile (0 = none)
     int token;     // 1 = serialise the k-loops of the two waves of a SIMD with an LDS token
+    int dbg;
     int tp;        // output column tiles per epilogue pass
     int ks;        // columns of x staged per k-chunk (multiple of 4; = K rounded up when the whole tile fits)
     int region;    // floats per wave region
@@ -189,7 +190,12 @@ __global__ void __launch_bounds__(512) dense_wlds_kernel(const DenseWArgs w) {
     const bool paired = w.waves == 8 && w.token != 0;
     if (t < 4) reinterpret_cast<int *>(lds + (size_t)w.ktot_pad * WLD + (size_t)w.waves * w.region)[t] = 0;
 
-    // ---- W^T image, once per block: Wt[koff + k][j] = W(n0 + j, k) ----
+    // ---- W^T image, once per block: Wt[koff + k][j] = W(n0 + j, k), zero where j >= ncols or k >= K ----
+    // Zero fill first, then only the valid (j, k) pairs: the loaded value goes to LDS as it is.  (Masking it with
+    // `valid ? lv : 0` made hipcc sink every load under its own branch with its own s_waitcnt vmcnt(0): 8 serialised HBM
+    // round trips per iteration, ~35 us per launch.)
+    for (int i = t; i < w.ktot_pad * WLD; i += nthreads) Wt[i] = 0.0f;
+    __syncthreads();
     {
         int koff = 0;
         for (int seg = 0; seg < a.nseg; ++seg) {
@@ -197,8 +203,8 @@ __global__ void __launch_bounds__(512) dense_wlds_kernel(const DenseWArgs w) {
             const float *__restrict__ W = a.W[seg];
             const int64_t sj = a.w_layout == 0 ? a.ldw[seg] : 1;   // element strides of W(j, k): one load expression
             const int64_t sk = a.w_layout == 0 ? 1 : a.ldw[seg];  // for both layouts (no per-element branch)
-            const int total = Kp * NT * 32;
-            constexpr int WB = 8;  // independent loads in flight per thread (same reason as the x staging below)
+            const int total = K * ncols;
+            constexpr int WB = 8;  // independent loads in flight per thread
             for (int idx0 = t; idx0 < total; idx0 += nthreads * WB) {
                 float v[WB];
                 int dst[WB];
@@ -206,13 +212,11 @@ __global__ void __launch_bounds__(512) dense_wlds_kernel(const DenseWArgs w) {
                 for (int u = 0; u < WB; ++u) {
                     const int idx = idx0 + u * nthreads;
                     const int idc = min(idx, total - 1);
-                    int j, k;
-                    if (a.w_layout == 0) { j = idc / Kp; k = idc - j * Kp; }   // consecutive threads walk k (contiguous in W)
-                    else                 { k = idc / (NT * 32); j = idc - k * (NT * 32); }
-                    dst[u] = idx < total ? (koff + k) * WLD + j : -1;
-                    const int jc = min(j, ncols - 1), kc = min(k, K - 1);  // clamped: the load itself is unconditional
-                    const float lv = W[(int64_t)(n0 + jc) * sj + (int64_t)kc * sk];
-                    v[u] = (j < ncols && k < K) ? lv : 0.0f;
+                    int jj, k;
+                    if (a.w_layout == 0) { jj = idc / K; k = idc - jj * K; }       // consecutive threads walk k (contiguous in W)
+                    else                 { k = idc / ncols; jj = idc - k * ncols; }
+                    dst[u] = idx < total ? (koff + k) * WLD + jj : -1;
+                    v[u] = W[(int64_t)(n0 + jj) * sj + (int64_t)k * sk];
                 }
 #pragma unroll
                 for (int u = 0; u < WB; ++u)
@@ -259,7 +263,8 @@ __global__ void __launch_bounds__(512) dense_wlds_kernel(const DenseWArgs w) {
                 const int kcn = min(w.ks, K - kc0);          // real columns in this chunk (may be odd at the tail)
                 const int kcp = min(w.ks, Kp - kc0);         // even number of k-steps' worth
                 // ---- stage x[m0 : m0+32][kc0 : kc0+kcn] into the A-operand image xs[row][k] ----
-                if (vec && (kcn & 3) == 0) {
+                if (w.dbg & 1) {
+                } else if (vec && (kcn & 3) == 0) {
                     // batches of SB independent 16-byte loads per lane, THEN the LDS writes: a plain load->write loop
                     // serialises one HBM round trip per iteration (measured: waves parked 42 % of their cycles)
                     // Lane -> (row, column) by shifts, no integer division: lpr = 2^k >= q lanes cover one row's q float4
@@ -324,6 +329,11 @@ __global__ void __launch_bounds__(512) dense_wlds_kernel(const DenseWArgs w) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) b0[nt] = wb[nt * 32];
                 int kk = 0;
+                if (w.dbg & 4) kk = kcp;
+                // sched_barrier(0) pins the order "reads of the NEXT k-step, then the MFMAs of THIS one": left alone, hipcc's
+                // scheduler sinks each read group to just before its first use and folds both register sets into one
+                // (ISA: ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma three times per iteration: the k-loop alone ran at 74 % of
+                // the matrix pipe's rate).
                 for (; kk + 4 <= kcp; kk += 4) {
                     {
                         const float *wk = wb + (kk + 2) * WLD;
@@ -331,9 +341,11 @@ __global__ void __launch_bounds__(512) dense_wlds_kernel(const DenseWArgs w) {
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt) b1[nt] = wk[nt * 32];
                     }
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
                         acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0[nt], acc[nt], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                     {
                         const int kn = min(kk + 4, kcp - 2);     // past the end: re-read the last step (unused)
                         const float *wk = wb + kn * WLD;
@@ -341,9 +353,11 @@ __global__ void __launch_bounds__(512) dense_wlds_kernel(const DenseWArgs w) {
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt) b0[nt] = wk[nt * 32];
                     }
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
                         acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1[nt], acc[nt], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 if (kk < kcp) {   // kcp % 4 == 2: one k-step left, its operands are already in set 0
 #pragma unroll
@@ -363,7 +377,7 @@ __global__ void __launch_bounds__(512) dense_wlds_kernel(const DenseWArgs w) {
         // The region is sized for the x image; the output tile goes through it in passes of w.tp column tiles.
         const int colb = lane & 31, rowb = 4 * (lane >> 5);
         const bool vec_ok = (a.Dout & 3) == 0 && (n0 & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.out) & 15) == 0);
-        for (int c_lo = 0; c_lo < ncols; c_lo += w.tp * 32) {
+        for (int c_lo = (w.dbg & 2) ? ncols : 0; c_lo < ncols; c_lo += w.tp * 32) {
             const int c_hi = min(ncols, c_lo + w.tp * 32);
             const int pc = c_hi - c_lo;
 #pragma unroll
@@ -513,6 +527,7 @@ extern "C" int gnnmp_dense_f32(const float *x1, const float *W1, int64_t D1, int
             w.ks = c.ks;
             w.skew = knob(KNOB_DENSE_PREFETCH) & 15;          // experiment knob (slot 7): low 4 bits = s_sleep(127) count,
             w.token = (knob(KNOB_DENSE_PREFETCH) >> 4) & 1;   //                           bit 4 = matrix-pipe token
+            w.dbg = knob(KNOB_DENSE_PREFETCH) >> 8;
             w.region = (int)c.region;
             w.ktot_pad = ktot;
             const int64_t n_row_tiles = (N + 31) / 32;
