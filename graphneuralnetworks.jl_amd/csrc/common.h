@@ -33,8 +33,8 @@ enum Knob {
     KNOB_DENSE_GENERIC = 6,  // 1 = force the K-chunked dense kernel (default 0: W-resident kernel when it fits)
     KNOB_DENSE_PREFETCH = 7,  // W-resident dense kernel scheduling: bit 4 = per-SIMD matrix-pipe token, low 4 bits =
                               // start skew of waves 4-7 in s_sleep(127) units.  Default 17 (token + 1): 0.83 -> 0.72 ms
-                              // at 2.4M x 100 => 100.  (A register prefetch of the next tile was tried and removed:
-                              // 1.13 vs 0.82 ms.)
+                              // at 2.4M x 100 => 100.  Bit 5 = turn the cross-tile register prefetch OFF (on by default; its
+                              // first version spilled — 270 VGPRs — and was slower: see dense.hip).
     KNOB_GAT_FAST_EXP = 8,   // 1 = v_exp_f32-based exp in the one-pass GAT kernel (experiment; default 0 = accurate expf)
     KNOB_GRADW_SLABS = 9,    // ΔW kernel: slabs per CU (0 = auto)
     KNOB_GRADW_RP = 10,      // ΔW kernel: row pairs loaded per batch (0 = auto, else 2|4|8)

@@ -165,7 +165,7 @@ struct DenseWArgs {
     int old_;      // leading dimension of the wave-private output image (multiple of 4)
     int skew;      // s_sleep(127) repetitions for waves 4-7 before their first tile (0 = none)
     int token;     // 1 = serialise the k-loops of the two waves of a SIMD with an LDS token
-    int dbg;
+    int prefetch;  // 1 = cross-tile register prefetch of the next x block (one-segment, whole-K staging)
     int tp;        // output column tiles per epilogue pass
     int ks;        // columns of x staged per k-chunk (multiple of 4; = K rounded up when the whole tile fits)
     int region;    // floats per wave region
@@ -244,6 +244,36 @@ __global__ void __launch_bounds__(512) dense_wlds_kernel(const DenseWArgs w) {
         for (int i = 0; i < w.skew; ++i) __builtin_amdgcn_s_sleep(127);
     }
     const int64_t tile_stride = (int64_t)gridDim.x * w.waves;
+    // Cross-tile prefetch (one segment, whole-K staging, 16-byte-aligned rows): the NEXT full tile's 32 x K block is loaded
+    // into registers before this tile's k-loop starts, so its HBM round trip hides under this wave's own MFMAs (products
+    // 100 => 100: 740 -> 700 us).  The 64 prefetch registers double as the staging batch of the non-prefetch path — kept
+    // apart, the kernel needed 270 VGPRs and spilled (-20 %).
+    constexpr int PF = 16;                                   // float4 per lane: 32 rows x 128 columns at most
+    const bool pf_on = w.prefetch && a.nseg == 1 && w.ks >= ((a.K[0] + 1) & ~1) && (a.K[0] & 3) == 0 &&
+                       ((reinterpret_cast<uintptr_t>(a.x[0]) & 15) == 0);
+    float4 pfv[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) pfv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    int pf_l2 = 0;
+    while ((1 << pf_l2) < (a.K[0] >> 2)) ++pf_l2;
+    const int pf_rpi = 64 >> pf_l2, pf_c4 = lane & ((1 << pf_l2) - 1), pf_rsub = lane >> pf_l2;
+    const int pf_nit = pf_rpi >= 32 ? 1 : 32 / pf_rpi;
+    const bool pf_lane = pf_c4 < (a.K[0] >> 2) && pf_rsub < 32;
+    const int64_t pf_off = (int64_t)min(pf_rsub, 31) * a.K[0] + (pf_lane ? pf_c4 : 0) * 4;
+#define GNNMP_PF_LOAD(T)                                                                                         \
+    {                                                                                                            \
+        const float *xl_ = a.x[0] + (T) * 32 * (int64_t)a.K[0] + pf_off;                                         \
+        _Pragma("unroll") for (int u = 0; u < PF; ++u)                                                           \
+            pfv[u] = *reinterpret_cast<const float4 *>(xl_ + (int64_t)min(u, pf_nit - 1) * pf_rpi * a.K[0]);     \
+    }
+    bool pf_have = false;
+    {
+        const int64_t t0 = (int64_t)blockIdx.x * w.waves + wave;
+        if (pf_on && t0 < n_tiles && (t0 + 1) * 32 <= a.N) {
+            GNNMP_PF_LOAD(t0)
+            pf_have = true;
+        }
+    }
     for (int64_t tile = (int64_t)blockIdx.x * w.waves + wave; tile < n_tiles; tile += tile_stride) {
         const int64_t m0 = tile * 32;
         const int rows = (int)min<int64_t>(32, a.N - m0);
@@ -263,7 +293,19 @@ __global__ void __launch_bounds__(512) dense_wlds_kernel(const DenseWArgs w) {
                 const int kcn = min(w.ks, K - kc0);          // real columns in this chunk (may be odd at the tail)
                 const int kcp = min(w.ks, Kp - kc0);         // even number of k-steps' worth
                 // ---- stage x[m0 : m0+32][kc0 : kc0+kcn] into the A-operand image xs[row][k] ----
-                if (w.dbg & 1) {
+                if (pf_have) {
+                    // this tile's block is already in registers: image it, then put the next full tile's loads in flight
+                    float *dl = reg + pf_rsub * XLD + pf_c4 * 4;
+#pragma unroll
+                    for (int u = 0; u < PF; ++u) {
+                        if (pf_lane && u < pf_nit) {
+                            float *d = dl + u * pf_rpi * XLD;
+                            d[0] = pfv[u].x; d[1] = pfv[u].y; d[2] = pfv[u].z; d[3] = pfv[u].w;
+                        }
+                    }
+                    const int64_t nx = tile + tile_stride;
+                    pf_have = nx < n_tiles && (nx + 1) * 32 <= a.N;
+                    if (pf_have) GNNMP_PF_LOAD(nx)
                 } else if (vec && (kcn & 3) == 0) {
                     // batches of SB independent 16-byte loads per lane, THEN the LDS writes: a plain load->write loop
                     // serialises one HBM round trip per iteration (measured: waves parked 42 % of their cycles)
@@ -281,8 +323,9 @@ __global__ void __launch_bounds__(512) dense_wlds_kernel(const DenseWArgs w) {
                     const float *xl = x + (int64_t)min(rsub, 31) * K + kc0 + (c4 < q ? c4 : 0) * 4;
                     float *dl = reg + rsub * XLD + c4 * 4;
                     const int nit = rpi >= 32 ? 1 : 32 / rpi;
+                    static_assert(SB == PF, "the staging batch lives in the prefetch registers (idle on this path)");
+                    float4 (&v)[PF] = pfv;
                     for (int it0 = 0; it0 < nit; it0 += SB) {
-                        float4 v[SB];
 #pragma unroll
                         for (int u = 0; u < SB; ++u) {       // unconditional (clamped) loads: no per-element branch + wait
                             const int it = min(it0 + u, nit - 1);
@@ -329,7 +372,6 @@ __global__ void __launch_bounds__(512) dense_wlds_kernel(const DenseWArgs w) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) b0[nt] = wb[nt * 32];
                 int kk = 0;
-                if (w.dbg & 4) kk = kcp;
                 // sched_barrier(0) pins the order "reads of the NEXT k-step, then the MFMAs of THIS one": left alone, hipcc's
                 // scheduler sinks each read group to just before its first use and folds both register sets into one
                 // (ISA: ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma three times per iteration: the k-loop alone ran at 74 % of
@@ -377,7 +419,7 @@ __global__ void __launch_bounds__(512) dense_wlds_kernel(const DenseWArgs w) {
         // The region is sized for the x image; the output tile goes through it in passes of w.tp column tiles.
         const int colb = lane & 31, rowb = 4 * (lane >> 5);
         const bool vec_ok = (a.Dout & 3) == 0 && (n0 & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.out) & 15) == 0);
-        for (int c_lo = (w.dbg & 2) ? ncols : 0; c_lo < ncols; c_lo += w.tp * 32) {
+        for (int c_lo = 0; c_lo < ncols; c_lo += w.tp * 32) {
             const int c_hi = min(ncols, c_lo + w.tp * 32);
             const int pc = c_hi - c_lo;
 #pragma unroll
@@ -527,7 +569,7 @@ extern "C" int gnnmp_dense_f32(const float *x1, const float *W1, int64_t D1, int
             w.ks = c.ks;
             w.skew = knob(KNOB_DENSE_PREFETCH) & 15;          // experiment knob (slot 7): low 4 bits = s_sleep(127) count,
             w.token = (knob(KNOB_DENSE_PREFETCH) >> 4) & 1;   //                           bit 4 = matrix-pipe token
-            w.dbg = knob(KNOB_DENSE_PREFETCH) >> 8;
+            w.prefetch = ((knob(KNOB_DENSE_PREFETCH) >> 5) & 1) ^ 1;   //                  bit 5 = cross-tile prefetch OFF
             w.region = (int)c.region;
             w.ktot_pad = ktot;
             const int64_t n_row_tiles = (N + 31) / 32;
