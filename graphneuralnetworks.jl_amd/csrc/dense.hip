@@ -366,46 +366,42 @@ __global__ void __launch_bounds__(512) dense_wlds_kernel(const DenseWArgs w) {
                     }
                     __builtin_amdgcn_wave_barrier();
                 }
-                // two register sets in ping-pong (no moves): set 1 is loaded while set 0 feeds the matrix pipe and back
-                float a0 = xa[0], a1;
-                float b0[NT], b1[NT];
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) b0[nt] = wb[nt * 32];
-                int kk = 0;
-                // sched_barrier(0) pins the order "reads of the NEXT k-step, then the MFMAs of THIS one": left alone, hipcc's
-                // scheduler sinks each read group to just before its first use and folds both register sets into one
-                // (ISA: ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma three times per iteration: the k-loop alone ran at 74 % of
-                // the matrix pipe's rate).
-                for (; kk + 4 <= kcp; kk += 4) {
-                    {
-                        const float *wk = wb + (kk + 2) * WLD;
-                        a1 = xa[kk + 2];
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) b1[nt] = wk[nt * 32];
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0[nt], acc[nt], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    {
-                        const int kn = min(kk + 4, kcp - 2);     // past the end: re-read the last step (unused)
-                        const float *wk = wb + kn * WLD;
-                        a0 = xa[kn];
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) b0[nt] = wk[nt * 32];
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1[nt], acc[nt], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
+                // Three operand sets in rotation (no moves): the reads of k-step s + 2 are issued before the MFMAs of k-step s,
+                // i.e. every LDS read has two MFMA groups (~512 cycles) to return — the other waves of the CU write their x
+                // images and output tiles through the same LDS, and one group of slack was not always enough.
+                // sched_barrier(0) pins that order: left alone, hipcc's scheduler sinks each read group to just before its
+                // first use and folds the register sets into one (ISA: ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma three times
+                // per iteration).
+                const int nsteps = kcp >> 1;
+#define GNNMP_RD(A, B, STEP)                                                        \
+    {                                                                               \
+        const int st_ = min((STEP), nsteps - 1) * 2;                                \
+        const float *wk_ = wb + st_ * WLD;                                          \
+        A = xa[st_];                                                                \
+        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) B[nt] = wk_[nt * 32];     \
+    }
+#define GNNMP_MM(A, B)                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                                   \
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(A, B[nt], acc[nt], 0, 0, 0);                     \
+    __builtin_amdgcn_sched_barrier(0);
+                float a0, a1, a2;
+                float b0[NT], b1[NT], b2[NT];
+                GNNMP_RD(a0, b0, 0)
+                GNNMP_RD(a1, b1, 1)
+                int st = 0;
+                for (; st + 3 <= nsteps; st += 3) {
+                    GNNMP_RD(a2, b2, st + 2)
+                    GNNMP_MM(a0, b0)
+                    GNNMP_RD(a0, b0, st + 3)
+                    GNNMP_MM(a1, b1)
+                    GNNMP_RD(a1, b1, st + 4)
+                    GNNMP_MM(a2, b2)
                 }
-                if (kk < kcp) {   // kcp % 4 == 2: one k-step left, its operands are already in set 0
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0[nt], acc[nt], 0, 0, 0);
-                }
+                if (st < nsteps) { GNNMP_MM(a0, b0) }          // set 0 holds step st, set 1 step st + 1
+                if (st + 1 < nsteps) { GNNMP_MM(a1, b1) }
+#undef GNNMP_RD
+#undef GNNMP_MM
                 if (paired) {
                     if (lane == 0) atomicExch(tok, 0);
                 }
