@@ -92,13 +92,20 @@ __device__ __forceinline__ void gat_online_range(const GatFusedArgs &a, int beg,
             float v[U][VEC];                                  // K_j
             float w[MODE == GNNMP_ATTN_DOT ? U : 1][VEC];     // V_j when it is a different array
             float es[U];
+            // all U source ids first (one LDS round trip for the batch), then the U row loads back to back; the edge term's
+            // uniform branch sits after them (between the loads it made hipcc wait for every ds_bpermute separately)
+            int cj[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) cj[u] = __shfl(c, gbase + min(j + u, n - 1), 64);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int cj = __shfl(c, gbase + min(j + u, n - 1), 64);
-                Vec<VEC>::load(a.Wx_src + (int64_t)cj * a.D + fc, v[u]);
-                if (MODE == GNNMP_ATTN_DOT) Vec<VEC>::load(a.Wx_val + (int64_t)cj * a.D + fc, w[MODE == GNNMP_ATTN_DOT ? u : 0]);
+                Vec<VEC>::load(a.Wx_src + (int64_t)cj[u] * a.D + fc, v[u]);
+                if (MODE == GNNMP_ATTN_DOT) Vec<VEC>::load(a.Wx_val + (int64_t)cj[u] * a.D + fc, w[MODE == GNNMP_ATTN_DOT ? u : 0]);
                 es[u] = 0.0f;
-                if (edge_term) {
+            }
+            if (edge_term) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
                     const int ej = __shfl(ev, gbase + min(j + u, n - 1), 64);
                     es[u] = a.escore[(int64_t)ej * a.H + r.h];
                 }
