@@ -35,7 +35,7 @@ enum Knob {
                               // start skew of waves 4-7 in s_sleep(127) units.  Default 17 (token + 1): 0.83 -> 0.72 ms
                               // at 2.4M x 100 => 100.  Bit 5 = turn the cross-tile register prefetch OFF (on by default; its
                               // first version spilled — 270 VGPRs — and was slower: see dense.hip).
-    KNOB_GAT_FAST_EXP = 8,   // 1 = v_exp_f32-based exp in the one-pass GAT kernel (experiment; default 0 = accurate expf)
+    KNOB_GAT_FAST_EXP = 8,   // retired: the one-pass attention kernel always uses v_exp_f32 now (gat_fused.hip, gexp)
     KNOB_GRADW_SLABS = 9,    // ΔW kernel: slabs per CU (0 = auto)
     KNOB_GRADW_RP = 10,      // ΔW kernel: row pairs loaded per batch (0 = auto, else 2|4|8)
     KNOB_GRADW_MIN_ROWS = 11,  // ΔW kernel: rows-per-slab floor (0 = auto: ~3 slabs per CU on small inputs, 512 on large)

@@ -48,9 +48,9 @@ struct GatFusedArgs {
     int n_rows;
     int n_src;
     int log2g;
+    int off24;            // 1: row offsets fit the 24-bit multiply (see gat_online_range)
     int lph;              // lanes per head = C / VEC (power of two; the whole group when H = 1)
     int act;
-    int fast_exp;
     float slope;
     float scale;          // DOT: divisor (sqrt(out)); COS: multiplier (β)
     int long_thresh;
@@ -59,8 +59,18 @@ struct GatFusedArgs {
     int waves;
 };
 
+// internal fifth mode: GAT with the per-edge logit term (gnnmp_gat_conv_edge_f32) — a compile-time property, so the headline
+// kernel carries no trace of it (as a runtime flag both logit variants were computed and selected per edge)
+constexpr int ATTN_GAT_EDGE = 4;
+__host__ __device__ constexpr bool is_gat(int mode) { return mode == GNNMP_ATTN_GAT || mode == ATTN_GAT_EDGE; }
+
 __device__ __forceinline__ float lrelu(float x, float slope) { return x > 0.0f ? x : x * slope; }
-__device__ __forceinline__ float gexp(float x, int fast) { return fast ? __expf(x) : expf(x); }
+// exp of a softmax exponent (x <= 0): v_exp_f32 on x * log2(e).  The product's rounding puts a relative error of
+// |x| * 6e-8 on exp(x), i.e. an ABSOLUTE error of at most 0.37 * 6e-8 = 2.2e-8 on a weight in (0, 1] — below fp32
+// epsilon of the weights that matter — for 2 instructions instead of libm's 12 (PMC: the kernel was at 84 % VALU
+// utilisation, 9 exponentials per batch of 8 edges were a quarter of its instructions; a RUNTIME fast/accurate switch
+// had made it evaluate both).  exp(-inf) = 0 and NaN propagate as with expf.
+__device__ __forceinline__ float gexp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
 
 // what a lane keeps for the whole row: its coefficient slice, its slice of Q_i, and one per-head scalar
 template <int VEC>
@@ -76,7 +86,7 @@ struct LaneRow {
 // is a compile-time constant), ONE rescale of the running state to the batch maximum and U exponentials — no branch
 // anywhere, so the scheduler interleaves all of it under the loads.  Slots past the end of the row re-read the last
 // edge with logit -inf (weight exactly 0).
-template <int VEC, int U, int LPH, int MODE>
+template <int VEC, int U, int LPH, int MODE, bool OFF24>
 __device__ __forceinline__ void gat_online_range(const GatFusedArgs &a, int beg, int end, int lig,
                                                  int gbase, int G, int fc, const LaneRow<VEC> &r,
                                                  float &m, float &den, float acc[VEC]) {
@@ -85,7 +95,7 @@ __device__ __forceinline__ void gat_online_range(const GatFusedArgs &a, int beg,
         const int c = p < end ? a.col[p] : 0;
         // edge features (gat_conv with dense_e): the edge's share of the logit, a_e . We_k, precomputed per edge and head,
         // is fetched by original edge position (uniform branch: absent for the headline layer)
-        const bool edge_term = MODE == GNNMP_ATTN_GAT && a.escore != nullptr;
+        constexpr bool edge_term = MODE == ATTN_GAT_EDGE;
         const int ev = (edge_term && p < end) ? a.eid[p] : 0;
         const int n = min(G, end - base);
         for (int j = 0; j < n; j += U) {
@@ -99,8 +109,11 @@ __device__ __forceinline__ void gat_online_range(const GatFusedArgs &a, int beg,
             for (int u = 0; u < U; ++u) cj[u] = __shfl(c, gbase + min(j + u, n - 1), 64);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                Vec<VEC>::load(a.Wx_src + (int64_t)cj[u] * a.D + fc, v[u]);
-                if (MODE == GNNMP_ATTN_DOT) Vec<VEC>::load(a.Wx_val + (int64_t)cj[u] * a.D + fc, w[MODE == GNNMP_ATTN_DOT ? u : 0]);
+                // OFF24 (fewer than 2^24 rows of fewer than 2^24 floats, fewer than 2^32 floats in all): the row offset is
+                // ONE full-rate v_mad_u32_u24 instead of a quarter-rate 64-bit multiply-add per edge
+                const int64_t o = OFF24 ? (int64_t)(uint32_t)(__umul24(cj[u], a.D) + fc) : (int64_t)cj[u] * a.D + fc;
+                Vec<VEC>::load(a.Wx_src + o, v[u]);
+                if (MODE == GNNMP_ATTN_DOT) Vec<VEC>::load(a.Wx_val + o, w[MODE == GNNMP_ATTN_DOT ? u : 0]);
                 es[u] = 0.0f;
             }
             if (edge_term) {
@@ -117,7 +130,7 @@ __device__ __forceinline__ void gat_online_range(const GatFusedArgs &a, int beg,
                 nn[u] = 0.0f;
 #pragma unroll
                 for (int q = 0; q < VEC; ++q) {
-                    if (MODE == GNNMP_ATTN_GAT) l[u] = fmaf(r.ca[q], v[u][q], l[u]);
+                    if (is_gat(MODE)) l[u] = fmaf(r.ca[q], v[u][q], l[u]);
                     if (MODE == GNNMP_ATTN_GATV2) l[u] = fmaf(r.ca[q], lrelu(r.vi[q] + v[u][q], a.slope), l[u]);
                     if (MODE == GNNMP_ATTN_DOT) l[u] = fmaf(r.vi[q], v[u][q], l[u]);
                     if (MODE == GNNMP_ATTN_COS) {
@@ -135,20 +148,20 @@ __device__ __forceinline__ void gat_online_range(const GatFusedArgs &a, int beg,
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 float lu = l[u];
-                if (MODE == GNNMP_ATTN_GAT) lu = lrelu(edge_term ? (r.s0 + lu) + es[u] : r.s0 + lu, a.slope);
+                if (is_gat(MODE)) lu = lrelu(edge_term ? (r.s0 + lu) + es[u] : r.s0 + lu, a.slope);
                 if (MODE == GNNMP_ATTN_DOT) lu = lu / a.scale;
                 if (MODE == GNNMP_ATTN_COS) lu = a.scale * (lu / (r.s0 * sqrtf(nn[u])));
                 l[u] = (j + u < n) ? lu : -__builtin_inff();
                 mn = fmaxf(mn, l[u]);
             }
-            const float sc = gexp(m - mn, a.fast_exp);   // exp(0) = 1 when the maximum did not move, exp(-inf) = 0 the first time
+            const float sc = gexp(m - mn);   // exp(0) = 1 when the maximum did not move, exp(-inf) = 0 the first time
             den *= sc;
 #pragma unroll
             for (int q = 0; q < VEC; ++q) acc[q] *= sc;
             m = mn;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const float pe = gexp(l[u] - m, a.fast_exp);
+                const float pe = gexp(l[u] - m);
                 den += pe;
 #pragma unroll
                 for (int q = 0; q < VEC; ++q)
@@ -216,7 +229,7 @@ __global__ void __launch_bounds__(256) gat_fused_rows_kernel(const GatFusedArgs 
             r.vi[q] = active ? qi[q] : 0.0f;
             r.ca[q] = 0.0f;
         }
-        if (MODE == GNNMP_ATTN_GAT) {
+        if (is_gat(MODE)) {
             const float *ah = a.a + (int64_t)h * 2 * a.C + c0;
             float sd = 0.0f;
 #pragma unroll
@@ -244,7 +257,10 @@ __global__ void __launch_bounds__(256) gat_fused_rows_kernel(const GatFusedArgs 
     float acc[VEC];
 #pragma unroll
     for (int q = 0; q < VEC; ++q) acc[q] = 0.0f;
-    gat_online_range<VEC, U, LPH, MODE>(a, beg, end, lig, gbase, G, fc, r, m, den, acc);
+    if (a.off24)
+        gat_online_range<VEC, U, LPH, MODE, true>(a, beg, end, lig, gbase, G, fc, r, m, den, acc);
+    else
+        gat_online_range<VEC, U, LPH, MODE, false>(a, beg, end, lig, gbase, G, fc, r, m, den, acc);
     if (is_chunk) {
         if (active) {
             const int LN = a.D / VEC;
@@ -400,9 +416,9 @@ static int launch_gat_fused(GatFusedArgs a, hipStream_t stream) {
         const int blk = 64 * waves;
         if (MODE == GNNMP_ATTN_DOT) {
             launch_rows_lph<VEC, 4, MODE>(a, grid, blk, stream);   // two rows per edge in flight: half the batch
-        } else if (MODE == GNNMP_ATTN_GAT && U == 4) {
+        } else if (is_gat(MODE) && U == 4) {
             gat_fused_rows_kernel<VEC, 4, 0, MODE><<<grid, blk, 0, stream>>>(a);
-        } else if (MODE == GNNMP_ATTN_GAT && U == 2) {
+        } else if (is_gat(MODE) && U == 2) {
             gat_fused_rows_kernel<VEC, 2, 0, MODE><<<grid, blk, 0, stream>>>(a);
         } else {
             launch_rows_lph<VEC, 8, MODE>(a, grid, blk, stream);
@@ -500,18 +516,18 @@ static int attn_conv_impl(gnnmp_graph_t *plan, int mode, const float *Q, const f
     g.log2g = log2g;
     g.lph = lph_code(lph, log2g);   // odd head widths (C = 7 classes, ...) sum their lanes one by one
     g.act = act;
-    g.fast_exp = knob(KNOB_GAT_FAST_EXP);
     g.slope = negative_slope;
     g.scale = scale;
     g.long_thresh = plan->long_thresh;
     g.cpx = 0;
     g.nbc = 0;
     g.waves = 4;
+    g.off24 = plan->n_src < (1 << 24) && D < (1 << 24) && (int64_t)plan->n_src * D < (1ll << 32);
     switch (mode) {
         case GNNMP_ATTN_GATV2: return launch_mode<GNNMP_ATTN_GATV2>(g, vec, stream);
         case GNNMP_ATTN_DOT: return launch_mode<GNNMP_ATTN_DOT>(g, vec, stream);
         case GNNMP_ATTN_COS: return launch_mode<GNNMP_ATTN_COS>(g, vec, stream);
-        default: return launch_mode<GNNMP_ATTN_GAT>(g, vec, stream);
+        default: return g.escore ? launch_mode<ATTN_GAT_EDGE>(g, vec, stream) : launch_mode<GNNMP_ATTN_GAT>(g, vec, stream);
     }
 }
 
