@@ -65,12 +65,9 @@ constexpr int ATTN_GAT_EDGE = 4;
 __host__ __device__ constexpr bool is_gat(int mode) { return mode == GNNMP_ATTN_GAT || mode == ATTN_GAT_EDGE; }
 
 __device__ __forceinline__ float lrelu(float x, float slope) { return x > 0.0f ? x : x * slope; }
-// exp of a softmax exponent (x <= 0): v_exp_f32 on x * log2(e).  The product's rounding puts a relative error of
-// |x| * 6e-8 on exp(x), i.e. an ABSOLUTE error of at most 0.37 * 6e-8 = 2.2e-8 on a weight in (0, 1] — below fp32
-// epsilon of the weights that matter — for 2 instructions instead of libm's 12 (PMC: the kernel was at 84 % VALU
-// utilisation, 9 exponentials per batch of 8 edges were a quarter of its instructions; a RUNTIME fast/accurate switch
-// had made it evaluate both).  exp(-inf) = 0 and NaN propagate as with expf.
-__device__ __forceinline__ float gexp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+// softmax_exp (common.h): PMC showed this kernel at 84 % VALU utilisation with 9 libm exponentials per batch of 8 edges a
+// quarter of its instructions (and a RUNTIME fast/accurate switch had made it evaluate both)
+__device__ __forceinline__ float gexp(float x) { return softmax_exp(x); }
 
 // what a lane keeps for the whole row: its coefficient slice, its slice of Q_i, and one per-head scalar
 template <int VEC>
