@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dst_kernel(const AttnBwdArgs a) 
             for (int u = 0; u < U; ++u) {
                 float lu = l[u];
                 if (MODE == GNNMP_ATTN_DOT) lu = lu / a.scale;
-                float al = softmax_exp(lu - m) * rden;
+                float al = expf(lu - m) * rden;
                 al = (j + u < n) ? al : 0.0f;
                 const float ag = al * g[u];
                 S1 += ag;
@@ -313,7 +313,7 @@ __global__ void __launch_bounds__(256) attn_bwd_src_kernel(const AttnBwdArgs a) 
             for (int u = 0; u < U; ++u) {
                 float lu = l[u];
                 if (MODE == GNNMP_ATTN_DOT) lu = lu / a.scale;
-                float al = softmax_exp(lu - ln[u].x) * ln[u].y;
+                float al = expf(lu - ln[u].x) * ln[u].y;
                 al = (j + u < n) ? al : 0.0f;
                 const float dl = al * (g[u] - ln[u].z);
 #pragma unroll

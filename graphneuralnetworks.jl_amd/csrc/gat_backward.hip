@@ -133,7 +133,7 @@ __global__ void __launch_bounds__(256) gat_bwd_dst_kernel(const GatBwdArgs a) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const float z = sd + d[u];
-                float al = softmax_exp(lrelu_b(z, a.slope) - m) * rden;
+                float al = expf(lrelu_b(z, a.slope) - m) * rden;
                 al = (j + u < n) ? al : 0.0f;
                 const float s = z > 0.0f ? 1.0f : a.slope;
                 const float ag = al * g[u];
@@ -249,7 +249,7 @@ __global__ void __launch_bounds__(256) gat_bwd_src_kernel(const GatBwdArgs a) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const float z = ln[u].x + ss;
-                float al = softmax_exp(lrelu_b(z, a.slope) - ln[u].y) * ln[u].z;
+                float al = expf(lrelu_b(z, a.slope) - ln[u].y) * ln[u].z;
                 al = (j + u < n) ? al : 0.0f;
                 const float s = z > 0.0f ? 1.0f : a.slope;
                 dss = fmaf(al * (g[u] - ln[u].w), s, dss);

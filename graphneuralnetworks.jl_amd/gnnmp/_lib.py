@@ -9,7 +9,7 @@ import ctypes
 import os
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG, "lib", "libgnnmp.so")
+LIB_PATH = os.environ.get("GNNMP_LIB") or os.path.join(_PKG, "lib", "libgnnmp.so")   # GNNMP_LIB: another build of the same ABI
 
 OK, EINVAL, EBOUNDS, EALLOC, ELAUNCH, EUNSUPPORTED = 0, -1, -2, -3, -4, -5
 SUM, MEAN, MAX, MIN = 0, 1, 2, 3
