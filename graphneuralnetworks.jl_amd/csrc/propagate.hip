@@ -144,14 +144,25 @@ __device__ __forceinline__ void reduce_range(const ReduceArgs &a, int beg, int e
             float em[EMAT ? U : 1][VEC];
             float em2[(EMAT && GATED == 2) ? U : 1][VEC];
             float wj[U], sj[U];
+            // every cross-lane broadcast of the batch first (one LDS round trip), then the row loads back to back
+            int cjs[U], ejs[EMAT ? U : 1];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int jj = min(j + u, n - 1);
-                const int cj = __shfl(c, gbase + jj, 64);
+                cjs[u] = __shfl(c, gbase + jj, 64);
+                if (EMAT) ejs[EMAT ? u : 0] = __shfl(ev, gbase + jj, 64);
+                if (SCALED) {
+                    wj[u] = __shfl(wv, gbase + jj, 64);
+                    sj[u] = __shfl(sv, gbase + jj, 64);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int cj = cjs[u];
                 if (EMAT) {
                     // e .* xj with e (D, E'): the edge's own row of factors, by original edge position; self loops the
                     // plan added carry no features and weigh 1
-                    const int ej = __shfl(ev, gbase + jj, 64);
+                    const int ej = ejs[EMAT ? u : 0];
                     if (GATED == 2) {   // the edge's share of both pre-activations (additive: absent = 0)
                         if (active && (j + u < n) && ej < a.n_edges) {
                             Vec<VEC>::load(a.emat + (int64_t)ej * 2 * a.D + f0, em[EMAT ? u : 0]);
@@ -166,10 +177,6 @@ __device__ __forceinline__ void reduce_range(const ReduceArgs &a, int beg, int e
 #pragma unroll
                         for (int q = 0; q < VEC; ++q) em[EMAT ? u : 0][q] = 1.0f;
                     }
-                }
-                if (SCALED) {
-                    wj[u] = __shfl(wv, gbase + jj, 64);
-                    sj[u] = __shfl(sv, gbase + jj, 64);
                 }
                 if (active && (j + u < n)) {
                     if (GATED) {
