@@ -19,8 +19,8 @@ import gnnmp  # noqa: E402
 from gnnmp import _lib as L  # noqa: E402
 from gnnmp import synth  # noqa: E402
 
-KNOBS = {"vec": 0, "log2g": 1, "unroll": 2, "xcd": 3, "long": 4, "waves": 5, "fastexp": 8}
-DEFAULTS = {"vec": 0, "log2g": -1, "unroll": 0, "xcd": 1, "long": 0, "waves": 0, "fastexp": 0}
+KNOBS = {"vec": 0, "log2g": 1, "unroll": 2, "xcd": 3, "long": 4, "waves": 5}
+DEFAULTS = {"vec": 0, "log2g": -1, "unroll": 0, "xcd": 1, "long": 0, "waves": 0}
 
 
 def set_knobs(**kw):
@@ -117,7 +117,7 @@ def main():
         print(f"== {kind}: N={N} E={Ecur} D={D} maxdeg={plan.max_degree} long={plan.n_long}")
         variants = [dict()]
         if not args.quick:
-            variants += [dict(fastexp=1), dict(fastexp=1, waves=1), dict(unroll=2), dict(unroll=8), dict(waves=1), dict(waves=2), dict(xcd=0),
+            variants += [dict(unroll=2), dict(unroll=8), dict(waves=1), dict(waves=2), dict(xcd=0),
                          dict(xcd=0, unroll=8), dict(xcd=0, waves=1), dict(xcd=0, waves=2), dict(xcd=0, unroll=8, waves=1),
                          dict(xcd=0, unroll=8, waves=2), dict(vec=2, log2g=6)]
         for v in variants:
