@@ -379,6 +379,65 @@ __global__ void __launch_bounds__(256) csr_combine_kernel(const ReduceArgs a) {
     finalize_store<VEC, OP>(a, row, a.rowptr[row + 1] - a.rowptr[row], f0, active, acc);
 }
 
+// nn_conv's propagate (GNNlib/src/layers/conv.jl:260-273): the message of edge k is W_k x_j with W_k = reshape(nn(e_k), out, in)
+// — an (out, in) matrix PER EDGE, read once, by original edge position (`we`, Julia column-major: element (o, c) at o + out * c).
+// One group of G >= out lanes per destination (virtual) row, lane o owns output feature o: for every in-channel the out
+// weights of the edge are one contiguous, coalesced load and x_j[c] is a broadcast.  Edges in original order, products
+// rounded then added (the reference runs a batched gemm: tolerance, not bits).  Chunks of long rows leave raw partials for
+// csr_combine_kernel like every other row kernel.
+template <int OP>
+__global__ void __launch_bounds__(256) nn_rows_kernel(const ReduceArgs a, const float *__restrict__ we, int Din) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int G = 1 << a.log2g;
+    const int lig = lane & (G - 1);
+    const int grp = lane >> a.log2g;
+    const int rpw = 64 >> a.log2g;
+    const int64_t v64 = ((int64_t)blockIdx.x * a.waves + wave) * rpw + grp;
+    if (v64 >= (int64_t)a.n_rows + a.n_chunks) return;
+    const int v = (int)v64;
+    const int o = (int)blockIdx.y * G + lig;
+    const bool active = o < a.D;
+    int row = 0, beg, end;
+    const bool is_chunk = v < a.n_chunks;
+    if (is_chunk) {
+        beg = a.chunk_beg[v];
+        end = a.chunk_end[v];
+    } else {
+        row = v - a.n_chunks;
+        beg = a.rowptr[row];
+        end = a.rowptr[row + 1];
+        if (end - beg > a.long_thresh) return;
+    }
+    float acc = op_identity<OP>();
+    const int oc = active ? o : 0;
+    for (int p = beg; p < end; ++p) {
+        const int cj = a.idx[p], ej = a.eid[p];
+        if (ej >= a.n_edges) continue;                       // a self loop the plan added: no edge features, no message
+        const float *wk = we + (int64_t)ej * a.D * Din + oc;
+        const float *xr = a.x + (int64_t)cj * Din;
+        float m = 0.0f;
+        int c = 0;
+        for (; c + 4 <= Din; c += 4) {                       // four weight columns in flight
+            const float w0 = wk[(int64_t)(c + 0) * a.D], w1 = wk[(int64_t)(c + 1) * a.D];
+            const float w2 = wk[(int64_t)(c + 2) * a.D], w3 = wk[(int64_t)(c + 3) * a.D];
+            const float4 xv = make_float4(xr[c], xr[c + 1], xr[c + 2], xr[c + 3]);
+            m = m + w0 * xv.x;
+            m = m + w1 * xv.y;
+            m = m + w2 * xv.z;
+            m = m + w3 * xv.w;
+        }
+        for (; c < Din; ++c) m = m + wk[(int64_t)c * a.D] * xr[c];
+        acc = op_apply<OP>(acc, m);
+    }
+    if (is_chunk) {
+        if (active) a.partial[(int64_t)v * a.D + o] = acc;
+        return;
+    }
+    float av[1] = {acc};
+    finalize_store<1, OP>(a, row, end - beg, o, active, av);
+}
+
 template <int VEC, int OP, bool SCALED, int U, bool EMAT = false, bool EXPSUB = false, int GATED = 0>
 static int launch_reduce(const ReduceArgs &a0, hipStream_t stream) {
     ReduceArgs a = a0;
@@ -692,6 +751,63 @@ int gnnmp_propagate_cg_f32(gnnmp_graph_t *plan, const float *fs_i, const float *
         return fail(GNNMP_EINVAL, "propagate_cg: null pointer");
     return run_reduce(plan, plan->col, GNNMP_SUM, fs_j, nullptr, nullptr, nullptr, nullptr, nullptr, out, D, (hipStream_t)stream,
                       fs_e, nullptr, fs_i, 2, act);
+}
+
+int gnnmp_propagate_nn_f32(gnnmp_graph_t *p, int aggr, const float *xj, const float *we, float *out, int64_t Din, int64_t Dout,
+                           gnnmp_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!p) return fail(GNNMP_EINVAL, "propagate_nn: null plan");
+    if (int rc = check_aggr(aggr, "propagate_nn")) return rc;
+    if (Din <= 0 || Dout <= 0 || Din > (1 << 16) || Dout > (1 << 16)) return fail(GNNMP_EINVAL, "propagate_nn: bad size");
+    if (p->n_dst == 0) return GNNMP_OK;
+    if (!out || ((!xj || !we) && p->n_total > 0)) return fail(GNNMP_EINVAL, "propagate_nn: null pointer");
+    if (p->n_chunks > 0) {
+        if (int rc = ensure_workspace(p, (size_t)p->n_chunks * (size_t)Dout)) return rc;
+    }
+    ReduceArgs a = {};
+    a.rowptr = p->rowptr;
+    a.idx = p->col;
+    a.eid = p->eid;
+    a.x = xj;
+    a.out = out;
+    a.partial = p->ws;
+    a.chunk_row = p->chunk_row;
+    a.chunk_beg = p->chunk_beg;
+    a.chunk_end = p->chunk_end;
+    a.long_rows = p->long_rows;
+    a.long_cptr = p->long_cptr;
+    a.n_chunks = p->n_chunks;
+    a.n_long = p->n_long;
+    a.D = (int)Dout;
+    a.n_rows = (int)p->n_dst;
+    a.n_src = (int)p->n_src;
+    a.n_edges = (int)p->n_edges;
+    a.mean = (aggr == GNNMP_MEAN);
+    a.long_thresh = p->long_thresh;
+    a.waves = 4;
+    a.log2g = pick_log2g(Dout);
+    const int G = 1 << a.log2g;
+    const int tiles = (int)((Dout + G - 1) / G);
+    const int64_t nvirt = (int64_t)a.n_rows + a.n_chunks;
+    const int64_t rows_per_block = (int64_t)(64 / G) * a.waves;
+    dim3 grid((unsigned)((nvirt + rows_per_block - 1) / rows_per_block), (unsigned)tiles);
+    const int op = (aggr == GNNMP_MAX) ? OP_MAX : (aggr == GNNMP_MIN ? OP_MIN : OP_SUM);
+    switch (op) {
+        case OP_SUM: nn_rows_kernel<OP_SUM><<<grid, 64 * a.waves, 0, stream>>>(a, we, (int)Din); break;
+        case OP_MAX: nn_rows_kernel<OP_MAX><<<grid, 64 * a.waves, 0, stream>>>(a, we, (int)Din); break;
+        default: nn_rows_kernel<OP_MIN><<<grid, 64 * a.waves, 0, stream>>>(a, we, (int)Din); break;
+    }
+    GNNMP_LAUNCH_CHECK("nn_rows_kernel");
+    if (a.n_long > 0) {
+        dim3 cg((unsigned)a.n_long, (unsigned)tiles);
+        switch (op) {
+            case OP_SUM: csr_combine_kernel<1, OP_SUM><<<cg, 256, 0, stream>>>(a); break;
+            case OP_MAX: csr_combine_kernel<1, OP_MAX><<<cg, 256, 0, stream>>>(a); break;
+            default: csr_combine_kernel<1, OP_MIN><<<cg, 256, 0, stream>>>(a); break;
+        }
+        GNNMP_LAUNCH_CHECK("csr_combine_kernel");
+    }
+    return GNNMP_OK;
 }
 
 int gnnmp_propagate_slots_f32(gnnmp_graph_t *plan, int aggr, const float *xj, const float *w_slot,

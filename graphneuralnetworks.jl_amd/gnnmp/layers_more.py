@@ -1,4 +1,4 @@
-"""More layers of the reference's zoo that run on the same kernels: CGConv, EdgeConv, GatedGraphConv, DConv.
+"""More layers of the reference's zoo that run on the same kernels: CGConv, EdgeConv, GatedGraphConv, DConv, NNConv.
 GNNlib/src/layers/conv.jl  cg_conv :304-333, edge_conv :237-246, gated_graph_conv :218-233, d_conv :696-725;
 constructors GraphNeuralNetworks/src/layers/conv.jl :925-931 (CGConv), :582 (EdgeConv), :525-530 (GatedGraphConv),
 :1584-1589 (DConv).
@@ -236,3 +236,42 @@ class DConv:
 
     def __call__(self, g, x):
         return d_conv(self, g, x)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# NNConv
+# ---------------------------------------------------------------------------------------------------------
+def nn_conv(l, g: GNNGraph, x, e):
+    """conv.jl:260-273: m = propagate(W_k x_j with W_k = reshape(nn(e)_k, out, in), aggr); σ.(weight * x .+ m .+ bias).
+    nn(e) is formed once ([E][out * in], as the reference does); the per-edge matrix-vector products and the aggregation
+    are one pass (gnnmp_propagate_nn_f32) — the (out, E) message array is never built."""
+    check_num_nodes(g, x)
+    check_num_edges(g, e)
+    x = x.contiguous()
+    out, nin = l.weight.shape
+    assert x.shape[1] == nin
+    we = e.contiguous()
+    for layer in (l.nn if isinstance(l.nn, (list, tuple)) else [l.nn]):
+        we = layer(we)
+    assert we.shape == (g.num_edges, out * nin), "NNConv: nn must map edge features to out * in channels"
+    m = torch.empty((g.num_nodes, out), dtype=torch.float32, device=x.device)
+    L.check(L.load().gnnmp_propagate_nn_f32(g.plan(False).handle, aggr_code(l.aggr), L.ptr(x), L.ptr(we.contiguous()), L.ptr(m),
+                                            nin, out, L.stream_ptr()))
+    from .layers import bias_act
+    return bias_act(_add(dense(x, l.weight), m), l.bias, l.sigma)
+
+
+class NNConv:
+    """NNConv(in => out, nn, σ = identity; aggr = +, bias = true) — GraphNeuralNetworks/src/layers/conv.jl (edge-conditioned
+    convolution); `nn`: a gnnmp Dense or list of layers mapping edge features to out * in channels"""
+
+    takes_graph = True
+
+    def __init__(self, ch, nn, sigma=None, aggr="+", bias=True, device="cuda", seed=None):
+        cin, out = ch
+        self.nn, self.sigma, self.aggr = nn, sigma, aggr
+        self.weight = glorot_uniform(out, cin, device=device, seed=seed)
+        self.bias = torch.zeros(out, dtype=torch.float32, device=device) if bias else None
+
+    def __call__(self, g, x, e):
+        return nn_conv(self, g, x, e)

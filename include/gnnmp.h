@@ -241,6 +241,11 @@ int gnnmp_propagate_gated_f32(gnnmp_graph_t *plan, int aggr, const float *gate_i
  * One pass over the edges; the (2D, E) pre-activations of the reference are never built. */
 int gnnmp_propagate_cg_f32(gnnmp_graph_t *plan, const float *fs_i, const float *fs_j, const float *fs_e, int act,
                            float *out, int64_t D, gnnmp_stream_t stream);
+/* nn_conv's propagate (GNNlib/src/layers/conv.jl:260-273): out[i] = aggr_{k: j -> i} W_k x_j with one (Dout, Din) matrix per
+ * edge, W_k = reshape(l.nn(e)[:, k], Dout, Din) — `we` is nn(e) as the reference holds it, [n_edges][Dout * Din] in
+ * original edge order, element (o, c) of edge k at we[k][o + Dout * c].  The (Dout, E) message array is never built. */
+int gnnmp_propagate_nn_f32(gnnmp_graph_t *plan, int aggr, const float *xj, const float *we, float *out, int64_t Din,
+                           int64_t Dout, gnnmp_stream_t stream);
 int gnnmp_propagate_slots_f32(gnnmp_graph_t *plan, int aggr, const float *xj, const float *w_slot,
                               const float *ss_slot, const float *scale_dst, float *out, int64_t D,
                               gnnmp_stream_t stream);

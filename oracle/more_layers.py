@@ -112,3 +112,24 @@ def d_conv(s, t, n, x, weights, bias, k, edge_weight=None):
         h = ((h + mm(W(0, i), T2_in)).astype(f32) + mm(W(1, i), T2_out)).astype(f32)
         T1_in, T1_out = T2_in, T2_out
     return h if bias is None else (h + O._f32(bias)[None, :]).astype(f32)
+
+
+def nn_conv(s, t, n, x, e, nn, weight, bias, act=None, aggr="+"):
+    """nn_conv (conv.jl:260-273): W_k = reshape(nn(e)[:, k], out, in) per edge (column-major), message W_k x_j, then
+    σ.(weight * x .+ m .+ bias).  nn = [(W, b, act), ...] a chain of Dense layers on the edge features."""
+    s, t = O._i64(s), O._i64(t)
+    x = O._f32(x)
+    z = O._f32(e)
+    for W, b, a_ in nn:
+        z = _dense(z, W, b, a_)
+    out, nin = weight.shape
+    Wk = z.reshape(len(s), nin, out).transpose(0, 2, 1)             # [E][out][in]: element (o, c) at o + out * c
+    xj = O.gather(x, s)
+    msg = np.zeros((len(s), out), f32)
+    for c in range(nin):                                            # batched_mul: products rounded, summed over in-channels
+        msg = (msg + (Wk[:, :, c] * xj[:, c:c + 1]).astype(f32)).astype(f32)
+    m = O.scatter({"+": O.SUM, "mean": O.MEAN, "max": O.MAX, "min": O.MIN}[aggr], msg, t, n)
+    y = ((O.matmul(O._f32(weight), x, True) + m).astype(f32))
+    if bias is not None:
+        y = (y + O._f32(bias)[None, :]).astype(f32)
+    return ACT[act](y)

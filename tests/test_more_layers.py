@@ -250,3 +250,51 @@ def test_hip_d_conv_vs_oracle(gm, ML, Din, Dout, k, weighted):
     y = l(g, dev(x)).cpu().numpy()
     ref = ML.d_conv(s, t, n, x, W, b, k, ew)
     assert rel(y, ref.astype(np.float64)) < 2e-5
+
+
+def test_oracle_nn_conv_vs_float64_edge_loop(oracle, ML):
+    rng = np.random.default_rng(17)
+    n, nin, out, ein = 25, 4, 3, 5
+    s, t = graph(rng, n, 160)
+    x = rng.standard_normal((n, nin)).astype(np.float32)
+    e = rng.standard_normal((len(s), ein)).astype(np.float32)
+    Wn, bn = (rng.standard_normal((out * nin, ein)) * 0.4).astype(np.float32), (rng.standard_normal(out * nin) * 0.1).astype(np.float32)
+    W, b = (rng.standard_normal((out, nin)) * 0.4).astype(np.float32), (rng.standard_normal(out) * 0.1).astype(np.float32)
+    for aggr in ("+", "mean"):
+        y = ML.nn_conv(s, t, n, x, e, [(Wn, bn, "relu")], W, b, "relu", aggr)
+        ref = np.zeros((n, out))
+        cnt = np.zeros(n)
+        for k in range(len(s)):
+            We = np.maximum(Wn.astype(np.float64) @ e[k] + bn, 0).reshape(nin, out).T      # column-major (out, in)
+            ref[t[k] - 1] += We @ x[s[k] - 1].astype(np.float64)
+            cnt[t[k] - 1] += 1
+        if aggr == "mean":
+            ref = ref / np.maximum(cnt, 1)[:, None]
+        ref = np.maximum(x.astype(np.float64) @ W.T.astype(np.float64) + ref + b, 0)
+        assert rel(y, ref) < 5e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nin,out,ein,aggr", [(16, 16, 8, "+"), (10, 7, 4, "mean"), (32, 64, 6, "max"), (5, 3, 2, "+")])
+def test_hip_nn_conv_vs_oracle(gm, ML, nin, out, ein, aggr):
+    rng = np.random.default_rng(nin + out)
+    n, E = 1200, 16000
+    s, t = graph(rng, n, E, hubs=True)
+    if aggr == "max":                                       # every node needs an in-edge (-Inf + x otherwise: fine, but NaN-free)
+        s = np.concatenate([s, np.roll(np.arange(1, n + 1), 1)])
+        t = np.concatenate([t, np.arange(1, n + 1)])
+        E = len(s)
+    x = rng.standard_normal((n, nin)).astype(np.float32)
+    e = rng.standard_normal((E, ein)).astype(np.float32)
+    g = gm.GNNGraph(dev(s), dev(t), num_nodes=n)
+    nnl = gm.Dense((ein, out * nin), "relu", seed=3)
+    nnl.bias = dev((rng.standard_normal(out * nin) * 0.1).astype(np.float32))
+    l = gm.NNConv((nin, out), nnl, "relu", aggr=aggr, seed=5)
+    l.bias = dev((rng.standard_normal(out) * 0.1).astype(np.float32))
+    y = l(g, dev(x), dev(e)).cpu().numpy()
+    ref = ML.nn_conv(s, t, n, x, e, [(nnl.weight.cpu().numpy(), nnl.bias.cpu().numpy(), "relu")], l.weight.cpu().numpy(),
+                     l.bias.cpu().numpy(), "relu", aggr)
+    assert y.shape == ref.shape == (n, out)
+    assert rel(y, ref.astype(np.float64)) < 1e-5
+    y2 = l(g, dev(x), dev(e)).cpu().numpy()
+    np.testing.assert_array_equal(y, y2)
