@@ -1,4 +1,4 @@
-"""More layers of the reference's zoo that run on the same kernels: CGConv, EdgeConv, GatedGraphConv, DConv, NNConv.
+"""More layers of the reference's zoo that run on the same kernels: CGConv, EdgeConv, GatedGraphConv, DConv, NNConv, MEGNetConv.
 GNNlib/src/layers/conv.jl  cg_conv :304-333, edge_conv :237-246, gated_graph_conv :218-233, d_conv :696-725;
 constructors GraphNeuralNetworks/src/layers/conv.jl :925-931 (CGConv), :582 (EdgeConv), :525-530 (GatedGraphConv),
 :1584-1589 (DConv).
@@ -275,3 +275,50 @@ class NNConv:
 
     def __call__(self, g, x, e):
         return nn_conv(self, g, x, e)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# MEGNetConv
+# ---------------------------------------------------------------------------------------------------------
+def megnet_conv(l, g: GNNGraph, x, e):
+    """conv.jl:356-368: ē = ϕe(vcat(xi, xj, e)), xᵉ = aggregate_neighbors(g, aggr, ē), x̄ = ϕv(vcat(x, xᵉ)) -> (x̄, ē).
+    Neither vcat is materialised: the first Dense of each chain takes its blocks as separate contractions."""
+    from .layers import bias_act
+    check_num_nodes(g, x)
+    check_num_edges(g, e)
+    x, e = x.contiguous(), e.contiguous()
+    n_in, n_e = x.shape[1], e.shape[1]
+    pe, pv = list(l.phi_e), list(l.phi_v)
+    first = pe[0]
+    assert isinstance(first, Dense) and first.weight.shape[1] == 2 * n_in + n_e, "MEGNetConv: ϕe must start with Dense(2 in + ein => ...)"
+    xi, xj = _gather(x, g.t, g.index_base), _gather(x, g.s, g.index_base)
+    W = first.weight
+    eb = _add(dense(xi, W[:, :n_in], None, None, x2=xj, W2=W[:, n_in:2 * n_in]), dense(e, W[:, 2 * n_in:]))
+    eb = bias_act(eb, first.bias, first.sigma)
+    for layer in pe[1:]:
+        eb = layer(eb)
+    xe = _scatter_plan(l.aggr, eb, g.plan(False))
+    fv = pv[0]
+    assert isinstance(fv, Dense) and fv.weight.shape[1] == n_in + xe.shape[1], "MEGNetConv: ϕv must start with Dense(in + out => ...)"
+    xb = dense(x, fv.weight[:, :n_in], fv.bias, fv.sigma, x2=xe, W2=fv.weight[:, n_in:])
+    for layer in pv[1:]:
+        xb = layer(xb)
+    return xb, eb
+
+
+class MEGNetConv:
+    """MEGNetConv(in => out; aggr = mean) or MEGNetConv(ϕe, ϕv; aggr = mean) with ϕe / ϕv lists of gnnmp Dense layers
+    (default: Dense(3 in => out, relu), Dense(out => out) and Dense(in + out => out, relu), Dense(out => out))"""
+
+    takes_graph = True
+
+    def __init__(self, ch=None, phi_e=None, phi_v=None, aggr="mean", device="cuda", seed=None):
+        if ch is not None:
+            nin, nout = ch
+            sd = (lambda k: None if seed is None else seed + k)
+            phi_e = [Dense((3 * nin, nout), "relu", device=device, seed=sd(0)), Dense((nout, nout), None, device=device, seed=sd(1))]
+            phi_v = [Dense((nin + nout, nout), "relu", device=device, seed=sd(2)), Dense((nout, nout), None, device=device, seed=sd(3))]
+        self.phi_e, self.phi_v, self.aggr = phi_e, phi_v, aggr
+
+    def __call__(self, g, x, e):
+        return megnet_conv(self, g, x, e)

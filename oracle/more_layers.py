@@ -133,3 +133,18 @@ def nn_conv(s, t, n, x, e, nn, weight, bias, act=None, aggr="+"):
     if bias is not None:
         y = (y + O._f32(bias)[None, :]).astype(f32)
     return ACT[act](y)
+
+
+def megnet_conv(s, t, n, x, e, phi_e, phi_v, aggr="mean"):
+    """megnet_conv (conv.jl:356-368): ē = ϕe(vcat(xi, xj, e)) per edge, xᵉ = aggregate_neighbors(g, aggr, ē),
+    x̄ = ϕv(vcat(x, xᵉ)); returns (x̄, ē).  phi_e / phi_v = [(W, b, act), ...] chains of Dense layers."""
+    s, t = O._i64(s), O._i64(t)
+    x = O._f32(x)
+    z = np.concatenate([O.gather(x, t), O.gather(x, s), O._f32(e)], axis=1)
+    for W, b, a_ in phi_e:
+        z = _dense(z, W, b, a_)
+    xe = O.scatter({"+": O.SUM, "mean": O.MEAN, "max": O.MAX, "min": O.MIN}[aggr], z, t, n)
+    v = np.concatenate([x, xe], axis=1)
+    for W, b, a_ in phi_v:
+        v = _dense(v, W, b, a_)
+    return v, z

@@ -298,3 +298,27 @@ def test_hip_nn_conv_vs_oracle(gm, ML, nin, out, ein, aggr):
     assert rel(y, ref.astype(np.float64)) < 1e-5
     y2 = l(g, dev(x), dev(e)).cpu().numpy()
     np.testing.assert_array_equal(y, y2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nin,nout,aggr", [(12, 16, "mean"), (7, 5, "+"), (32, 32, "max")])
+def test_hip_megnet_conv_vs_oracle(gm, ML, nin, nout, aggr):
+    """MEGNetConv(in => out) with edge features of `in` channels (the reference's default ϕe takes 3 in)"""
+    rng = np.random.default_rng(nin * 3 + nout)
+    n, E = 1300, 18000
+    s, t = graph(rng, n, E, hubs=True)
+    s = np.concatenate([s, np.roll(np.arange(1, n + 1), 1)])
+    t = np.concatenate([t, np.arange(1, n + 1)])
+    E = len(s)
+    x = rng.standard_normal((n, nin)).astype(np.float32)
+    e = rng.standard_normal((E, nin)).astype(np.float32)
+    g = gm.GNNGraph(dev(s), dev(t), num_nodes=n)
+    l = gm.MEGNetConv((nin, nout), aggr=aggr, seed=7)
+    for d in l.phi_e + l.phi_v:
+        d.bias = dev((rng.standard_normal(d.bias.numel()) * 0.1).astype(np.float32))
+    xb, eb = l(g, dev(x), dev(e))
+    chain = lambda ds: [(d.weight.cpu().numpy(), d.bias.cpu().numpy(), d.sigma) for d in ds]
+    rx, re_ = ML.megnet_conv(s, t, n, x, e, chain(l.phi_e), chain(l.phi_v), aggr)
+    assert xb.shape == rx.shape == (n, nout) and eb.shape == re_.shape == (E, nout)
+    assert rel(eb.cpu().numpy(), re_.astype(np.float64)) < 1e-5
+    assert rel(xb.cpu().numpy(), rx.astype(np.float64)) < 1e-5
