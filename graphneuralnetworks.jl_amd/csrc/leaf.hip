@@ -258,6 +258,27 @@ __global__ void __launch_bounds__(256) gru_pointwise_kernel(const float *__restr
     const float c = tanhf(gx[o + 2 * D] + r * gh[o + 2 * D] + bn);
     out[i] = (1.0f - z) * c + z * h[i];
 }
+// gmm_conv's mixture weights (GNNlib/src/layers/conv.jl:379-385), statement by statement:
+//   w[d][k][e] = ((e[d][e] - mu[d][k])^2) / 2;  w = w .* sigma_inv[d][k]^2;  w[k][e] = exp(sum over d)
+// written once per (edge, kernel k) and repeated over the C output channels of block k: out[e][k * C + c], the (C * K, E)
+// factor array `propagate(e_mul_xj, g, mean; xj = (out, K, N), e = (1, K, E))` broadcasts to.
+__global__ void __launch_bounds__(256) gmm_weights_kernel(const float *__restrict__ e, const float *__restrict__ mu,
+                                                          const float *__restrict__ sinv, float *__restrict__ out, int64_t E,
+                                                          int ein, int K, int C) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= E * K * C) return;
+    const int64_t ed = i / ((int64_t)K * C);
+    const int k = (int)((i / C) % K);
+    float s = 0.0f;
+    for (int d = 0; d < ein; ++d) {
+        const float df = e[ed * ein + d] - mu[k * ein + d];   // mu, sigma_inv: Julia (ein, K) column-major = [K][ein]
+        const float si = sinv[k * ein + d];
+        float w = (df * df) / 2.0f;
+        w = w * (si * si);
+        s = s + w;
+    }
+    out[i] = expf(s);
+}
 // flag[0] = 1 if idx[k] > idx[k+1] for some k
 __global__ void __launch_bounds__(256) unsorted_kernel(const void *idx, int idx_bytes, int64_t n, int *flag) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -397,6 +418,17 @@ int gnnmp_gru_pointwise_f32(const float *gx, const float *gh, const float *b, co
     if (!gx || !gh || !h || !out) return fail(GNNMP_EINVAL, "gru_pointwise: null pointer");
     gru_pointwise_kernel<<<(unsigned)((N * D + 255) / 256), 256, 0, stream>>>(gx, gh, b, h, out, N, (int)D);
     GNNMP_LAUNCH_CHECK("gru_pointwise_kernel");
+    return GNNMP_OK;
+}
+
+int gnnmp_gmm_weights_f32(const float *e, const float *mu, const float *sigma_inv, float *out, int64_t E, int64_t ein, int64_t K,
+                          int64_t C, gnnmp_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (E < 0 || ein <= 0 || K <= 0 || C <= 0 || K * C > (1 << 20)) return fail(GNNMP_EINVAL, "gmm_weights: bad size");
+    if (E == 0) return GNNMP_OK;
+    if (!e || !mu || !sigma_inv || !out) return fail(GNNMP_EINVAL, "gmm_weights: null pointer");
+    gmm_weights_kernel<<<(unsigned)((E * K * C + 255) / 256), 256, 0, stream>>>(e, mu, sigma_inv, out, E, (int)ein, (int)K, (int)C);
+    GNNMP_LAUNCH_CHECK("gmm_weights_kernel");
     return GNNMP_OK;
 }
 

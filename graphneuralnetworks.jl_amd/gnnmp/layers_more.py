@@ -1,4 +1,4 @@
-"""More layers of the reference's zoo that run on the same kernels: CGConv, EdgeConv, GatedGraphConv, DConv, NNConv, MEGNetConv.
+"""More layers of the reference's zoo that run on the same kernels: CGConv, EdgeConv, GatedGraphConv, DConv, NNConv, MEGNetConv, GMMConv.
 GNNlib/src/layers/conv.jl  cg_conv :304-333, edge_conv :237-246, gated_graph_conv :218-233, d_conv :696-725;
 constructors GraphNeuralNetworks/src/layers/conv.jl :925-931 (CGConv), :582 (EdgeConv), :525-530 (GatedGraphConv),
 :1584-1589 (DConv).
@@ -322,3 +322,53 @@ class MEGNetConv:
 
     def __call__(self, g, x, e):
         return megnet_conv(self, g, x, e)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# GMMConv
+# ---------------------------------------------------------------------------------------------------------
+def gmm_conv(l, g: GNNGraph, x, e):
+    """conv.jl:372-401: Gaussian mixture weights per edge and kernel, `propagate(e_mul_xj, g, mean)` of the K blocks of
+    dense_x(x), mean over the kernels, σ.(m .+ bias), optional residual"""
+    check_num_nodes(g, x)
+    (nin, ein), out = l.ch
+    assert e.shape[1] == ein and e.shape[0] == g.num_edges, "Pseudo-cordinate dimension is not equal to (ein,num_edge)"
+    x, e = x.contiguous(), e.contiguous()
+    lib = L.load()
+    K = l.K
+    w = torch.empty((g.num_edges, K * out), dtype=torch.float32, device=x.device)
+    L.check(lib.gnnmp_gmm_weights_f32(L.ptr(e), L.ptr(l.mu), L.ptr(l.sigma_inv), L.ptr(w), g.num_edges, ein, K, out, L.stream_ptr()))
+    xj = dense(x, l.dense_x_weight)                           # [N][K * out]: kernel k's block at k * out
+    m = torch.empty((g.num_nodes, K * out), dtype=torch.float32, device=x.device)
+    L.check(lib.gnnmp_propagate_emul_f32(g.plan(False).handle, L.MEAN, L.ptr(xj), L.ptr(w), L.ptr(m), K * out, L.stream_ptr()))
+    y = torch.empty((g.num_nodes, out), dtype=torch.float32, device=x.device)
+    from .layers import _act_code
+    code, post = _act_code(l.sigma)
+    L.check(lib.gnnmp_head_mean_f32(L.ptr(m), L.ptr(l.bias), code, L.ptr(y), g.num_nodes, K, out, L.stream_ptr()))
+    if post is not None:
+        y = post(y)
+    if l.residual:
+        if x.shape[1] == out:
+            y = _add(y, x)
+        else:
+            import warnings
+            warnings.warn("Residual not applied : output feature is not equal to input_feature")
+    return y
+
+
+class GMMConv:
+    """GMMConv((in, ein) => out, σ = identity; K = 1, bias = true, residual = false): mu, sigma_inv [K][ein] (Julia (ein, K))"""
+
+    takes_graph = True
+
+    def __init__(self, ch, sigma=None, K=1, bias=True, residual=False, device="cuda", seed=None):
+        (nin, ein), out = ch
+        sd = (lambda k: None if seed is None else seed + k)
+        self.ch, self.sigma, self.K, self.residual = ((nin, ein), out), sigma, int(K), bool(residual)
+        self.mu = glorot_uniform(K, ein, device=device, seed=sd(0))
+        self.sigma_inv = glorot_uniform(K, ein, device=device, seed=sd(1))
+        self.bias = torch.zeros(out, dtype=torch.float32, device=device) if bias else None
+        self.dense_x_weight = glorot_uniform(out * K, nin, device=device, seed=sd(2))
+
+    def __call__(self, g, x, e):
+        return gmm_conv(self, g, x, e)

@@ -368,6 +368,12 @@ int gnnmp_head_mean_f32(const float *y, const float *bias, int act, float *out, 
                         int64_t C, gnnmp_stream_t stream);
 /* its pullback: dy[n][h][c] = dz[n][c] / H (the heads' gradient of `mean(x, dims = 2)`) */
 int gnnmp_head_mean_grad_f32(const float *dz, float *dy, int64_t N, int64_t H, int64_t C, gnnmp_stream_t stream);
+/* gmm_conv's mixture weights (GNNlib/src/layers/conv.jl:379-385): out[e][k * C + c] = exp(Σ_d ((e[e][d] - mu[k][d])^2 / 2) *
+ * sigma_inv[k][d]^2) for every edge, kernel k and (repeated) output channel c — the factor array of the layer's
+ * `propagate(e_mul_xj, g, mean; xj = reshape(dense_x(x), out, K, :), e = w)`, ready for gnnmp_propagate_emul_f32.
+ * mu, sigma_inv: Julia (ein, K) column-major = [K][ein]. */
+int gnnmp_gmm_weights_f32(const float *e, const float *mu, const float *sigma_inv, float *out, int64_t E, int64_t ein,
+                          int64_t K, int64_t C, gnnmp_stream_t stream);
 /* Flux.GRUCell's pointwise part — the cell of gated_graph_conv (GNNlib/src/layers/conv.jl:228-232): gx = Wi m and
  * gh = Wh h are [N][3D] (gates r, z, candidate), b [3D] or NULL:
  *   r = σ(gx_r + gh_r + b_r), z = σ(gx_z + gh_z + b_z), h~ = tanh(gx_n + r .* gh_n + b_n), out = (1 - z) .* h~ + z .* h */

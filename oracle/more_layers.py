@@ -148,3 +148,31 @@ def megnet_conv(s, t, n, x, e, phi_e, phi_v, aggr="mean"):
     for W, b, a_ in phi_v:
         v = _dense(v, W, b, a_)
     return v, z
+
+
+def gmm_conv(s, t, n, x, e, mu, sigma_inv, dense_x_weight, bias, act=None, K=1, residual=False):
+    """gmm_conv (conv.jl:372-401).  mu, sigma_inv: [K][ein] (Julia (ein, K)); dense_x_weight: [out * K][in]; the mixture
+    weights are exp(+Σ ...) exactly as the reference writes them."""
+    s, t = O._i64(s), O._i64(t)
+    x, e = O._f32(x), O._f32(e)
+    mu, sinv = O._f32(mu), O._f32(sigma_inv)
+    out = dense_x_weight.shape[0] // K
+    w = ((e[:, None, :] - mu[None, :, :]) ** 2).astype(f32) / f32(2)                # [E][K][ein]
+    w = (w * (sinv ** 2).astype(f32)[None]).astype(f32)
+    acc = np.zeros(w.shape[:2], f32)
+    for d in range(w.shape[2]):
+        acc = (acc + w[:, :, d]).astype(f32)
+    w = np.exp(acc).astype(f32)                                                     # [E][K]
+    xj = O.matmul(O._f32(dense_x_weight), x, True).reshape(n, K, out)               # feature o of kernel k at k * out + o
+    msg = (w[:, :, None] * O.gather(xj.reshape(n, K * out), s).reshape(len(s), K, out)).astype(f32)
+    m = O.scatter(O.MEAN, msg.reshape(len(s), K * out), t, n).reshape(n, K, out)
+    tot = np.zeros((n, out), f32)
+    for k in range(K):
+        tot = (tot + m[:, k]).astype(f32)
+    m = (tot / f32(K)).astype(f32)                                                  # mean(m, dims = 2)
+    if bias is not None:
+        m = (m + O._f32(bias)[None, :]).astype(f32)
+    m = ACT[act](m)
+    if residual and x.shape[1] == out:
+        m = (m + x).astype(f32)
+    return m

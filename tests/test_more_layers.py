@@ -322,3 +322,43 @@ def test_hip_megnet_conv_vs_oracle(gm, ML, nin, nout, aggr):
     assert xb.shape == rx.shape == (n, nout) and eb.shape == re_.shape == (E, nout)
     assert rel(eb.cpu().numpy(), re_.astype(np.float64)) < 1e-5
     assert rel(xb.cpu().numpy(), rx.astype(np.float64)) < 1e-5
+
+
+def test_oracle_gmm_conv_vs_float64_edge_loop(oracle, ML):
+    rng = np.random.default_rng(23)
+    n, nin, ein, out, K = 25, 6, 3, 4, 3
+    s, t = graph(rng, n, 170)
+    x = rng.standard_normal((n, nin)).astype(np.float32)
+    e = (rng.standard_normal((len(s), ein)) * 0.5).astype(np.float32)
+    mu = (rng.standard_normal((K, ein)) * 0.5).astype(np.float32)
+    si = (rng.standard_normal((K, ein)) * 0.7).astype(np.float32)
+    W = (rng.standard_normal((out * K, nin)) * 0.4).astype(np.float32)
+    b = (rng.standard_normal(out) * 0.1).astype(np.float32)
+    y = ML.gmm_conv(s, t, n, x, e, mu, si, W, b, "relu", K=K)
+    xj = (x.astype(np.float64) @ W.T.astype(np.float64)).reshape(n, K, out)
+    acc = np.zeros((n, K, out))
+    cnt = np.zeros(n)
+    for k in range(len(s)):
+        w = np.exp((((e[k].astype(np.float64)[None, :] - mu) ** 2) / 2 * si.astype(np.float64) ** 2).sum(1))   # [K]
+        acc[t[k] - 1] += w[:, None] * xj[s[k] - 1]
+        cnt[t[k] - 1] += 1
+    ref = np.maximum((acc / np.maximum(cnt, 1)[:, None, None]).mean(1) + b, 0)
+    assert rel(y, ref) < 5e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nin,ein,out,K,act,residual", [(16, 4, 16, 3, "relu", True), (10, 2, 7, 1, None, False), (32, 5, 24, 4, "relu", False)])
+def test_hip_gmm_conv_vs_oracle(gm, ML, nin, ein, out, K, act, residual):
+    rng = np.random.default_rng(nin + K)
+    n, E = 1300, 18000
+    s, t = graph(rng, n, E, hubs=True)
+    x = rng.standard_normal((n, nin)).astype(np.float32)
+    e = (rng.standard_normal((E, ein)) * 0.5).astype(np.float32)
+    g = gm.GNNGraph(dev(s), dev(t), num_nodes=n)
+    l = gm.GMMConv(((nin, ein), out), act, K=K, residual=residual, seed=9)
+    l.bias = dev((rng.standard_normal(out) * 0.1).astype(np.float32))
+    y = l(g, dev(x), dev(e)).cpu().numpy()
+    ref = ML.gmm_conv(s, t, n, x, e, l.mu.cpu().numpy(), l.sigma_inv.cpu().numpy(), l.dense_x_weight.cpu().numpy(),
+                      l.bias.cpu().numpy(), act, K=K, residual=residual)
+    assert y.shape == ref.shape == (n, out)
+    assert rel(y, ref.astype(np.float64)) < 1e-5
