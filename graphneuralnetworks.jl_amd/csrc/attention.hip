@@ -295,6 +295,12 @@ __global__ void __launch_bounds__(256) bias_act_kernel(const float *x, const flo
     float v = x[i];
     if (bias) v = v + bias[i % D];
     if (act == GNNMP_ACT_RELU) v = v < 0.0f ? 0.0f : v;
+    if (act == GNNMP_ACT_SOFTPLUS) v = log1pf(expf(-fabsf(v))) + (v < 0.0f ? 0.0f : v);   // NNlib.softplus
+    if (act == GNNMP_ACT_TANH) v = tanhf(v);
+    if (act == GNNMP_ACT_SWISH) {                       // NNlib.swish = x * sigmoid(x)
+        const float t = expf(-fabsf(v));
+        v = v * (v >= 0.0f ? 1.0f / (1.0f + t) : t / (1.0f + t));
+    }
     out[i] = v;
 }
 
@@ -368,7 +374,7 @@ int gnnmp_bias_act_f32(const float *x, const float *bias, int act, float *out, i
                        gnnmp_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (N < 0 || D < 0 || D > (1 << 20)) return fail(GNNMP_EINVAL, "bias_act: bad size");
-    if (act != GNNMP_ACT_IDENTITY && act != GNNMP_ACT_RELU) return fail(GNNMP_EINVAL, "bias_act: bad act %d", act);
+    if (act < GNNMP_ACT_IDENTITY || act > GNNMP_ACT_SWISH) return fail(GNNMP_EINVAL, "bias_act: bad act %d", act);
     if (N == 0 || D == 0) return GNNMP_OK;
     if (!x || !out) return fail(GNNMP_EINVAL, "bias_act: null pointer");
     const int64_t total = N * D;

@@ -279,6 +279,18 @@ __global__ void __launch_bounds__(256) gmm_weights_kernel(const float *__restric
     }
     out[i] = expf(s);
 }
+// egnn_conv (conv.jl:465-467): sqnorm = sum(x_diff .^ 2, dims = 1); x_diff ./ (sqrt.(sqnorm) .+ eps) — rows are coordinates
+// (D = 3 typically): one thread per row, features added in order
+__global__ void __launch_bounds__(256) row_sqnorm_normalize_kernel(const float *__restrict__ x, float *__restrict__ sq,
+                                                                   float *__restrict__ xn, float eps, int64_t N, int D) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= N) return;
+    float s = 0.0f;
+    for (int d = 0; d < D; ++d) { const float v = x[r * D + d]; s = s + v * v; }
+    if (sq) sq[r] = s;
+    const float den = sqrtf(s) + eps;
+    if (xn) for (int d = 0; d < D; ++d) xn[r * D + d] = x[r * D + d] / den;
+}
 // flag[0] = 1 if idx[k] > idx[k+1] for some k
 __global__ void __launch_bounds__(256) unsorted_kernel(const void *idx, int idx_bytes, int64_t n, int *flag) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -429,6 +441,16 @@ int gnnmp_gmm_weights_f32(const float *e, const float *mu, const float *sigma_in
     if (!e || !mu || !sigma_inv || !out) return fail(GNNMP_EINVAL, "gmm_weights: null pointer");
     gmm_weights_kernel<<<(unsigned)((E * K * C + 255) / 256), 256, 0, stream>>>(e, mu, sigma_inv, out, E, (int)ein, (int)K, (int)C);
     GNNMP_LAUNCH_CHECK("gmm_weights_kernel");
+    return GNNMP_OK;
+}
+
+int gnnmp_row_sqnorm_normalize_f32(const float *x, float *sq, float *xn, float eps, int64_t N, int64_t D, gnnmp_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (N < 0 || D <= 0 || D > (1 << 20)) return fail(GNNMP_EINVAL, "row_sqnorm_normalize: bad size");
+    if (N == 0) return GNNMP_OK;
+    if (!x || (!sq && !xn)) return fail(GNNMP_EINVAL, "row_sqnorm_normalize: null pointer");
+    row_sqnorm_normalize_kernel<<<(unsigned)((N + 255) / 256), 256, 0, stream>>>(x, sq, xn, eps, N, (int)D);
+    GNNMP_LAUNCH_CHECK("row_sqnorm_normalize_kernel");
     return GNNMP_OK;
 }
 

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("GNNMP_LIB") or os.path.join(_PKG, "lib", "libgnnmp.so
 OK, EINVAL, EBOUNDS, EALLOC, ELAUNCH, EUNSUPPORTED = 0, -1, -2, -3, -4, -5
 SUM, MEAN, MAX, MIN = 0, 1, 2, 3
 COPY_XJ, W_MUL_XJ = 0, 1
-ACT_IDENTITY, ACT_RELU, ACT_SOFTPLUS, ACT_TANH = 0, 1, 2, 3
+ACT_IDENTITY, ACT_RELU, ACT_SOFTPLUS, ACT_TANH, ACT_SWISH = 0, 1, 2, 3, 4
 LONG_ROW = 512
 
 # every symbol include/gnnmp.h declares (tests check the library exports exactly these)
@@ -35,7 +35,7 @@ SYMBOLS = (
     "gnnmp_edge_dot_f32", "gnnmp_edge_dot_plan_f32", "gnnmp_propagate_maxmin_grad_f32",
     "gnnmp_head_mean_f32", "gnnmp_head_mean_grad_f32", "gnnmp_add_f32", "gnnmp_axpy_f32", "gnnmp_mul_rows_f32", "gnnmp_is_sorted",
     "gnnmp_act_grad_f32", "gnnmp_dense_grad_workspace", "gnnmp_dense_grad_w_f32",
-    "gnnmp_row_normalize_f32", "gnnmp_row_normalize_grad_f32", "gnnmp_propagate_cg_f32", "gnnmp_gru_pointwise_f32", "gnnmp_propagate_nn_f32", "gnnmp_gmm_weights_f32",
+    "gnnmp_row_normalize_f32", "gnnmp_row_normalize_grad_f32", "gnnmp_propagate_cg_f32", "gnnmp_gru_pointwise_f32", "gnnmp_propagate_nn_f32", "gnnmp_gmm_weights_f32", "gnnmp_row_sqnorm_normalize_f32",
 )
 
 
@@ -106,6 +106,7 @@ def load():
         "gnnmp_propagate_cg_f32": [vp, vp, vp, vp, i, vp, i64, vp],
         "gnnmp_propagate_nn_f32": [vp, i, vp, vp, vp, i64, i64, vp],
         "gnnmp_gmm_weights_f32": [vp, vp, vp, vp, i64, i64, i64, i64, vp],
+        "gnnmp_row_sqnorm_normalize_f32": [vp, vp, vp, f, i64, i64, vp],
         "gnnmp_gru_pointwise_f32": [vp, vp, vp, vp, vp, i64, i64, vp],
         "gnnmp_row_normalize_grad_f32": [vp, vp, vp, vp, vp, vp, vp, f, i64, i64, vp],
         "gnnmp_add_f32": [vp, vp, vp, i64, vp],

@@ -1,4 +1,4 @@
-"""More layers of the reference's zoo that run on the same kernels: CGConv, EdgeConv, GatedGraphConv, DConv, NNConv, MEGNetConv, GMMConv.
+"""More layers of the reference's zoo that run on the same kernels: CGConv, EdgeConv, GatedGraphConv, DConv, NNConv, MEGNetConv, GMMConv, EGNNConv.
 GNNlib/src/layers/conv.jl  cg_conv :304-333, edge_conv :237-246, gated_graph_conv :218-233, d_conv :696-725;
 constructors GraphNeuralNetworks/src/layers/conv.jl :925-931 (CGConv), :582 (EdgeConv), :525-530 (GatedGraphConv),
 :1584-1589 (DConv).
@@ -372,3 +372,82 @@ class GMMConv:
 
     def __call__(self, g, x, e):
         return gmm_conv(self, g, x, e)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# EGNNConv
+# ---------------------------------------------------------------------------------------------------------
+_ACT_CODES = {None: L.ACT_IDENTITY, "identity": L.ACT_IDENTITY, "relu": L.ACT_RELU, "softplus": L.ACT_SOFTPLUS,
+              "tanh": L.ACT_TANH, "swish": L.ACT_SWISH}
+
+
+def _bias_act_code(x, bias, act):
+    out = torch.empty_like(x)
+    b = None if bias is None else bias.contiguous()
+    L.check(L.load().gnnmp_bias_act_f32(L.ptr(x), L.ptr(b), _ACT_CODES[act], L.ptr(out), x.shape[0], x.shape[1], L.stream_ptr()))
+    return out
+
+
+def _chain(layers, z):
+    """a chain of (weight, bias, act) Dense layers, activations from the gnnmp_act set (swish included)"""
+    for W, b, act in layers:
+        z = _bias_act_code(dense(z, W), b, act)
+    return z
+
+
+def egnn_conv(l, g: GNNGraph, h, x, e=None):
+    """conv.jl:459-495 -> (h', x'): radial feature and normalised coordinate difference per edge, ϕe on
+    vcat(h_i, h_j, |x_i - x_j|², e) without the vcat, ϕx scaling the differences, sum / mean aggregation, ϕh on (h, Σ)."""
+    check_num_nodes(g, h)
+    nin, ein = l.num_features["in"], l.num_features["edge"]
+    if ein > 0:
+        assert e is not None, "Edge features must be provided."
+    assert h.shape[1] == nin, "Input features must match layer input size."
+    h, x = h.contiguous(), x.contiguous()
+    lib = L.load()
+    E, Dx = g.num_edges, x.shape[1]
+    xd = torch.empty((E, Dx), dtype=torch.float32, device=x.device)
+    L.check(lib.gnnmp_edge_sub_f32(L.ptr(x), L.ptr(x), L.ptr(g.s), L.ptr(g.t), g.idx_bytes, g.index_base, E, 0, L.ptr(xd), Dx,
+                                   L.stream_ptr()))                                       # xi_sub_xj
+    sq = torch.empty((E, 1), dtype=torch.float32, device=x.device)
+    xn = torch.empty_like(xd)
+    L.check(lib.gnnmp_row_sqnorm_normalize_f32(L.ptr(xd), L.ptr(sq), L.ptr(xn), 1e-6, E, Dx, L.stream_ptr()))
+    hi, hj = _gather(h, g.t, g.index_base), _gather(h, g.s, g.index_base)
+    (W0, b0, a0), rest = l.phi_e[0], l.phi_e[1:]
+    assert W0.shape[1] == 2 * nin + 1 + ein
+    tail = sq if ein == 0 else torch.cat([sq, e.contiguous()], dim=1)                     # (1 + ein, E): memory plumbing
+    pre = _add(dense(hi, W0[:, :nin], None, None, x2=hj, W2=W0[:, nin:2 * nin]), dense(tail, W0[:, 2 * nin:]))
+    mh = _chain(rest, _bias_act_code(pre, b0, a0))
+    mx = _chain(l.phi_x, mh)                                                              # (1, E)
+    mxd = torch.empty_like(xn)
+    L.check(lib.gnnmp_mul_rows_f32(L.ptr(mx), 1, L.ptr(xn), L.ptr(mxd), E, Dx, L.stream_ptr()))
+    plan = g.plan(False)
+    h_aggr, x_aggr = _scatter_plan("+", mh, plan), _scatter_plan("mean", mxd, plan)
+    (Wh, bh, ah), resth = l.phi_h[0], l.phi_h[1:]
+    hn = _chain(resth, _bias_act_code(dense(h, Wh[:, :nin], None, None, x2=h_aggr, W2=Wh[:, nin:]), bh, ah))
+    return (_add(h, hn) if l.residual else hn), _add(x, x_aggr)
+
+
+class EGNNConv:
+    """EGNNConv((in, ein) => out; hidden_size = 2 in, residual = false): ϕe, ϕx, ϕh as lists of (weight, bias, act) with the
+    reference's shapes and swish activations (GraphNeuralNetworks/src/layers/conv.jl:1364-1385)"""
+
+    takes_graph = True
+
+    def __init__(self, ch, hidden_size=None, residual=False, device="cuda", seed=None):
+        cin, out = ch
+        nin, ein = cin if isinstance(cin, (tuple, list)) else (cin, 0)
+        hid = 2 * nin if hidden_size is None else int(hidden_size)
+        if residual:
+            assert nin == out, "Residual connection only possible if in_size == out_size"
+        sd = iter(range(0 if seed is None else seed, 10 ** 9))
+        z = lambda k: torch.zeros(k, dtype=torch.float32, device=device)
+        mk = lambda o, i, act, bias=True: (glorot_uniform(o, i, device=device, seed=next(sd)), z(o) if bias else None, act)
+        self.phi_e = [mk(hid, 2 * nin + ein + 1, "swish"), mk(hid, hid, "swish")]
+        self.phi_h = [mk(hid, nin + hid, "swish"), mk(out, hid, None)]
+        self.phi_x = [mk(hid, hid, "swish"), mk(1, hid, None, bias=False)]
+        self.num_features = {"in": nin, "edge": ein, "out": out, "hidden": hid}
+        self.residual = bool(residual)
+
+    def __call__(self, g, h, x, e=None):
+        return egnn_conv(self, g, h, x, e)

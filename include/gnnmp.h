@@ -62,8 +62,11 @@ typedef enum { GNNMP_SUM = 0, GNNMP_MEAN = 1, GNNMP_MAX = 2, GNNMP_MIN = 3 } gnn
 typedef enum { GNNMP_COPY_XJ = 0, GNNMP_W_MUL_XJ = 1 } gnnmp_msg;
 
 /* activation fused into gnnmp_dense_f32's epilogue (the layers' `σ`): IDENTITY and RELU everywhere an `act` is taken;
- * SOFTPLUS (NNlib.softplus = log1p(exp(-|x|)) + relu(x)) and TANH only as the second factor of gnnmp_propagate_cg_f32. */
-typedef enum { GNNMP_ACT_IDENTITY = 0, GNNMP_ACT_RELU = 1, GNNMP_ACT_SOFTPLUS = 2, GNNMP_ACT_TANH = 3 } gnnmp_act;
+ * SOFTPLUS (NNlib.softplus = log1p(exp(-|x|)) + relu(x)) and TANH also as the second factor of gnnmp_propagate_cg_f32 and
+ * in gnnmp_bias_act_f32; SWISH (x * sigmoid(x), egnn_conv's Dense layers) in gnnmp_bias_act_f32 only. */
+typedef enum {
+    GNNMP_ACT_IDENTITY = 0, GNNMP_ACT_RELU = 1, GNNMP_ACT_SOFTPLUS = 2, GNNMP_ACT_TANH = 3, GNNMP_ACT_SWISH = 4
+} gnnmp_act;
 /* per-edge attention logit of gnnmp_attn_conv_f32 (Q_i = row i of the target array, K_j = row j of the source array) */
 typedef enum {
     GNNMP_ATTN_GAT = 0,   /* leakyrelu(a[h][0:C] . Q_i + a[h][C:2C] . K_j)      gat_message   conv.jl:152-167 */
@@ -374,6 +377,10 @@ int gnnmp_head_mean_grad_f32(const float *dz, float *dy, int64_t N, int64_t H, i
  * mu, sigma_inv: Julia (ein, K) column-major = [K][ein]. */
 int gnnmp_gmm_weights_f32(const float *e, const float *mu, const float *sigma_inv, float *out, int64_t E, int64_t ein,
                           int64_t K, int64_t C, gnnmp_stream_t stream);
+/* egnn_conv's radial features (GNNlib/src/layers/conv.jl:465-467): sq[k] = sum(x_diff[k][:] .^ 2) and
+ * xn[k][:] = x_diff[k][:] / (sqrt(sq[k]) + eps) for every row k (eps = 1f-6 in the reference). */
+int gnnmp_row_sqnorm_normalize_f32(const float *x, float *sq, float *xn, float eps, int64_t N, int64_t D,
+                                   gnnmp_stream_t stream);
 /* Flux.GRUCell's pointwise part — the cell of gated_graph_conv (GNNlib/src/layers/conv.jl:228-232): gx = Wi m and
  * gh = Wh h are [N][3D] (gates r, z, candidate), b [3D] or NULL:
  *   r = σ(gx_r + gh_r + b_r), z = σ(gx_z + gh_z + b_z), h~ = tanh(gx_n + r .* gh_n + b_n), out = (1 - z) .* h~ + z .* h */

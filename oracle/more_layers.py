@@ -176,3 +176,37 @@ def gmm_conv(s, t, n, x, e, mu, sigma_inv, dense_x_weight, bias, act=None, K=1, 
     if residual and x.shape[1] == out:
         m = (m + x).astype(f32)
     return m
+
+
+def swish(x):
+    x = np.asarray(x, f32)
+    return (x * sigmoid(x)).astype(f32)
+
+
+ACT["swish"] = swish
+
+
+def egnn_conv(s, t, n, h, x, e, phi_e, phi_x, phi_h, residual=False):
+    """egnn_conv (conv.jl:459-495): returns (h', x').  phi_* = [(W, b, act), ...] chains of Dense layers."""
+    s, t = O._i64(s), O._i64(t)
+    h, x = O._f32(h), O._f32(x)
+    xd = (O.gather(x, t) - O.gather(x, s)).astype(f32)                       # xi_sub_xj
+    sq = np.zeros((len(s), 1), f32)
+    for d in range(xd.shape[1]):
+        sq = (sq + (xd[:, d:d + 1] * xd[:, d:d + 1]).astype(f32)).astype(f32)
+    xd = (xd / (np.sqrt(sq).astype(f32) + f32(1e-6))).astype(f32)
+    f = np.concatenate([O.gather(h, t), O.gather(h, s), sq] + ([] if e is None else [O._f32(e)]), axis=1)
+    mh = f
+    for W, b, a_ in phi_e:
+        mh = _dense(mh, W, b, a_)
+    mx = mh
+    for W, b, a_ in phi_x:
+        mx = _dense(mx, W, b, a_)
+    mx = (mx * xd).astype(f32)
+    h_aggr = O.scatter(O.SUM, mh, t, n)
+    x_aggr = O.scatter(O.MEAN, mx, t, n)
+    hn = np.concatenate([h, h_aggr], axis=1)
+    for W, b, a_ in phi_h:
+        hn = _dense(hn, W, b, a_)
+    hout = (h + hn).astype(f32) if residual else hn
+    return hout, (x + x_aggr).astype(f32)

@@ -362,3 +362,55 @@ def test_hip_gmm_conv_vs_oracle(gm, ML, nin, ein, out, K, act, residual):
                       l.bias.cpu().numpy(), act, K=K, residual=residual)
     assert y.shape == ref.shape == (n, out)
     assert rel(y, ref.astype(np.float64)) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nin,ein,out,hid,residual", [(8, 0, 8, 16, True), (6, 3, 10, 12, False), (16, 2, 16, 32, True)])
+def test_hip_egnn_conv_vs_oracle(gm, ML, nin, ein, out, hid, residual):
+    rng = np.random.default_rng(nin + hid)
+    n, E = 1200, 14000
+    s, t = graph(rng, n, E, hubs=True)
+    h = rng.standard_normal((n, nin)).astype(np.float32)
+    x = rng.standard_normal((n, 3)).astype(np.float32)
+    e = rng.standard_normal((E, ein)).astype(np.float32) if ein else None
+    g = gm.GNNGraph(dev(s), dev(t), num_nodes=n)
+    l = gm.EGNNConv(((nin, ein), out), hidden_size=hid, residual=residual, seed=11)
+    scale = lambda W: W * 0.5
+    for chain in (l.phi_e, l.phi_x, l.phi_h):
+        for i, (W, b, a_) in enumerate(chain):
+            chain[i] = (scale(W), None if b is None else dev((rng.standard_normal(b.numel()) * 0.1).astype(np.float32)), a_)
+    hn, xn = l(g, dev(h), dev(x), None if e is None else dev(e))
+    c = lambda ch: [(W.cpu().numpy(), None if b is None else b.cpu().numpy(), a_) for W, b, a_ in ch]
+    rh, rx = ML.egnn_conv(s, t, n, h, x, e, c(l.phi_e), c(l.phi_x), c(l.phi_h), residual)
+    assert hn.shape == rh.shape == (n, out) and xn.shape == rx.shape == (n, 3)
+    assert rel(hn.cpu().numpy(), rh.astype(np.float64)) < 2e-5
+    assert rel(xn.cpu().numpy(), rx.astype(np.float64)) < 2e-5
+
+
+def test_oracle_egnn_conv_vs_float64_edge_loop(oracle, ML):
+    rng = np.random.default_rng(29)
+    n, nin, ein, out, hid = 20, 4, 2, 5, 6
+    s, t = graph(rng, n, 120)
+    h = rng.standard_normal((n, nin)).astype(np.float32)
+    x = rng.standard_normal((n, 3)).astype(np.float32)
+    e = rng.standard_normal((len(s), ein)).astype(np.float32)
+    mk = lambda o, i, act, bias=True: ((rng.standard_normal((o, i)) * 0.4).astype(np.float32),
+                                       (rng.standard_normal(o) * 0.1).astype(np.float32) if bias else None, act)
+    pe = [mk(hid, 2 * nin + ein + 1, "swish"), mk(hid, hid, "swish")]
+    ph = [mk(hid, nin + hid, "swish"), mk(out, hid, None)]
+    px = [mk(hid, hid, "swish"), mk(1, hid, None, bias=False)]
+    rh, rx = ML.egnn_conv(s, t, n, h, x, e, pe, px, ph, False)
+    sw = lambda v: v / (1 + np.exp(-v))
+    act = {"swish": sw, None: lambda v: v}
+    run = lambda ch, v: [v := act[a_](W.astype(np.float64) @ v + (0 if b is None else b)) for W, b, a_ in ch][-1]
+    ha, xa, cnt = np.zeros((n, hid)), np.zeros((n, 3)), np.zeros(n)
+    for k in range(len(s)):
+        d = x[t[k] - 1].astype(np.float64) - x[s[k] - 1]
+        sq = (d * d).sum()
+        mh = run(pe, np.concatenate([h[t[k] - 1], h[s[k] - 1], [sq], e[k]]).astype(np.float64))
+        ha[t[k] - 1] += mh
+        xa[t[k] - 1] += run(px, mh) * d / (np.sqrt(sq) + 1e-6)
+        cnt[t[k] - 1] += 1
+    want_h = np.stack([run(ph, np.concatenate([h[i].astype(np.float64), ha[i]])) for i in range(n)])
+    want_x = x + xa / np.maximum(cnt, 1)[:, None]
+    assert rel(rh, want_h) < 1e-5 and rel(rx, want_x) < 1e-5
