@@ -1,4 +1,4 @@
-"""More layers of the reference's zoo that run on the same kernels: CGConv, EdgeConv, GatedGraphConv, DConv, NNConv, MEGNetConv, GMMConv, EGNNConv.
+"""More layers of the reference's zoo that run on the same kernels: CGConv, EdgeConv, GatedGraphConv, DConv, NNConv, MEGNetConv, GMMConv, EGNNConv, ChebConv.
 GNNlib/src/layers/conv.jl  cg_conv :304-333, edge_conv :237-246, gated_graph_conv :218-233, d_conv :696-725;
 constructors GraphNeuralNetworks/src/layers/conv.jl :925-931 (CGConv), :582 (EdgeConv), :525-530 (GatedGraphConv),
 :1584-1589 (DConv).
@@ -451,3 +451,130 @@ class EGNNConv:
 
     def __call__(self, g, h, x, e=None):
         return egnn_conv(self, g, h, x, e)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# ChebConv
+# ---------------------------------------------------------------------------------------------------------
+def _colsum1(v):
+    """deterministic sum of an (N, 1) column on the device -> python float"""
+    from .backward import dense_grad_w
+    return float(dense_grad_w(v, v, need_w=False)[1][0])
+
+
+def _vdot(a, b):
+    p = torch.empty_like(a)
+    L.check(L.load().gnnmp_mul_rows_f32(L.ptr(a), 1, L.ptr(b), L.ptr(p), a.shape[0], 1, L.stream_ptr()))
+    return _colsum1(p)
+
+
+def _axpy(alpha, x, y):
+    out = torch.empty_like(x)
+    L.check(L.load().gnnmp_axpy_f32(float(alpha), L.ptr(x), L.ptr(y), L.ptr(out), x.numel(), L.stream_ptr()))
+    return out
+
+
+def scaled_laplacian_op(g: GNNGraph, steps: int = 64, seed: int = 0):
+    """(c, ss_slot, w_slot, λmax) of scaled_laplacian(g) (GNNGraphs/src/query.jl:442-479) for an undirected graph, never as a
+    matrix: Ã v is one fused hop (out-degree normalisation as the kernel's source / destination factors), λmax = eigmax(I - Ã)
+    by `steps` Lanczos iterations whose vector work (hop, dot, axpy) runs on the device; the recurrence scalars and the
+    eigenvalues of the small tridiagonal matrix are host float64 (the reference's own eigsolve, KrylovKit, is host code too).
+    Cached on the graph."""
+    import numpy as np
+    from .layers import _inv_sqrt
+    from .sampling import is_bidirected
+    key = ("cheb", None if g.w is None else (g.w.data_ptr(), g.w._version))
+    hit = g._cache.get(key)
+    if hit is not None:
+        return hit
+    assert is_bidirected(g), "ChebConv: the scaled Laplacian is taken of an undirected (bidirected) graph"
+    lib = L.load()
+    plan = g.plan(False)
+    d = degree(g, dir="out")
+    assert bool((d != 0).all()), "Graph contains isolated nodes, cannot compute `normalized_adjacency`."
+    c = _inv_sqrt(d)
+    ss = torch.empty(plan.n_total, dtype=torch.float32, device=g.device)
+    L.check(lib.gnnmp_plan_slot_gather_f32(plan.handle, 0, L.ptr(c), L.ptr(ss), L.stream_ptr()))
+    ws = None
+    if g.w is not None:
+        ws = torch.empty(plan.n_total, dtype=torch.float32, device=g.device)
+        L.check(lib.gnnmp_plan_slot_gather_f32(plan.handle, 1, L.ptr(g.w), L.ptr(ws), L.stream_ptr()))
+    N = g.num_nodes
+
+    def lap(v):                                             # L v = v - Ã v
+        av = torch.empty_like(v)
+        L.check(lib.gnnmp_propagate_slots_f32(plan.handle, L.SUM, L.ptr(v), L.ptr(ws), L.ptr(ss), L.ptr(c), L.ptr(av), 1,
+                                              L.stream_ptr()))
+        return _axpy(-1.0, av, v)
+
+    gen = torch.Generator(device="cpu").manual_seed(seed)
+    zero = torch.zeros((N, 1), dtype=torch.float32, device=g.device)
+    v = torch.randn((N, 1), generator=gen, dtype=torch.float32).to(g.device)
+    v = _axpy(1.0 / np.sqrt(_vdot(v, v)), v, zero)
+    vp, beta = zero, 0.0
+    al, be = [], []
+    for j in range(min(steps, N)):
+        w = lap(v)
+        a = _vdot(w, v)
+        w = _axpy(-a, v, w)
+        if j > 0:
+            w = _axpy(-beta, vp, w)
+        al.append(a)
+        beta = float(np.sqrt(max(_vdot(w, w), 0.0)))
+        if beta < 1e-6:
+            break
+        be.append(beta)
+        vp, v = v, _axpy(1.0 / beta, w, zero)
+    k = len(al)
+    T = np.diag(np.array(al, np.float64)) + np.diag(np.array(be[:k - 1], np.float64), 1) + np.diag(np.array(be[:k - 1], np.float64), -1)
+    lam = float(np.linalg.eigvalsh(T)[-1])
+    g._cache[key] = (c, ss, ws, lam)
+    return g._cache[key]
+
+
+def cheb_conv(l, g: GNNGraph, x):
+    """conv.jl:83-98: Z_1 = X, Z_2 = X L̃, Z_k = 2 Z_{k-1} L̃ - Z_{k-2}, Y = Σ W_k Z_k .+ bias with L̃ = 2/λmax (I - Ã) - I
+    applied as (2/λmax - 1) Z - (2/λmax) Ã Z: one fused hop + two axpy per order"""
+    check_num_nodes(g, x)
+    assert x.shape[1] == l.weight.shape[2], "Input feature size must match input channel size."
+    c, ss, ws, lam = scaled_laplacian_op(g)
+    lib = L.load()
+    plan = g.plan(False)
+    x = x.contiguous()
+
+    def times_L(Z):
+        az = torch.empty_like(Z)
+        L.check(lib.gnnmp_propagate_slots_f32(plan.handle, L.SUM, L.ptr(Z), L.ptr(ws), L.ptr(ss), L.ptr(c), L.ptr(az), Z.shape[1],
+                                              L.stream_ptr()))
+        zero = torch.zeros_like(Z)
+        return _axpy(-2.0 / lam, az, _axpy(2.0 / lam - 1.0, Z, zero))
+
+    Zp, Z = x, None
+    Y = dense(Zp, l.weight[0])
+    if l.k > 1:
+        Z = times_L(x)
+        Y = _add(Y, dense(Z, l.weight[1]))
+    for i in range(2, l.k):
+        LZ = times_L(Z)
+        Z, Zp = _axpy(-1.0, Zp, _add(LZ, LZ)), Z
+        Y = _add(Y, dense(Z, l.weight[i]))
+    if l.bias is not None:
+        from .layers import bias_act
+        Y = bias_act(Y, l.bias, None)
+    return Y
+
+
+class ChebConv:
+    """ChebConv(in => out, k; bias = true): weight [k][out][in] (Julia (out, in, k))"""
+
+    takes_graph = True
+
+    def __init__(self, ch, k, bias=True, device="cuda", seed=None):
+        cin, out = ch
+        self.k = int(k)
+        sd = (lambda j: None if seed is None else seed + j)
+        self.weight = torch.stack([glorot_uniform(out, cin, device=device, seed=sd(i)) for i in range(k)]).contiguous()
+        self.bias = torch.zeros(out, dtype=torch.float32, device=device) if bias else None
+
+    def __call__(self, g, x):
+        return cheb_conv(self, g, x)

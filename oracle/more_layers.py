@@ -210,3 +210,35 @@ def egnn_conv(s, t, n, h, x, e, phi_e, phi_x, phi_h, residual=False):
         hn = _dense(hn, W, b, a_)
     hout = (h + hn).astype(f32) if residual else hn
     return hout, (x + x_aggr).astype(f32)
+
+
+def scaled_laplacian_dense(s, t, n, edge_weight=None):
+    """scaled_laplacian(g, Float32) (GNNGraphs/src/query.jl:442-479) as a dense float64 matrix: A[s, t] (dir = :out, multi-edges
+    summed), degs = sum(A, dims = 2), Ã = D^-1/2 A D^-1/2, L = I - Ã, λmax = eigmax(Symmetric(L)), 2/λmax L - I.  The
+    reference's eigsolve is KrylovKit (un-vendored); eigmax of the same symmetric matrix by LAPACK here."""
+    s, t = O._i64(s), O._i64(t)
+    A = np.zeros((n, n))
+    np.add.at(A, (s - 1, t - 1), 1.0 if edge_weight is None else np.asarray(edge_weight, np.float64))
+    d = A.sum(1)
+    assert (d != 0).all(), "Graph contains isolated nodes, cannot compute `normalized_adjacency`."
+    c = 1.0 / np.sqrt(d)
+    Lm = np.eye(n) - c[:, None] * A * c[None, :]
+    lam = np.linalg.eigvalsh(np.triu(Lm) + np.triu(Lm, 1).T)[-1]                   # Symmetric(L): the upper triangle
+    return 2.0 / lam * Lm - np.eye(n), lam
+
+
+def cheb_conv(s, t, n, x, weight, bias, k, edge_weight=None):
+    """cheb_conv (conv.jl:83-98): Z_1 = X, Z_2 = X L̃, Z_k = 2 Z_{k-1} L̃ - Z_{k-2}; Y = Σ W_k Z_k + b.  weight: [k][out][in].
+    Float32 recurrences on the float32 image of the dense L̃ (the reference holds L̃ as a Float32 matrix)."""
+    x = O._f32(x)
+    Lt, _ = scaled_laplacian_dense(s, t, n, edge_weight)
+    Lt = Lt.astype(f32)
+    mmL = lambda Z: (Lt.T.astype(f32) @ Z).astype(f32)                              # (Z * L̃)[:, j] = Σ_i Z[:, i] L̃[i, j]
+    Zp, Z = x, mmL(x)
+    Y = O.matmul(O._f32(weight[0]), Zp, True)
+    if k > 1:
+        Y = (Y + O.matmul(O._f32(weight[1]), Z, True)).astype(f32)
+    for i in range(2, k):
+        Z, Zp = ((f32(2) * mmL(Z)).astype(f32) - Zp).astype(f32), Z
+        Y = (Y + O.matmul(O._f32(weight[i]), Z, True)).astype(f32)
+    return Y if bias is None else (Y + O._f32(bias)[None, :]).astype(f32)

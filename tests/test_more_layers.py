@@ -414,3 +414,55 @@ def test_oracle_egnn_conv_vs_float64_edge_loop(oracle, ML):
     want_h = np.stack([run(ph, np.concatenate([h[i].astype(np.float64), ha[i]])) for i in range(n)])
     want_x = x + xa / np.maximum(cnt, 1)[:, None]
     assert rel(rh, want_h) < 1e-5 and rel(rx, want_x) < 1e-5
+
+
+def undirected(rng, n, E):
+    a = rng.integers(1, n + 1, E)
+    b = rng.integers(1, n + 1, E)
+    k = a != b
+    a, b = a[k], b[k]
+    ring = np.arange(1, n + 1)                                      # no isolated node
+    a, b = np.concatenate([a, ring]), np.concatenate([b, np.roll(ring, 1)])
+    return np.concatenate([a, b]), np.concatenate([b, a])
+
+
+def test_oracle_cheb_conv_k2_closed_form(oracle, ML):
+    """k = 2 on a 4-cycle: L = I - A/2 has eigenvalues {0, 1, 1, 2} -> λmax = 2, L̃ = L - I = -A/2"""
+    s = np.array([1, 2, 2, 3, 3, 4, 4, 1])
+    t = np.array([2, 1, 3, 2, 4, 3, 1, 4])
+    Lt, lam = ML.scaled_laplacian_dense(s, t, 4)
+    assert lam == pytest.approx(2.0, abs=1e-12)
+    A = np.zeros((4, 4))
+    A[s - 1, t - 1] = 1
+    np.testing.assert_allclose(Lt, -A / 2, atol=1e-12)
+    x = np.arange(8, dtype=np.float32).reshape(4, 2)
+    W = np.stack([np.eye(2, dtype=np.float32), 2 * np.eye(2, dtype=np.float32)])
+    y = ML.cheb_conv(s, t, 4, x, W, None, 2)
+    np.testing.assert_allclose(y, x + 2 * (-A.T / 2) @ x, rtol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Din,Dout,k,weighted", [(8, 6, 1, False), (12, 12, 2, False), (16, 8, 3, False), (10, 10, 4, True)])
+def test_hip_cheb_conv_vs_oracle(gm, ML, Din, Dout, k, weighted):
+    import torch
+    rng = np.random.default_rng(Din + k)
+    n = 400
+    s, t = undirected(rng, n, 1500)
+    ew = None
+    if weighted:
+        half = (rng.random(len(s) // 2) + 0.5).astype(np.float32)
+        ew = np.concatenate([half, half])                            # symmetric weights
+    x = rng.standard_normal((n, Din)).astype(np.float32)
+    W = (rng.standard_normal((k, Dout, Din)) * 0.3).astype(np.float32)
+    b = (rng.standard_normal(Dout) * 0.1).astype(np.float32)
+    g = gm.GNNGraph(dev(s), dev(t), None if ew is None else dev(ew), num_nodes=n)
+    l = gm.ChebConv((Din, Dout), k)
+    l.weight, l.bias = dev(W), dev(b)
+    y = l(g, dev(x)).cpu().numpy()
+    ref = ML.cheb_conv(s, t, n, x, W, b, k, ew)
+    from gnnmp.layers_more import scaled_laplacian_op
+    lam = scaled_laplacian_op(g)[3]
+    assert lam == pytest.approx(ML.scaled_laplacian_dense(s, t, n, ew)[1], rel=2e-6)      # Lanczos vs LAPACK
+    assert rel(y, ref.astype(np.float64)) < 2e-5
+    with pytest.raises(AssertionError):
+        gm.ChebConv((Din, Dout), 2)(gm.GNNGraph(dev(s[:50]), dev(t[:50]), num_nodes=n), dev(x))     # directed / isolated
