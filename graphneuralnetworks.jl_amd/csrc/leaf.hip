@@ -291,6 +291,35 @@ __global__ void __launch_bounds__(256) row_sqnorm_normalize_kernel(const float *
     const float den = sqrtf(s) + eps;
     if (xn) for (int d = 0; d < D; ++d) xn[r * D + d] = x[r * D + d] / den;
 }
+// Flux.LSTMCell's pointwise part (the cell of set2set_pool, GNNlib/src/layers/pool.jl:31-44; Flux 0.16, un-vendored):
+// g = Wi x + Wh h + b is [N][4D] with the gates in the order input, forget, cell, output:
+//   c' = σ(forget) .* c + σ(input) .* tanh(cell),   h' = σ(output) .* tanh(c')
+__global__ void __launch_bounds__(256) lstm_pointwise_kernel(const float *__restrict__ gx, const float *__restrict__ gh,
+                                                             const float *__restrict__ b, const float *__restrict__ c,
+                                                             float *__restrict__ h_out, float *__restrict__ c_out, int64_t N,
+                                                             int D) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * D) return;
+    const int64_t n = i / D;
+    const int d = (int)(i - n * D);
+    const int64_t o = n * 4 * D + d;
+    float g4[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) g4[q] = gx[o + q * D] + gh[o + q * D] + (b ? b[q * D + d] : 0.0f);
+    auto sg = [](float x) { const float t = expf(-fabsf(x)); return x >= 0.0f ? 1.0f / (1.0f + t) : t / (1.0f + t); };
+    const float cn = sg(g4[1]) * c[i] + sg(g4[0]) * tanhf(g4[2]);
+    c_out[i] = cn;
+    h_out[i] = sg(g4[3]) * tanhf(cn);
+}
+// out[n] = sum(a[n][:] .* b[n][:]) — `sum(qn .* x, dims = 1)` of set2set_pool; features added in order
+__global__ void __launch_bounds__(256) rowdot_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                     float *__restrict__ out, int64_t N, int D) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.0f;
+    for (int d = 0; d < D; ++d) s = s + a[n * D + d] * b[n * D + d];
+    out[n] = s;
+}
 // flag[0] = 1 if idx[k] > idx[k+1] for some k
 __global__ void __launch_bounds__(256) unsorted_kernel(const void *idx, int idx_bytes, int64_t n, int *flag) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -451,6 +480,27 @@ int gnnmp_row_sqnorm_normalize_f32(const float *x, float *sq, float *xn, float e
     if (!x || (!sq && !xn)) return fail(GNNMP_EINVAL, "row_sqnorm_normalize: null pointer");
     row_sqnorm_normalize_kernel<<<(unsigned)((N + 255) / 256), 256, 0, stream>>>(x, sq, xn, eps, N, (int)D);
     GNNMP_LAUNCH_CHECK("row_sqnorm_normalize_kernel");
+    return GNNMP_OK;
+}
+
+int gnnmp_lstm_pointwise_f32(const float *gx, const float *gh, const float *b, const float *c, float *h_out, float *c_out,
+                             int64_t N, int64_t D, gnnmp_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (N < 0 || D <= 0 || D > (1 << 20)) return fail(GNNMP_EINVAL, "lstm_pointwise: bad size");
+    if (N == 0) return GNNMP_OK;
+    if (!gx || !gh || !c || !h_out || !c_out) return fail(GNNMP_EINVAL, "lstm_pointwise: null pointer");
+    lstm_pointwise_kernel<<<(unsigned)((N * D + 255) / 256), 256, 0, stream>>>(gx, gh, b, c, h_out, c_out, N, (int)D);
+    GNNMP_LAUNCH_CHECK("lstm_pointwise_kernel");
+    return GNNMP_OK;
+}
+
+int gnnmp_rowdot_f32(const float *a, const float *b, float *out, int64_t N, int64_t D, gnnmp_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (N < 0 || D <= 0 || D > (1 << 20)) return fail(GNNMP_EINVAL, "rowdot: bad size");
+    if (N == 0) return GNNMP_OK;
+    if (!a || !b || !out) return fail(GNNMP_EINVAL, "rowdot: null pointer");
+    rowdot_kernel<<<(unsigned)((N + 255) / 256), 256, 0, stream>>>(a, b, out, N, (int)D);
+    GNNMP_LAUNCH_CHECK("rowdot_kernel");
     return GNNMP_OK;
 }
 

@@ -15,8 +15,8 @@ from .layers_attn import (AGNNConv, GATv2Conv, GINConv, TransformerConv, agnn_co
 from .layers_khop import (GlobalAttentionPool, ResGatedGraphConv, SGConv, TAGConv, global_attention_pool,  # noqa: F401
                           res_gated_graph_conv, sg_conv, tag_conv)
 from .layers_more import (CGConv, ChebConv, DConv, EdgeConv, EGNNConv, GatedGraphConv, GMMConv, MEGNetConv,  # noqa: F401
-                          NNConv, cg_conv, cheb_conv, d_conv, edge_conv, egnn_conv, gated_graph_conv, gmm_conv,
-                          megnet_conv, nn_conv)
+                          NNConv, Set2Set, cg_conv, cheb_conv, d_conv, edge_conv, egnn_conv, gated_graph_conv, gmm_conv,
+                          megnet_conv, nn_conv, set2set_pool)
 from .sampling import (NeighborLoader, NodeSet, has_self_loops, induced_subgraph, is_bidirected, sample_neighbors,  # noqa: F401
                        sort_edge_index)
 from .utils import (broadcast_edges, broadcast_nodes, expand_srcdst, reduce_edges, reduce_nodes,  # noqa: F401

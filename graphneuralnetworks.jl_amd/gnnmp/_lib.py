@@ -35,7 +35,7 @@ SYMBOLS = (
     "gnnmp_edge_dot_f32", "gnnmp_edge_dot_plan_f32", "gnnmp_propagate_maxmin_grad_f32",
     "gnnmp_head_mean_f32", "gnnmp_head_mean_grad_f32", "gnnmp_add_f32", "gnnmp_axpy_f32", "gnnmp_mul_rows_f32", "gnnmp_is_sorted",
     "gnnmp_act_grad_f32", "gnnmp_dense_grad_workspace", "gnnmp_dense_grad_w_f32",
-    "gnnmp_row_normalize_f32", "gnnmp_row_normalize_grad_f32", "gnnmp_propagate_cg_f32", "gnnmp_gru_pointwise_f32", "gnnmp_propagate_nn_f32", "gnnmp_gmm_weights_f32", "gnnmp_row_sqnorm_normalize_f32",
+    "gnnmp_row_normalize_f32", "gnnmp_row_normalize_grad_f32", "gnnmp_propagate_cg_f32", "gnnmp_gru_pointwise_f32", "gnnmp_propagate_nn_f32", "gnnmp_gmm_weights_f32", "gnnmp_row_sqnorm_normalize_f32", "gnnmp_lstm_pointwise_f32", "gnnmp_rowdot_f32",
 )
 
 
@@ -107,6 +107,8 @@ def load():
         "gnnmp_propagate_nn_f32": [vp, i, vp, vp, vp, i64, i64, vp],
         "gnnmp_gmm_weights_f32": [vp, vp, vp, vp, i64, i64, i64, i64, vp],
         "gnnmp_row_sqnorm_normalize_f32": [vp, vp, vp, f, i64, i64, vp],
+        "gnnmp_lstm_pointwise_f32": [vp, vp, vp, vp, vp, vp, i64, i64, vp],
+        "gnnmp_rowdot_f32": [vp, vp, vp, i64, i64, vp],
         "gnnmp_gru_pointwise_f32": [vp, vp, vp, vp, vp, i64, i64, vp],
         "gnnmp_row_normalize_grad_f32": [vp, vp, vp, vp, vp, vp, vp, f, i64, i64, vp],
         "gnnmp_add_f32": [vp, vp, vp, i64, vp],

@@ -1,4 +1,4 @@
-"""More layers of the reference's zoo that run on the same kernels: CGConv, EdgeConv, GatedGraphConv, DConv, NNConv, MEGNetConv, GMMConv, EGNNConv, ChebConv.
+"""More layers of the reference's zoo that run on the same kernels: CGConv, EdgeConv, GatedGraphConv, DConv, NNConv, MEGNetConv, GMMConv, EGNNConv, ChebConv, and the Set2Set pool.
 GNNlib/src/layers/conv.jl  cg_conv :304-333, edge_conv :237-246, gated_graph_conv :218-233, d_conv :696-725;
 constructors GraphNeuralNetworks/src/layers/conv.jl :925-931 (CGConv), :582 (EdgeConv), :525-530 (GatedGraphConv),
 :1584-1589 (DConv).
@@ -578,3 +578,52 @@ class ChebConv:
 
     def __call__(self, g, x):
         return cheb_conv(self, g, x)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Set2Set
+# ---------------------------------------------------------------------------------------------------------
+def set2set_pool(l, g: GNNGraph, x):
+    """GNNlib/src/layers/pool.jl:31-44: num_iters rounds of LSTM query -> broadcast_nodes -> softmax_nodes of q . x ->
+    reduce_nodes(+, x .* α) -> q* = vcat(q, r); returns [num_graphs][2 n_in]"""
+    from .utils import broadcast_nodes, reduce_nodes, softmax_nodes
+    check_num_nodes(g, x)
+    x = x.contiguous()
+    N, n_in = x.shape
+    G = g.num_graphs
+    lib = L.load()
+    z = lambda r, c: torch.zeros((r, c), dtype=torch.float32, device=x.device)
+    q, r, h, c = z(G, n_in), z(G, n_in), z(G, n_in), z(G, n_in)
+    for _ in range(l.num_iters):
+        gx = dense(q, l.Wi[:, :n_in], None, None, x2=r, W2=l.Wi[:, n_in:])       # Wi * vcat(q, r) without the vcat
+        gh = dense(h, l.Wh)
+        hn, cn = torch.empty_like(h), torch.empty_like(c)
+        L.check(lib.gnnmp_lstm_pointwise_f32(L.ptr(gx), L.ptr(gh), L.ptr(l.b), L.ptr(c), L.ptr(hn), L.ptr(cn), G, n_in,
+                                             L.stream_ptr()))
+        h, c = hn, cn
+        q = h
+        qn = broadcast_nodes(g, q)
+        sc = torch.empty((N, 1), dtype=torch.float32, device=x.device)
+        L.check(lib.gnnmp_rowdot_f32(L.ptr(qn), L.ptr(x), L.ptr(sc), N, n_in, L.stream_ptr()))
+        alpha = softmax_nodes(g, sc)
+        xa = torch.empty_like(x)
+        L.check(lib.gnnmp_mul_rows_f32(L.ptr(alpha), 1, L.ptr(x), L.ptr(xa), N, n_in, L.stream_ptr()))
+        r = reduce_nodes("+", g, xa)
+    return torch.cat([q, r], dim=1)                                               # vcat(q, r): memory plumbing
+
+
+class Set2Set:
+    """Set2Set(n_in, n_iters, n_layers = 1): LSTMCell(2 n_in => n_in) — Wi [4 n_in][2 n_in], Wh [4 n_in][n_in], b [4 n_in]"""
+
+    takes_graph = True
+
+    def __init__(self, n_in, n_iters, n_layers=1, device="cuda", seed=None):
+        assert n_layers == 1, "multiple layers not implemented yet"
+        sd = (lambda k: None if seed is None else seed + k)
+        self.num_iters = int(n_iters)
+        self.Wi = glorot_uniform(4 * n_in, 2 * n_in, device=device, seed=sd(0))
+        self.Wh = glorot_uniform(4 * n_in, n_in, device=device, seed=sd(1))
+        self.b = torch.zeros(4 * n_in, dtype=torch.float32, device=device)
+
+    def __call__(self, g, x):
+        return set2set_pool(self, g, x)

@@ -381,6 +381,13 @@ int gnnmp_gmm_weights_f32(const float *e, const float *mu, const float *sigma_in
  * xn[k][:] = x_diff[k][:] / (sqrt(sq[k]) + eps) for every row k (eps = 1f-6 in the reference). */
 int gnnmp_row_sqnorm_normalize_f32(const float *x, float *sq, float *xn, float eps, int64_t N, int64_t D,
                                    gnnmp_stream_t stream);
+/* Flux.LSTMCell's pointwise part — the cell of set2set_pool (GNNlib/src/layers/pool.jl:31-44): gx = Wi x and gh = Wh h are
+ * [N][4D] (gates input, forget, cell, output), b [4D] or NULL:
+ *   c_out = σ(forget) .* c + σ(input) .* tanh(cell),  h_out = σ(output) .* tanh(c_out) */
+int gnnmp_lstm_pointwise_f32(const float *gx, const float *gh, const float *b, const float *c, float *h_out, float *c_out,
+                             int64_t N, int64_t D, gnnmp_stream_t stream);
+/* out[n] = sum(a[n][:] .* b[n][:]) — `sum(qn .* x, dims = 1)` of set2set_pool (pool.jl:39) */
+int gnnmp_rowdot_f32(const float *a, const float *b, float *out, int64_t N, int64_t D, gnnmp_stream_t stream);
 /* Flux.GRUCell's pointwise part — the cell of gated_graph_conv (GNNlib/src/layers/conv.jl:228-232): gx = Wi m and
  * gh = Wh h are [N][3D] (gates r, z, candidate), b [3D] or NULL:
  *   r = σ(gx_r + gh_r + b_r), z = σ(gx_z + gh_z + b_z), h~ = tanh(gx_n + r .* gh_n + b_n), out = (1 - z) .* h~ + z .* h */

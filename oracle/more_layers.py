@@ -242,3 +242,33 @@ def cheb_conv(s, t, n, x, weight, bias, k, edge_weight=None):
         Z, Zp = ((f32(2) * mmL(Z)).astype(f32) - Zp).astype(f32), Z
         Y = (Y + O.matmul(O._f32(weight[i]), Z, True)).astype(f32)
     return Y if bias is None else (Y + O._f32(bias)[None, :]).astype(f32)
+
+
+def set2set_pool(graph_indicator, num_graphs, x, Wi, Wh, b, num_iters):
+    """set2set_pool (GNNlib/src/layers/pool.jl:31-44) with Flux.LSTMCell restated (gates input, forget, cell, output of
+    Wi x + Wh h + b; un-vendored Flux 0.16).  graph_indicator 1-based; returns [num_graphs][2 n_in]."""
+    x = O._f32(x)
+    gi = O._i64(graph_indicator)
+    n_in = x.shape[1]
+    G = num_graphs
+    qstar = np.zeros((G, 2 * n_in), f32)
+    h = np.zeros((G, n_in), f32)
+    c = np.zeros((G, n_in), f32)
+    bb = np.zeros(4 * n_in, f32) if b is None else O._f32(b)
+    for _ in range(num_iters):
+        g4 = ((O.matmul(O._f32(Wi), qstar, True) + O.matmul(O._f32(Wh), h, True)).astype(f32) + bb[None, :]).astype(f32)
+        i_, f_, cc, o_ = (g4[:, k * n_in:(k + 1) * n_in] for k in range(4))
+        c = ((sigmoid(f_) * c).astype(f32) + (sigmoid(i_) * np.tanh(cc).astype(f32)).astype(f32)).astype(f32)
+        h = (sigmoid(o_) * np.tanh(c).astype(f32)).astype(f32)
+        q = h
+        qn = O.gather(q, gi)                                                      # broadcast_nodes
+        sc = np.zeros((x.shape[0], 1), f32)
+        for d in range(n_in):
+            sc = (sc + (qn[:, d:d + 1] * x[:, d:d + 1]).astype(f32)).astype(f32)
+        mx = O.scatter(O.MAX, sc, gi, G)                                          # softmax_nodes
+        num = np.exp(sc - O.gather(mx, gi)).astype(f32)
+        den = O.scatter(O.SUM, num, gi, G)
+        alpha = (num / O.gather(den, gi)).astype(f32)
+        r = O.scatter(O.SUM, (x * alpha).astype(f32), gi, G)
+        qstar = np.concatenate([q, r], axis=1)
+    return qstar

@@ -466,3 +466,27 @@ def test_hip_cheb_conv_vs_oracle(gm, ML, Din, Dout, k, weighted):
     assert rel(y, ref.astype(np.float64)) < 2e-5
     with pytest.raises(AssertionError):
         gm.ChebConv((Din, Dout), 2)(gm.GNNGraph(dev(s[:50]), dev(t[:50]), num_nodes=n), dev(x))     # directed / isolated
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_in,iters,G", [(8, 3, 40), (16, 2, 300), (5, 4, 1)])
+def test_hip_set2set_pool_vs_oracle(gm, ML, n_in, iters, G):
+    rng = np.random.default_rng(n_in + G)
+    sizes = rng.integers(3, 40, G)
+    if G == 1:
+        sizes = np.array([3000])                                    # one large graph: the segment-plan path of the helpers
+    gs = []
+    for k, m in enumerate(sizes):
+        a = rng.integers(1, m + 1, 3 * m)
+        b = rng.integers(1, m + 1, 3 * m)
+        gs.append(gm.GNNGraph(dev(a), dev(b), num_nodes=int(m)))
+    g = gm.batch(gs)
+    n = int(sizes.sum())
+    x = rng.standard_normal((n, n_in)).astype(np.float32)
+    l = gm.Set2Set(n_in, iters, seed=13)
+    l.b = dev((rng.standard_normal(4 * n_in) * 0.1).astype(np.float32))
+    y = l(g, dev(x)).cpu().numpy()
+    gi = np.repeat(np.arange(1, G + 1), sizes)
+    ref = ML.set2set_pool(gi, G, x, l.Wi.cpu().numpy(), l.Wh.cpu().numpy(), l.b.cpu().numpy(), iters)
+    assert y.shape == ref.shape == (G, 2 * n_in)
+    assert rel(y, ref.astype(np.float64)) < 2e-5
