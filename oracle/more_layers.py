@@ -1,11 +1,14 @@
-"""CPU restatement of CGConv, EdgeConv, GatedGraphConv and DConv (GNNlib/src/layers/conv.jl cg_conv :304-333, edge_conv
-:237-246, gated_graph_conv :218-233, d_conv :696-725) — TEST INFRASTRUCTURE ONLY (same rules as oracle.py).  Statement by
+"""CPU restatement of CGConv, EdgeConv, GatedGraphConv, DConv, NNConv, MEGNetConv, GMMConv, EGNNConv, ChebConv and the
+Set2Set pool (GNNlib/src/layers/conv.jl cg_conv :304-333, edge_conv :237-246, gated_graph_conv :218-233, d_conv :696-725,
+nn_conv :260-273, megnet_conv :356-368, gmm_conv :372-401, egnn_conv :459-495, cheb_conv :83-98; layers/pool.jl
+set2set_pool :31-44) — TEST INFRASTRUCTURE ONLY (same rules as oracle.py).  Statement by
 statement on the pinned primitives (gather, scatter, propagate, degree, matmul), float32, in the reference's order: the
 per-edge `vcat`s and the (2nin + ein, E) / (2D, E) arrays ARE materialised here, as the reference does.
 
 No known-answer vectors exist in the reference for these layers (test/layers/conv.jl checks sizes and gradients) and the
-GRU cell lives in un-vendored Flux 0.16 (restated from its published definition: Wi, Wh without bias, one bias vector b,
-gates in the order r, z, candidate; sigmoid_fast / tanh_fast are restated as the exact functions) — parity unpinned beyond
+GRU / LSTM cells live in un-vendored Flux 0.16 (restated from their published definitions: Wi, Wh without bias, one bias
+vector b, gates in the order r, z, candidate / input, forget, cell, output; sigmoid_fast / tanh_fast are restated as the
+exact functions), ChebConv's eigmax in un-vendored KrylovKit (LAPACK on the same symmetric matrix here) — parity unpinned beyond
 the float64 identities tests/test_more_layers.py checks (dense-adjacency formulations)."""
 from __future__ import annotations
 

@@ -1,4 +1,4 @@
-"""CGConv, EdgeConv, GatedGraphConv, DConv.  CPU: the oracle restatements (oracle/more_layers.py, float32, the reference's
+"""CGConv, EdgeConv, GatedGraphConv, DConv, NNConv, MEGNetConv, GMMConv, EGNNConv, ChebConv, Set2Set.  CPU: the oracle restatements (oracle/more_layers.py, float32, the reference's
 statement order with every per-edge array materialised) against independent float64 formulations (per-edge loops / dense
 adjacency algebra).  GPU: the HIP compositions (gnnmp/layers_more.py) against the oracle on graphs with hub rows."""
 import numpy as np
