@@ -80,3 +80,35 @@ def tag_conv_ad(l, g: GNNGraph, x, edge_weight=None):
         term = _DenseFn.apply(sum_pow, l.weight, None, None)
         total = term if it == 0 else _AddFn.apply(total, term)
     return _BiasFn.apply(total, l.bias) if l.bias is not None else total
+
+
+class _AxpyFn(torch.autograd.Function):
+    """alpha .* x .+ y on the device; alpha a constant (gin_conv's ϵ is not trainable in the reference)"""
+
+    @staticmethod
+    def forward(ctx, x, y, alpha):
+        ctx.alpha = float(alpha)
+        out = torch.empty_like(x)
+        L.check(L.load().gnnmp_axpy_f32(ctx.alpha, L.ptr(x.contiguous()), L.ptr(y.contiguous()), L.ptr(out), x.numel(),
+                                        L.stream_ptr()))
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        d = d.contiguous()
+        dx = torch.empty_like(d)
+        zero = torch.zeros_like(d)
+        L.check(L.load().gnnmp_axpy_f32(ctx.alpha, L.ptr(d), L.ptr(zero), L.ptr(dx), d.numel(), L.stream_ptr()))
+        return dx, d, None
+
+
+def gin_conv_ad(l, g: GNNGraph, x):
+    """differentiable gin_conv (conv.jl:250-256) for `nn` a gnnmp Dense or a list of them: gradients w.r.t. x and the Dense
+    parameters; propagate(copy_xj, aggr) through its own pullback (any aggr)"""
+    from .backward import propagate_ad
+    check_num_nodes(g, x)
+    m = propagate_ad(g, l.aggr, x)
+    z = _AxpyFn.apply(x, m, 1.0 + float(l.eps))
+    for layer in (l.nn if isinstance(l.nn, (list, tuple)) else [l.nn]):
+        z = _DenseFn.apply(z, layer.weight, layer.bias, layer.sigma)
+    return z

@@ -58,3 +58,42 @@ def test_hip_khop_backward_adjoint_identity(gm, oracle, layer, Din, Dout, k, wei
         rhs = (Wp.astype(np.float64) * l.weight.grad.cpu().numpy()).sum()
         assert abs(lhs - rhs) <= 2e-4 * max(abs(lhs), np.linalg.norm(Wp) * np.linalg.norm(l.weight.grad.cpu().numpy()) * 1e-2)
     np.testing.assert_allclose(l.bias.grad.cpu().numpy(), r64.sum(0), rtol=2e-5, atol=1e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("aggr,D,Dout", [("+", 16, 12), ("mean", 10, 10)])
+def test_hip_gin_backward_vs_rule_by_rule_float64(gm, aggr, D, Dout):
+    """gin_conv with nn = Dense(relu): y = relu(W z + b), z = (1 + ϵ) x + aggr_j x_j — every pullback rule written out"""
+    from gnnmp.backward_khop import gin_conv_ad
+    rng = np.random.default_rng(D)
+    n, E, eps = 1200, 14000, 0.3
+    s = rng.integers(1, n + 1, E)
+    t = rng.integers(1, n + 1, E)
+    t[:1500] = 5
+    x = rng.standard_normal((n, D)).astype(np.float32)
+    r = rng.standard_normal((n, Dout)).astype(np.float32)
+    g = gm.GNNGraph(dev(s), dev(t), num_nodes=n)
+    nn = gm.Dense((D, Dout), "relu", seed=4)
+    nn.bias = dev((rng.standard_normal(Dout) * 0.1).astype(np.float32))
+    l = gm.GINConv(nn, eps, aggr=aggr)
+    nn.weight.requires_grad_(True)
+    nn.bias.requires_grad_(True)
+    xt = dev(x).requires_grad_(True)
+    y = gin_conv_ad(l, g, xt)
+    assert bool((y == l(g, dev(x))).all())                          # same forward as the plain layer
+    (y * dev(r)).sum().backward()
+    W, b = nn.weight.detach().cpu().numpy().astype(np.float64), nn.bias.detach().cpu().numpy().astype(np.float64)
+    x64 = x.astype(np.float64)
+    A = np.zeros((n, n))
+    np.add.at(A, (t - 1, s - 1), 1.0)
+    if aggr == "mean":
+        A = A / np.maximum(A.sum(1, keepdims=True), 1)
+    z = (1 + np.float32(eps)).astype(np.float64) * x64 + A @ x64
+    pre = z @ W.T + b
+    dz = (r * (pre > 0)) @ W
+    want = {"x": (1 + np.float32(eps)).astype(np.float64) * dz + A.T @ dz, "W": (r * (pre > 0)).T @ z, "b": (r * (pre > 0)).sum(0)}
+    safe = np.abs(pre) > 1e-4                                        # relu kinks: fp32 / fp64 may disagree on the sign there
+    assert safe.mean() > 0.999
+    for got, ref in ((xt.grad, want["x"]), (nn.weight.grad, want["W"]), (nn.bias.grad, want["b"])):
+        gn = got.cpu().numpy()
+        assert np.linalg.norm(gn - ref) <= 2e-4 * np.linalg.norm(ref)
