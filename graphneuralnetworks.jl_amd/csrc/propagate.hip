@@ -411,24 +411,47 @@ __global__ void __launch_bounds__(256) nn_rows_kernel(const ReduceArgs a, const 
     }
     float acc = op_identity<OP>();
     const int oc = active ? o : 0;
-    for (int p = beg; p < end; ++p) {
-        const int cj = a.idx[p], ej = a.eid[p];
-        if (ej >= a.n_edges) continue;                       // a self loop the plan added: no edge features, no message
-        const float *wk = we + (int64_t)ej * a.D * Din + oc;
-        const float *xr = a.x + (int64_t)cj * Din;
-        float m = 0.0f;
-        int c = 0;
-        for (; c + 4 <= Din; c += 4) {                       // four weight columns in flight
-            const float w0 = wk[(int64_t)(c + 0) * a.D], w1 = wk[(int64_t)(c + 1) * a.D];
-            const float w2 = wk[(int64_t)(c + 2) * a.D], w3 = wk[(int64_t)(c + 3) * a.D];
-            const float4 xv = make_float4(xr[c], xr[c + 1], xr[c + 2], xr[c + 3]);
-            m = m + w0 * xv.x;
-            m = m + w1 * xv.y;
-            m = m + w2 * xv.z;
-            m = m + w3 * xv.w;
+    // EB edges at a time: their EB x 2 in-channel loads are independent (a row walks its edges alone — with one edge in flight
+    // the kernel ran at a third of the HBM rate); messages are still formed per edge and folded in edge order.  Slots past
+    // the end re-read the last edge and are not folded.
+    constexpr int EB = 4;
+    for (int p0 = beg; p0 < end; p0 += EB) {
+        const float *wk[EB], *xr[EB];
+        bool ok[EB];
+#pragma unroll
+        for (int u = 0; u < EB; ++u) {
+            const int p = min(p0 + u, end - 1);
+            const int cj = a.idx[p], ej = a.eid[p];
+            ok[u] = p0 + u < end && ej < a.n_edges;          // a self loop the plan added: no edge features, no message
+            wk[u] = we + (int64_t)min(ej, a.n_edges - 1) * a.D * Din + oc;
+            xr[u] = a.x + (int64_t)cj * Din;
         }
-        for (; c < Din; ++c) m = m + wk[(int64_t)c * a.D] * xr[c];
-        acc = op_apply<OP>(acc, m);
+        float m[EB];
+#pragma unroll
+        for (int u = 0; u < EB; ++u) m[u] = 0.0f;
+        int c = 0;
+        for (; c + 2 <= Din; c += 2) {
+            float w0[EB], w1[EB], x0[EB], x1[EB];
+#pragma unroll
+            for (int u = 0; u < EB; ++u) {
+                w0[u] = wk[u][(int64_t)c * a.D];
+                w1[u] = wk[u][(int64_t)(c + 1) * a.D];
+                x0[u] = xr[u][c];
+                x1[u] = xr[u][c + 1];
+            }
+#pragma unroll
+            for (int u = 0; u < EB; ++u) {
+                m[u] = m[u] + w0[u] * x0[u];
+                m[u] = m[u] + w1[u] * x1[u];
+            }
+        }
+        if (c < Din) {
+#pragma unroll
+            for (int u = 0; u < EB; ++u) m[u] = m[u] + wk[u][(int64_t)c * a.D] * xr[u][c];
+        }
+#pragma unroll
+        for (int u = 0; u < EB; ++u)
+            if (ok[u]) acc = op_apply<OP>(acc, m[u]);
     }
     if (is_chunk) {
         if (active) a.partial[(int64_t)v * a.D + o] = acc;

@@ -75,6 +75,12 @@ lg = gnnmp.GatedGraphConv(D, 2, seed=1); row("GatedGraphConv(100, 2 layers) laye
 ld = gnnmp.DConv((D, D), 2, seed=1); row("DConv(100=>100, k=2) layer", t(lambda: ld(g, x)))
 del lc, lg, ld
 torch.cuda.empty_cache()
+we = torch.randn((E, 64), device="cuda") * 0.1            # nn(e) for an 8 => 8 NNConv: one (8, 8) matrix per edge
+x8 = torch.randn((N, 8), device="cuda"); o8 = torch.empty((N, 8), device="cuda")
+row("NNConv propagate (8 => 8): per-edge matvec + aggregation", t(lambda: L.check(L.load().gnnmp_propagate_nn_f32(
+    g.plan(False).handle, L.SUM, L.ptr(x8), L.ptr(we), L.ptr(o8), 8, 8, L.stream_ptr()))), E * (4 * 64 + 4 * 8 + 8) + N * 4 * 8)
+del we, x8, o8
+torch.cuda.empty_cache()
 eh = torch.randn((E, H), device="cuda")
 row("softmax_edge_neighbors, H=8", t(lambda: gnnmp.softmax_edge_neighbors(g, eh)), E * (8 * H + 4))
 del eh
