@@ -7,14 +7,18 @@ features already resident in HBM, plans (dst-sorted CSR) built before the timed 
 value = edges traversed per second, whole job = n_gpus * 2 * E' / step time (ranks are independent replicas with
 different feature batches: weak scaling, no data-path collective — SURVEY.md §8e).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload products|arxiv] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload products|arxiv|batched|rowpart] [--no-cpu-baseline]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+`python bench.py --gpus N` with N > 1 and no launcher environment re-executes itself under torch.distributed.run with N
+ranks on 127.0.0.1 (one process per GPU, RCCL); it exits non-zero — never degrades to one rank — if the node has fewer GPUs.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline     — the dominant kernel's algorithmic bytes / its average duration measured with HIP events on the launch
                  stream inside the timed region, against the 8 TB/s HBM peak (MI355X_MICROARCH.md)
   cpu_baseline — the CPU oracle (a port of the reference's algorithm; Julia is not installed) timed on the host, rank 0,
-                 N=1 only, on a bounded arxiv-shaped sample of the same two layers.
+                 N=1 only, on a bounded sample: the same two layers on a 1/32-scale products-shaped graph, plus the GCN layer
+                 once on the full products-shaped graph (the same workload as the GPU side).
 """
 import argparse
 import json
@@ -48,8 +52,18 @@ def alg_bytes_gat_aggregate(N, Ep, H, C):
     return Ep * (4 * H * C + 4) + N * (8 * H * C + 8)
 
 
-def cpu_baseline(seed_graph=0):
-    """The reference's algorithm (oracle port) for the same two layers on an arxiv-shaped sample, single thread."""
+def compulsory_bytes(N, Ep, D_in, D_out):
+    """SURVEY.md §8d's compulsory bound for an aggregation: every input row read once, every output row written once, and
+    the index (int32 col per edge + rowptr).  What an ideal cache would leave of the algorithmic bytes."""
+    return 4 * N * D_in + 4 * N * D_out + 4 * Ep + 4 * (N + 1)
+
+
+def cpu_baseline(products_graph=None):
+    """The reference's algorithm (oracle port), single thread, on the paths the reference takes with CPU arrays: GCNConv through
+    the SpMM fast path (COO -> CSC rebuild + CSC sweep per call, msgpass.jl:215-238), GATConv through gather -> message ->
+    scatter with materialised (D, E') temporaries.  Sample: both layers of the bench step once on a 1/32-scale products-shaped
+    graph (same generator, same degree law, D = 100), and — when the caller passes the full graph — the GCN layer once at
+    full size, so that one leg of the ratio is the identical workload."""
     import numpy as np
     from gnnmp import synth
     from oracle import oracle as orc
@@ -58,38 +72,53 @@ def cpu_baseline(seed_graph=0):
     except Exception:  # pragma: no cover
         threadpool_limits = None
     orc.build()
-    N, D = synth.ARXIV["N"], 128
-    s, t = synth.arxiv_like(seed=seed_graph)
+    D, H, C = synth.PRODUCTS["D"], 8, 16
+    SCALE = 32
+    N = synth.PRODUCTS["N"] // SCALE
+    E = (synth.PRODUCTS["E"] // SCALE) & ~1
+    s, t = synth.products_like(N=N, E=E, seed=5)
     x = synth.features(N, D, seed=1)
     rng = np.random.default_rng(0)
     W = (rng.standard_normal((D, D)) * 0.1).astype(np.float32)
     b = np.zeros(D, np.float32)
-    Wd = (rng.standard_normal((128, D)) * 0.1).astype(np.float32)
-    a = (rng.standard_normal((32, 8)) * 0.1).astype(np.float32)
+    Wd = (rng.standard_normal((H * C, D)) * 0.1).astype(np.float32)
+    ba = np.zeros(H * C, np.float32)
+    a = (rng.standard_normal((2 * C, H)) * 0.1).astype(np.float32)
     Ep = len(s) + N
 
     def run():
         t0 = time.perf_counter()
-        orc.gcn_conv(s, t, N, x, W, b, "relu", fast_path=True)      # what the reference runs on CPU arrays: sparse() rebuild
-        t1 = time.perf_counter()                                    # + dense x CSC product per call (msgpass.jl:215-218)
-        orc.gat_conv(s, t, N, x, Wd, a, b, "relu", heads=8)         # generic gather -> message -> scatter (no fast path)
+        orc.gcn_conv(s, t, N, x, W, b, "relu", fast_path=True)
+        t1 = time.perf_counter()
+        orc.gat_conv(s, t, N, x, Wd, a, ba, "relu", heads=H)
         t2 = time.perf_counter()
         orc.gcn_conv(s, t, N, x, W, b, "relu", fast_path=False)     # the generic path for GCN too (what its GPU ext does)
         t3 = time.perf_counter()
-        return t1 - t0, t2 - t1, t3 - t2
+        full = None
+        if products_graph is not None:
+            sf, tf, xf = products_graph
+            t4 = time.perf_counter()
+            orc.gcn_conv(sf, tf, xf.shape[0], xf, W, b, "relu", fast_path=True)
+            full = time.perf_counter() - t4
+        return t1 - t0, t2 - t1, t3 - t2, full
 
     if threadpool_limits is not None:
         with threadpool_limits(limits=1):
-            tg, ta, tgg = run()
+            tg, ta, tgg, tfull = run()
     else:
-        tg, ta, tgg = run()
+        tg, ta, tgg, tfull = run()
     out = {
         "value": 2 * Ep / (tg + ta), "unit": "edges/s", "cores": 1, "kind": "port",
-        "sample": f"arxiv-shaped graph N={N} E'={Ep} D=128: GCNConv(128=>128)+GATConv(128=>16,h=8) forward once on the "
-                  f"paths the reference takes with CPU arrays: GCN through the SpMM fast path (COO->CSC rebuild + CSC sweep "
-                  f"per call) {tg:.2f}s, GAT through gather->message->scatter with materialised (D,E') temporaries {ta:.2f}s",
+        "sample": f"1/{SCALE}-scale products-shaped graph N={N} E'={Ep} D={D}: GCNConv({D}=>{D},relu)+GATConv({D}=>{C},h={H},relu) "
+                  f"forward once on the paths the reference takes with CPU arrays: GCN through the SpMM fast path (COO->CSC "
+                  f"rebuild + CSC sweep per call) {tg:.2f}s, GAT through gather->message->scatter with materialised (D,E') "
+                  f"temporaries {ta:.2f}s"
+                  + (f"; plus the GCN layer once on the FULL products-shaped graph: {tfull:.1f}s" if tfull else ""),
         "gcn_edges_per_s": Ep / tg, "gat_edges_per_s": Ep / ta, "gcn_generic_path_edges_per_s": Ep / tgg,
     }
+    if tfull:
+        Epf = len(products_graph[0]) + products_graph[2].shape[0]
+        out["gcn_full_products"] = {"E_prime": Epf, "seconds": tfull, "edges_per_s": Epf / tfull}
     try:
         # a fair "best CPU" line — OpenMP CSR aggregation on every host core, CSR built once (NOT the
         # reference's algorithm: its CPU propagate is single-threaded)
@@ -236,6 +265,42 @@ def run_rowpart(args, rank, world, dist, barrier):
         dist.destroy_process_group()
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) outside a launcher: become N ranks under torch.distributed.run on 127.0.0.1."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} requested but this node exposes {have} GPU(s); refusing to run fewer ranks")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("[bench] self-launch:", " ".join(cmd))
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def traffic_from_profiles(workload, kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (bench.py cannot collect counters itself): value plus
+    where it came from, so that a stale number is visible in the line."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            doc = json.load(f)
+        pt = doc.get(workload, {}).get(kernel)
+        if pt:
+            return pt["hbm_read_bytes"] + pt["hbm_write_bytes"], {
+                "file": "profiles/pmc_traffic.json", "passes": pt.get("source"), "round": pt.get("round", doc.get("_round")),
+                "measured_at_commit": pt.get("commit", doc.get("_commit")),
+                "note": "constant from the committed rocprofv3 --pmc passes of this same command, not measured by this run"}
+    except OSError:
+        pass
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -245,28 +310,36 @@ def main():
                     help="products (default, the BASELINE.json metric) | arxiv | batched (config 5: 8192 graphs sharded "
                          "by graph across the ranks, one RCCL all-gather of logits per step; strong scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the arxiv-shape side measurements")
+    ap.add_argument("--no-extras", action="store_true", help="skip the side measurements (other configs, 8d protocol)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ and "MASTER_ADDR" in os.environ
+    if args.gpus > 1 and not launched:
+        self_launch(args)
 
     import numpy as np
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(os.environ.get("WORLD_SIZE", "1")) if launched else 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ):   # launched by torch.distributed.run
+    if launched:                               # launched by torch.distributed.run (also for world == 1)
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    assert args.gpus == world or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     import gnnmp
     from gnnmp import _lib as L
     from gnnmp import synth
+    from gnnmp.layers import gcn_norm_cache
     gnnmp.load()
 
     def barrier():
@@ -290,9 +363,12 @@ def main():
         s, t = synth.arxiv_like()
     H, C = 8, 16
     Ep = E + N
-    x = torch.from_numpy(synth.features(N, D, seed=1 + rank)).cuda()
+    x_host = synth.features(N, D, seed=1 + rank)
+    x = torch.from_numpy(x_host).cuda()
     sd, td = torch.from_numpy(s).cuda(), torch.from_numpy(t).cuda()
-    del s, t
+    keep_host = rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "products"
+    if not keep_host:
+        del s, t, x_host
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     g = gnnmp.GNNGraph(sd, td, num_nodes=N, _validated=True)
@@ -301,6 +377,12 @@ def main():
     plan_ms = (time.perf_counter() - t0) * 1e3
     gcn = gnnmp.GCNConv((D, D), "relu", seed=11)
     gat = gnnmp.GATConv((D, C), "relu", heads=H, seed=12)
+    # per-graph GCN constants (degree, 1/sqrt(d), slot-ordered coefficients): plan-time work like the CSR itself, done once per
+    # graph and reported next to plan_create_ms (the reference recomputes them inside every call)
+    t0 = time.perf_counter()
+    cvec, c_slot, _ = gcn_norm_cache(g, True, None)
+    torch.cuda.synchronize()
+    norm_cache_ms = (time.perf_counter() - t0) * 1e3
 
     def step():
         y1 = gcn(g, x)
@@ -309,8 +391,7 @@ def main():
 
     # ---- events around the two candidate dominant kernels (recorded on the launch stream) --------------------
     lib = L.load()
-    step()                        # fills the per-graph normalisation cache (slot-ordered coefficients)
-    cvec, c_slot, _ = g._cache[("gcn_norm", True, False)]
+    step()
     out_p = torch.empty((N, D), dtype=torch.float32, device="cuda")
     Wx = gnnmp.dense(x, gat.dense_x_weight)
     a_hc = gat.a_hc               # keep alive: raw pointers below
@@ -358,24 +439,24 @@ def main():
     b_gat = alg_bytes_gat_aggregate(N, Ep, H, C)
     kern = {
         "gcn_propagate": {"kernel": "csr_rows_kernel", "ms": tp_avg, "ms_median": tp_med,
-                          "alg_bytes": b_prop, "GBs": b_prop / tp_avg / 1e6},
+                          "alg_bytes": b_prop, "GBs": b_prop / tp_avg / 1e6,
+                          "compulsory_bytes": compulsory_bytes(N, Ep, D, D)},
         "gat_aggregate": {"kernel": "gat_fused_rows_kernel", "ms": tg_avg, "ms_median": tg_med,
-                          "alg_bytes": b_gat, "GBs": b_gat / tg_avg / 1e6},
+                          "alg_bytes": b_gat, "GBs": b_gat / tg_avg / 1e6,
+                          "compulsory_bytes": compulsory_bytes(N, Ep, H * C, H * C) + 4 * N * H * C},
     }
+    for k in kern.values():   # the secondary line of SURVEY.md §8d: rate against the bytes an ideal cache could not avoid
+        k["compulsory_GBs"] = k["compulsory_bytes"] / k["ms"] / 1e6
     dom = max(kern, key=lambda k: kern[k]["ms"])
-    traffic = None   # HBM bytes per launch from the committed PMC passes (bench.py cannot collect counters itself)
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            pt = json.load(f).get(args.workload, {}).get(kern[dom]["kernel"])
-        if pt:
-            traffic = pt["hbm_read_bytes"] + pt["hbm_write_bytes"]
-    except OSError:
-        pass
+    traffic, traffic_source = traffic_from_profiles(args.workload, kern[dom]["kernel"])
     roofline = {"bound": "hbm", "kernel": kern[dom]["kernel"], "call": dom, "achieved": kern[dom]["GBs"],
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kern[dom]["GBs"] / HBM_PEAK_GBS, "traffic": traffic,
-                "alg_bytes_per_launch": kern[dom]["alg_bytes"], "avg_ms": kern[dom]["ms"]}
+                "traffic_source": traffic_source,
+                "alg_bytes_per_launch": kern[dom]["alg_bytes"], "avg_ms": kern[dom]["ms"],
+                "compulsory_bytes": kern[dom]["compulsory_bytes"],
+                "compulsory_frac": kern[dom]["compulsory_GBs"] / HBM_PEAK_GBS}
 
-    # layer-level split and the arxiv-shape configs (BASELINE.json configs[1], configs[2]) as side lines
+    # layer-level split and the other configs of BASELINE.json as side lines
     def layer_time(fn, iters):
         fn()
         torch.cuda.synchronize()
@@ -385,17 +466,24 @@ def main():
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / iters * 1e3
 
-    extras = {"plan_create_ms": plan_ms, "kernels": kern,
+    extras = {"plan_create_ms": plan_ms, "norm_cache_ms": norm_cache_ms, "kernels": kern,
               "gcn_layer_ms": layer_time(lambda: gcn(g, x), 5), "gat_layer_ms": layer_time(lambda: gat(g, x), 5),
               "max_in_degree": plan.max_degree, "long_rows": plan.n_long}
     extras["gcn_layer_edges_per_s"] = Ep / extras["gcn_layer_ms"] * 1e3
     extras["gat_layer_edges_per_s"] = Ep / extras["gat_layer_ms"] * 1e3
+    if not args.no_extras:
+        # SURVEY.md §8d's timing protocol next to the driver's K/W: >= 20 warm-up, >= 100 timed steps, per-step HIP events, median
+        for _ in range(max(0, 20 - args.warmup)):
+            step()
+        _, med = event_time(step, 100)
+        extras["protocol_8d"] = {"warmup": max(20, args.warmup), "timed_steps": 100, "median_ms_per_step": med,
+                                 "edges_per_s_at_median": world * 2 * Ep / med * 1e3}
     # the dense contractions (the only MFMA work on the path): events around gnnmp_dense_f32, against the fp32 MFMA peak
-    MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+    MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32, 64 FLOP/clk/SIMD
     t_dg, _ = event_time(lambda: gnnmp.dense(out_p, gcn.weight, gcn.bias, "relu"), iters)
     t_da, _ = event_time(lambda: gnnmp.dense(x, gat.dense_x_weight), iters)
     extras["dense"] = {
-        "kernel": "dense_wlds_kernel (v_mfma_f32_32x32x2_f32)", "peak_TFs": MFMA_F32_PEAK_TF,
+        "kernel": "dense kernels (fp32 MFMA)", "peak_TFs": MFMA_F32_PEAK_TF,
         "gcn_W_x": {"shape": f"{N}x{D}=>{D}", "ms": t_dg, "TFs": 2.0 * N * D * D / t_dg / 1e9,
                     "frac": 2.0 * N * D * D / t_dg / 1e9 / MFMA_F32_PEAK_TF},
         "gat_dense_x": {"shape": f"{N}x{D}=>{H * C}", "ms": t_da, "TFs": 2.0 * N * D * H * C / t_da / 1e9,
@@ -409,6 +497,7 @@ def main():
         extras["sage_products"] = {"E": E, "layer_ms_mean": t_sm, "layer_ms_sum": t_ss,
                                    "edges_per_s_mean": E / t_sm * 1e3, "edges_per_s_sum": E / t_ss * 1e3}
         del out_p, out_g, Wx, sage
+        # configs 2 and 3: arxiv shape
         Na, Da = synth.ARXIV["N"], synth.ARXIV["D"]
         sa, ta = synth.arxiv_like()
         ga = gnnmp.GNNGraph(torch.from_numpy(sa).cuda(), torch.from_numpy(ta).cuda(), num_nodes=Na, _validated=True)
@@ -420,6 +509,19 @@ def main():
         taa = layer_time(lambda: gat_a(ga, xa), 50)
         extras["arxiv"] = {"E_prime": Epa, "gcn_layer_ms": tga, "gat_layer_ms": taa,
                            "gcn_edges_per_s": Epa / tga * 1e3, "gat_edges_per_s": Epa / taa * 1e3}
+        del ga, xa
+        # config 5 on this one GPU: 8192 graphs, GraphConv x2 + GlobalPool(mean) + Dense (the N-GPU line is --workload batched)
+        members = synth.batched_graphs(G=8192)
+        rngb = np.random.default_rng(4)
+        xs = [rngb.standard_normal((n, 16), dtype=np.float32) for _, _, n in members]
+        gb = gnnmp.batch_arrays(members, xs)
+        gb.plan(False)
+        model = gnnmp.GNNChain(gnnmp.GraphConv((16, 128), "relu", seed=21), gnnmp.GraphConv((128, 128), "relu", seed=22),
+                               gnnmp.GlobalPool("mean"), gnnmp.Dense((128, 2), seed=23))
+        tb = layer_time(lambda: model(gb, gb.x), 50)
+        extras["batched"] = {"graphs": 8192, "nodes": gb.num_nodes, "edges": gb.num_edges, "ms_per_step": tb,
+                             "graphs_per_s": 8192 / tb * 1e3, "edges_per_s": 2 * gb.num_edges / tb * 1e3}
+        del gb, model
 
     result = {
         "metric": "edges/sec (fwd) GCNConv+GATConv, ogbn-products-shape; achieved HBM GB/s vs peak",
@@ -436,7 +538,7 @@ def main():
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            result["cpu_baseline"] = cpu_baseline()
+            result["cpu_baseline"] = cpu_baseline((s, t, x_host) if keep_host else None)
         except Exception as e:  # the baseline must never take the bench line down
             result["cpu_baseline"] = {"value": None, "unit": "edges/s", "cores": 1, "kind": "port", "sample": f"failed: {e}"}
     if rank == 0:

@@ -22,12 +22,7 @@ from .msgpass import _flat, aggr_code
 
 def plan_transposed(g: GNNGraph, add_self_loops: bool = False) -> Plan:
     """plan of the reversed edge index (t, s): row j lists the edges that LEAVE j, in original edge order"""
-    key = ("T", bool(add_self_loops))
-    p = g._plans.get(key)
-    if p is None:
-        p = Plan(g.t, g.s, g.num_nodes, g.num_nodes, g.index_base, bool(add_self_loops), validate=False)
-        g._plans[key] = p
-    return p
+    return g.plan_transposed(add_self_loops)
 
 
 def _in_count(g: GNNGraph, add_self_loops: bool):

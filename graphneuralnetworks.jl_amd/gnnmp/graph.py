@@ -123,6 +123,9 @@ class GNNGraph:
         self.device = device
         self._plans = {}
         self._cache = {}   # per-graph constants in plan slot order (GCN normalisation, graph weights)
+        # True once a validating plan build (or the caller, for indices the library itself produced) has established
+        # base <= s, t < n + base (convert.jl:47-54).  Every plan built while it is False validates.
+        self._indices_validated = bool(_validated)
         if not _validated:
             self.plan(False)  # builds the CSR plan and validates 1 <= s,t <= n (convert.jl:47-54)
 
@@ -131,7 +134,21 @@ class GNNGraph:
         key = bool(add_self_loops)
         p = self._plans.get(key)
         if p is None:
-            p = Plan(self.s, self.t, self.num_nodes, self.num_nodes, self.index_base, key, validate=not key)
+            p = Plan(self.s, self.t, self.num_nodes, self.num_nodes, self.index_base, key,
+                     validate=not self._indices_validated)
+            self._indices_validated = True
+            self._plans[key] = p
+        return p
+
+    def plan_transposed(self, add_self_loops: bool = False) -> Plan:
+        """plan of the reversed edge index (t, s): row j lists the edges that LEAVE j, in original edge order (out-degrees,
+        the adjoints' walk, out-neighbour sampling)"""
+        key = ("T", bool(add_self_loops))
+        p = self._plans.get(key)
+        if p is None:
+            p = Plan(self.t, self.s, self.num_nodes, self.num_nodes, self.index_base, key[1],
+                     validate=not self._indices_validated)
+            self._indices_validated = True
             self._plans[key] = p
         return p
 
@@ -211,11 +228,13 @@ def graph_indicator(g: GNNGraph, edges: bool = False):
     return gi
 
 
-def degree(g: GNNGraph, T=torch.float32, dir: str = "in", edge_weight=True):
-    """degree(g, T; dir, edge_weight) — GNNGraphs/src/query.jl:314-331,355-369.
+def degree(g: GNNGraph, T=None, dir: str = "out", edge_weight=True):
+    """degree(g, T = nothing; dir = :out, edge_weight = true) — GNNGraphs/src/query.jl:314-331,355-369: same defaults.
 
     edge_weight: True (use the graph's weights if any), False/None (count edges) or a weight vector.
-    Computed in Float32 on the device (the element type gcn_conv asks for, conv.jl:43,53-55)."""
+    T: None follows the reference's typing (query.jl:336-345): the weights' element type (Float32) when weights are used,
+    the index element type (Int64 / Int32) when edges are counted.  The count itself runs in Float32 on the device (the
+    element type gcn_conv asks for, conv.jl:43,53-55) and is exact below 2^24 edges per node."""
     assert dir in ("in", "out", "both")
     if isinstance(edge_weight, torch.Tensor) or isinstance(edge_weight, (list, tuple)):
         w = _as_f32(edge_weight, g.device)
@@ -230,10 +249,7 @@ def degree(g: GNNGraph, T=torch.float32, dir: str = "in", edge_weight=True):
         if d == "in":
             plan = g.plan(False)
         else:
-            plan = g._plans.get("T")
-            if plan is None:
-                plan = Plan(g.t, g.s, g.num_nodes, g.num_nodes, g.index_base, False, validate=False)
-                g._plans["T"] = plan
+            plan = g.plan_transposed()
         deg = torch.empty(g.num_nodes, dtype=torch.float32, device=g.device)
         L.check(lib.gnnmp_degree_f32(plan.handle, L.ptr(w), L.ptr(deg), L.stream_ptr()))
         if out is None:
@@ -242,7 +258,9 @@ def degree(g: GNNGraph, T=torch.float32, dir: str = "in", edge_weight=True):
             both = torch.empty_like(deg)
             L.check(lib.gnnmp_add_f32(L.ptr(out), L.ptr(deg), L.ptr(both), deg.numel(), L.stream_ptr()))
             out = both
-    if T is not None and T != torch.float32:
+    if T is None:
+        T = torch.float32 if w is not None else g.s.dtype
+    if T != torch.float32:
         out = out.to(T)
     return out
 
@@ -287,8 +305,20 @@ def batch_arrays(members, xs=None, index_base=1, device=None) -> GNNGraph:
     nn = np.zeros(G + 1, np.int64)
     ne[1:] = np.cumsum([len(m[0]) for m in members])
     nn[1:] = np.cumsum([int(m[2]) for m in members])
-    s_cat = torch.from_numpy(np.concatenate([np.asarray(m[0], np.int64) for m in members])).to(device)
-    t_cat = torch.from_numpy(np.concatenate([np.asarray(m[1], np.int64) for m in members])).to(device)
+    s_host = np.concatenate([np.asarray(m[0], np.int64) for m in members])
+    t_host = np.concatenate([np.asarray(m[1], np.int64) for m in members])
+    # every member's indices against ITS OWN num_nodes, as the reference asserts when each member graph is constructed
+    # (convert.jl:47-54): after the offsets are added an out-of-range index could land inside a neighbour's node range
+    hi = np.repeat(np.diff(nn), np.diff(ne)) + (index_base - 1)
+    for name, v in (("s", s_host), ("t", t_host)):
+        bad = np.nonzero((v < index_base) | (v > hi))[0]
+        if bad.size:
+            k = int(bad[0])
+            gi_bad = int(np.searchsorted(ne, k, side="right") - 1)
+            raise AssertionError(f"batch: {name}[{k - int(ne[gi_bad])}] = {int(v[k])} of member graph {gi_bad} is outside "
+                                 f"{index_base}..{int(hi[k])}")
+    s_cat = torch.from_numpy(s_host).to(device)
+    t_cat = torch.from_numpy(t_host).to(device)
     ned, nnd = torch.from_numpy(ne).to(device), torch.from_numpy(nn).to(device)
     s2, t2 = torch.empty_like(s_cat), torch.empty_like(t_cat)
     gi = torch.empty(int(nn[-1]), dtype=torch.int64, device=device)

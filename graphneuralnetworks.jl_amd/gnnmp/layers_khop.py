@@ -15,10 +15,13 @@ from .layers import dense, glorot_uniform
 
 def _norm_slots(g: GNNGraph, loops: bool, w):
     """(c, ss_slot, w_slot): c = 1 ./ sqrt.(degree(g; dir = :in, edge_weight)), the source factor and the edge weight in plan
-    slot order — constants of the graph, cached on it like gcn_conv's"""
+    slot order.  Constants of the graph when the weights are the graph's own (or absent): cached on it like gcn_conv's.  An
+    `edge_weight` ARGUMENT is never cached — its address and version say nothing about its contents once the caller frees it
+    and the allocator hands the same block to the next weight vector (and every distinct key would pin 2 E' floats)."""
     from .layers import _inv_sqrt
-    key = ("gcn_norm", bool(loops), w is not None, None if w is None else (w.data_ptr(), w._version))
-    hit = g._cache.get(key)
+    cacheable = w is None or w is g.w
+    key = ("gcn_norm_slots", bool(loops), w is not None)
+    hit = g._cache.get(key) if cacheable else None
     if hit is not None:
         return hit
     lib = L.load()
@@ -33,7 +36,8 @@ def _norm_slots(g: GNNGraph, loops: bool, w):
     if w is not None:
         ws = torch.empty(plan.n_total, dtype=torch.float32, device=g.device)
         L.check(lib.gnnmp_plan_slot_gather_f32(plan.handle, 1, L.ptr(w), L.ptr(ws), L.stream_ptr()))
-    g._cache[key] = (c, ss, ws)
+    if cacheable:
+        g._cache[key] = (c, ss, ws)
     return c, ss, ws
 
 

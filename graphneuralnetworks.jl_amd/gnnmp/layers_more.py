@@ -188,7 +188,7 @@ def d_conv(l, g: GNNGraph, x):
     from .backward import plan_transposed
     x = x.contiguous()
     lib = L.load()
-    deg_out, deg_in = degree(g, dir="out"), degree(g, dir="in")
+    deg_out, deg_in = degree(g, torch.float32, dir="out"), degree(g, torch.float32, dir="in")
     fplan, bplan = g.plan(False), plan_transposed(g, False)
     msg = L.COPY_XJ if g.w is None else L.W_MUL_XJ
     D = x.shape[1]
@@ -490,7 +490,7 @@ def scaled_laplacian_op(g: GNNGraph, steps: int = 64, seed: int = 0):
     assert is_bidirected(g), "ChebConv: the scaled Laplacian is taken of an undirected (bidirected) graph"
     lib = L.load()
     plan = g.plan(False)
-    d = degree(g, dir="out")
+    d = degree(g, torch.float32, dir="out")
     assert bool((d != 0).all()), "Graph contains isolated nodes, cannot compute `normalized_adjacency`."
     c = _inv_sqrt(d)
     ss = torch.empty(plan.n_total, dtype=torch.float32, device=g.device)

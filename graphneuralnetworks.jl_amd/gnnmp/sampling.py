@@ -57,12 +57,7 @@ def _take_index(v, pos, index_base):
 
 
 def _out_plan(g: GNNGraph) -> Plan:
-    key = ("T", False)
-    p = g._plans.get(key)
-    if p is None:
-        p = Plan(g.t, g.s, g.num_nodes, g.num_nodes, g.index_base, False, validate=False)
-        g._plans[key] = p
-    return p
+    return g.plan_transposed(False)
 
 
 def sample_neighbors(g: GNNGraph, nodes, K: int = -1, dir: str = "in", replace: bool = False, dropnodes: bool = False,

@@ -265,20 +265,28 @@ def gcn_conv(s, t, n, x, weight, bias=None, sigma=None, add_self_loops_=True, us
     return _act(sigma, x)
 
 
-def graph_conv(s, t, n, x, weight1, weight2, bias=None, sigma=None, aggr=SUM, blas=True):
+def _propagate_copy_xj(aggr, s, t, n, x, fast_path):
+    """propagate(copy_xj, g, aggr; xj = x) as the reference dispatches it on CPU arrays: `+` hits the SpMM specialisation
+    `xj * adjacency_matrix(g, weighted = false)` (msgpass.jl:215-218), every other aggr the generic path."""
+    if fast_path and _AGGR[aggr] == SUM:
+        return spmm_csc(s, t, n, x)
+    return propagate(aggr, s, t, n, x)
+
+
+def graph_conv(s, t, n, x, weight1, weight2, bias=None, sigma=None, aggr=SUM, blas=True, fast_path=False):
     """graph_conv — GNNlib/src/layers/conv.jl:102-108."""
     x = _f32(x)
-    m = propagate(aggr, s, t, n, x)
+    m = _propagate_copy_xj(aggr, s, t, n, x, fast_path)
     y = matmul(weight1, x, blas) + matmul(weight2, m, blas)
     if bias is not None:
         y = y + _f32(bias)[None, :]
     return _act(sigma, y)
 
 
-def sage_conv(s, t, n, x, weight, bias=None, sigma=None, aggr=MEAN, blas=True):
+def sage_conv(s, t, n, x, weight, bias=None, sigma=None, aggr=MEAN, blas=True, fast_path=False):
     """sage_conv — GNNlib/src/layers/conv.jl:277-283.  weight (Dout, 2*Din)."""
     x = _f32(x)
-    m = propagate(aggr, s, t, n, x)
+    m = _propagate_copy_xj(aggr, s, t, n, x, fast_path)
     y = matmul(weight, np.concatenate([x, m], axis=1), blas)
     if bias is not None:
         y = y + _f32(bias)[None, :]
