@@ -30,7 +30,8 @@ enum Knob {
     KNOB_XCD_REMAP = 3,    // 0 = off, 1 = auto (default: only when the gathered matrix fits the Infinity Cache), 2 = on
     KNOB_LONG_ROW = 4,     // long-row threshold (default GNNMP_LONG_ROW)
     KNOB_BLOCK_WAVES = 5,  // waves per block in the row kernels: 0 = auto (propagate 4, GAT 1), else 1..4
-    KNOB_DENSE_GENERIC = 6,  // 1 = force the K-chunked dense kernel (default 0: W-resident kernel when it fits)
+    KNOB_DENSE_GENERIC = 6,  // 0 = auto (dense_t16 on its shapes, else W-resident 32x32x2, else K-chunked), 1 = force K-chunked,
+                             // 2 = skip dense_t16 (round-1 kernels only)
     KNOB_DENSE_PREFETCH = 7,  // W-resident dense kernel scheduling: bit 4 = per-SIMD matrix-pipe token, low 4 bits =
                               // start skew of waves 4-7 in s_sleep(127) units.  Default 17 (token + 1): 0.83 -> 0.72 ms
                               // at 2.4M x 100 => 100.  Bit 5 = turn the cross-tile register prefetch OFF (on by default; its
@@ -39,7 +40,10 @@ enum Knob {
     KNOB_GRADW_SLABS = 9,    // ΔW kernel: slabs per CU (0 = auto)
     KNOB_GRADW_RP = 10,      // ΔW kernel: row pairs loaded per batch (0 = auto, else 2|4|8)
     KNOB_GRADW_MIN_ROWS = 11,  // ΔW kernel: rows-per-slab floor (0 = auto: ~3 slabs per CU on small inputs, 512 on large)
-    KNOB_COUNT = 12
+    KNOB_DENSE_T16_WAVES = 12, // dense_t16_kernel: waves per block (0 = auto, else 1..16)
+    KNOB_T16_DEBUG = 13,       // dense_t16_kernel phase ablation (experiments only): 1 = no stores, 2 = no x loads
+    KNOB_FUSED_WAVES = 14,     // fused_conv_kernel: 0 = auto (as many waves as LDS holds tiles for, <= 16), > 0 = cap, < 0 = never fuse
+    KNOB_COUNT = 15
 };
 int knob(int k);
 int device_cus();   // compute units of the current device, queried once (hipDeviceGetAttribute costs microseconds per call)
@@ -202,11 +206,16 @@ struct gnnmp_graph {
     // plan-owned workspace for the chunk partials (grown on demand; one stream at a time per plan)
     float *ws = nullptr;
     size_t ws_floats = 0;
+    // two device words {next tile, finished blocks} for the persistent fused kernel's dynamic tile hand-out (fused_conv.hip);
+    // zero between launches: the last block to finish resets them
+    uint32_t *ticket = nullptr;
 };
 
 namespace gnnmp {
 // make sure plan->ws holds at least `floats` floats (hipMalloc on growth; hipFree waits for in-flight work)
 int ensure_workspace(gnnmp_graph *p, size_t floats);
+// allocate + zero plan->ticket on first use
+int ensure_ticket(gnnmp_graph *p, hipStream_t stream);
 }
 
 namespace gnnmp {

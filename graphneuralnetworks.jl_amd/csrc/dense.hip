@@ -480,6 +480,9 @@ static int launch_wlds(const DenseWArgs &w, size_t lds_bytes, int col_tiles, int
     GNNMP_LAUNCH_CHECK("dense_wlds_kernel");
     return GNNMP_OK;
 }
+int dense_t16_try(const float *x1, const float *W1, int64_t D1, int64_t ldw1, const float *x2, const float *W2, int64_t D2,
+                  int64_t ldw2, int w_layout, const float *bias, int act, float *out, int64_t N, int64_t Dout,
+                  hipStream_t stream);   // dense_t16.hip
 }  // namespace gnnmp
 
 using namespace gnnmp;
@@ -495,6 +498,11 @@ extern "C" int gnnmp_dense_f32(const float *x1, const float *W1, int64_t D1, int
     if (act != GNNMP_ACT_IDENTITY && act != GNNMP_ACT_RELU) return fail(GNNMP_EINVAL, "dense: bad act %d", act);
     if (N == 0) return GNNMP_OK;
     if (!x1 || !W1 || !out || (D2 > 0 && (!x2 || !W2))) return fail(GNNMP_EINVAL, "dense: null pointer");
+    {
+        // the shapes of the hot path (K a multiple of 4, <= 128 per segment): operands straight from HBM, 16x16x4 MFMAs
+        const int rc = dense_t16_try(x1, W1, D1, ldw1, x2, W2, D2, ldw2, w_layout, bias, act, out, N, Dout, stream);
+        if (rc != 1) return rc;
+    }
     DenseArgs a;
     a.x[0] = x1; a.W[0] = W1; a.K[0] = (int)D1; a.ldw[0] = (int)ldw1;
     a.x[1] = x2; a.W[1] = W2; a.K[1] = (int)D2; a.ldw[1] = (int)ldw2;
@@ -555,7 +563,7 @@ extern "C" int gnnmp_dense_f32(const float *x1, const float *W1, int64_t D1, int
             const Cfg c64 = size_for(64);
             if (c64.waves == 8) c = c64;
         }
-        if (c.waves > 0 && N >= 256 && knob(KNOB_DENSE_GENERIC) == 0) {
+        if (c.waves > 0 && N >= 256 && knob(KNOB_DENSE_GENERIC) != 1) {
             DenseWArgs w;
             w.d = a;
             w.waves = c.waves;

@@ -15,7 +15,7 @@
 namespace gnnmp {
 
 static thread_local char g_err[512] = "";
-static int g_knobs[KNOB_COUNT] = {0, -1, 0, 1, 0, 0, 0, 17, 0, 0, 0, 0};
+static int g_knobs[KNOB_COUNT] = {0, -1, 0, 1, 0, 0, 0, 17, 0, 0, 0, 0, 0, 0, 0};
 
 int fail(int status, const char *fmt, ...) {
     va_list ap;
@@ -49,6 +49,15 @@ int ensure_workspace(gnnmp_graph *p, size_t floats) {
     hipError_t e = hipMalloc((void **)&p->ws, sizeof(float) * floats);
     if (e != hipSuccess) return hip_fail(e, "hipMalloc(plan workspace)");
     p->ws_floats = floats;
+    return GNNMP_OK;
+}
+
+int ensure_ticket(gnnmp_graph *p, hipStream_t stream) {
+    if (p->ticket) return GNNMP_OK;
+    hipError_t e = hipMalloc((void **)&p->ticket, 2 * sizeof(uint32_t));
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc(plan ticket)");
+    e = hipMemsetAsync(p->ticket, 0, 2 * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(plan ticket)");
     return GNNMP_OK;
 }
 
@@ -207,6 +216,7 @@ int gnnmp_plan_destroy(gnnmp_graph_t *p) {
     if (p->chunk_beg) (void)hipFree(p->chunk_beg);
     if (p->chunk_end) (void)hipFree(p->chunk_end);
     if (p->ws) (void)hipFree(p->ws);
+    if (p->ticket) (void)hipFree(p->ticket);
     delete p;
     return GNNMP_OK;
 }

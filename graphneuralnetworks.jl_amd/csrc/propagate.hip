@@ -15,226 +15,9 @@
 //     kernel as a virtual row whose result goes to a partial buffer, and a small second kernel folds each long row's
 //     partials in chunk order.  The dominant kernel therefore touches every edge exactly once and has no tail.
 //   - block -> row-chunk mapping is XCD-aware (contiguous destination ranges per XCD / L2).
-#include "common.h"
+#include "csr_reduce.h"
 
 namespace gnnmp {
-
-struct ReduceArgs {
-    const int32_t *rowptr;
-    const int32_t *idx;      // per slot: source row of x to read (plan->col, or plan->eid for scatter)
-    const int32_t *eid;      // per slot: original edge position (weights lookup); unused unless w
-    const float *x;          // [n_src][D]
-    const float *w;          // [n_edges] original order, nullable
-    const float *emat;       // [n_edges][D] original order: per-edge, per-feature factor (e_mul_xj with a matrix e)
-    const float *rowsub;     // [n_dst][D]: the message is exp(x - rowsub[row]) (softmax numerator, utils.jl:94)
-    const float *rowden;     // [n_dst][D]: softmax_write_kernel divides by it
-    float den_add;           // softmax_edges adds eps(T) to the denominator (utils.jl:71)
-    const float *gate_i;     // [n_dst][D] GATED = 1: message = sigmoid(gate_i[row] + x[j][0:D]) .* x[j][D:2D]  (x rows are 2D wide)
-                             // [n_dst][2D] GATED = 2 (cg_message, conv.jl:326-333): sigmoid(gate_i[row][0:D] + x[j][0:D] + e[0:D]) .*
-                             //   act(gate_i[row][D:2D] + x[j][D:2D] + e[D:2D]), e = emat row (2D wide) of the edge, optional
-    int gated;               // 0 | 1 | 2
-    int act;                 // GATED = 2: dense_s's activation (gnnmp_act)
-    const float *ss;         // [n_src] nullable
-    const float *w_slot;     // [E'] slot order, nullable (takes precedence over w)
-    const float *ss_slot;    // [E'] slot order, nullable (takes precedence over ss)
-    const float *sd;         // [n_dst] nullable
-    float *out;              // [n_dst][D]
-    float *partial;          // [n_chunks][D]
-    const int32_t *chunk_row, *chunk_beg, *chunk_end;
-    const int32_t *long_rows, *long_cptr;
-    int n_chunks;
-    int n_long;
-    int D;
-    int n_rows;
-    int n_src;               // rows of x (XCD-remap heuristic)
-    int n_edges;             // weights exist for eid < n_edges; others are 1
-    int log2g;
-    int mean;
-    int long_thresh;
-    int cpx;                 // logical blocks per XCD (grid.x = nbc + 8*cpx) ; 0 = no remap
-    int nbc;                 // leading blocks (chunk virtual rows) that are not remapped
-    int waves;               // waves per block
-};
-
-// The gated functors evaluate their activations once per edge and feature (6e9 times on the products shape): with libm's
-// expf / log1pf / tanhf the kernel is ALU-bound at 4x its HBM time.  These use the hardware transcendentals (v_exp_f32,
-// v_log_f32, v_rcp_f32: 1 ulp each) on the same formulas; measured deviation from the libm forms < 3e-7 relative, far
-// inside the 1e-5 parity bound of the layers that use them.
-__device__ __forceinline__ float hw_exp_neg_abs(float x) {   // exp(-|x|) in (0, 1]
-    return __builtin_amdgcn_exp2f(-fabsf(x) * 1.44269504088896341f);
-}
-// NNlib.sigmoid: t = exp(-abs(x)); ifelse(x >= 0, inv(1 + t), t / (1 + t))
-__device__ __forceinline__ float nn_sigmoid(float x) {
-    const float t = hw_exp_neg_abs(x);
-    const float r = __builtin_amdgcn_rcpf(1.0f + t);
-    return x >= 0.0f ? r : t * r;
-}
-// NNlib.softplus: log1p(exp(-abs(x))) + relu(x)
-__device__ __forceinline__ float nn_softplus(float x) {
-    const float t = hw_exp_neg_abs(x);
-    // log1p(t): log(1 + t) loses the low bits of a small t, the series t - t^2/2 + t^3/3 does not (t < 2^-8: error < t^4/4)
-    const float l = t < 0.00390625f ? t * (1.0f - t * (0.5f - t * 0.333333343f))
-                                    : __builtin_amdgcn_logf(1.0f + t) * 0.693147180559945309f;
-    return l + (x < 0.0f ? 0.0f : x);
-}
-// tanh: odd series near zero (where 1 - 2 / (1 + e^2x) cancels), the exponential form elsewhere
-__device__ __forceinline__ float nn_tanh(float x) {
-    const float ax = fabsf(x);
-    if (ax < 0.125f) {
-        const float x2 = x * x;
-        return x * (1.0f - x2 * (0.333333343f - x2 * (0.133333340f - x2 * 0.0539682545f)));
-    }
-    const float e = __builtin_amdgcn_exp2f(-2.0f * ax * 1.44269504088896341f);   // e^(-2|x|)
-    const float r = (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e);
-    return x < 0.0f ? -r : r;
-}
-
-// dense_s's σ of CGConv (constructor argument `act`, GraphNeuralNetworks/src/layers/conv.jl:925-930)
-__device__ __forceinline__ float cg_act(float x, int act) {
-    switch (act) {
-        case GNNMP_ACT_RELU: return x < 0.0f ? 0.0f : x;
-        case GNNMP_ACT_SOFTPLUS: return nn_softplus(x);
-        case GNNMP_ACT_TANH: return nn_tanh(x);
-        default: return x;
-    }
-}
-
-// reduce slots [beg, end) of one destination into acc[VEC]; all lanes of the group call this together.
-template <int VEC, int OP, bool SCALED, int U, bool EMAT = false, bool EXPSUB = false, int GATED = 0>
-__device__ __forceinline__ void reduce_range(const ReduceArgs &a, int beg, int end, int lig,
-                                             int gbase, int G, int f0, bool active,
-                                             float acc[VEC], int row = 0) {
-    float sub[VEC];
-#pragma unroll
-    for (int q = 0; q < VEC; ++q) sub[q] = 0.0f;
-    if (EXPSUB && active) Vec<VEC>::load(a.rowsub + (int64_t)row * a.D + f0, sub);
-    float sub2[VEC];
-#pragma unroll
-    for (int q = 0; q < VEC; ++q) sub2[q] = 0.0f;
-    if (GATED == 1 && active) Vec<VEC>::load(a.gate_i + (int64_t)row * a.D + f0, sub);   // Ax_i slice
-    if (GATED == 2 && active) {
-        Vec<VEC>::load(a.gate_i + (int64_t)row * 2 * a.D + f0, sub);                     // dense_f's share of x_i
-        Vec<VEC>::load(a.gate_i + (int64_t)row * 2 * a.D + a.D + f0, sub2);              // dense_s's share of x_i
-    }
-    const int64_t ldx = GATED ? 2 * (int64_t)a.D : (int64_t)a.D;
-    for (int base = beg; base < end; base += G) {
-        const int p = base + lig;
-        int c = 0, ev = 0;
-        float wv = 1.0f, sv = 1.0f;
-        if (p < end) {
-            c = a.idx[p];
-            if (EMAT) ev = a.eid[p];
-            if (SCALED) {
-                if (a.w_slot) {
-                    wv = a.w_slot[p];
-                } else if (a.w) {
-                    const int e = a.eid[p];
-                    if (e < a.n_edges) wv = a.w[e];
-                }
-                if (a.ss_slot)
-                    sv = a.ss_slot[p];
-                else if (a.ss)
-                    sv = a.ss[c];
-            }
-        }
-        const int n = min(G, end - base);
-        for (int j = 0; j < n; j += U) {
-            float v[U][VEC];
-            float gb[GATED ? U : 1][VEC];
-            float em[EMAT ? U : 1][VEC];
-            float em2[(EMAT && GATED == 2) ? U : 1][VEC];
-            float wj[U], sj[U];
-            // every cross-lane broadcast of the batch first (one LDS round trip), then the row loads back to back
-            int cjs[U], ejs[EMAT ? U : 1];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int jj = min(j + u, n - 1);
-                cjs[u] = __shfl(c, gbase + jj, 64);
-                if (EMAT) ejs[EMAT ? u : 0] = __shfl(ev, gbase + jj, 64);
-                if (SCALED) {
-                    wj[u] = __shfl(wv, gbase + jj, 64);
-                    sj[u] = __shfl(sv, gbase + jj, 64);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int cj = cjs[u];
-                if (EMAT) {
-                    // e .* xj with e (D, E'): the edge's own row of factors, by original edge position; self loops the
-                    // plan added carry no features and weigh 1
-                    const int ej = ejs[EMAT ? u : 0];
-                    if (GATED == 2) {   // the edge's share of both pre-activations (additive: absent = 0)
-                        if (active && (j + u < n) && ej < a.n_edges) {
-                            Vec<VEC>::load(a.emat + (int64_t)ej * 2 * a.D + f0, em[EMAT ? u : 0]);
-                            Vec<VEC>::load(a.emat + (int64_t)ej * 2 * a.D + a.D + f0, em2[(EMAT && GATED == 2) ? u : 0]);
-                        } else {
-#pragma unroll
-                            for (int q = 0; q < VEC; ++q) em[EMAT ? u : 0][q] = em2[(EMAT && GATED == 2) ? u : 0][q] = 0.0f;
-                        }
-                    } else if (active && (j + u < n) && ej < a.n_edges) {
-                        Vec<VEC>::load(a.emat + (int64_t)ej * a.D + f0, em[EMAT ? u : 0]);
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < VEC; ++q) em[EMAT ? u : 0][q] = 1.0f;
-                    }
-                }
-                if (active && (j + u < n)) {
-                    if (GATED) {
-                        Vec<VEC>::load(a.x + (int64_t)cj * ldx + f0, gb[GATED ? u : 0]);          // Bx_j
-                        Vec<VEC>::load(a.x + (int64_t)cj * ldx + a.D + f0, v[u]);                 // Vx_j
-                    } else {
-                        Vec<VEC>::load(a.x + (int64_t)cj * ldx + f0, v[u]);
-                    }
-                } else {
-#pragma unroll
-                    for (int q = 0; q < VEC; ++q) v[u][q] = 0.0f;
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (j + u < n) {
-#pragma unroll
-                    for (int q = 0; q < VEC; ++q) {
-                        float t = v[u][q];
-                        if (SCALED) {
-                            t = t * sj[u];  // xj .* cout'   (GNNlib/src/layers/conv.jl:59), rounded
-                            t = wj[u] * t;  // w .* xj        (GNNlib/src/msgpass.jl:203-208), rounded
-                        }
-                        if (EMAT && GATED != 2) t = em[EMAT ? u : 0][q] * t;  // e .* xj (GNNlib/src/msgpass.jl:187-191)
-                        if (EXPSUB) t = expf(t - sub[q]);        // num = exp.(e .- max_) (GNNlib/src/utils.jl:94)
-                        if (GATED == 1) t = nn_sigmoid(sub[q] + gb[GATED ? u : 0][q]) * t;   // sigmoid.(Ax_i .+ Bx_j) .* Vx_j (conv.jl:291)
-                        if (GATED == 2) {   // dense_f(z) .* dense_s(z), z = vcat(xi, xj, e): the K-sum in z's order (conv.jl:326-333)
-                            float f = sub[q] + gb[GATED ? u : 0][q], g = sub2[q] + t;
-                            if (EMAT) {
-                                f = f + em[EMAT ? u : 0][q];
-                                g = g + em2[(EMAT && GATED == 2) ? u : 0][q];
-                            }
-                            t = nn_sigmoid(f) * cg_act(g, a.act);
-                        }
-                        acc[q] = op_apply<OP>(acc[q], t);
-                    }
-                }
-            }
-        }
-    }
-}
-
-template <int VEC, int OP>
-__device__ __forceinline__ void finalize_store(const ReduceArgs &a, int row, int len, int f0,
-                                               bool active, float acc[VEC]) {
-    if (OP == OP_SUM && a.mean) {
-        // NNlib scatter(mean): dst = 0 .+ safe_div.(sum, count); count == 0 keeps the sum (0)
-        const float cnt = (float)len;
-#pragma unroll
-        for (int q = 0; q < VEC; ++q) acc[q] = 0.0f + (len == 0 ? acc[q] : acc[q] / cnt);
-    }
-    if (a.sd) {
-        const float s = a.sd[row];  // x .* cin'  (GNNlib/src/layers/conv.jl:67)
-#pragma unroll
-        for (int q = 0; q < VEC; ++q) acc[q] = acc[q] * s;
-    }
-    if (active) Vec<VEC>::store(a.out + (int64_t)row * a.D + f0, acc);
-}
 
 // virtual rows: [0, n_chunks) are chunks of long rows (raw partials), [n_chunks, n_chunks + n_rows) ordinary rows.
 template <int VEC, int OP, bool SCALED, int U, bool EMAT = false, bool EXPSUB = false, int GATED = 0>
@@ -376,7 +159,7 @@ __global__ void __launch_bounds__(256) csr_combine_kernel(const ReduceArgs a) {
 #pragma unroll
         for (int q = 0; q < VEC; ++q) acc[q] = op_apply<OP>(acc[q], red[((k << a.log2g) + lig) * VEC + q]);
     }
-    finalize_store<VEC, OP>(a, row, a.rowptr[row + 1] - a.rowptr[row], f0, active, acc);
+    finalize_store<VEC, OP>(a, row, a.rowptr[row + 1] - a.rowptr[row], f0, active, acc, a.compact_long ? r : -1);
 }
 
 // nn_conv's propagate (GNNlib/src/layers/conv.jl:260-273): the message of edge k is W_k x_j with W_k = reshape(nn(e_k), out, in)
@@ -538,12 +321,17 @@ static int dispatch_op(const ReduceArgs &a, int op, bool scaled, hipStream_t s) 
 int run_reduce(gnnmp_graph_t *p, const int32_t *idx, int aggr, const float *x, const float *w,
                const float *ss, const float *w_slot, const float *ss_slot, const float *sd, float *out,
                int64_t D, hipStream_t stream, const float *emat = nullptr, const float *rowsub = nullptr,
-               const float *gate_i = nullptr, int gated = 1, int act = 0) {
+               const float *gate_i = nullptr, int gated = 1, int act = 0, int long_only = 0) {
+    // long_only: reduce ONLY the split rows (their chunk virtual rows + the combine) and write row long_rows[r], finalised, to
+    // out[r] — a compact [n_long][D] buffer the fused kernel reads instead of walking those rows (the caller sized the
+    // workspace and passes out inside it)
     if (p->n_dst == 0 || D == 0) return GNNMP_OK;
-    if (p->n_chunks > 0) {
+    if (long_only && p->n_long == 0) return GNNMP_OK;
+    if (p->n_chunks > 0 && !long_only) {
         if (int rc = ensure_workspace(p, (size_t)p->n_chunks * (size_t)D)) return rc;
     }
     ReduceArgs a;
+    a.compact_long = long_only;
     a.rowptr = p->rowptr;
     a.idx = idx;
     a.eid = p->eid;
@@ -570,7 +358,7 @@ int run_reduce(gnnmp_graph_t *p, const int32_t *idx, int aggr, const float *x, c
     a.n_chunks = p->n_chunks;
     a.n_long = p->n_long;
     a.D = (int)D;
-    a.n_rows = (int)p->n_dst;
+    a.n_rows = long_only ? 0 : (int)p->n_dst;
     a.n_src = (int)p->n_src;
     a.n_edges = (int)p->n_edges;
     a.mean = (aggr == GNNMP_MEAN);

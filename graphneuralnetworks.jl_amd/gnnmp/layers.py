@@ -58,6 +58,36 @@ def dense(x, W, bias=None, sigma=None, x2=None, W2=None):
     return post(out) if post is not None else out
 
 
+def fused_conv(plan, aggr, xj, W_agg, bias=None, sigma=None, xi=None, W_root=None, w=None, scale_src=None, w_slot=None,
+               ss_slot=None, scale_dst=None, return_aggregate=False):
+    """act(W_root * xi + W_agg * A + bias) with A = the plan's aggregation of xj (same arguments as gnnmp_propagate_f32 /
+    gnnmp_propagate_slots_f32), in ONE kernel: A stays in LDS (csrc/fused_conv.hip).  Returns None when the shape is outside
+    the kernel's envelope (the caller then runs propagate + dense); with return_aggregate the pre-GEMM aggregate comes back
+    too (bit-identical to the unfused propagate: tests)."""
+    xf = _flat(xj)
+    D = xf.shape[1]
+    Dout = W_agg.shape[0]
+    assert W_agg.shape[1] == D and W_agg.stride(1) == 1
+    D1 = 0
+    if xi is not None:
+        xi = _flat(xi)
+        D1 = xi.shape[1]
+        assert W_root.shape == (Dout, D1) and W_root.stride(1) == 1
+    code, post = _act_code(sigma)
+    b = None if bias is None or bias is False else bias.contiguous()
+    out = torch.empty((plan.n_dst, Dout), dtype=torch.float32, device=xf.device)
+    agg = torch.empty((plan.n_dst, D), dtype=torch.float32, device=xf.device) if return_aggregate else None
+    lib = L.load()
+    rc = lib.gnnmp_fused_conv_f32(plan.handle, aggr, L.ptr(xf), L.ptr(w), L.ptr(scale_src), L.ptr(w_slot), L.ptr(ss_slot),
+                                  L.ptr(scale_dst), D, L.ptr(xi), D1, L.ptr(W_root), 0 if W_root is None else W_root.stride(0),
+                                  L.ptr(W_agg), W_agg.stride(0), 0, L.ptr(b), code, L.ptr(out), Dout, L.ptr(agg), L.stream_ptr())
+    if rc == L.EUNSUPPORTED:
+        return None
+    L.check(rc)
+    out = post(out) if post is not None else out
+    return (out, agg) if return_aggregate else out
+
+
 def bias_act(x, bias, sigma):
     code, post = _act_code(sigma)
     b = None if bias is None or bias is False else bias.contiguous()
@@ -140,6 +170,14 @@ def gcn_conv(l, g: GNNGraph, x, edge_weight=None, norm_fn=None, conv_weight=None
         L.check(lib.gnnmp_degree_f32(plan.handle, L.ptr(w), L.ptr(d), L.stream_ptr()))
         c = _inv_sqrt(d) if norm_fn is None else norm_fn(d).to(torch.float32).contiguous()
         c_slot = w_slot = None
+    if Dout >= Din:
+        # aggregate, then transform: one kernel, the (N, Din) aggregate never goes to HBM (conv.jl:59-71)
+        if c_slot is not None:
+            y = fused_conv(plan, L.SUM, x, weight, l.bias, l.sigma, w_slot=w_slot, ss_slot=c_slot, scale_dst=c)
+        else:
+            y = fused_conv(plan, L.SUM, x, weight, l.bias, l.sigma, w=w, scale_src=c, scale_dst=c)
+        if y is not None:
+            return y
     if c_slot is not None:
         xf = _flat(x)
         out = torch.empty((plan.n_dst, xf.shape[1]), dtype=torch.float32, device=x.device)
@@ -177,6 +215,9 @@ def graph_conv(l, g: GNNGraph, x):
     """GNNlib/src/layers/conv.jl:102-108: σ.(W1*xi .+ W2*propagate(copy_xj, g, aggr) .+ b)"""
     check_num_nodes(g, x)
     xj, xi = expand_srcdst(g, x)
+    y = fused_conv(g.plan(False), aggr_code(l.aggr), xj, l.weight2, l.bias, l.sigma, xi=xi, W_root=l.weight1)
+    if y is not None:
+        return y
     m = _fused(g, L.COPY_XJ, l.aggr, xj, None)
     return dense(xi, l.weight1, l.bias, l.sigma, x2=m, W2=l.weight2)
 
@@ -204,9 +245,12 @@ def sage_conv(l, g: GNNGraph, x):
     the first `in` columns of W multiply xi, the last `in` multiply the aggregate."""
     check_num_nodes(g, x)
     xj, xi = expand_srcdst(g, x)
-    m = _fused(g, L.COPY_XJ, l.aggr, xj, None)
     Din = xi.shape[1]
     W = l.weight
+    y = fused_conv(g.plan(False), aggr_code(l.aggr), xj, W[:, Din:], l.bias, l.sigma, xi=xi, W_root=W[:, :Din])
+    if y is not None:
+        return y
+    m = _fused(g, L.COPY_XJ, l.aggr, xj, None)
     return dense(xi, W[:, :Din], l.bias, l.sigma, x2=m, W2=W[:, Din:])
 
 

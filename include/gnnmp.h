@@ -448,6 +448,26 @@ int gnnmp_dense_f32(const float *x1, const float *W1, int64_t D1, int64_t ldw1, 
                     int act, float *out, int64_t N, int64_t Dout, gnnmp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Aggregate-then-transform in one kernel — the layer bodies whose dense product FOLLOWS the aggregation:
+ *   gcn_conv with Dout >= Din   σ.(W * (cin .* Σ_j w_j cout_j x_j) .+ b)      GNNlib/src/layers/conv.jl:59-71
+ *   graph_conv                  σ.(W1 * x_i .+ W2 * aggr_j x_j .+ b)           conv.jl:102-108
+ *   sage_conv                   σ.(W * vcat(x_i, aggr_j x_j) .+ b)             conv.jl:277-283
+ *     out[i][:] = act( W_root * xi[i][:]  +  W_agg * A[i][:]  + bias ),   A = gnnmp_propagate(_slots)_f32's result
+ * with A never written to HBM (it is BIT-IDENTICAL to what gnnmp_propagate_slots_f32 would return; pass agg_out to get it
+ * as well, e.g. to test that).  The aggregation arguments mean what they mean in gnnmp_propagate_f32 (w: per-edge weights in
+ * original order, scale_src / scale_dst per node) and gnnmp_propagate_slots_f32 (w_slot / ss_slot in plan slot order; they
+ * take precedence); scalings need aggr = SUM | MEAN.  xi = NULL / D1 = 0: no root term (gcn_conv).  W_root [Dout][D1] and
+ * W_agg [Dout][D] as in gnnmp_dense_f32 (w_layout, ldw).  Shapes taken: D, D1 multiples of 4 and <= 128, Dout a multiple of
+ * 4 and <= 128, 16-byte aligned arrays, >= 16 destinations; anything else returns GNNMP_EUNSUPPORTED and the caller runs
+ * gnnmp_propagate_f32 + gnnmp_dense_f32.  One stream at a time per plan (plan-owned workspace and tile ticket).
+ * ---------------------------------------------------------------------------------------------- */
+int gnnmp_fused_conv_f32(gnnmp_graph_t *plan, int aggr, const float *xj, const float *w, const float *scale_src,
+                         const float *w_slot, const float *ss_slot, const float *scale_dst, int64_t D, const float *xi,
+                         int64_t D1, const float *W_root, int64_t ldw_root, const float *W_agg, int64_t ldw_agg,
+                         int w_layout, const float *bias, int act, float *out, int64_t Dout, float *agg_out,
+                         gnnmp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Adjoints.  The reference trains through NNlib's rrules: ∇gather = scatter(+),
  * ∇scatter(+) = gather, ∇scatter(mean) = gather ./ count, ∇scatter(max|min) = (src .== gather(dst)) .* gather(Δ);
  * the CPU fast path through the adjacency_matrix rrule (GNNGraphs/src/query.jl:244-278).

@@ -1,0 +1,152 @@
+"""The fused aggregate-then-transform kernel (csrc/fused_conv.hip, gnnmp_fused_conv_f32) against the unfused HIP path and
+the oracle:
+  * the pre-GEMM aggregate it forms in LDS (returned through the optional agg_out) is BIT-IDENTICAL to gnnmp_propagate_f32 /
+    gnnmp_propagate_slots_f32 on the same plan — every aggr, scaled and not, rows the plan splits included;
+  * the layer output is within 1e-5 of the oracle's layer body (GNNlib/src/layers/conv.jl:59-71,102-108,277-283) and of the
+    unfused propagate + dense composition;
+  * repeated launches (the self re-arming tile ticket), shapes outside the envelope (fallback), bipartite inputs."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def gm():
+    import torch
+    assert torch.cuda.is_available()
+    import gnnmp
+    gnnmp.load()
+    return gnnmp
+
+
+def dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def close(got, ref, rtol=RTOL):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    assert got.shape == ref.shape
+    assert np.linalg.norm(got - ref) <= rtol * np.linalg.norm(ref) + 1e-30
+    assert np.abs(got - ref).max() <= 4 * rtol * np.abs(ref).max() + 1e-30
+
+
+def hub_graph(rng, n=3000, E=40000, hub_edges=(700, 1500, 90)):
+    """random multigraph + hubs above both split thresholds (64 on small graphs, 512) + isolated destinations"""
+    s = [rng.integers(1, n - 40, E)]
+    t = [rng.integers(1, n - 40, E)]
+    for k, m in enumerate(hub_edges):
+        s.append(rng.integers(1, n - 40, m))
+        t.append(np.full(m, 7 + 13 * k))
+    s, t = np.concatenate(s), np.concatenate(t)
+    p = rng.permutation(len(s))
+    return s[p].astype(np.int64), t[p].astype(np.int64), n
+
+
+@pytest.mark.parametrize("D,Dout", [(100, 100), (128, 128), (12, 20), (64, 8), (4, 4), (16, 128), (100, 36), (52, 100)])
+def test_aggregate_is_bit_identical_and_output_matches(gm, oracle, D, Dout):
+    import torch
+    from gnnmp import _lib as L
+    rng = np.random.default_rng(D * 131 + Dout)
+    s, t, n = hub_graph(rng)
+    x = rng.standard_normal((n, D)).astype(np.float32)
+    W = (rng.standard_normal((Dout, D)) * 0.2).astype(np.float32)
+    b = (rng.standard_normal(Dout) * 0.1).astype(np.float32)
+    w = (rng.random(len(s)) + 0.1).astype(np.float32)
+    g = gm.GNNGraph(dev(s), dev(t), dev(w), num_nodes=n)
+    xd, Wd, bd = dev(x), dev(W), dev(b)
+    for loops in (False, True):
+        plan = g.plan(loops)
+        for aggr, name in ((L.SUM, "+"), (L.MEAN, "mean"), (L.MAX, "max"), (L.MIN, "min")):
+            res = gm.fused_conv(plan, aggr, xd, Wd, bd, "relu", return_aggregate=True)
+            assert res is not None, "this shape is inside the fused kernel's envelope"
+            y, agg = res
+            ref_agg = torch.empty_like(agg)
+            L.check(L.load().gnnmp_propagate_f32(plan.handle, L.COPY_XJ, aggr, L.ptr(xd), None, None, None, L.ptr(ref_agg), D,
+                                                 L.stream_ptr()))
+            assert torch.equal(agg, ref_agg), f"aggregate differs from the unfused kernel (aggr {name}, loops {loops})"
+            y_ref = gm.dense(ref_agg, Wd, bd, "relu")
+            fin = torch.isfinite(y_ref).all(1) & torch.isfinite(ref_agg).all(1)      # max/min of empty rows: -Inf/+Inf, both paths
+            close(y[fin].cpu().numpy(), y_ref[fin].cpu().numpy())
+            assert torch.equal(torch.isfinite(y).all(1), torch.isfinite(y_ref).all(1))
+            # twice: same bits (no atomics on the data path; the ticket only changes who computes a tile)
+            assert torch.allclose(gm.fused_conv(plan, aggr, xd, Wd, bd, "relu"), y, rtol=0, atol=0, equal_nan=True)
+        # scaled sum (GCN's normalisation): per-edge weights + source / destination factors
+        c = dev((rng.random(n) + 0.5).astype(np.float32))
+        wfull = g.w
+        y, agg = gm.fused_conv(plan, L.SUM, xd, Wd, bd, None, w=wfull, scale_src=c, scale_dst=c, return_aggregate=True)
+        ref_agg = torch.empty_like(agg)
+        L.check(L.load().gnnmp_propagate_f32(plan.handle, L.W_MUL_XJ, L.SUM, L.ptr(xd), L.ptr(wfull), L.ptr(c), L.ptr(c),
+                                             L.ptr(ref_agg), D, L.stream_ptr()))
+        assert torch.equal(agg, ref_agg)
+        close(y.cpu().numpy(), gm.dense(ref_agg, Wd, bd).cpu().numpy())
+    # against the oracle, unscaled sum without loops
+    ref = oracle.matmul(W, oracle.propagate("+", s, t, n, x)) + b[None, :]
+    close(gm.fused_conv(g.plan(False), L.SUM, xd, Wd, bd).cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("D1,D,Dout", [(100, 100, 128), (16, 16, 128), (12, 12, 20), (8, 24, 64)])
+def test_root_segment(gm, oracle, D1, D, Dout):
+    """W_root * x_i + W_agg * aggregate (graph_conv / sage_conv, conv.jl:102-108,277-283), bipartite source / destination sets"""
+    import torch
+    from gnnmp import _lib as L
+    rng = np.random.default_rng(D1 + 7 * D + Dout)
+    n_src, n_dst, E = 500, 333, 6000
+    s, t = rng.integers(1, n_src + 1, E).astype(np.int64), rng.integers(1, n_dst + 1, E).astype(np.int64)
+    from gnnmp.graph import Plan
+    plan = Plan(dev(s), dev(t), n_src, n_dst, 1, False)
+    xj = rng.standard_normal((n_src, D)).astype(np.float32)
+    xi = rng.standard_normal((n_dst, D1)).astype(np.float32)
+    W1 = (rng.standard_normal((Dout, D1)) * 0.2).astype(np.float32)
+    W2 = (rng.standard_normal((Dout, D)) * 0.2).astype(np.float32)
+    b = (rng.standard_normal(Dout) * 0.1).astype(np.float32)
+    for aggr, name in ((L.SUM, "+"), (L.MEAN, "mean")):
+        y = gm.fused_conv(plan, aggr, dev(xj), dev(W2), dev(b), "relu", xi=dev(xi), W_root=dev(W1))
+        assert y is not None
+        m = oracle.propagate(name, s, t, n_src, xj, n_dst=n_dst)
+        ref = oracle._act("relu", oracle.matmul(W1, xi) + oracle.matmul(W2, m) + b[None, :])
+        close(y.cpu().numpy(), ref)
+
+
+def test_layers_take_the_fused_kernel_and_fall_back_outside_it(gm, oracle):
+    import torch
+    rng = np.random.default_rng(77)
+    s, t, n = hub_graph(rng, n=1200, E=15000)
+    g = gm.GNNGraph(dev(s), dev(t), num_nodes=n)
+    from gnnmp import _lib as L
+    # outside the envelope: D = 3 (not a multiple of 4), Dout = 132 > 128, Dout = 5
+    for D, Dout in ((3, 8), (8, 132), (8, 5)):
+        x = dev(rng.standard_normal((n, D)).astype(np.float32))
+        W = dev(rng.standard_normal((Dout, D)).astype(np.float32))
+        assert gm.fused_conv(g.plan(False), L.SUM, x, W) is None
+    # the layers give the oracle's answer on either side of the boundary
+    for Din, Dout in ((8, 16), (3, 16), (8, 132)):
+        x = rng.standard_normal((n, Din)).astype(np.float32)
+        for cls, orc in ((gm.GCNConv, "gcn"), (gm.SAGEConv, "sage"), (gm.GraphConv, "graph")):
+            l = cls((Din, Dout), "relu", seed=5)
+            y = l(g, dev(x)).cpu().numpy()
+            if orc == "gcn":
+                ref = oracle.gcn_conv(s, t, n, x, l.weight.cpu().numpy(), l.bias.cpu().numpy(), "relu")
+            elif orc == "sage":
+                ref = oracle.sage_conv(s, t, n, x, l.weight.cpu().numpy(), l.bias.cpu().numpy(), "relu", "mean")
+            else:
+                ref = oracle.graph_conv(s, t, n, x, l.weight1.cpu().numpy(), l.weight2.cpu().numpy(), l.bias.cpu().numpy(), "relu", "+")
+            close(y, ref)
+
+
+def test_many_launches_rearm_the_ticket(gm):
+    """200 back-to-back launches on one plan, alternating shapes: every one must see a zeroed ticket"""
+    import torch
+    from gnnmp import _lib as L
+    rng = np.random.default_rng(3)
+    s, t, n = hub_graph(rng, n=5000, E=60000)
+    g = gm.GNNGraph(dev(s), dev(t), num_nodes=n)
+    plan = g.plan(True)
+    xa, xb = dev(rng.standard_normal((n, 100)).astype(np.float32)), dev(rng.standard_normal((n, 16)).astype(np.float32))
+    Wa, Wb = dev(rng.standard_normal((100, 100)).astype(np.float32) * 0.1), dev(rng.standard_normal((32, 16)).astype(np.float32))
+    ya, yb = gm.fused_conv(plan, L.SUM, xa, Wa), gm.fused_conv(plan, L.MEAN, xb, Wb)
+    for _ in range(100):
+        assert torch.equal(gm.fused_conv(plan, L.SUM, xa, Wa), ya)
+        assert torch.equal(gm.fused_conv(plan, L.MEAN, xb, Wb), yb)
