@@ -90,10 +90,23 @@ __global__ void __launch_bounds__(1024) fused_conv_kernel(const FusedArgs a) {
     const int ntiles = (r.n_rows + 15) >> 4;
     const bool has_bias = a.bias != nullptr;
 
+    // Tile hand-out: the first 7/8 of the tiles are dealt statically (wave w takes w, w + W, w + 2 W, ...: no traffic), the last
+    // 1/8 by a device-wide ticket so that the waves that drew short rows finish the job.  (All tiles by ticket: one word takes
+    // ~88 atomics per microsecond, MI355X_MICROARCH.md "dequeue" — 10 600 tiles of the arxiv shape alone cost 120 us.)
+    const int total_waves = (int)gridDim.x * a.waves;
+    const int wave_global = (int)blockIdx.x * a.waves + wave;
+    const int n_static = (int)(((int64_t)ntiles * 7 / 8) / total_waves) * total_waves;
+    int next_static = wave_global;
     for (;;) {
-        int t = 0;
-        if (lane == 0) t = (int)atomicAdd(a.ticket, 1u);
-        t = __builtin_amdgcn_readfirstlane(t);
+        int t;
+        if (next_static < n_static) {
+            t = next_static;
+            next_static += total_waves;
+        } else {
+            t = 0;
+            if (lane == 0) t = n_static + (int)atomicAdd(a.ticket, 1u);
+            t = __builtin_amdgcn_readfirstlane(t);
+        }
         if (t >= ntiles) break;
         const int row0 = t * 16;
         // ---- 1. the 16 rows of the tile, rpw at a time ----
@@ -223,6 +236,12 @@ extern "C" int gnnmp_fused_conv_f32(gnnmp_graph_t *p, int aggr, const float *xj,
         knob(KNOB_FUSED_WAVES) < 0)
         return fail(GNNMP_EUNSUPPORTED, "fused_conv: shape not fused (D=%lld D1=%lld Dout=%lld)", (long long)D, (long long)D1,
                     (long long)Dout);
+    // Fusing removes the aggregate's HBM round trip (4 N D bytes written, then read by the dense kernel).  When the aggregate
+    // fits the 256 MiB Infinity Cache beside the features there is no HBM round trip to remove, and the unfused pair wins on
+    // occupancy (no LDS-resident W image => three times the gathering waves per CU): measured arxiv shape 178 vs 187 us,
+    // config 5 316 vs 369 us; products shape 5.32 -> 4.67 ms the other way.  knob 14 > 0 forces the fused kernel.
+    if (knob(KNOB_FUSED_WAVES) == 0 && (int64_t)p->n_dst * D * (int64_t)sizeof(float) < ((int64_t)128 << 20))
+        return fail(GNNMP_EUNSUPPORTED, "fused_conv: aggregate fits the Infinity Cache, unfused path is faster");
     // split rows first: chunk partials + combine into the compact buffer behind the partials
     const size_t pc = (size_t)p->n_chunks * (size_t)D, pl = (size_t)p->n_long * (size_t)D;
     if (int rc = ensure_workspace(p, pc + pl + 4)) return rc;

@@ -18,7 +18,11 @@ def gm():
     assert torch.cuda.is_available()
     import gnnmp
     gnnmp.load()
-    return gnnmp
+    # the library only fuses when the aggregate cannot stay in the Infinity Cache (>= 128 MB); these graphs are small, so
+    # force the fused kernel for the whole module (knob 14 > 0 = cap of waves per block, 16 = the automatic maximum)
+    gnnmp.tune(14, 16)
+    yield gnnmp
+    gnnmp.tune(14, 0)
 
 
 def dev(a):

@@ -1,27 +1,38 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence committed under profiles/ (run on the GPU box through gpurun):
-#   tools/profile_round.sh <tag>      e.g. r01  ->  gpurun_out/<tag>_*.csv
+#   tools/profile_round.sh <tag> [quick]     e.g. r02  ->  gpurun_out/<tag>_*.csv
 # One kernel-trace pass for durations, then one PMC pass per counter group (kernel-trace only, as the pool requires).
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
+QUICK=${2:-}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $REPO/bench.py --no-cpu-baseline --no-extras"
-run() {  # name, rocprof args..., -- bench args
+run() {  # name, rocprof args..., -- command in $CMD
     local name=$1; shift
     rm -rf "/tmp/prof_$name"
-    timeout 600 rocprofv3 "$@" -d "/tmp/prof_$name" -- $BENCH_ARGS > "$OUT/${TAG}_$name.log" 2>&1
+    timeout 600 rocprofv3 "$@" -d "/tmp/prof_$name" -- $CMD > "$OUT/${TAG}_$name.log" 2>&1
     local db
     db=$(find "/tmp/prof_$name" -name '*_results.db' | head -1)
     if [ -n "$db" ]; then python "$REPO/tools/rocpd_summary.py" "$db" > "$OUT/${TAG}_$name.csv"; else echo "no db for $name" >&2; fi
 }
-BENCH_ARGS="$BENCH --steps 20 --warmup 5"
+CMD="$BENCH --steps 20 --warmup 5"
 run bench_products_kernel_stats --kernel-trace --stats
-BENCH_ARGS="$BENCH --steps 3 --warmup 1"
+CMD="python $REPO/tools/small_configs.py arxiv"
+run arxiv_kernel_stats --kernel-trace --stats
+CMD="python $REPO/tools/small_configs.py batched"
+run batched_kernel_stats --kernel-trace --stats
+if [ -z "$QUICK" ]; then
+CMD="$BENCH --steps 3 --warmup 1"
 run pmc_rd --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_32B_sum
 run pmc_wr --kernel-trace --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_HIT_sum TCC_MISS_sum
 run pmc_fs --kernel-trace --pmc FETCH_SIZE
 run pmc_ws --kernel-trace --pmc WRITE_SIZE
+CMD="python $REPO/tools/dense_small.py shape=2449029,100,100"
+run dense_mfma --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE
+CMD="python $REPO/tools/dense_small.py shape=2449029,100,128"
+run dense128_mfma --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE
+fi
 ls -la "$OUT" | grep "$TAG"
