@@ -43,7 +43,8 @@ enum Knob {
     KNOB_DENSE_T16_WAVES = 12, // dense_t16_kernel: waves per block (0 = auto, else 1..16)
     KNOB_T16_DEBUG = 13,       // dense_t16_kernel phase ablation (experiments only): 1 = no stores, 2 = no x loads
     KNOB_FUSED_WAVES = 14,     // fused_conv_kernel: 0 = auto (as many waves as LDS holds tiles for, <= 16), > 0 = cap, < 0 = never fuse
-    KNOB_COUNT = 15
+    KNOB_ROW_ORDER = 15,       // 1 (default) = row kernels that share a wave between rows walk rows by decreasing length, 0 = by index
+    KNOB_COUNT = 16
 };
 int knob(int k);
 int device_cus();   // compute units of the current device, queried once (hipDeviceGetAttribute costs microseconds per call)
@@ -209,6 +210,11 @@ struct gnnmp_graph {
     // two device words {next tile, finished blocks} for the persistent fused kernel's dynamic tile hand-out (fused_conv.hip);
     // zero between launches: the last block to finish resets them
     uint32_t *ticket = nullptr;
+    // destination rows in order of decreasing length (stable), built on first use (ensure_row_order): the row kernels that
+    // put TWO OR MORE rows in a wave walk rows in this order so that the rows sharing a wave are equally long — adjacent
+    // rows of a power-law graph are not, and a wave runs as long as its longest row (products shape: 1.43x the instruction
+    // issue of perfectly packed rows with adjacent pairing, 1.13x with this order)
+    int32_t *row_order = nullptr;
 };
 
 namespace gnnmp {
@@ -216,6 +222,8 @@ namespace gnnmp {
 int ensure_workspace(gnnmp_graph *p, size_t floats);
 // allocate + zero plan->ticket on first use
 int ensure_ticket(gnnmp_graph *p, hipStream_t stream);
+// build plan->row_order on first use
+int ensure_row_order(gnnmp_graph *p, hipStream_t stream);
 }
 
 namespace gnnmp {

@@ -9,6 +9,7 @@ namespace gnnmp {
 
 struct ReduceArgs {
     const int32_t *rowptr;
+    const int32_t *row_order; // [n_rows] rows by decreasing length, or null (common.h: gnnmp_graph::row_order)
     const int32_t *idx;      // per slot: source row of x to read (plan->col, or plan->eid for scatter)
     const int32_t *eid;      // per slot: original edge position (weights lookup); unused unless w
     const float *x;          // [n_src][D]

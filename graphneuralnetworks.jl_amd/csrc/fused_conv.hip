@@ -111,7 +111,8 @@ __global__ void __launch_bounds__(1024) fused_conv_kernel(const FusedArgs a) {
         const int row0 = t * 16;
         // ---- 1. the 16 rows of the tile, rpw at a time ----
         for (int rr = grp; rr < 16; rr += rpw) {
-            const int row = row0 + rr;
+            int row = row0 + rr;
+            if (r.row_order && row < r.n_rows) row = r.row_order[row];
             float acc[VEC];
 #pragma unroll
             for (int v = 0; v < VEC; ++v) acc[v] = op_identity<OP>();
@@ -137,9 +138,11 @@ __global__ void __launch_bounds__(1024) fused_conv_kernel(const FusedArgs a) {
         f32x4 acc2[NCB];
 #pragma unroll
         for (int c = 0; c < NCB; ++c) acc2[c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        const int row = row0 + n;
+        const bool row_ok = row0 + n < r.n_rows;
+        int row = min(row0 + n, r.n_rows - 1);
+        if (r.row_order) row = r.row_order[row];
         if (a.xi) {
-            const float *xr = a.xi + (int64_t)min(row, r.n_rows - 1) * a.D1;
+            const float *xr = a.xi + (int64_t)row * a.D1;
             t16_segment_rt<NCB>(acc2, img, 0, a.D1 >> 2, n, q, [&](int kcol) { return *reinterpret_cast<const float4 *>(xr + kcol); });
         }
         {
@@ -154,7 +157,7 @@ __global__ void __launch_bounds__(1024) fused_conv_kernel(const FusedArgs a) {
                 t16_segment_rt<NCB>(acc2, img, rows0, D >> 2, n, q, ld);
             }
         }
-        t16_store<NCB>(acc2, bias4, has_bias, a.act, a.out + (int64_t)row * a.Dout, row < r.n_rows, ncols, q);
+        t16_store<NCB>(acc2, bias4, has_bias, a.act, a.out + (int64_t)row * a.Dout, row_ok, ncols, q);
         // the tile is rewritten by the next gather: program order within the wave keeps the reads above before those writes
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -242,6 +245,10 @@ extern "C" int gnnmp_fused_conv_f32(gnnmp_graph_t *p, int aggr, const float *xj,
     // config 5 316 vs 369 us; products shape 5.32 -> 4.67 ms the other way.  knob 14 > 0 forces the fused kernel.
     if (knob(KNOB_FUSED_WAVES) == 0 && (int64_t)p->n_dst * D * (int64_t)sizeof(float) < ((int64_t)128 << 20))
         return fail(GNNMP_EUNSUPPORTED, "fused_conv: aggregate fits the Infinity Cache, unfused path is faster");
+    // With a root term (graph_conv / sage_conv) a tile's MFMA phase doubles while the gathering waves stay capped at 16 per CU
+    // by the LDS image: measured SAGEConv(100 => 128) on the products shape 5.95 ms fused vs 5.79 ms unfused.  Not by default.
+    if (knob(KNOB_FUSED_WAVES) == 0 && D1 > 0)
+        return fail(GNNMP_EUNSUPPORTED, "fused_conv: root term, unfused path is faster");
     // split rows first: chunk partials + combine into the compact buffer behind the partials
     const size_t pc = (size_t)p->n_chunks * (size_t)D, pl = (size_t)p->n_long * (size_t)D;
     if (int rc = ensure_workspace(p, pc + pl + 4)) return rc;
@@ -272,6 +279,12 @@ extern "C" int gnnmp_fused_conv_f32(gnnmp_graph_t *p, int aggr, const float *xj,
     r.mean = (aggr == GNNMP_MEAN);
     r.long_thresh = p->long_thresh;
     r.log2g = pick_log2g((D + 3) / 4);
+    // >= 2 rows per wave: the rows of a wave should be equally long (only when output rows are whole 128-byte lines, see
+    // run_reduce in propagate.hip: measured 4.98 -> 6.02 ms with 400-byte rows)
+    if (knob(KNOB_ROW_ORDER) != 0 && r.log2g <= 5 && (Dout & 31) == 0 && (reinterpret_cast<uintptr_t>(out) & 127) == 0) {
+        if (int rc = ensure_row_order(p, stream)) return rc;
+        r.row_order = p->row_order;
+    }
     a.agg_long = agg_long;
     a.agg_out = agg_out;
     a.xi = D1 > 0 ? xi : nullptr;

@@ -30,6 +30,7 @@ namespace gnnmp {
 
 struct GatFusedArgs {
     const int32_t *rowptr;
+    const int32_t *row_order;   // [n_rows] rows by decreasing length, or null: virtual row v -> destination (see common.h)
     const int32_t *col;
     const float *Wx_src;  // K [n_src][D]
     const float *Wx_val;  // V [n_src][D] (== Wx_src unless MODE = DOT)
@@ -83,6 +84,85 @@ struct LaneRow {
 // is a compile-time constant), ONE rescale of the running state to the batch maximum and U exponentials — no branch
 // anywhere, so the scheduler interleaves all of it under the loads.  Slots past the end of the row re-read the last
 // edge with logit -inf (weight exactly 0).
+//   c / ev: this lane's source id / edge id of the G slots loaded for the current stretch of the row; j: first slot of the
+//   batch within the stretch, n: slots in the stretch.
+template <int VEC, int U, int LPH, int MODE, bool OFF24>
+__device__ __forceinline__ void gat_batch(const GatFusedArgs &a, int c, int ev, int gbase, int j, int n, int fc,
+                                          const LaneRow<VEC> &r, float &m, float &den, float acc[VEC]) {
+    constexpr bool edge_term = MODE == ATTN_GAT_EDGE;
+    float v[U][VEC];                                  // K_j
+    float w[MODE == GNNMP_ATTN_DOT ? U : 1][VEC];     // V_j when it is a different array
+    float es[U];
+    // all U source ids first (one LDS round trip for the batch), then the U row loads back to back; the edge term's
+    // uniform branch sits after them (between the loads it made hipcc wait for every ds_bpermute separately)
+    int cj[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) cj[u] = __shfl(c, gbase + min(j + u, n - 1), 64);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        // OFF24 (fewer than 2^24 rows of fewer than 2^24 floats, fewer than 2^32 floats in all): the row offset is
+        // ONE full-rate v_mad_u32_u24 instead of a quarter-rate 64-bit multiply-add per edge
+        const int64_t o = OFF24 ? (int64_t)(uint32_t)(__umul24(cj[u], a.D) + fc) : (int64_t)cj[u] * a.D + fc;
+        Vec<VEC>::load(a.Wx_src + o, v[u]);
+        if (MODE == GNNMP_ATTN_DOT) Vec<VEC>::load(a.Wx_val + o, w[MODE == GNNMP_ATTN_DOT ? u : 0]);
+        es[u] = 0.0f;
+    }
+    if (edge_term) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int ej = __shfl(ev, gbase + min(j + u, n - 1), 64);
+            es[u] = a.escore[(int64_t)ej * a.H + r.h];
+        }
+    }
+    float l[U], nn[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        l[u] = 0.0f;
+        nn[u] = 0.0f;
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+            if (is_gat(MODE)) l[u] = fmaf(r.ca[q], v[u][q], l[u]);
+            if (MODE == GNNMP_ATTN_GATV2) l[u] = fmaf(r.ca[q], lrelu(r.vi[q] + v[u][q], a.slope), l[u]);
+            if (MODE == GNNMP_ATTN_DOT) l[u] = fmaf(r.vi[q], v[u][q], l[u]);
+            if (MODE == GNNMP_ATTN_COS) {
+                l[u] = fmaf(r.vi[q], v[u][q], l[u]);
+                nn[u] = fmaf(v[u][q] * r.am, v[u][q], nn[u]);
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        l[u] = group_sum<LPH>(l[u], a.lph);
+        if (MODE == GNNMP_ATTN_COS) nn[u] = group_sum<LPH>(nn[u], a.lph);
+    }
+    float mn = m;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        float lu = l[u];
+        if (is_gat(MODE)) lu = lrelu(edge_term ? (r.s0 + lu) + es[u] : r.s0 + lu, a.slope);
+        if (MODE == GNNMP_ATTN_DOT) lu = lu / a.scale;
+        if (MODE == GNNMP_ATTN_COS) lu = a.scale * (lu / (r.s0 * sqrtf(nn[u])));
+        l[u] = (j + u < n) ? lu : -__builtin_inff();
+        mn = fmaxf(mn, l[u]);
+    }
+    const float sc = gexp(m - mn);   // exp(0) = 1 when the maximum did not move, exp(-inf) = 0 the first time
+    den *= sc;
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) acc[q] *= sc;
+    m = mn;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const float pe = gexp(l[u] - m);
+        den += pe;
+#pragma unroll
+        for (int q = 0; q < VEC; ++q)
+            acc[q] = fmaf(pe, MODE == GNNMP_ATTN_DOT ? w[MODE == GNNMP_ATTN_DOT ? u : 0][q] : v[u][q], acc[q]);
+    }
+}
+
+// A row = stretches of G slots (one coalesced load of source ids per stretch), each stretch = full batches of U edges and,
+// for what is left, ONE batch of the smallest width in {U/4, U/2, U} that holds it: a row of 9 edges costs 8 + 2 slots, not
+// 16 (on the products shape a third of the rows are shorter than two batches: padded batches were 12 % of all issue slots).
 template <int VEC, int U, int LPH, int MODE, bool OFF24>
 __device__ __forceinline__ void gat_online_range(const GatFusedArgs &a, int beg, int end, int lig,
                                                  int gbase, int G, int fc, const LaneRow<VEC> &r,
@@ -95,75 +175,16 @@ __device__ __forceinline__ void gat_online_range(const GatFusedArgs &a, int beg,
         constexpr bool edge_term = MODE == ATTN_GAT_EDGE;
         const int ev = (edge_term && p < end) ? a.eid[p] : 0;
         const int n = min(G, end - base);
-        for (int j = 0; j < n; j += U) {
-            float v[U][VEC];                                  // K_j
-            float w[MODE == GNNMP_ATTN_DOT ? U : 1][VEC];     // V_j when it is a different array
-            float es[U];
-            // all U source ids first (one LDS round trip for the batch), then the U row loads back to back; the edge term's
-            // uniform branch sits after them (between the loads it made hipcc wait for every ds_bpermute separately)
-            int cj[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) cj[u] = __shfl(c, gbase + min(j + u, n - 1), 64);
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                // OFF24 (fewer than 2^24 rows of fewer than 2^24 floats, fewer than 2^32 floats in all): the row offset is
-                // ONE full-rate v_mad_u32_u24 instead of a quarter-rate 64-bit multiply-add per edge
-                const int64_t o = OFF24 ? (int64_t)(uint32_t)(__umul24(cj[u], a.D) + fc) : (int64_t)cj[u] * a.D + fc;
-                Vec<VEC>::load(a.Wx_src + o, v[u]);
-                if (MODE == GNNMP_ATTN_DOT) Vec<VEC>::load(a.Wx_val + o, w[MODE == GNNMP_ATTN_DOT ? u : 0]);
-                es[u] = 0.0f;
-            }
-            if (edge_term) {
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int ej = __shfl(ev, gbase + min(j + u, n - 1), 64);
-                    es[u] = a.escore[(int64_t)ej * a.H + r.h];
-                }
-            }
-            float l[U], nn[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                l[u] = 0.0f;
-                nn[u] = 0.0f;
-#pragma unroll
-                for (int q = 0; q < VEC; ++q) {
-                    if (is_gat(MODE)) l[u] = fmaf(r.ca[q], v[u][q], l[u]);
-                    if (MODE == GNNMP_ATTN_GATV2) l[u] = fmaf(r.ca[q], lrelu(r.vi[q] + v[u][q], a.slope), l[u]);
-                    if (MODE == GNNMP_ATTN_DOT) l[u] = fmaf(r.vi[q], v[u][q], l[u]);
-                    if (MODE == GNNMP_ATTN_COS) {
-                        l[u] = fmaf(r.vi[q], v[u][q], l[u]);
-                        nn[u] = fmaf(v[u][q] * r.am, v[u][q], nn[u]);
-                    }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                l[u] = group_sum<LPH>(l[u], a.lph);
-                if (MODE == GNNMP_ATTN_COS) nn[u] = group_sum<LPH>(nn[u], a.lph);
-            }
-            float mn = m;
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                float lu = l[u];
-                if (is_gat(MODE)) lu = lrelu(edge_term ? (r.s0 + lu) + es[u] : r.s0 + lu, a.slope);
-                if (MODE == GNNMP_ATTN_DOT) lu = lu / a.scale;
-                if (MODE == GNNMP_ATTN_COS) lu = a.scale * (lu / (r.s0 * sqrtf(nn[u])));
-                l[u] = (j + u < n) ? lu : -__builtin_inff();
-                mn = fmaxf(mn, l[u]);
-            }
-            const float sc = gexp(m - mn);   // exp(0) = 1 when the maximum did not move, exp(-inf) = 0 the first time
-            den *= sc;
-#pragma unroll
-            for (int q = 0; q < VEC; ++q) acc[q] *= sc;
-            m = mn;
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const float pe = gexp(l[u] - m);
-                den += pe;
-#pragma unroll
-                for (int q = 0; q < VEC; ++q)
-                    acc[q] = fmaf(pe, MODE == GNNMP_ATTN_DOT ? w[MODE == GNNMP_ATTN_DOT ? u : 0][q] : v[u][q], acc[q]);
-            }
+        int j = 0;
+        for (; j + U <= n; j += U) gat_batch<VEC, U, LPH, MODE, OFF24>(a, c, ev, gbase, j, n, fc, r, m, den, acc);
+        const int rem = n - j;
+        if (rem > 0) {
+            if (U >= 8 && rem <= U / 4)
+                gat_batch<VEC, (U >= 8 ? U / 4 : U), LPH, MODE, OFF24>(a, c, ev, gbase, j, n, fc, r, m, den, acc);
+            else if (U >= 4 && rem <= U / 2)
+                gat_batch<VEC, (U >= 4 ? U / 2 : U), LPH, MODE, OFF24>(a, c, ev, gbase, j, n, fc, r, m, den, acc);
+            else
+                gat_batch<VEC, U, LPH, MODE, OFF24>(a, c, ev, gbase, j, n, fc, r, m, den, acc);
         }
     }
 }
@@ -206,6 +227,7 @@ __global__ void __launch_bounds__(256) gat_fused_rows_kernel(const GatFusedArgs 
         end = a.chunk_end[v];
     } else {
         row = v - a.n_chunks;
+        if (a.row_order) row = a.row_order[row];
         beg = a.rowptr[row];
         end = a.rowptr[row + 1];
         if (end - beg > a.long_thresh) return;
@@ -487,6 +509,11 @@ static int attn_conv_impl(gnnmp_graph_t *plan, int mode, const float *Q, const f
     }
     GatFusedArgs g;
     g.rowptr = plan->rowptr;
+    g.row_order = nullptr;
+    if (knob(KNOB_ROW_ORDER) != 0 && lanes <= 32) {   // two or more rows per wave: pair rows of equal length
+        if (int rc = ensure_row_order(plan, stream)) return rc;
+        g.row_order = plan->row_order;
+    }
     g.col = plan->col;
     g.Wx_src = K;
     g.Wx_val = V;

@@ -15,7 +15,7 @@
 namespace gnnmp {
 
 static thread_local char g_err[512] = "";
-static int g_knobs[KNOB_COUNT] = {0, -1, 0, 1, 0, 0, 0, 17, 0, 0, 0, 0, 0, 0, 0};
+static int g_knobs[KNOB_COUNT] = {0, -1, 0, 1, 0, 0, 0, 17, 0, 0, 0, 0, 0, 0, 0, 1};
 
 int fail(int status, const char *fmt, ...) {
     va_list ap;
@@ -58,6 +58,49 @@ int ensure_ticket(gnnmp_graph *p, hipStream_t stream) {
     if (e != hipSuccess) return hip_fail(e, "hipMalloc(plan ticket)");
     e = hipMemsetAsync(p->ticket, 0, 2 * sizeof(uint32_t), stream);
     if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(plan ticket)");
+    return GNNMP_OK;
+}
+
+__global__ void plan_degree_keys(const int32_t *rowptr, int64_t n, int maxdeg, uint32_t *keys, uint32_t *vals) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    keys[i] = (uint32_t)(maxdeg - (rowptr[i + 1] - rowptr[i]));   // ascending key = descending length
+    vals[i] = (uint32_t)i;
+}
+
+int ensure_row_order(gnnmp_graph *p, hipStream_t stream) {
+    if (p->row_order || p->n_dst == 0) return GNNMP_OK;
+    const size_t n = (size_t)p->n_dst;
+    uint32_t *kin = nullptr, *kout = nullptr, *vin = nullptr;
+    int32_t *order = nullptr;
+    void *tmp = nullptr;
+    int rc = GNNMP_OK;
+    hipError_t e = hipSuccess;
+    unsigned bits = 1;
+    while (bits < 32 && ((int64_t)1 << bits) <= p->max_degree) ++bits;
+    size_t tmp_bytes = 0;
+    if ((e = hipMalloc((void **)&kin, 4 * n)) != hipSuccess || (e = hipMalloc((void **)&kout, 4 * n)) != hipSuccess ||
+        (e = hipMalloc((void **)&vin, 4 * n)) != hipSuccess || (e = hipMalloc((void **)&order, 4 * n)) != hipSuccess) {
+        rc = hip_fail(e, "hipMalloc(row order)");
+    } else {
+        plan_degree_keys<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(p->rowptr, p->n_dst, (int)p->max_degree, kin, vin);
+        e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, kin, kout, vin, reinterpret_cast<uint32_t *>(order), n, 0, bits, stream);
+        if (e == hipSuccess) e = hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 16));
+        if (e == hipSuccess)
+            e = rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, vin, reinterpret_cast<uint32_t *>(order), n, 0, bits, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);   // the temporaries are freed below
+        if (e != hipSuccess) rc = hip_fail(e, "row order sort");
+    }
+    if (kin) (void)hipFree(kin);
+    if (kout) (void)hipFree(kout);
+    if (vin) (void)hipFree(vin);
+    if (tmp) (void)hipFree(tmp);
+    if (rc != GNNMP_OK) {
+        if (order) (void)hipFree(order);
+        return rc;
+    }
+    p->row_order = order;
+    p->bytes += (int64_t)(4 * n);
     return GNNMP_OK;
 }
 
@@ -217,6 +260,7 @@ int gnnmp_plan_destroy(gnnmp_graph_t *p) {
     if (p->chunk_end) (void)hipFree(p->chunk_end);
     if (p->ws) (void)hipFree(p->ws);
     if (p->ticket) (void)hipFree(p->ticket);
+    if (p->row_order) (void)hipFree(p->row_order);
     delete p;
     return GNNMP_OK;
 }

@@ -44,7 +44,8 @@ __global__ void __launch_bounds__(256) csr_rows_kernel(const ReduceArgs a) {
         if (active) Vec<VEC>::store(a.partial + (int64_t)v * a.D + f0, acc);
         return;
     }
-    const int row = v - a.n_chunks;
+    int row = v - a.n_chunks;
+    if (a.row_order) row = a.row_order[row];
     const int beg = a.rowptr[row];
     const int end = a.rowptr[row + 1];
     if (end - beg > a.long_thresh) return;  // split row: its chunks are virtual rows, folded by csr_combine_kernel
@@ -333,6 +334,7 @@ int run_reduce(gnnmp_graph_t *p, const int32_t *idx, int aggr, const float *x, c
     ReduceArgs a;
     a.compact_long = long_only;
     a.rowptr = p->rowptr;
+    a.row_order = nullptr;
     a.idx = idx;
     a.eid = p->eid;
     a.x = x;
@@ -370,6 +372,13 @@ int run_reduce(gnnmp_graph_t *p, const int32_t *idx, int aggr, const float *x, c
     if (emat && (reinterpret_cast<uintptr_t>(emat) & (4 * vec - 1)) != 0) vec = 1;
     if (gate_i && (reinterpret_cast<uintptr_t>(gate_i) & (4 * vec - 1)) != 0) vec = 1;
     a.log2g = pick_log2g((D + vec - 1) / vec);
+    // >= 2 rows per wave: pair rows of equal length — but only when an output row is whole 128-byte lines: out of index order,
+    // rows of 400 bytes (D = 100) leave every line half written by one wave and finished by another, measured 4.75 -> 5.11 ms
+    if (!long_only && knob(KNOB_ROW_ORDER) != 0 && a.log2g <= 5 && idx == p->col && (D & 31) == 0 &&
+        (reinterpret_cast<uintptr_t>(out) & 127) == 0) {
+        if (int rc = ensure_row_order(p, stream)) return rc;
+        a.row_order = p->row_order;
+    }
     const int op = (aggr == GNNMP_MAX) ? OP_MAX : (aggr == GNNMP_MIN ? OP_MIN : OP_SUM);
     const bool scaled = w || ss || w_slot || ss_slot;
     switch (vec) {
