@@ -1,21 +1,28 @@
 # GNNlibGnnmpExt.jl — the reference-side binding of libgnnmp.so (include/gnnmp.h).
 #
-# This is the file a GNNlib.jl maintainer adds next to GNNlib/ext/GNNlibAMDGPUExt.jl (declare `Gnnmp_jll` or a path to
-# libgnnmp.so plus `AMDGPU` as weakdeps in GNNlib/Project.toml:17-23, extension = ["AMDGPU"]).  It replaces the three
-# methods of GNNlibAMDGPUExt.jl:13-32 — which today only *disable* the SpMM fast path on ROCm arrays and fall back to
-# gather -> message -> atomic scatter — with calls into the fused HIP kernels, and adds the fused GCN / GAT / pooling
-# fast paths.  Julia is NOT available in the build container, so this file is written against the reference's sources
-# but has never been executed; it is kept deliberately thin (every method is a size check + one @ccall) and it mirrors
-# 1:1 the ctypes host layer in graphneuralnetworks.jl_amd/gnnmp/, which IS tested on an MI355X.
+# This is the file a GNNlib.jl maintainer adds next to GNNlib/ext/GNNlibAMDGPUExt.jl (GNNlib/Project.toml:17-23: `AMDGPU`
+# is already a weakdep; this extension replaces GNNlibAMDGPUExt in `[extensions]`, ChainRulesCore is already a hard
+# dependency, :5).  It replaces the three methods of GNNlibAMDGPUExt.jl:13-32 — which today only *disable* the SpMM fast
+# path on ROCm arrays and fall back to gather -> message -> atomic scatter — with calls into the fused HIP kernels, keeps
+# them differentiable (ChainRulesCore rrules on every wrapper that hides a @ccall), and routes the four layer bodies of
+# the hot path (gcn_conv, graph_conv / sage_conv through `propagate`, gat_conv) to the fused kernels.
 #
-# Layout contract: Julia's column-major (D, N) feature matrix is exactly the C row-major [N][D] the library wants, and
-# GNNGraph's COO vectors (1-based Int64, or Int32) are passed untouched (idx_bytes, index_base = 1).
+# Julia is NOT available in the build container, so this file is written against the reference's sources but has never
+# been executed.  What IS executed is the C ABI it calls: tests/test_c_harness.py drives the same entry points with the same
+# argument conventions from a plain C program that owns its memory through hipMalloc (no torch anywhere), and
+# graphneuralnetworks.jl_amd/gnnmp/ is the tested mirror of every wrapper below.
+#
+# Layout contract: Julia's column-major (D, N) feature matrix is exactly the C row-major [N][D] the library wants;
+# GNNGraph's COO vectors (1-based Int64, or Int32) are passed untouched (idx_bytes, index_base = 1); a Julia weight
+# matrix (Dout, Din) column-major is C row-major [Din][Dout], i.e. gnnmp_dense_f32's w_layout = 1 with ldw = Dout.
 
 module GNNlibGnnmpExt
 
 using AMDGPU: AMDGPU, ROCArray, ROCVector, ROCMatrix, AnyROCMatrix
+using ChainRulesCore: ChainRulesCore, NoTangent, ZeroTangent, unthunk, @non_differentiable
 using GNNlib: GNNlib, propagate, copy_xj, e_mul_xj, w_mul_xj
 using GNNGraphs: GNNGraphs, GNNGraph, COO_T, edge_index, get_edge_weight, check_num_nodes, check_num_edges
+using NNlib: relu
 using Statistics: mean
 
 const libgnnmp = get(ENV, "GNNMP_LIB", "libgnnmp.so")
@@ -25,6 +32,7 @@ struct GnnmpError <: Exception
     status::Cint
     msg::String
 end
+const EUNSUPPORTED = Cint(-5)
 function check(status::Cint)
     status == 0 && return nothing
     msg = unsafe_string(@ccall libgnnmp.gnnmp_last_error()::Cstring)
@@ -40,27 +48,65 @@ aggr_code(::typeof(mean)) = MEAN
 aggr_code(::typeof(max)) = MAX
 aggr_code(::typeof(min)) = MIN
 const FusedAggr = Union{typeof(+), typeof(mean), typeof(max), typeof(min)}
+act_code(::typeof(identity)) = Cint(0)
+act_code(::typeof(relu)) = Cint(1)
+act_code(σ) = nothing                                              # anything else: applied as a broadcast afterwards
 
-# ---- plan cache: one dst-sorted CSR per (s, t) pair, keyed by the identity of the index vectors -----------------------
+# ---- plans: one dst-sorted CSR per (s, t, num_nodes, self_loops, direction) ---------------------------------------------
 mutable struct Plan
     handle::Ptr{Cvoid}
     function Plan(s::ROCVector{I}, t::ROCVector{I}, n_src::Int, n_dst::Int, self_loops::Bool) where {I <: Union{Int32, Int64}}
         h = Ref{Ptr{Cvoid}}(C_NULL)
+        # validate = 1: GNNGraph construction does not range-check device vectors (convert.jl:47-54 runs on the CPU copy only)
         check(@ccall libgnnmp.gnnmp_plan_create(h::Ptr{Ptr{Cvoid}}, devptr(s)::Ptr{Cvoid}, devptr(t)::Ptr{Cvoid},
                                                 sizeof(I)::Cint, 1::Cint, n_src::Int64, n_dst::Int64,
-                                                length(s)::Int64, self_loops::Cint, 0::Cint,
+                                                length(s)::Int64, self_loops::Cint, 1::Cint,
                                                 stream_ptr()::Ptr{Cvoid})::Cint)
         p = new(h[])
         finalizer(p -> (@ccall libgnnmp.gnnmp_plan_destroy(p.handle::Ptr{Cvoid})::Cint), p)
         return p
     end
 end
-const PLANS = WeakKeyDict{Any, Dict{Bool, Plan}}()   # GNNGraph is immutable and shares s, t across copies (gnngraph.jl:187-211)
-function plan(g::GNNGraph{<:COO_T}; self_loops::Bool = false)
-    s, t = edge_index(g)
-    d = get!(() -> Dict{Bool, Plan}(), PLANS, s)
-    get!(() -> Plan(s, t, g.num_nodes, g.num_nodes, self_loops), d, self_loops)
+
+# The cache is keyed on the IDENTITY of the two index vectors plus everything else a plan depends on.  (Round 1 keyed a
+# WeakKeyDict on `s` alone: two graphs sharing s but not t, or num_nodes, got the first graph's plan — and WeakKeyDict hashes
+# array CONTENTS, a scalar-indexing O(E) walk of a ROCVector per call.)  GNNGraph is immutable and shares s, t across copies
+# (gnngraph.jl:187-211), so identity is the right notion of "same graph".  objectids are recycled after collection: every
+# entry carries a liveness flag that finalizers on s and t clear (a finalizer must not lock or allocate — storing a Bool
+# is all it does), and a lookup that finds a dead entry rebuilds it.
+struct PlanKey
+    s::UInt
+    t::UInt
+    n::Int
+    self_loops::Bool
+    transposed::Bool
 end
+mutable struct PlanEntry
+    plan::Plan
+    @atomic alive::Bool
+end
+const PLANS = Dict{PlanKey, PlanEntry}()
+const PLANS_LOCK = ReentrantLock()
+
+function plan(g::GNNGraph{<:COO_T}; self_loops::Bool = false, transposed::Bool = false)
+    s, t = edge_index(g)
+    key = PlanKey(objectid(s), objectid(t), g.num_nodes, self_loops, transposed)
+    lock(PLANS_LOCK) do
+        ent = get(PLANS, key, nothing)
+        if ent === nothing || !(@atomic ent.alive)
+            length(PLANS) > 256 && filter!(kv -> (@atomic kv.second.alive), PLANS)   # drop the plans of collected graphs
+            p = transposed ? Plan(t, s, g.num_nodes, g.num_nodes, self_loops) : Plan(s, t, g.num_nodes, g.num_nodes, self_loops)
+            ent = PlanEntry(p, true)
+            let ent = ent
+                finalizer(_ -> (@atomic ent.alive = false), s)
+                finalizer(_ -> (@atomic ent.alive = false), t)
+            end
+            PLANS[key] = ent
+        end
+        ent.plan
+    end
+end
+@non_differentiable plan(::Any...)
 
 # ---- propagate: replaces GNNlib/ext/GNNlibAMDGPUExt.jl:13-32 (and extends it to mean / max / min) ----------------------
 function fused_propagate(g::GNNGraph, aggr, xj::AnyROCMatrix{Float32}, w; self_loops = false, scale_src = nothing,
@@ -90,7 +136,60 @@ function GNNlib.propagate(::typeof(w_mul_xj), g::GNNGraph{<:COO_T}, aggr::FusedA
     fused_propagate(g, aggr, xj, get_edge_weight(g))              # the CPU fast path's weighted adjacency (msgpass.jl:234-238)
 end
 
+# in-degree counts (Float32) of the plan's rows: the mean adjoint divides by them
+function in_count(g::GNNGraph, self_loops::Bool)
+    d = AMDGPU.zeros(Float32, g.num_nodes)
+    check(@ccall libgnnmp.gnnmp_degree_f32(plan(g; self_loops).handle::Ptr{Cvoid}, C_NULL::Ptr{Cvoid}, devptr(d)::Ptr{Cvoid},
+                                           stream_ptr()::Ptr{Cvoid})::Cint)
+    return d
+end
+@non_differentiable in_count(::Any...)
+
+# The pullback Zygote would compose from NNlib's rules for gather -> message -> scatter (∇scatter(+) = gather, ∇scatter(mean)
+# = gather ./ count, ∇scatter(max|min) = (src .== gather(dst)) .* gather(Δ), ∇gather = scatter(+)), as three kernels:
+#   Δxj: the SAME fused kernel on the plan of the reversed edge index (scale_src and scale_dst swap roles);
+#   Δw : one dot product per edge, walked in plan order;   max / min: their own kernel (ties all receive Δ, like NNlib).
+# Mirror of graphneuralnetworks.jl_amd/gnnmp/backward.py (tested against the oracle's restatement of NNlib's rules).
+function ChainRulesCore.rrule(::typeof(fused_propagate), g::GNNGraph, aggr, xj::AnyROCMatrix{Float32}, w;
+                              self_loops = false, scale_src = nothing, scale_dst = nothing)
+    y = fused_propagate(g, aggr, xj, w; self_loops, scale_src, scale_dst)
+    function fused_propagate_pullback(Δ̄)
+        Δ = convert(typeof(y), unthunk(Δ̄))
+        D = size(Δ, 1)
+        pt = plan(g; self_loops, transposed = true)
+        Δx = similar(xj)
+        if aggr === max || aggr === min
+            @assert w === nothing && scale_src === nothing && scale_dst === nothing
+            check(@ccall libgnnmp.gnnmp_propagate_maxmin_grad_f32(pt.handle::Ptr{Cvoid}, devptr(xj)::Ptr{Cvoid},
+                      devptr(y)::Ptr{Cvoid}, devptr(Δ)::Ptr{Cvoid}, devptr(Δx)::Ptr{Cvoid}, D::Int64,
+                      stream_ptr()::Ptr{Cvoid})::Cint)
+            return NoTangent(), NoTangent(), NoTangent(), Δx, NoTangent()
+        end
+        sd = scale_dst
+        if aggr === mean
+            inv = 1f0 ./ max.(in_count(g, self_loops), 1f0)
+            sd = sd === nothing ? inv : sd .* inv
+        end
+        # out_i = sd_i Σ_k w_k ss_{s_k} x_{s_k}  =>  Δx_j = ss_j Σ_{k: s_k = j} w_k (sd Δ)_{t_k}: source factor sd, destination factor ss
+        check(@ccall libgnnmp.gnnmp_propagate_f32(pt.handle::Ptr{Cvoid}, (w === nothing ? 0 : 1)::Cint, SUM::Cint,
+                  devptr(Δ)::Ptr{Cvoid}, devptr(w)::Ptr{Cvoid}, devptr(sd)::Ptr{Cvoid}, devptr(scale_src)::Ptr{Cvoid},
+                  devptr(Δx)::Ptr{Cvoid}, D::Int64, stream_ptr()::Ptr{Cvoid})::Cint)
+        Δw = NoTangent()
+        if w !== nothing
+            @assert !self_loops "Δw with plan-added self loops: the appended edges carry no weight to differentiate"
+            Δs = sd === nothing ? Δ : Δ .* reshape(sd, 1, :)
+            xs = scale_src === nothing ? xj : xj .* reshape(scale_src, 1, :)
+            Δw = similar(w)
+            check(@ccall libgnnmp.gnnmp_edge_dot_plan_f32(plan(g).handle::Ptr{Cvoid}, devptr(Δs)::Ptr{Cvoid},
+                      devptr(xs)::Ptr{Cvoid}, devptr(Δw)::Ptr{Cvoid}, D::Int64, stream_ptr()::Ptr{Cvoid})::Cint)
+        end
+        return NoTangent(), NoTangent(), NoTangent(), Δx, Δw
+    end
+    return y, fused_propagate_pullback
+end
+
 # ---- leaf ops for arbitrary closures: GNNGraphs/src/gatherscatter.jl:4,12-18 ------------------------------------------
+# _gather keeps NNlib's rrule semantics through its own rule: ∇gather(x, i) = scatter(+, Δ, i) on a throw-away plan
 function GNNGraphs._gather(x::ROCArray{Float32}, i::ROCVector{I}) where {I <: Union{Int32, Int64}}
     D = prod(size(x)[1:(end - 1)])
     out = similar(x, size(x)[1:(end - 1)]..., length(i))
@@ -99,19 +198,44 @@ function GNNGraphs._gather(x::ROCArray{Float32}, i::ROCVector{I}) where {I <: Un
                                            stream_ptr()::Ptr{Cvoid})::Cint)
     return out
 end
-# deterministic, edge-order scatter through the plan of the graph's targets; used by aggregate_neighbors
-function GNNlib.aggregate_neighbors(g::GNNGraph{<:COO_T}, aggr::FusedAggr, m::ROCArray{Float32})
-    check_num_edges(g, m)
-    p = plan(g)
+function scatter_plan(p::Plan, aggr, m::ROCArray{Float32}, n::Int)
     D = prod(size(m)[1:(end - 1)])
-    out = similar(m, size(m)[1:(end - 1)]..., g.num_nodes)
+    out = similar(m, size(m)[1:(end - 1)]..., n)
     check(@ccall libgnnmp.gnnmp_scatter_f32(p.handle::Ptr{Cvoid}, aggr_code(aggr)::Cint, devptr(m)::Ptr{Cvoid},
                                             devptr(out)::Ptr{Cvoid}, D::Int64, stream_ptr()::Ptr{Cvoid})::Cint)
     return out
 end
+function ChainRulesCore.rrule(::typeof(GNNGraphs._gather), x::ROCArray{Float32}, i::ROCVector{I}) where {I <: Union{Int32, Int64}}
+    y = GNNGraphs._gather(x, i)
+    n = size(x)[end]
+    function gather_pullback(Δ̄)
+        Δ = convert(typeof(y), unthunk(Δ̄))
+        ar = ROCArray(collect(I, 1:length(i)))
+        Δx = scatter_plan(Plan(ar, i, length(i), n, false), +, Δ, n)
+        return NoTangent(), Δx, NoTangent()
+    end
+    return y, gather_pullback
+end
+# deterministic, edge-order scatter through the plan of the graph's targets; used by aggregate_neighbors.  Differentiable
+# for + and mean (∇scatter = gather [./ count]); max / min closures keep the generic NNlib path (no override below).
+function GNNlib.aggregate_neighbors(g::GNNGraph{<:COO_T}, aggr::Union{typeof(+), typeof(mean)}, m::ROCArray{Float32})
+    check_num_edges(g, m)
+    scatter_edges(g, aggr, m)
+end
+scatter_edges(g, aggr, m) = scatter_plan(plan(g), aggr, m, g.num_nodes)
+function ChainRulesCore.rrule(::typeof(scatter_edges), g, aggr, m::ROCArray{Float32})
+    y = scatter_edges(g, aggr, m)
+    function scatter_edges_pullback(Δ̄)
+        Δ = convert(typeof(y), unthunk(Δ̄))
+        _, t = edge_index(g)
+        Δs = aggr === mean ? Δ ./ reshape(max.(in_count(g, false), 1f0), ntuple(_ -> 1, ndims(Δ) - 1)..., :) : Δ
+        return NoTangent(), NoTangent(), NoTangent(), GNNGraphs._gather(Δs, t)
+    end
+    return y, scatter_edges_pullback
+end
 
 # ---- softmax_edge_neighbors: GNNlib/src/utils.jl:84-97 ----------------------------------------------------------------
-function GNNlib.softmax_edge_neighbors(g::GNNGraph{<:COO_T}, e::ROCArray{Float32})
+function edge_softmax(g::GNNGraph{<:COO_T}, e::ROCArray{Float32})
     @assert size(e)[end] == g.num_edges
     H = prod(size(e)[1:(end - 1)])
     out = similar(e)
@@ -119,9 +243,21 @@ function GNNlib.softmax_edge_neighbors(g::GNNGraph{<:COO_T}, e::ROCArray{Float32
                                                  devptr(out)::Ptr{Cvoid}, H::Int64, stream_ptr()::Ptr{Cvoid})::Cint)
     return out
 end
+GNNlib.softmax_edge_neighbors(g::GNNGraph{<:COO_T}, e::ROCArray{Float32}) = edge_softmax(g, e)
+# softmax pullback per destination: Δe = α .* (Δα .- Σ_{N(i)} α Δα) — two calls of kernels that already exist
+function ChainRulesCore.rrule(::typeof(edge_softmax), g::GNNGraph{<:COO_T}, e::ROCArray{Float32})
+    α = edge_softmax(g, e)
+    function edge_softmax_pullback(Δ̄)
+        Δ = convert(typeof(α), unthunk(Δ̄))
+        _, t = edge_index(g)
+        s = GNNGraphs._gather(scatter_edges(g, +, α .* Δ), t)
+        return NoTangent(), NoTangent(), α .* (Δ .- s)
+    end
+    return α, edge_softmax_pullback
+end
 
 # ---- reduce_nodes / global_pool: GNNlib/src/utils.jl:12-16 (batch-built indicators are sorted) ---------------------------
-function GNNlib.reduce_nodes(aggr::FusedAggr, g::GNNGraph, x::AnyROCMatrix{Float32})
+function segment_pool(aggr, g::GNNGraph, x::AnyROCMatrix{Float32})
     @assert size(x)[end] == g.num_nodes
     gi = GNNGraphs.graph_indicator(g)
     D = size(x, 1)
@@ -132,21 +268,173 @@ function GNNlib.reduce_nodes(aggr::FusedAggr, g::GNNGraph, x::AnyROCMatrix{Float
                                                  stream_ptr()::Ptr{Cvoid})::Cint)
     return out
 end
+GNNlib.reduce_nodes(aggr::Union{typeof(+), typeof(mean)}, g::GNNGraph, x::AnyROCMatrix{Float32}) = segment_pool(aggr, g, x)
+function ChainRulesCore.rrule(::typeof(segment_pool), aggr, g::GNNGraph, x::AnyROCMatrix{Float32})
+    y = segment_pool(aggr, g, x)
+    function segment_pool_pullback(Δ̄)
+        Δ = convert(typeof(y), unthunk(Δ̄))
+        gi = GNNGraphs.graph_indicator(g)
+        if aggr === mean
+            cnt = segment_pool(+, g, AMDGPU.ones(Float32, 1, g.num_nodes))
+            Δ = Δ ./ max.(cnt, 1f0)
+        end
+        return NoTangent(), NoTangent(), NoTangent(), GNNGraphs._gather(Δ, gi)      # broadcast_nodes
+    end
+    return y, segment_pool_pullback
+end
 
-# ---- fused GATConv attention path: GNNlib/src/layers/conv.jl:112-150 with e === nothing, dropout = 0 --------------------
-# (called from a gat_conv method specialised on ROCArray inputs: Wx = reshape(l.dense_x(x), C, H, N) is the (C*H, N)
-#  matrix as stored, `a` is l.a as stored — see the NOTE below.)
-function gat_attention(g::GNNGraph{<:COO_T}, Wx::AnyROCMatrix{Float32}, a::ROCMatrix{Float32}, slope::Float32,
-                       bias, relu::Bool, heads::Int, chout::Int; self_loops::Bool)
-    out = similar(Wx)
-    check(@ccall libgnnmp.gnnmp_gat_conv_f32(plan(g; self_loops).handle::Ptr{Cvoid}, devptr(Wx)::Ptr{Cvoid},
-                                             C_NULL::Ptr{Cvoid}, devptr(a)::Ptr{Cvoid}, slope::Cfloat,
-                                             devptr(bias)::Ptr{Cvoid}, Cint(relu)::Cint, devptr(out)::Ptr{Cvoid},
-                                             heads::Int64, chout::Int64, stream_ptr()::Ptr{Cvoid})::Cint)
+# ---- dense: act.(W * x1 (+ W2 * x2) .+ b) on the fp32 MFMA kernels -------------------------------------------------------
+function dense(W::ROCMatrix{Float32}, x::AnyROCMatrix{Float32}, b, σ; W2 = nothing, x2 = nothing)
+    Dout, D1 = size(W)
+    @assert size(x, 1) == D1
+    N = size(x, 2)
+    D2 = x2 === nothing ? 0 : size(x2, 1)
+    code = act_code(σ)
+    out = similar(x, Dout, N)
+    bias = b isa AbstractArray ? b : nothing                      # Flux stores `false` for bias = false
+    check(@ccall libgnnmp.gnnmp_dense_f32(devptr(x)::Ptr{Cvoid}, devptr(W)::Ptr{Cvoid}, D1::Int64, Dout::Int64,
+              devptr(x2)::Ptr{Cvoid}, devptr(W2)::Ptr{Cvoid}, D2::Int64, Dout::Int64, 1::Cint, devptr(bias)::Ptr{Cvoid},
+              something(code, Cint(0))::Cint, devptr(out)::Ptr{Cvoid}, N::Int64, Dout::Int64, stream_ptr()::Ptr{Cvoid})::Cint)
+    return code === nothing ? σ.(out) : out
+end
+function ChainRulesCore.rrule(::typeof(dense), W::ROCMatrix{Float32}, x::AnyROCMatrix{Float32}, b, σ)
+    code = act_code(σ)
+    code === nothing && error("gnnmp dense adjoint covers identity and relu; use Flux.Dense for other activations")
+    y = dense(W, x, b, σ)
+    function dense_pullback(Δ̄)
+        Δ = convert(typeof(y), unthunk(Δ̄))
+        Dout, K = size(W)
+        N = size(x, 2)
+        Δz = similar(Δ)
+        check(@ccall libgnnmp.gnnmp_act_grad_f32(devptr(Δ)::Ptr{Cvoid}, devptr(y)::Ptr{Cvoid}, code::Cint, devptr(Δz)::Ptr{Cvoid},
+                  length(Δ)::Int64, stream_ptr()::Ptr{Cvoid})::Cint)
+        nws = @ccall libgnnmp.gnnmp_dense_grad_workspace(N::Int64, Dout::Int64, K::Int64)::Int64
+        ws = AMDGPU.zeros(Float32, max(nws, 1))
+        ΔWt = similar(W, K, Dout)                                 # the kernel writes C row-major [Dout][K] = Julia (K, Dout)
+        Δb = b isa AbstractArray ? similar(b) : nothing
+        check(@ccall libgnnmp.gnnmp_dense_grad_w_f32(devptr(Δz)::Ptr{Cvoid}, devptr(x)::Ptr{Cvoid}, N::Int64, Dout::Int64,
+                  K::Int64, devptr(ΔWt)::Ptr{Cvoid}, devptr(Δb)::Ptr{Cvoid}, devptr(ws)::Ptr{Cvoid}, length(ws)::Int64,
+                  stream_ptr()::Ptr{Cvoid})::Cint)
+        # Δx = W' * Δz: the forward kernel with the weight read the other way round (w_layout = 0: Julia (Dout, K) is C [K][Dout])
+        Δx = similar(x)
+        check(@ccall libgnnmp.gnnmp_dense_f32(devptr(Δz)::Ptr{Cvoid}, devptr(W)::Ptr{Cvoid}, Dout::Int64, Dout::Int64,
+                  C_NULL::Ptr{Cvoid}, C_NULL::Ptr{Cvoid}, 0::Int64, 0::Int64, 0::Cint, C_NULL::Ptr{Cvoid}, 0::Cint,
+                  devptr(Δx)::Ptr{Cvoid}, N::Int64, K::Int64, stream_ptr()::Ptr{Cvoid})::Cint)
+        return NoTangent(), permutedims(ΔWt), Δx, (Δb === nothing ? NoTangent() : Δb), NoTangent()
+    end
+    return y, dense_pullback
+end
+
+# ---- gcn_conv: GNNlib/src/layers/conv.jl:14-72 on ROCm arrays ------------------------------------------------------------
+# Same statements as the reference body, with (i) add_self_loops inside the plan instead of an index concatenation,
+# (ii) `xj .* cout'`, the propagate and `x .* cin'` as ONE kernel (the scalings are its per-node factors), (iii) `weight * x`,
+# `.+ bias`, σ on the MFMA kernel — and, when Dout >= Din and nothing is being differentiated, aggregation and product in one
+# launch (gnnmp_fused_conv_f32).  Every step is a wrapper with an rrule, so Zygote differentiates the composition.
+function gcn_normalisation(l, g::GNNGraph, edge_weight, norm_fn)
+    p = plan(g; self_loops = l.add_self_loops)
+    w = edge_weight !== nothing ? edge_weight : (l.use_edge_weight ? get_edge_weight(g) : nothing)
+    d = AMDGPU.zeros(Float32, g.num_nodes)
+    check(@ccall libgnnmp.gnnmp_degree_f32(p.handle::Ptr{Cvoid}, devptr(w)::Ptr{Cvoid}, devptr(d)::Ptr{Cvoid},
+                                           stream_ptr()::Ptr{Cvoid})::Cint)   # plan-added self loops weigh 1 (conv.jl:28-33)
+    return norm_fn(d), w
+end
+@non_differentiable gcn_normalisation(::Any...)
+
+function GNNlib.gcn_conv(l, g::GNNGraph{<:COO_T}, x::AnyROCMatrix{Float32}, edge_weight::EW, norm_fn::F,
+                         conv_weight::CW) where {EW <: Union{Nothing, ROCVector{Float32}}, CW <: Union{Nothing, ROCMatrix{Float32}}, F}
+    GNNlib.check_gcnconv_input(g, edge_weight)
+    weight = conv_weight === nothing ? l.weight : conv_weight
+    size(weight) == size(l.weight) ||
+        throw(ArgumentError("The weight matrix has the wrong size. Expected $(size(l.weight)) but got $(size(weight))"))
+    check_num_nodes(g, x)
+    Dout, Din = size(weight)
+    c, w = gcn_normalisation(l, g, edge_weight, norm_fn)
+    if Dout < Din
+        x = dense(weight, x, nothing, identity)                    # multiply before convolution (conv.jl:36-40)
+    end
+    x = fused_propagate(g, +, x, w; self_loops = l.add_self_loops, scale_src = c, scale_dst = c)
+    if Dout >= Din
+        return dense(weight, x, l.bias, l.σ)
+    end
+    return l.σ.(x .+ l.bias)
+end
+
+# inference-only one-kernel form of the Dout >= Din branch (call it from a layer's forward when no gradient is needed)
+function gcn_conv_fused(l, g::GNNGraph{<:COO_T}, x::AnyROCMatrix{Float32}; norm_fn = d -> 1f0 ./ sqrt.(d))
+    weight = l.weight
+    Dout, Din = size(weight)
+    code = act_code(l.σ)
+    (Dout >= Din && code !== nothing) || return GNNlib.gcn_conv(l, g, x, nothing, norm_fn, nothing)
+    c, w = gcn_normalisation(l, g, nothing, norm_fn)
+    out = similar(x, Dout, g.num_nodes)
+    bias = l.bias isa AbstractArray ? l.bias : nothing
+    st = @ccall libgnnmp.gnnmp_fused_conv_f32(plan(g; self_loops = l.add_self_loops).handle::Ptr{Cvoid}, SUM::Cint,
+              devptr(x)::Ptr{Cvoid}, devptr(w)::Ptr{Cvoid}, devptr(c)::Ptr{Cvoid}, C_NULL::Ptr{Cvoid}, C_NULL::Ptr{Cvoid},
+              devptr(c)::Ptr{Cvoid}, Din::Int64, C_NULL::Ptr{Cvoid}, 0::Int64, C_NULL::Ptr{Cvoid}, 0::Int64,
+              devptr(weight)::Ptr{Cvoid}, Dout::Int64, 1::Cint, devptr(bias)::Ptr{Cvoid}, code::Cint, devptr(out)::Ptr{Cvoid},
+              Dout::Int64, C_NULL::Ptr{Cvoid}, stream_ptr()::Ptr{Cvoid})::Cint
+    st == EUNSUPPORTED && return GNNlib.gcn_conv(l, g, x, nothing, norm_fn, nothing)   # shape outside the fused kernel
+    check(st)
     return out
 end
-# NOTE on `a`: Julia stores l.a of size (2C, H) column-major = C row-major [H][2C]: exactly the layout gnnmp.h asks for,
-# so `l.a` itself is passed — no permutedims.
+
+# ---- gat_conv: GNNlib/src/layers/conv.jl:112-167 with e === nothing -------------------------------------------------------
+# Wx = reshape(l.dense_x(x), C, H, N) is the (C*H, N) matrix as stored; l.a (2C, H) column-major is C row-major [H][2C]:
+# exactly the layout gnnmp.h asks for, so `l.a` itself is passed — no permutedims.  The forward saves (max, denominator)
+# per destination and head for the pullback (8 bytes instead of α: 4 H bytes per EDGE).
+function gat_attention(g::GNNGraph{<:COO_T}, Wx::AnyROCMatrix{Float32}, a::ROCMatrix{Float32}, slope::Float32,
+                       heads::Int, self_loops::Bool)
+    out, _ = gat_attention_stats(g, Wx, a, slope, heads, self_loops, false)
+    return out
+end
+function gat_attention_stats(g, Wx, a, slope, heads, self_loops, want_stats)
+    chout = size(Wx, 1) ÷ heads
+    out = similar(Wx)
+    p = plan(g; self_loops)
+    if want_stats
+        stats = similar(Wx, 2, heads, g.num_nodes)
+        check(@ccall libgnnmp.gnnmp_gat_conv_stats_f32(p.handle::Ptr{Cvoid}, devptr(Wx)::Ptr{Cvoid}, C_NULL::Ptr{Cvoid},
+                  devptr(a)::Ptr{Cvoid}, slope::Cfloat, C_NULL::Ptr{Cvoid}, 0::Cint, devptr(out)::Ptr{Cvoid},
+                  devptr(stats)::Ptr{Cvoid}, heads::Int64, chout::Int64, stream_ptr()::Ptr{Cvoid})::Cint)
+        return out, stats
+    end
+    check(@ccall libgnnmp.gnnmp_gat_conv_f32(p.handle::Ptr{Cvoid}, devptr(Wx)::Ptr{Cvoid}, C_NULL::Ptr{Cvoid},
+              devptr(a)::Ptr{Cvoid}, slope::Cfloat, C_NULL::Ptr{Cvoid}, 0::Cint, devptr(out)::Ptr{Cvoid}, heads::Int64,
+              chout::Int64, stream_ptr()::Ptr{Cvoid})::Cint)
+    return out, nothing
+end
+function ChainRulesCore.rrule(::typeof(gat_attention), g::GNNGraph{<:COO_T}, Wx::AnyROCMatrix{Float32}, a::ROCMatrix{Float32},
+                              slope::Float32, heads::Int, self_loops::Bool)
+    out, stats = gat_attention_stats(g, Wx, a, slope, heads, self_loops, true)
+    function gat_attention_pullback(Δ̄)
+        Δ = convert(typeof(out), unthunk(Δ̄))
+        chout = size(Wx, 1) ÷ heads
+        N = g.num_nodes
+        ΔWx, Δa = similar(Wx), similar(a)
+        line = similar(Wx, 4, heads, N)                           # scratch the kernel asks the caller for (gnnmp.h)
+        dsd, dss = similar(Wx, heads, N), similar(Wx, heads, N)
+        check(@ccall libgnnmp.gnnmp_gat_conv_grad_f32(plan(g; self_loops).handle::Ptr{Cvoid},
+                  plan(g; self_loops, transposed = true).handle::Ptr{Cvoid}, devptr(Wx)::Ptr{Cvoid}, C_NULL::Ptr{Cvoid},
+                  devptr(a)::Ptr{Cvoid}, slope::Cfloat, devptr(stats)::Ptr{Cvoid}, devptr(Δ)::Ptr{Cvoid},
+                  devptr(line)::Ptr{Cvoid}, devptr(dsd)::Ptr{Cvoid}, devptr(dss)::Ptr{Cvoid}, devptr(ΔWx)::Ptr{Cvoid},
+                  C_NULL::Ptr{Cvoid}, devptr(Δa)::Ptr{Cvoid}, heads::Int64, chout::Int64, stream_ptr()::Ptr{Cvoid})::Cint)
+        return NoTangent(), NoTangent(), ΔWx, Δa, NoTangent(), NoTangent(), NoTangent()
+    end
+    return out, gat_attention_pullback
+end
+
+function GNNlib.gat_conv(l, g::GNNGraph{<:COO_T}, x::AnyROCMatrix{Float32}, e::Nothing = nothing)
+    check_num_nodes(g, x)
+    @assert l.dense_e === nothing "Input edge features required for this layer"
+    l.dropout == 0 || return invoke(GNNlib.gat_conv, Tuple{Any, GNNlib.AbstractGNNGraph, Any, Nothing}, l, g, x, e)
+    _, chout = l.channel
+    Wx = l.dense_x(x)                                              # (C*H, N)
+    y = gat_attention(g, Wx, l.a, Float32(l.negative_slope), l.heads, l.add_self_loops)
+    if !l.concat
+        y = reshape(mean(reshape(y, chout, l.heads, :), dims = 2), chout, :)
+    end
+    return l.σ.(y .+ l.bias)
+end
 
 # ---- the other attention layers on the same one-pass kernel (gnnmp_attn_conv_f32) -----------------------------------------
 # mode 1: gatv2_conv (conv.jl:171-214; Q = Wxi, K = Wxj, a = l.a (C, H) as stored)   mode 2: transformer_conv attention
@@ -170,35 +458,5 @@ function GNNGraphs.sort_edge_index(u::ROCVector{I}, v::ROCVector{I}) where {I <:
                                                 stream_ptr()::Ptr{Cvoid})::Cint)
     return uo, vo
 end
-
-# ---- adjoints (needs ChainRulesCore as a further weakdep) ---------------------------------------------------------------
-# Zygote reaches the methods above only if they carry rrules.  The pullback of the fused propagate w.r.t. xj is the same
-# kernel on the plan of the reversed edge index; w.r.t. the edge weights it is one dot product per edge; max / min have
-# their own kernel.  (Mirror of graphneuralnetworks.jl_amd/gnnmp/backward.py, which is tested against NNlib's rules.)
-#
-# using ChainRulesCore
-# plan_t(g; self_loops = false) = (s, t = edge_index(g); Plan(t, s, g.num_nodes, g.num_nodes, self_loops))   # cached like plan()
-#
-# function ChainRulesCore.rrule(::typeof(fused_propagate), g, aggr::Union{typeof(+), typeof(mean)}, xj, w; kws...)
-#     y = fused_propagate(g, aggr, xj, w; kws...)
-#     function pullback(Δ)
-#         Δ = unthunk(Δ); D = size(Δ, 1)
-#         sd = aggr === mean ? 1f0 ./ max.(degree(g, Float32; dir = :in), 1f0) : nothing
-#         Δx = similar(xj)
-#         check(@ccall libgnnmp.gnnmp_propagate_f32(plan_t(g).handle::Ptr{Cvoid}, (w === nothing ? 0 : 1)::Cint, SUM::Cint,
-#                   devptr(Δ)::Ptr{Cvoid}, devptr(w)::Ptr{Cvoid}, devptr(sd)::Ptr{Cvoid}, C_NULL::Ptr{Cvoid},
-#                   devptr(Δx)::Ptr{Cvoid}, D::Int64, stream_ptr()::Ptr{Cvoid})::Cint)
-#         Δw = w === nothing ? NoTangent() : begin
-#             out = similar(w)
-#             Δs = sd === nothing ? Δ : Δ .* sd'
-#             check(@ccall libgnnmp.gnnmp_edge_dot_plan_f32(plan(g).handle::Ptr{Cvoid}, devptr(Δs)::Ptr{Cvoid},
-#                       devptr(xj)::Ptr{Cvoid}, devptr(out)::Ptr{Cvoid}, D::Int64, stream_ptr()::Ptr{Cvoid})::Cint)
-#             out
-#         end
-#         return NoTangent(), NoTangent(), NoTangent(), Δx, Δw
-#     end
-#     return y, pullback
-# end
-# (max / min: gnnmp_propagate_maxmin_grad_f32(plan_t(g).handle, xj, y, Δ, Δx, D, stream).)
 
 end # module
