@@ -28,8 +28,13 @@ struct T16Args {
     int dbg;                // experiment bits: 1 = no stores, 2 = no x loads (same row for every tile)
 };
 
+// threads per block the register budget allows: four waves per SIMD (<= 128 VGPRs) up to seven column blocks; with eight, the
+// accumulators (32) + two row buffers (2 x 28-32) + the two-deep A-operand buffer (32) need ~140: three waves per SIMD
+template <int NCB>
+constexpr int t16_max_threads() { return NCB >= 8 ? 768 : 1024; }
+
 template <int NCB, int MAXB, int KQ1, int KQ2>
-__global__ void __launch_bounds__(1024) dense_t16_kernel(const T16Args a) {
+__global__ void __launch_bounds__(t16_max_threads<NCB>()) dense_t16_kernel(const T16Args a) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     constexpr int DP = NCB * 16;
     f32x4 *img = reinterpret_cast<f32x4 *>(lds_raw);
@@ -130,9 +135,10 @@ static int launch_t16(const T16Args &a0, hipStream_t stream) {
     const int cus = device_cus();
     const int64_t ntiles = (a.N + 15) / 16;
     // waves per block: 16 (four per SIMD) on large inputs; on small ones fewer, so that every CU gets a block
-    int waves = (int)std::min<int64_t>(16, std::max<int64_t>(4, (ntiles + cus - 1) / cus));
+    constexpr int max_waves = t16_max_threads<NCB>() / 64;
+    int waves = (int)std::min<int64_t>(max_waves, std::max<int64_t>(4, (ntiles + cus - 1) / cus));
     const int kw = knob(KNOB_DENSE_T16_WAVES);
-    if (kw >= 1 && kw <= 16) waves = kw;
+    if (kw >= 1 && kw <= max_waves) waves = kw;
     a.waves = waves;
     a.dbg = knob(KNOB_T16_DEBUG);
     const int64_t gx = std::min<int64_t>(cus, (ntiles + waves - 1) / waves);

@@ -113,24 +113,81 @@ __device__ __forceinline__ void t16_load(float4 (&xv)[MAXB], int q, XLoad xload)
         }
     }
 }
-// ... and run the segment's blocks on them.  sched_barriers keep hipcc from hoisting every block's LDS reads to the top of
-// the unrolled code (49 x 4 registers: it spilled 100-190 VGPRs).
+// ... and run the segment's blocks on them, as a software pipeline over GROUPS of up to four column blocks: while the MFMAs of
+// group S run (16 instructions, 512 cycles of the matrix pipe), the A operands of group S + 1 — the next column blocks of this
+// k-block, or the first ones of the next k-block — are already being read from LDS into the other half of a two-deep
+// register buffer.  Left to itself hipcc issues each group's ds_reads immediately before the MFMAs that need them: every
+// k-block then starts with an exposed LDS round trip (PMC: matrix pipe 82 % busy with NO memory traffic at all).  The
+// sched_barriers pin the order (and keep hipcc from hoisting ALL reads to the top: 49 x 4 registers, 100-190 spills).
+template <int NCB, int KQ>
+struct T16Steps {
+    static constexpr int nfull = KQ >> 2, rem = KQ & 3;
+    static constexpr int NG = (NCB + 3) / 4;                       // groups per k-block
+    static constexpr int nblocks = nfull + (rem ? 1 : 0);
+    static constexpr int total = nblocks * NG;
+};
+// read group S's A operands: full blocks (and rem > 1 tails) one ds_read_b128 per column block; a rem = 1 tail one scalar
+template <int NCB, int KQ, int S>
+__device__ __forceinline__ void t16_group_read(f32x4 (&w)[4], const f32x4 *__restrict__ img, int kq0, int n, int q) {
+    using St = T16Steps<NCB, KQ>;
+    constexpr int DP = NCB * 16;
+    constexpr int j = S / St::NG, c0 = (S % St::NG) * 4;
+    if constexpr (j < St::nfull || St::rem > 1) {
+        const f32x4 *wr = img + (kq0 + 4 * j + q) * DP + n + 16 * c0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c0 + c < NCB) w[c] = wr[16 * c];
+    } else {
+        const float *wr = reinterpret_cast<const float *>(img + (kq0 + 4 * j) * DP + n + 16 * c0) + q;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c0 + c < NCB) w[c][0] = wr[64 * c];
+    }
+}
+template <int NCB, int KQ, int S, int MAXB>
+__device__ __forceinline__ void t16_group_mfma(f32x4 (&acc)[NCB], const f32x4 (&w)[4], const float4 (&xv)[MAXB], int q) {
+    using St = T16Steps<NCB, KQ>;
+    constexpr int j = S / St::NG, c0 = (S % St::NG) * 4;
+    if constexpr (j < St::nfull || St::rem > 1) {
+        // i-major: consecutive MFMAs never share an accumulator (a dependent 16x16x4 pair costs 40 cycles instead of 32)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c0 + c < NCB) acc[c0 + c] = mfma16(w[c][0], xv[j].x, acc[c0 + c]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c0 + c < NCB) acc[c0 + c] = mfma16(w[c][1], xv[j].y, acc[c0 + c]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c0 + c < NCB) acc[c0 + c] = mfma16(w[c][2], xv[j].z, acc[c0 + c]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c0 + c < NCB) acc[c0 + c] = mfma16(w[c][3], xv[j].w, acc[c0 + c]);
+    } else {
+        const float xs = q == 0 ? xv[j].x : (q == 1 ? xv[j].y : (q == 2 ? xv[j].z : xv[j].w));
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c0 + c < NCB) acc[c0 + c] = mfma16(w[c][0], xs, acc[c0 + c]);
+    }
+}
+template <int NCB, int MAXB, int KQ, int S>
+__device__ __forceinline__ void t16_pipeline(f32x4 (&acc)[NCB], const f32x4 *__restrict__ img, int kq0, int n, int q,
+                                             const float4 (&xv)[MAXB], f32x4 (&wa)[4], f32x4 (&wb)[4]) {
+    using St = T16Steps<NCB, KQ>;
+    if constexpr (S < St::total) {
+        // wa holds group S; fetch group S + 1 into wb, then compute S from wa; roles swap in the next step
+        if constexpr (S + 1 < St::total) t16_group_read<NCB, KQ, S + 1>(wb, img, kq0, n, q);
+        __builtin_amdgcn_sched_barrier(0);
+        t16_group_mfma<NCB, KQ, S, MAXB>(acc, wa, xv, q);
+        __builtin_amdgcn_sched_barrier(0);
+        t16_pipeline<NCB, MAXB, KQ, S + 1>(acc, img, kq0, n, q, xv, wb, wa);
+    }
+}
 template <int NCB, int MAXB, int KQ>
 __device__ __forceinline__ void t16_compute(f32x4 (&acc)[NCB], const f32x4 *__restrict__ img, int kq0, int n, int q,
                                             const float4 (&xv)[MAXB]) {
-    constexpr int DP = NCB * 16;
-    constexpr int nfull = KQ >> 2, rem = KQ & 3;
-#pragma unroll
-    for (int j = 0; j < MAXB; ++j) {
-        if (j < nfull || (j == nfull && rem > 1)) {
-            __builtin_amdgcn_sched_barrier(0);
-            t16_block<NCB>(acc, img + (kq0 + 4 * j + q) * DP + n, xv[j]);
-        } else if (j == nfull && rem == 1) {
-            __builtin_amdgcn_sched_barrier(0);
-            t16_tail1<NCB>(acc, img + (kq0 + 4 * j) * DP, n, q, xv[j]);
-        }
-    }
-    __builtin_amdgcn_sched_barrier(0);
+    f32x4 wa[4], wb[4];
+    t16_group_read<NCB, KQ, 0>(wa, img, kq0, n, q);
+    t16_pipeline<NCB, MAXB, KQ, 0>(acc, img, kq0, n, q, xv, wa, wb);
 }
 
 // Run-time K: a loop over the blocks with the next block's load in flight during the current block's MFMAs.
