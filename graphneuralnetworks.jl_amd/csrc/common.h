@@ -43,7 +43,8 @@ enum Knob {
     KNOB_DENSE_T16_WAVES = 12, // dense_t16_kernel: waves per block (0 = auto, else 1..16)
     KNOB_T16_DEBUG = 13,       // dense_t16_kernel phase ablation (experiments only): 1 = no stores, 2 = no x loads
     KNOB_FUSED_WAVES = 14,     // fused_conv_kernel: 0 = auto (as many waves as LDS holds tiles for, <= 16), > 0 = cap, < 0 = never fuse
-    KNOB_ROW_ORDER = 15,       // 1 (default) = row kernels that share a wave between rows walk rows by decreasing length, 0 = by index
+    KNOB_ROW_ORDER = 15,       // rows by decreasing length in the row kernels that share a wave between rows: 0 = never,
+                               // 1 (default) = when the gathered matrix exceeds the Infinity Cache, 2 = always (use_row_order)
     KNOB_COUNT = 16
 };
 int knob(int k);
@@ -249,6 +250,16 @@ inline bool use_xcd_remap(int64_t n_src, int64_t D, int64_t chunks) {
     if (k == 0 || chunks < 64) return false;
     if (k == 2) return true;
     return n_src * D * (int64_t)sizeof(float) <= ((int64_t)128 << 20);
+}
+// Walk rows by decreasing length (gnnmp_graph::row_order)?  Only where the walk streams from HBM: knob 15 = 1 (default) applies it
+// when the gathered matrix does NOT fit the Infinity Cache (products shape: one-pass attention 5.08 -> 4.92 ms); on the arxiv
+// shape (everything cache-resident, split rows and the heaviest rows first in the order) it measured 175 -> 184 us, and 261 us
+// together with the XCD-contiguous block mapping, which then puts all heavy rows on one XCD.  knob 15 = 2 forces it.
+inline bool use_row_order(int64_t n_src, int64_t D) {
+    const int k = knob(KNOB_ROW_ORDER);
+    if (k == 0) return false;
+    if (k == 2) return true;
+    return n_src * D * (int64_t)sizeof(float) > ((int64_t)128 << 20);
 }
 // lanes per row group: smallest power of two >= D / vec, clamped to [1, 64]
 inline int pick_log2g(int64_t lanes_needed) {

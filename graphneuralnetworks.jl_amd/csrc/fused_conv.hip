@@ -281,7 +281,7 @@ extern "C" int gnnmp_fused_conv_f32(gnnmp_graph_t *p, int aggr, const float *xj,
     r.log2g = pick_log2g((D + 3) / 4);
     // >= 2 rows per wave: the rows of a wave should be equally long (only when output rows are whole 128-byte lines, see
     // run_reduce in propagate.hip: measured 4.98 -> 6.02 ms with 400-byte rows)
-    if (knob(KNOB_ROW_ORDER) != 0 && r.log2g <= 5 && (Dout & 31) == 0 && (reinterpret_cast<uintptr_t>(out) & 127) == 0) {
+    if (use_row_order(p->n_src, D) && r.log2g <= 5 && (Dout & 31) == 0 && (reinterpret_cast<uintptr_t>(out) & 127) == 0) {
         if (int rc = ensure_row_order(p, stream)) return rc;
         r.row_order = p->row_order;
     }

@@ -510,7 +510,7 @@ static int attn_conv_impl(gnnmp_graph_t *plan, int mode, const float *Q, const f
     GatFusedArgs g;
     g.rowptr = plan->rowptr;
     g.row_order = nullptr;
-    if (knob(KNOB_ROW_ORDER) != 0 && lanes <= 32) {   // two or more rows per wave: pair rows of equal length
+    if (use_row_order(plan->n_src, D) && lanes <= 32) {   // two or more rows per wave: pair rows of equal length
         if (int rc = ensure_row_order(plan, stream)) return rc;
         g.row_order = plan->row_order;
     }

@@ -374,7 +374,7 @@ int run_reduce(gnnmp_graph_t *p, const int32_t *idx, int aggr, const float *x, c
     a.log2g = pick_log2g((D + vec - 1) / vec);
     // >= 2 rows per wave: pair rows of equal length — but only when an output row is whole 128-byte lines: out of index order,
     // rows of 400 bytes (D = 100) leave every line half written by one wave and finished by another, measured 4.75 -> 5.11 ms
-    if (!long_only && knob(KNOB_ROW_ORDER) != 0 && a.log2g <= 5 && idx == p->col && (D & 31) == 0 &&
+    if (!long_only && use_row_order(p->n_src, D) && a.log2g <= 5 && idx == p->col && (D & 31) == 0 &&
         (reinterpret_cast<uintptr_t>(out) & 127) == 0) {
         if (int rc = ensure_row_order(p, stream)) return rc;
         a.row_order = p->row_order;

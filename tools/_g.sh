@@ -1,4 +1,6 @@
-python tools/dense_t16_bench.py waves=0,8,12
-python tools/dense_small.py shape=2449029,100,100 13=3
-python tools/dense_small.py shape=2449029,100,128 13=3
-python tools/gcn_layer_one.py
+python tools/small_configs.py arxiv 15=0
+python tools/small_configs.py arxiv 15=1
+python tools/small_configs.py arxiv 15=1 3=0
+python tools/small_configs.py arxiv 15=0 3=0
+python tools/small_configs.py batched 15=0
+python tools/small_configs.py batched 15=1
