@@ -43,8 +43,8 @@ enum Knob {
     KNOB_DENSE_T16_WAVES = 12, // dense_t16_kernel: waves per block (0 = auto, else 1..16)
     KNOB_T16_DEBUG = 13,       // dense_t16_kernel phase ablation (experiments only): 1 = no stores, 2 = no x loads
     KNOB_FUSED_WAVES = 14,     // fused_conv_kernel: 0 = auto (as many waves as LDS holds tiles for, <= 16), > 0 = cap, < 0 = never fuse
-    KNOB_ROW_ORDER = 15,       // rows by decreasing length in the row kernels that share a wave between rows: 0 = never,
-                               // 1 (default) = when the gathered matrix exceeds the Infinity Cache, 2 = always (use_row_order)
+    KNOB_ROW_ORDER = 15,       // rows by decreasing length in the row kernels that share a wave between rows: 0 (default) = never,
+                               // 1 = when the gathered matrix exceeds the Infinity Cache, 2 = always (use_row_order)
     KNOB_COUNT = 16
 };
 int knob(int k);
@@ -251,10 +251,15 @@ inline bool use_xcd_remap(int64_t n_src, int64_t D, int64_t chunks) {
     if (k == 2) return true;
     return n_src * D * (int64_t)sizeof(float) <= ((int64_t)128 << 20);
 }
-// Walk rows by decreasing length (gnnmp_graph::row_order)?  Only where the walk streams from HBM: knob 15 = 1 (default) applies it
-// when the gathered matrix does NOT fit the Infinity Cache (products shape: one-pass attention 5.08 -> 4.92 ms); on the arxiv
-// shape (everything cache-resident, split rows and the heaviest rows first in the order) it measured 175 -> 184 us, and 261 us
-// together with the XCD-contiguous block mapping, which then puts all heavy rows on one XCD.  knob 15 = 2 forces it.
+// Walk rows by decreasing length (gnnmp_graph::row_order)?  OFF by default (knob 15 = 0).  The idea: a wave shares its lanes
+// between two or more rows and runs as long as the longest, so pairing rows of equal length removes idle issue slots (products
+// shape: 1.43x -> 1.13x of the perfectly packed instruction count).  Measured on the one-pass attention kernel, products shape:
+// one box 5.08 -> 4.92 ms, five later boxes 5.17 -> 5.38 ms (same binary, same-box A/B each time; sustained back-to-back
+// launches 4.82 vs 4.92 ms at 1 350-1 370 W of the 1 400 W socket limit): the kernel sits at the HBM / power limit and the
+// scattered row order costs as much as the saved issue slots give.  With 400-byte rows (D = 100) it is plainly worse (every
+// 128-byte line of the output is finished by a different wave: 4.75 -> 5.11 ms), and on cache-resident graphs too (arxiv shape
+// 175 -> 184 us; 261 us with the XCD-contiguous block mapping, which puts all heavy rows on one XCD).  knob 15 = 1: on when
+// the gathered matrix exceeds the Infinity Cache; 2: always.
 inline bool use_row_order(int64_t n_src, int64_t D) {
     const int k = knob(KNOB_ROW_ORDER);
     if (k == 0) return false;
