@@ -107,6 +107,9 @@ template <>
 struct Vec<4> {
     using T = float4;
     static __device__ __forceinline__ void load(const float *p, float v[4]) {
+        // (a streaming / `nt` hint on these row gathers was tried: 5.18 -> 6.84 ms on the one-pass attention kernel,
+        // 4.75 -> 6.52 ms on the GCN propagate, products shape — the L2 line fills it skips are the coalescing buffer of the
+        // four lanes that share a 64-byte sector)
         float4 t = *reinterpret_cast<const float4 *>(p);
         v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
     }
