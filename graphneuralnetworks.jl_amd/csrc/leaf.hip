@@ -144,6 +144,52 @@ __global__ void __launch_bounds__(256) segment_pool_kernel(const float *x, const
     }
 }
 
+// Segment boundaries of a sorted indicator, O(1) depth: node i starts every graph id in (seg[i-1], seg[i]] (empty graphs between
+// two non-empty ones start — and end — where the next one starts); ids past the last node's graph start at N.
+__global__ void __launch_bounds__(256) segment_bounds_kernel(const void *seg, int idx_bytes, int base, int64_t N, int64_t Gn,
+                                                             int64_t *ptr) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > N) return;
+    const int64_t prev = i == 0 ? -1 : load_index(seg, i - 1, idx_bytes, base);
+    const int64_t cur = i == N ? Gn : load_index(seg, i, idx_bytes, base);
+    for (int64_t k = max(prev + 1, (int64_t)0); k <= min(cur, Gn); ++k) ptr[k] = i;
+}
+
+// reduce_nodes with the boundaries given: one lane group per graph streams its contiguous rows, 8 in flight, sum in node order
+template <int VEC, int OP>
+__global__ void __launch_bounds__(256) segment_pool_ptr_kernel(const float *x, const int64_t *ptr, float *out, int D, int64_t Gn,
+                                                               int log2g, int mean) {
+    const int G = 1 << log2g;
+    const int lig = threadIdx.x & (G - 1);
+    const int64_t g = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> log2g;
+    if (g >= Gn) return;
+    const int64_t beg = ptr[g], end = ptr[g + 1];
+    const float cnt = (float)(end - beg);
+    constexpr int U = 8;
+    for (int f = lig * VEC; f < D; f += G * VEC) {
+        float acc[VEC];
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) acc[q] = op_identity<OP>();
+        for (int64_t n = beg; n < end; n += U) {
+            float v[U][VEC];
+#pragma unroll
+            for (int u = 0; u < U; ++u) Vec<VEC>::load(x + min(n + u, end - 1) * D + f, v[u]);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (n + u < end) {
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) acc[q] = op_apply<OP>(acc[q], v[u][q]);
+                }
+            }
+        }
+        if (OP == OP_SUM && mean) {
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) acc[q] = 0.0f + (end == beg ? acc[q] : acc[q] / cnt);
+        }
+        Vec<VEC>::store(out + g * D + f, acc);
+    }
+}
+
 // ---- small elementwise helpers so that no arithmetic of the layer bodies is left to the host framework --------------
 __global__ void __launch_bounds__(256) add_kernel(const float *a, const float *b, float *out, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -601,6 +647,48 @@ int gnnmp_segment_pool_f32(int aggr, const float *x, const void *seg_ids, int id
 #undef POOL_OP
 #undef POOL_LAUNCH
     GNNMP_LAUNCH_CHECK("segment_pool_kernel");
+    return GNNMP_OK;
+}
+
+int gnnmp_segment_bounds(const void *seg_ids, int idx_bytes, int index_base, int64_t N, int64_t G, int64_t *ptr,
+                         gnnmp_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (idx_bytes != 4 && idx_bytes != 8) return fail(GNNMP_EINVAL, "segment_bounds: idx_bytes %d", idx_bytes);
+    if (index_base != 0 && index_base != 1) return fail(GNNMP_EINVAL, "segment_bounds: index_base %d", index_base);
+    if (N < 0 || G < 0) return fail(GNNMP_EINVAL, "segment_bounds: bad size");
+    if (!ptr || (N > 0 && !seg_ids)) return fail(GNNMP_EINVAL, "segment_bounds: null pointer");
+    segment_bounds_kernel<<<(unsigned)((N + 1 + 255) / 256), 256, 0, stream>>>(seg_ids, idx_bytes, index_base, N, G, ptr);
+    GNNMP_LAUNCH_CHECK("segment_bounds_kernel");
+    return GNNMP_OK;
+}
+
+int gnnmp_segment_pool_ptr_f32(int aggr, const float *x, const int64_t *seg_ptr, float *out, int64_t D, int64_t N, int64_t G,
+                               gnnmp_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (aggr < GNNMP_SUM || aggr > GNNMP_MIN) return fail(GNNMP_EINVAL, "segment_pool_ptr: bad aggr %d", aggr);
+    if (N < 0 || G < 0 || D < 0 || D > (1 << 20)) return fail(GNNMP_EINVAL, "segment_pool_ptr: bad size");
+    if (G == 0 || D == 0) return GNNMP_OK;
+    if (!out || !seg_ptr || (N > 0 && !x)) return fail(GNNMP_EINVAL, "segment_pool_ptr: null pointer");
+    const int vec = pick_vec(D, x, out);
+    const int log2g = pick_log2g((D + vec - 1) / vec);
+    const int64_t threads = G << log2g;
+    const unsigned nb = (unsigned)((threads + 255) / 256);
+    const int mean = aggr == GNNMP_MEAN;
+#define POOLP_LAUNCH(V, O) segment_pool_ptr_kernel<V, O><<<nb, 256, 0, stream>>>(x, seg_ptr, out, (int)D, G, log2g, mean)
+#define POOLP_OP(V)                                             \
+    do {                                                        \
+        if (aggr == GNNMP_MAX) POOLP_LAUNCH(V, OP_MAX);         \
+        else if (aggr == GNNMP_MIN) POOLP_LAUNCH(V, OP_MIN);    \
+        else POOLP_LAUNCH(V, OP_SUM);                           \
+    } while (0)
+    switch (vec) {
+        case 4: POOLP_OP(4); break;
+        case 2: POOLP_OP(2); break;
+        default: POOLP_OP(1); break;
+    }
+#undef POOLP_OP
+#undef POOLP_LAUNCH
+    GNNMP_LAUNCH_CHECK("segment_pool_ptr_kernel");
     return GNNMP_OK;
 }
 

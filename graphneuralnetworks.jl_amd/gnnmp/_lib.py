@@ -31,7 +31,7 @@ SYMBOLS = (
     "gnnmp_gat_conv_edge_f32", "gnnmp_gat_conv_stats_f32", "gnnmp_gat_conv_grad_f32", "gnnmp_attn_conv_f32",
     "gnnmp_attn_conv_grad_f32",
     "gnnmp_bias_act_f32",
-    "gnnmp_segment_pool_f32", "gnnmp_dense_f32", "gnnmp_fused_conv_f32",
+    "gnnmp_segment_pool_f32", "gnnmp_segment_bounds", "gnnmp_segment_pool_ptr_f32", "gnnmp_dense_f32", "gnnmp_fused_conv_f32",
     "gnnmp_edge_dot_f32", "gnnmp_edge_dot_plan_f32", "gnnmp_propagate_maxmin_grad_f32",
     "gnnmp_head_mean_f32", "gnnmp_head_mean_grad_f32", "gnnmp_add_f32", "gnnmp_axpy_f32", "gnnmp_mul_rows_f32", "gnnmp_is_sorted",
     "gnnmp_act_grad_f32", "gnnmp_dense_grad_workspace", "gnnmp_dense_grad_w_f32",
@@ -97,6 +97,8 @@ def load():
         "gnnmp_gat_aggregate_f32": [vp, vp, vp, vp, f, vp, i, vp, vp, i64, i64, vp],
         "gnnmp_bias_act_f32": [vp, vp, i, vp, i64, i64, vp],
         "gnnmp_segment_pool_f32": [i, vp, vp, i, i, vp, i64, i64, i64, vp],
+        "gnnmp_segment_bounds": [vp, i, i, i64, i64, vp, vp],
+        "gnnmp_segment_pool_ptr_f32": [i, vp, vp, vp, i64, i64, i64, vp],
         "gnnmp_dense_f32": [vp, vp, i64, i64, vp, vp, i64, i64, i, vp, i, vp, i64, i64, vp],
         "gnnmp_fused_conv_f32": [vp, i, vp, vp, vp, vp, vp, vp, i64, vp, i64, vp, i64, vp, i64, i, vp, i, vp, i64, vp, vp],
         "gnnmp_edge_dot_f32": [vp, vp, vp, vp, i, i, i64, i64, vp, vp],

@@ -48,6 +48,17 @@ def reduce_nodes(aggr, g, x, num_graphs=None, sorted_indicator=None):
         plan = _segment_plan(g, gi, "nodes") if isinstance(g, GNNGraph) else _idx_plan(gi, G, base)
         return _scatter_plan(aggr, x, plan)
     out = torch.empty((G,) + tuple(x.shape[1:]), dtype=torch.float32, device=x.device)
+    if isinstance(g, GNNGraph):
+        # the segment boundaries are a constant of the batched graph (like its plans): one pass over the indicator, cached
+        sp = g._cache.get("node_ptr")
+        if sp is None:
+            sp = torch.empty(G + 1, dtype=torch.int64, device=x.device)
+            L.check(L.load().gnnmp_segment_bounds(L.ptr(gi), 8 if gi.dtype == torch.int64 else 4, base, xf.shape[0], G, L.ptr(sp),
+                                                  L.stream_ptr()))
+            g._cache["node_ptr"] = sp
+        L.check(L.load().gnnmp_segment_pool_ptr_f32(aggr_code(aggr), L.ptr(xf), L.ptr(sp), L.ptr(out), xf.shape[1], xf.shape[0], G,
+                                                    L.stream_ptr()))
+        return out
     L.check(L.load().gnnmp_segment_pool_f32(aggr_code(aggr), L.ptr(xf), L.ptr(gi), 8 if gi.dtype == torch.int64 else 4,
                                             base, L.ptr(out), xf.shape[1], xf.shape[0], G, L.stream_ptr()))
     return out

@@ -432,6 +432,14 @@ int gnnmp_bias_act_f32(const float *x, const float *bias, int act, float *out, i
 int gnnmp_segment_pool_f32(int aggr, const float *x, const void *seg_ids, int idx_bytes,
                            int index_base, float *out, int64_t D, int64_t N, int64_t G,
                            gnnmp_stream_t stream);
+/* The same with the segment boundaries precomputed — a constant of the batched graph, like its plan:
+ *   gnnmp_segment_bounds   seg_ptr[k] = first node of graph k (k = 0..G; seg_ptr[G] = N), from the sorted indicator, one pass
+ *   gnnmp_segment_pool_ptr_f32   the pooling itself: no per-call binary search of the indicator (two 18-step chains of
+ *                          dependent loads per graph at N = 245 k: half the kernel's time on the batched config) */
+int gnnmp_segment_bounds(const void *seg_ids, int idx_bytes, int index_base, int64_t N, int64_t G, int64_t *seg_ptr,
+                         gnnmp_stream_t stream);
+int gnnmp_segment_pool_ptr_f32(int aggr, const float *x, const int64_t *seg_ptr, float *out, int64_t D, int64_t N, int64_t G,
+                               gnnmp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Dense feature contraction of the layer bodies (the only MFMA work on the path):

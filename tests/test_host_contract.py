@@ -98,3 +98,19 @@ def test_khop_edge_weight_argument_is_never_served_from_a_stale_cache(gm, oracle
         ref = KO.sg_conv(s, t, n, x, l.weight.cpu().numpy(), l.bias.cpu().numpy(), 2, edge_weight=w)
         assert np.linalg.norm(y - ref) <= 1e-5 * np.linalg.norm(ref)
     assert not any(k[0] == "gcn_norm_slots" and k[2] for k in g._cache if isinstance(k, tuple))   # nothing pinned
+
+
+def test_segment_bounds_with_empty_graphs(gm, oracle):
+    """reduce_nodes through the cached segment boundaries (gnnmp_segment_bounds + gnnmp_segment_pool_ptr_f32): graphs without
+    nodes at the front, in the middle and at the end keep the identity of the aggregation, like NNlib.scatter"""
+    rng = np.random.default_rng(9)
+    gi = np.array([2, 2, 2, 4, 5, 5, 5, 5, 8, 8], np.int64)          # graphs 1, 3, 6, 7, 9, 10 are empty
+    G, n, D = 10, len(gi), 12
+    x = rng.standard_normal((n, D)).astype(np.float32)
+    g = gm.GNNGraph(dev(np.array([1, 2], np.int64)), dev(np.array([2, 3], np.int64)), num_nodes=n, graph_indicator=dev(gi),
+                    num_graphs=G)
+    for aggr in ("+", "mean", "max", "min"):
+        got = gm.reduce_nodes(aggr, g, dev(x)).cpu().numpy()
+        np.testing.assert_array_equal(got, oracle.scatter(aggr, x, gi, G))
+    sp = g._cache["node_ptr"].cpu().numpy()
+    np.testing.assert_array_equal(sp, [0, 0, 3, 3, 4, 8, 8, 8, 10, 10, 10])
