@@ -224,6 +224,10 @@ def run_rowpart(args, rank, world, dist, barrier):
 
     def local_layer(l):
         def f(h):
+            # one kernel when the rank's aggregate cannot stay in the Infinity Cache (the library decides), else propagate + dense
+            y = gnnmp.fused_conv(plan, L.SUM, h, l.weight, l.bias, "relu", scale_src=c, scale_dst=cl)
+            if y is not None:
+                return y
             L.check(lib.gnnmp_propagate_f32(plan.handle, L.COPY_XJ, L.SUM, L.ptr(h), None, L.ptr(c), L.ptr(cl), L.ptr(agg), D,
                                             L.stream_ptr()))
             return gnnmp.dense(agg, l.weight, l.bias, "relu")
@@ -403,7 +407,8 @@ def main():
 
     def k_gcn_fused():   # the GCN layer as the library runs it on this shape: aggregation + W + bias + relu in one kernel
         y = gnnmp.fused_conv(plan, L.SUM, x, gcn.weight, gcn.bias, "relu", ss_slot=c_slot, scale_dst=cvec)
-        assert y is not None, "the products-shape GCN layer is inside the fused kernel's envelope"
+        if y is None:     # small graphs (aggregate fits the Infinity Cache) are not fused by the library: time the layer as it runs
+            gcn(g, x)
 
     def k_gat():
         L.check(lib.gnnmp_gat_conv_f32(plan.handle, L.ptr(Wx), None, L.ptr(a_hc), 0.2, L.ptr(gat.bias), L.ACT_RELU,
@@ -448,7 +453,8 @@ def main():
                           "compulsory_bytes": compulsory_bytes(N, Ep, D, D)},
         # same algorithmic bytes as the propagate alone: the fused kernel reads what the propagate reads and writes the (N, Dout = D)
         # layer output instead of the (N, D) aggregate; the W image (40 KB per block) is not counted
-        "gcn_fused_layer": {"kernel": "fused_conv_kernel", "ms": tf_avg, "ms_median": tf_med,
+        "gcn_fused_layer": {"kernel": "fused_conv_kernel" if args.workload == "products" else "csr_rows_kernel + dense_t16_kernel",
+                            "ms": tf_avg, "ms_median": tf_med,
                             "alg_bytes": b_prop, "GBs": b_prop / tf_avg / 1e6,
                             "compulsory_bytes": compulsory_bytes(N, Ep, D, D),
                             "note": "includes the split rows' chunk pass + combine (two small launches before the fused kernel)"},
