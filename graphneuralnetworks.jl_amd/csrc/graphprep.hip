@@ -9,10 +9,9 @@
 #include <cstring>
 #include <algorithm>
 
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_scan.hpp>
 
 #include "common.h"
+#include "sort_scan.h"
 
 namespace gnnmp {
 
@@ -54,30 +53,30 @@ __global__ void self_loop_kernel(const void *u, const void *v, int idx_bytes, in
             goto done;                                  \
         }                                               \
     } while (0)
+#define PREP_G(expr)                                    \
+    do {                                                \
+        rc = (expr);                                    \
+        if (rc != GNNMP_OK) goto done;                  \
+    } while (0)
 
 // sorted keys of the pairs (first, second) into keys_out (device, E entries); scratch freed before returning
 static int sorted_pair_keys(const void *first, const void *second, int idx_bytes, int base, int64_t E, uint64_t *keys_out,
                             hipStream_t stream) {
     int rc = GNNMP_OK;
     uint64_t *keys_in = nullptr;
-    void *tmp = nullptr;
     int *flag = nullptr;
     int hflag = 0;
-    size_t tmp_bytes = 0;
     PREP_HIP(hipMalloc((void **)&keys_in, sizeof(uint64_t) * (size_t)std::max<int64_t>(E, 1)));
     PREP_HIP(hipMalloc((void **)&flag, sizeof(int)));
     PREP_HIP(hipMemsetAsync(flag, 0, sizeof(int), stream));
     pack_pairs_kernel<<<nb(E), 256, 0, stream>>>(first, second, idx_bytes, base, E, keys_in, flag);
     PREP_HIP(hipGetLastError());
-    PREP_HIP(rocprim::radix_sort_keys(nullptr, tmp_bytes, keys_in, keys_out, (size_t)E, 0, 64, stream));
-    PREP_HIP(hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 16)));
-    PREP_HIP(rocprim::radix_sort_keys(tmp, tmp_bytes, keys_in, keys_out, (size_t)E, 0, 64, stream));
+    PREP_G(radix_sort_keys_u64(keys_in, keys_out, (size_t)E, 0, 64, stream));
     PREP_HIP(hipMemcpyAsync(&hflag, flag, sizeof(int), hipMemcpyDeviceToHost, stream));
     PREP_HIP(hipStreamSynchronize(stream));
     if (hflag) rc = fail(GNNMP_EBOUNDS, "sort_edge_index: an index is negative or does not fit 32 bits");
 done:
     if (keys_in) (void)hipFree(keys_in);
-    if (tmp) (void)hipFree(tmp);
     if (flag) (void)hipFree(flag);
     return rc;
 }
@@ -396,10 +395,8 @@ int gnnmp_sample_neighbors(gnnmp_graph_t *plan, const void *nodes, int idx_bytes
     if (!nodes) return fail(GNNMP_EINVAL, "sample_neighbors: null nodes");
     int rc = GNNMP_OK;
     int64_t *counts = nullptr;
-    void *tmp = nullptr;
     int *flag = nullptr;
     int hflag = 0;
-    size_t tmp_bytes = 0;
     int64_t tot = 0;
     PREP_HIP(prep_alloc((void **)&counts, sizeof(int64_t) * (size_t)(n_nodes + 1)));
     PREP_HIP(prep_alloc((void **)&flag, sizeof(int)));
@@ -408,11 +405,7 @@ int gnnmp_sample_neighbors(gnnmp_graph_t *plan, const void *nodes, int idx_bytes
     sample_counts_kernel<<<nb(n_nodes), 256, 0, stream>>>(plan->rowptr, nodes, idx_bytes, index_base, n_nodes, plan->n_dst,
                                                           K, replace, counts, flag);
     PREP_HIP(hipGetLastError());
-    PREP_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, counts, offsets, (int64_t)0, (size_t)(n_nodes + 1),
-                                     rocprim::plus<int64_t>(), stream));
-    PREP_HIP(prep_alloc(&tmp, tmp_bytes));
-    PREP_HIP(rocprim::exclusive_scan(tmp, tmp_bytes, counts, offsets, (int64_t)0, (size_t)(n_nodes + 1),
-                                     rocprim::plus<int64_t>(), stream));
+    PREP_G(exclusive_scan_i64(counts, offsets, (size_t)(n_nodes + 1), stream));
     PREP_HIP(hipMemcpyAsync(&tot, offsets + n_nodes, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
     PREP_HIP(hipMemcpyAsync(&hflag, flag, sizeof(int), hipMemcpyDeviceToHost, stream));
     PREP_HIP(hipStreamSynchronize(stream));
@@ -437,7 +430,6 @@ int gnnmp_sample_neighbors(gnnmp_graph_t *plan, const void *nodes, int idx_bytes
     }
 done:
     prep_free(counts, sizeof(int64_t) * (size_t)(n_nodes + 1));
-    prep_free(tmp, tmp_bytes);
     prep_free(flag, sizeof(int));
     return rc;
 }
@@ -455,10 +447,8 @@ int gnnmp_unique_append(int32_t *map, int32_t *first, int64_t n_nodes, const voi
     if (!map || !first || !cand || !list_out) return fail(GNNMP_EINVAL, "unique_append: null pointer");
     int rc = GNNMP_OK;
     int64_t *flags = nullptr, *pos = nullptr;
-    void *tmp = nullptr;
     int *bad = nullptr;
     int hbad = 0;
-    size_t tmp_bytes = 0;
     int64_t tot = 0;
     PREP_HIP(prep_alloc((void **)&flags, sizeof(int64_t) * (size_t)(n_cand + 1)));
     PREP_HIP(prep_alloc((void **)&pos, sizeof(int64_t) * (size_t)(n_cand + 1)));
@@ -468,11 +458,7 @@ int gnnmp_unique_append(int32_t *map, int32_t *first, int64_t n_nodes, const voi
     unique_min_kernel<<<nb(n_cand), 256, 0, stream>>>(cand, idx_bytes, index_base, n_cand, n_nodes, map, first);
     unique_flag_kernel<<<nb(n_cand + 1), 256, 0, stream>>>(cand, idx_bytes, index_base, n_cand, n_nodes, map, first, flags);
     PREP_HIP(hipGetLastError());
-    PREP_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, flags, pos, (int64_t)0, (size_t)(n_cand + 1),
-                                     rocprim::plus<int64_t>(), stream));
-    PREP_HIP(prep_alloc(&tmp, tmp_bytes));
-    PREP_HIP(rocprim::exclusive_scan(tmp, tmp_bytes, flags, pos, (int64_t)0, (size_t)(n_cand + 1),
-                                     rocprim::plus<int64_t>(), stream));
+    PREP_G(exclusive_scan_i64(flags, pos, (size_t)(n_cand + 1), stream));
     unique_write_kernel<<<nb(n_cand), 256, 0, stream>>>(cand, idx_bytes, index_base, n_cand, flags, pos, set_size, map,
                                                         list_out);
     PREP_HIP(hipGetLastError());
@@ -484,7 +470,6 @@ int gnnmp_unique_append(int32_t *map, int32_t *first, int64_t n_nodes, const voi
 done:
     prep_free(flags, sizeof(int64_t) * (size_t)(n_cand + 1));
     prep_free(pos, sizeof(int64_t) * (size_t)(n_cand + 1));
-    prep_free(tmp, tmp_bytes);
     prep_free(bad, sizeof(int));
     return rc;
 }
@@ -504,18 +489,12 @@ int gnnmp_induced_subgraph(gnnmp_graph_t *plan, const int32_t *map, const void *
     if (!map || !nodes) return fail(GNNMP_EINVAL, "induced_subgraph: null pointer");
     int rc = GNNMP_OK;
     int64_t *counts = nullptr;
-    void *tmp = nullptr;
-    size_t tmp_bytes = 0;
     int64_t tot = 0;
     PREP_HIP(prep_alloc((void **)&counts, sizeof(int64_t) * (size_t)(n_nodes + 1)));
     induced_count_kernel<<<nb((n_nodes + 1) * 64), 256, 0, stream>>>(plan->rowptr, plan->col, map, nodes, idx_bytes, index_base,
                                                               n_nodes, counts);
     PREP_HIP(hipGetLastError());
-    PREP_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, counts, offsets, (int64_t)0, (size_t)(n_nodes + 1),
-                                     rocprim::plus<int64_t>(), stream));
-    PREP_HIP(prep_alloc(&tmp, tmp_bytes));
-    PREP_HIP(rocprim::exclusive_scan(tmp, tmp_bytes, counts, offsets, (int64_t)0, (size_t)(n_nodes + 1),
-                                     rocprim::plus<int64_t>(), stream));
+    PREP_G(exclusive_scan_i64(counts, offsets, (size_t)(n_nodes + 1), stream));
     PREP_HIP(hipMemcpyAsync(&tot, offsets + n_nodes, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
     PREP_HIP(hipStreamSynchronize(stream));
     *total = tot;
@@ -536,7 +515,6 @@ int gnnmp_induced_subgraph(gnnmp_graph_t *plan, const int32_t *map, const void *
     }
 done:
     prep_free(counts, sizeof(int64_t) * (size_t)(n_nodes + 1));
-    prep_free(tmp, tmp_bytes);
     return rc;
 }
 

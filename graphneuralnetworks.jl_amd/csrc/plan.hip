@@ -8,9 +8,9 @@
 #include <algorithm>
 #include <vector>
 
-#include <rocprim/device/device_radix_sort.hpp>
 
 #include "common.h"
+#include "sort_scan.h"
 
 namespace gnnmp {
 
@@ -73,28 +73,20 @@ int ensure_row_order(gnnmp_graph *p, hipStream_t stream) {
     const size_t n = (size_t)p->n_dst;
     uint32_t *kin = nullptr, *kout = nullptr, *vin = nullptr;
     int32_t *order = nullptr;
-    void *tmp = nullptr;
     int rc = GNNMP_OK;
     hipError_t e = hipSuccess;
     unsigned bits = 1;
     while (bits < 32 && ((int64_t)1 << bits) <= p->max_degree) ++bits;
-    size_t tmp_bytes = 0;
     if ((e = hipMalloc((void **)&kin, 4 * n)) != hipSuccess || (e = hipMalloc((void **)&kout, 4 * n)) != hipSuccess ||
         (e = hipMalloc((void **)&vin, 4 * n)) != hipSuccess || (e = hipMalloc((void **)&order, 4 * n)) != hipSuccess) {
         rc = hip_fail(e, "hipMalloc(row order)");
     } else {
         plan_degree_keys<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(p->rowptr, p->n_dst, (int)p->max_degree, kin, vin);
-        e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, kin, kout, vin, reinterpret_cast<uint32_t *>(order), n, 0, bits, stream);
-        if (e == hipSuccess) e = hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 16));
-        if (e == hipSuccess)
-            e = rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, vin, reinterpret_cast<uint32_t *>(order), n, 0, bits, stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(stream);   // the temporaries are freed below
-        if (e != hipSuccess) rc = hip_fail(e, "row order sort");
+        rc = radix_sort_pairs_u32(kin, kout, vin, reinterpret_cast<uint32_t *>(order), n, 0, (int)bits, stream);   // syncs the stream
     }
     if (kin) (void)hipFree(kin);
     if (kout) (void)hipFree(kout);
     if (vin) (void)hipFree(vin);
-    if (tmp) (void)hipFree(tmp);
     if (rc != GNNMP_OK) {
         if (order) (void)hipFree(order);
         return rc;
@@ -304,7 +296,6 @@ int gnnmp_plan_create(gnnmp_graph_t **out, const void *src, const void *dst, int
     }
 
     uint32_t *keys_in = nullptr, *keys_out = nullptr, *vals_in = nullptr;
-    void *tmp = nullptr;
     int *flags = nullptr;  // [0] bad index, [1] long count, [2] max degree
     int32_t *long_tmp = nullptr;
     int rc = GNNMP_OK;
@@ -348,14 +339,9 @@ int gnnmp_plan_create(gnnmp_graph_t **out, const void *src, const void *dst, int
         // stable LSD radix sort of (dst, edge position) on the bits that can be set
         unsigned bits = 1;
         while (bits < 32 && ((int64_t)1 << bits) < n_dst) ++bits;
-        size_t tmp_bytes = 0;
-        PLAN_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_in, keys_out, vals_in,
-                                           reinterpret_cast<uint32_t *>(p->eid), (size_t)Etot, 0,
-                                           bits, stream));
-        PLAN_HIP(hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 16)));
-        PLAN_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, vals_in,
-                                           reinterpret_cast<uint32_t *>(p->eid), (size_t)Etot, 0,
-                                           bits, stream));
+        rc = radix_sort_pairs_u32(keys_in, keys_out, vals_in, reinterpret_cast<uint32_t *>(p->eid), (size_t)Etot, 0, (int)bits,
+                                  stream);
+        if (rc != GNNMP_OK) goto done;
         plan_col<<<nblocks(Etot, BS), BS, 0, stream>>>(src, idx_bytes, index_base, n_edges, Etot,
                                                        reinterpret_cast<uint32_t *>(p->eid), p->col);
         PLAN_HIP(hipGetLastError());
@@ -416,7 +402,6 @@ done:
     if (keys_in) (void)hipFree(keys_in);
     if (keys_out) (void)hipFree(keys_out);
     if (vals_in) (void)hipFree(vals_in);
-    if (tmp) (void)hipFree(tmp);
     if (flags) (void)hipFree(flags);
     if (long_tmp) (void)hipFree(long_tmp);
 #undef PLAN_HIP

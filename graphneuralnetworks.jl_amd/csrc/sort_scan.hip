@@ -1,0 +1,274 @@
+// sort_scan.hip — the two primitives graph preparation needs, hand-written for gfx950 (round 1 called rocPRIM for them):
+//   * a STABLE least-significant-digit radix sort (8-bit digits) of 32-bit keys with 32-bit payloads — the destination sort
+//     behind the plan (dst, edge position) and the row order — and of bare 64-bit keys (sort_edge_index's packed (s, t) pairs);
+//   * an exclusive prefix sum of 32- or 64-bit integers (the digit-count tables of the sort, rowptr-like offset arrays).
+// Off the timed path (a plan is built once per graph), but part of the drop-in all the same.
+//
+// One pass of the sort = three launches over wave-private tiles of 2 048 consecutive elements:
+//   rs_hist    every wave counts its tile's digits in a private 256-entry LDS table (ds_add), writes them DIGIT-MAJOR
+//              (counts[digit][tile]) so that one flat exclusive scan yields every (digit, tile) pair's first output slot;
+//   scan       reduce-then-scan over 4 096-element chunks (wave shuffles + one LDS hop);
+//   rs_scatter every wave walks its tile again 64 elements at a time IN ORDER: the lanes holding equal digits are found with 8
+//              ballots (one per digit bit), a lane's rank among them is a popcount of the lower lanes — no sorting network, no
+//              atomics — and the digit's running offset lives in the wave's LDS table.  Element order inside a tile and tile
+//              order inside a digit are both preserved, so every pass is stable and so is the whole sort.
+#include <algorithm>
+
+#include "common.h"
+#include "sort_scan.h"
+
+namespace gnnmp {
+
+constexpr int RS_WT = 2048;        // elements per wave tile
+constexpr int RS_WPB = 4;          // waves per block
+constexpr int SC_CHUNK = 4096;     // elements per scan block (256 threads x 16)
+
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <class K>
+__global__ void __launch_bounds__(64 * RS_WPB) rs_hist(const K *__restrict__ keys, size_t n, int shift, uint32_t *__restrict__ counts,
+                                                       size_t n_tiles) {
+    __shared__ uint32_t h[RS_WPB][256];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const size_t tile = (size_t)blockIdx.x * RS_WPB + w;
+    if (tile >= n_tiles) return;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) h[w][lane + 64 * k] = 0;
+    wave_lds_sync();
+    const size_t base = tile * RS_WT;
+#pragma unroll 4
+    for (int s = 0; s < RS_WT / 64; ++s) {
+        const size_t i = base + (size_t)s * 64 + lane;
+        if (i < n) atomicAdd(&h[w][(int)((keys[i] >> shift) & 255)], 1u);
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) counts[(size_t)(lane + 64 * k) * n_tiles + tile] = h[w][lane + 64 * k];
+}
+
+template <class K, bool PAIRS>
+__global__ void __launch_bounds__(64 * RS_WPB) rs_scatter(const K *__restrict__ keys, const uint32_t *__restrict__ vals, size_t n,
+                                                          int shift, const uint32_t *__restrict__ offsets, size_t n_tiles,
+                                                          K *__restrict__ keys_out, uint32_t *__restrict__ vals_out) {
+    __shared__ uint32_t off[RS_WPB][256];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const size_t tile = (size_t)blockIdx.x * RS_WPB + w;
+    if (tile >= n_tiles) return;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) off[w][lane + 64 * k] = offsets[(size_t)(lane + 64 * k) * n_tiles + tile];
+    wave_lds_sync();
+    const size_t base = tile * RS_WT;
+    const uint64_t lower = (1ull << lane) - 1ull;
+    for (int s = 0; s < RS_WT / 64; ++s) {
+        const size_t i = base + (size_t)s * 64 + lane;
+        const bool valid = i < n;
+        const K key = valid ? keys[i] : (K)0;
+        const int d = (int)((key >> shift) & 255);
+        uint64_t same = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const uint64_t m = __ballot(valid && ((d >> b) & 1));
+            same &= ((d >> b) & 1) ? m : ~m;
+        }
+        const int rank = __popcll(same & lower);
+        const uint32_t first = off[w][d];
+        wave_lds_sync();                                   // every lane has read its digit's offset before a leader moves it
+        if (valid && rank == 0) off[w][d] = first + (uint32_t)__popcll(same);
+        wave_lds_sync();
+        if (valid) {
+            keys_out[first + rank] = key;
+            if (PAIRS) vals_out[first + rank] = vals[i];
+        }
+    }
+}
+
+// ---- exclusive scan: out[i] = sum of in[0 .. i-1] ---------------------------------------------------------------------
+template <class T>
+__device__ __forceinline__ T wave_inclusive_scan(T v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const T u = __shfl_up(v, o, 64);
+        if (lane >= o) v += u;
+    }
+    return v;
+}
+
+template <class T>
+__global__ void __launch_bounds__(256) scan_reduce(const T *__restrict__ in, size_t n, T *__restrict__ block_sums) {
+    __shared__ T ws[4];
+    const size_t base = (size_t)blockIdx.x * SC_CHUNK;
+    T s = 0;
+    for (int k = 0; k < SC_CHUNK / 256; ++k) {
+        const size_t i = base + (size_t)k * 256 + threadIdx.x;
+        if (i < n) s += in[i];
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) ws[w] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+// one block: exclusive scan of the block sums in place (any length: the block walks it in strides with a running carry)
+template <class T>
+__global__ void __launch_bounds__(1024) scan_block_sums(T *__restrict__ sums, size_t m) {
+    __shared__ T ws[16];
+    __shared__ T carry_s;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (size_t base = 0; base < m; base += 1024) {
+        const size_t i = base + threadIdx.x;
+        const T v = i < m ? sums[i] : (T)0;
+        const T inc = wave_inclusive_scan(v, lane);
+        if (lane == 63) ws[w] = inc;
+        __syncthreads();
+        T wave_off = 0;
+        for (int k = 0; k < w; ++k) wave_off += ws[k];
+        const T carry = carry_s;
+        if (i < m) sums[i] = carry + wave_off + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + wave_off + inc;
+        __syncthreads();
+    }
+}
+
+template <class T>
+__global__ void __launch_bounds__(256) scan_apply(const T *__restrict__ in, size_t n, const T *__restrict__ block_offsets,
+                                                  T *__restrict__ out) {
+    __shared__ T ws[4];
+    const size_t base = (size_t)blockIdx.x * SC_CHUNK;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // thread t owns the 16 consecutive elements base + 16 t .. + 15: sequential local scan, then a block scan of the thread totals
+    T v[SC_CHUNK / 256];
+    T tot = 0;
+#pragma unroll
+    for (int k = 0; k < SC_CHUNK / 256; ++k) {
+        const size_t i = base + (size_t)threadIdx.x * (SC_CHUNK / 256) + k;
+        v[k] = i < n ? in[i] : (T)0;
+        tot += v[k];
+    }
+    const T inc = wave_inclusive_scan(tot, lane);
+    if (lane == 63) ws[w] = inc;
+    __syncthreads();
+    T pre = block_offsets[blockIdx.x] + inc - tot;
+    for (int k = 0; k < w; ++k) pre += ws[k];
+#pragma unroll
+    for (int k = 0; k < SC_CHUNK / 256; ++k) {
+        const size_t i = base + (size_t)threadIdx.x * (SC_CHUNK / 256) + k;
+        if (i < n) out[i] = pre;
+        pre += v[k];
+    }
+}
+
+// enqueue the three scan launches; sums: workspace of scan_blocks(n) entries
+static inline size_t scan_blocks(size_t n) { return (n + SC_CHUNK - 1) / SC_CHUNK; }
+template <class T>
+static void exclusive_scan_enqueue(const T *in, T *out, size_t n, T *sums, hipStream_t stream) {
+    const size_t nb = scan_blocks(n);
+    scan_reduce<T><<<(unsigned)nb, 256, 0, stream>>>(in, n, sums);
+    scan_block_sums<T><<<1, 1024, 0, stream>>>(sums, nb);
+    scan_apply<T><<<(unsigned)nb, 256, 0, stream>>>(in, n, sums, out);
+}
+template <class T>
+static int exclusive_scan_impl(const T *in, T *out, size_t n, hipStream_t stream) {
+    if (n == 0) return GNNMP_OK;
+    T *sums = nullptr;
+    GNNMP_HIP(hipMalloc((void **)&sums, sizeof(T) * scan_blocks(n)));
+    exclusive_scan_enqueue<T>(in, out, n, sums, stream);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);     // the block sums are freed below
+    (void)hipFree(sums);
+    if (e != hipSuccess) return hip_fail(e, "exclusive_scan");
+    return GNNMP_OK;
+}
+
+int exclusive_scan_i64(const int64_t *in, int64_t *out, size_t n, hipStream_t stream) {
+    return exclusive_scan_impl<int64_t>(in, out, n, stream);
+}
+int exclusive_scan_u32(const uint32_t *in, uint32_t *out, size_t n, hipStream_t stream) {
+    return exclusive_scan_impl<uint32_t>(in, out, n, stream);
+}
+
+// ---- the sort ---------------------------------------------------------------------------------------------------------
+// digit_start[d] = first output slot of digit d (= offsets[d][tile 0]); a pass whose digit is the same for every key
+// (one bucket holds all n: the zero bytes of a packed (s, t) pair, the high byte of a 22-bit destination) moves nothing
+__global__ void rs_digit_starts(const uint32_t *__restrict__ offsets, size_t n_tiles, uint32_t *__restrict__ starts) {
+    starts[threadIdx.x] = offsets[(size_t)threadIdx.x * n_tiles];
+}
+
+template <class K, bool PAIRS>
+static int radix_sort_impl(const K *keys_in, K *keys_out, const uint32_t *vals_in, uint32_t *vals_out, size_t n, int begin_bit,
+                           int end_bit, hipStream_t stream) {
+    if (n == 0) return GNNMP_OK;
+    if (n >= ((size_t)1 << 32)) return fail(GNNMP_EUNSUPPORTED, "radix sort: %zu elements exceed the 32-bit offset tables", n);
+    const int passes = std::max(1, (end_bit - begin_bit + 7) / 8);
+    const size_t n_tiles = (n + RS_WT - 1) / RS_WT;
+    const size_t m = 256 * n_tiles;
+    K *ktmp = nullptr;
+    uint32_t *vtmp = nullptr, *counts = nullptr, *sums = nullptr, *starts = nullptr;
+    uint32_t hstarts[256];
+    int rc = GNNMP_OK;
+    hipError_t e = hipMalloc((void **)&counts, sizeof(uint32_t) * m);
+    if (e == hipSuccess) e = hipMalloc((void **)&sums, sizeof(uint32_t) * scan_blocks(m));
+    if (e == hipSuccess) e = hipMalloc((void **)&starts, sizeof(uint32_t) * 256);
+    if (e == hipSuccess) e = hipMalloc((void **)&ktmp, sizeof(K) * n);
+    if (e == hipSuccess && PAIRS) e = hipMalloc((void **)&vtmp, sizeof(uint32_t) * n);
+    if (e != hipSuccess) rc = hip_fail(e, "hipMalloc(radix sort temporaries)");
+    const unsigned blocks = (unsigned)((n_tiles + RS_WPB - 1) / RS_WPB);
+    const K *ksrc = keys_in;
+    const uint32_t *vsrc = vals_in;
+    for (int p = 0; p < passes && rc == GNNMP_OK; ++p) {
+        const int shift = begin_bit + 8 * p;
+        rs_hist<K><<<blocks, 64 * RS_WPB, 0, stream>>>(ksrc, n, shift, counts, n_tiles);
+        exclusive_scan_enqueue<uint32_t>(counts, counts, m, sums, stream);
+        rs_digit_starts<<<1, 256, 0, stream>>>(counts, n_tiles, starts);
+        e = hipMemcpyAsync(hstarts, starts, sizeof(hstarts), hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) { rc = hip_fail(e, "radix sort pass"); break; }
+        bool trivial = false;                              // some digit holds every key <=> its bucket is [0, n)
+        for (int d = 0; d < 256 && !trivial; ++d) {
+            const size_t lo = hstarts[d], hi = d + 1 < 256 ? (size_t)hstarts[d + 1] : n;
+            trivial = lo == 0 && hi == n;
+        }
+        if (trivial) continue;
+        // destination: whichever of (out, tmp) does not hold the current source
+        K *kdst = (ksrc == keys_out) ? ktmp : keys_out;
+        uint32_t *vdst = (ksrc == keys_out) ? vtmp : vals_out;
+        rs_scatter<K, PAIRS><<<blocks, 64 * RS_WPB, 0, stream>>>(ksrc, vsrc, n, shift, counts, n_tiles, kdst, vdst);
+        e = hipGetLastError();
+        if (e != hipSuccess) rc = hip_fail(e, "radix sort pass");
+        ksrc = kdst;
+        vsrc = vdst;
+    }
+    if (rc == GNNMP_OK && ksrc != keys_out) {              // every pass was trivial, or the last one landed in the temporary
+        e = hipMemcpyAsync(keys_out, ksrc, sizeof(K) * n, hipMemcpyDeviceToDevice, stream);
+        if (e == hipSuccess && PAIRS) e = hipMemcpyAsync(vals_out, vsrc, sizeof(uint32_t) * n, hipMemcpyDeviceToDevice, stream);
+        if (e != hipSuccess) rc = hip_fail(e, "radix sort copy-out");
+    }
+    if (rc == GNNMP_OK) {
+        e = hipStreamSynchronize(stream);                    // temporaries are freed below
+        if (e != hipSuccess) rc = hip_fail(e, "radix sort");
+    }
+    if (counts) (void)hipFree(counts);
+    if (sums) (void)hipFree(sums);
+    if (starts) (void)hipFree(starts);
+    if (ktmp) (void)hipFree(ktmp);
+    if (vtmp) (void)hipFree(vtmp);
+    return rc;
+}
+
+int radix_sort_pairs_u32(const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out, size_t n,
+                         int begin_bit, int end_bit, hipStream_t stream) {
+    return radix_sort_impl<uint32_t, true>(keys_in, keys_out, vals_in, vals_out, n, begin_bit, end_bit, stream);
+}
+int radix_sort_keys_u64(const uint64_t *keys_in, uint64_t *keys_out, size_t n, int begin_bit, int end_bit, hipStream_t stream) {
+    return radix_sort_impl<uint64_t, false>(keys_in, keys_out, nullptr, nullptr, n, begin_bit, end_bit, stream);
+}
+
+}  // namespace gnnmp

@@ -226,3 +226,29 @@ def test_sample_neighbors_large_counts_uniqueness_uniformity(gm):
     assert len(e) == 20000 and set(e) <= set(np.nonzero(t == 9)[0] + 1)
     cnt = np.bincount(e, minlength=E + 1)[np.nonzero(t == 9)[0] + 1]
     assert abs(cnt.mean() - 20000 / d) < 1e-9 and cnt.std() < 3.0 * np.sqrt(20000 / d)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("E", [1, 2, 63, 64, 65, 2047, 2048, 2049, 4097, 70001, 300007])
+@pytest.mark.parametrize("n", [1, 3, 255, 256, 257, 70000])
+def test_sort_and_scan_primitives_at_tile_boundaries(gm, E, n):
+    """the hand-written radix sort / scan (csrc/sort_scan.hip) through their callers, at sizes around the 64-lane step, the
+    2 048-element wave tile, the 4 096-element scan chunk and the 8-bit digit: the plan's stable destination sort against
+    numpy's stable argsort (bit-exact index outputs), sort_edge_index against numpy's lexsort"""
+    import torch
+    rng = np.random.default_rng(E * 7 + n)
+    s = rng.integers(1, n + 1, E).astype(np.int64)
+    t = rng.integers(1, n + 1, E).astype(np.int64)
+    g = gm.GNNGraph(torch.from_numpy(s).cuda(), torch.from_numpy(t).cuda(), num_nodes=n)
+    for loops in (False, True):
+        rowptr, col, eid = (v.cpu().numpy() for v in g.plan(loops).export())
+        s2 = np.concatenate([s, np.arange(1, n + 1)]) if loops else s
+        t2 = np.concatenate([t, np.arange(1, n + 1)]) if loops else t
+        order = np.argsort(t2, kind="stable")
+        np.testing.assert_array_equal(eid, order.astype(np.int32))
+        np.testing.assert_array_equal(col, (s2[order] - 1).astype(np.int32))
+        np.testing.assert_array_equal(rowptr, np.concatenate([[0], np.cumsum(np.bincount(t2 - 1, minlength=n))]).astype(np.int32))
+    a, b = gm.sort_edge_index(g.s, g.t)
+    o = np.lexsort((t, s))
+    np.testing.assert_array_equal(a.cpu().numpy(), s[o])
+    np.testing.assert_array_equal(b.cpu().numpy(), t[o])
