@@ -211,8 +211,8 @@ struct gnnmp_graph {
     // plan-owned workspace for the chunk partials (grown on demand; one stream at a time per plan)
     float *ws = nullptr;
     size_t ws_floats = 0;
-    // two device words {next tile, finished blocks} for the persistent fused kernel's dynamic tile hand-out (fused_conv.hip);
-    // zero between launches: the last block to finish resets them
+    // device word(s) for the persistent fused kernel's dynamic tile hand-out (fused_conv.hip), zeroed by a memset node before
+    // every launch
     uint32_t *ticket = nullptr;
     // destination rows in order of decreasing length (stable), built on first use (ensure_row_order): the row kernels that
     // put TWO OR MORE rows in a wave walk rows in this order so that the rows sharing a wave are equally long — adjacent

@@ -38,7 +38,7 @@ struct FusedArgs {
     int Dout;
     int stride;               // floats per LDS tile row (== 8 mod 16)
     int waves;
-    uint32_t *ticket;         // {next tile, finished blocks}
+    uint32_t *ticket;         // next dynamically dealt tile (zeroed by the host before every launch)
 };
 
 // slot of `row` in the sorted list of split rows (it is there: the caller checked the row's length)
@@ -163,15 +163,6 @@ __global__ void __launch_bounds__(1024) fused_conv_kernel(const FusedArgs a) {
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    // the last block to finish re-arms the ticket for the next launch (every block has stopped drawing by then)
-    __syncthreads();
-    if (tid == 0) {
-        const unsigned done = atomicAdd(a.ticket + 1, 1u);
-        if (done == gridDim.x - 1) {
-            atomicExch(a.ticket, 0u);
-            atomicExch(a.ticket + 1, 0u);
-        }
-    }
 }
 
 template <int NCB, int KQA, int OP, bool SCALED>
@@ -192,6 +183,9 @@ static int launch_fused(FusedArgs &a, size_t img_bytes, hipStream_t stream) {
     }
     const int ntiles = (a.r.n_rows + 15) / 16;
     const int gx = std::min(device_cus(), (ntiles + waves - 1) / waves);
+    // the ticket starts every launch at zero: an 8-byte memset node on the same stream (a kernel that re-armed it itself would
+    // leave it dirty after a failed launch and the next one would silently skip tiles)
+    GNNMP_HIP(hipMemsetAsync(a.ticket, 0, 2 * sizeof(uint32_t), stream));
     fused_conv_kernel<NCB, KQA, OP, SCALED><<<gx, 64 * waves, img_bytes + (size_t)waves * tile_bytes, stream>>>(a);
     GNNMP_LAUNCH_CHECK("fused_conv_kernel");
     return GNNMP_OK;

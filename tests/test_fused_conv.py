@@ -140,7 +140,7 @@ def test_layers_take_the_fused_kernel_and_fall_back_outside_it(gm, oracle):
             close(y, ref)
 
 
-def test_many_launches_rearm_the_ticket(gm):
+def test_many_launches_start_from_a_zeroed_ticket(gm):
     """200 back-to-back launches on one plan, alternating shapes: every one must see a zeroed ticket"""
     import torch
     from gnnmp import _lib as L
