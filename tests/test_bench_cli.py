@@ -1,0 +1,50 @@
+"""bench.py's launcher contract, checkable without a GPU: `--gpus N` must never silently run fewer ranks (the
+round-1 harness reported n_gpus = 1 for `python bench.py --gpus 8`), and the JSON helpers are self-consistent."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run(*args, env=None):
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, env=e, timeout=600)
+
+
+def test_more_gpus_than_the_node_has_is_refused():
+    import torch
+    have = torch.cuda.device_count()
+    r = run("--gpus", str(have + 2))
+    assert r.returncode != 0
+    assert "refusing to run fewer ranks" in (r.stdout + r.stderr)
+    assert not any(l.startswith("{") for l in r.stdout.splitlines()), "no bench line may be printed by a refused run"
+
+
+def test_gpus_must_match_the_launcher_world_size():
+    """under a launcher (RANK / WORLD_SIZE / MASTER_ADDR set) a --gpus that disagrees with WORLD_SIZE is an error, not a downgrade"""
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("CPU-only check (on a GPU box the run would start)")
+    r = run("--gpus", "4", env={"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "2", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29999"})
+    assert r.returncode != 0          # no GPU here: refuses before anything else; with GPUs it would refuse on the mismatch
+
+
+def test_byte_models():
+    sys.path.insert(0, ROOT)
+    import bench
+    N, Ep, D, H, C = 2449029, 64308169, 100, 8, 16
+    assert bench.alg_bytes_gcn_propagate(N, Ep, D) == Ep * 404 + 8 * (N + 1) + 4 * N * D + 8 * N
+    assert bench.alg_bytes_gat_aggregate(N, Ep, H, C) == Ep * 516 + N * 1032
+    # SURVEY §8d's compulsory bound: every input and output row once + the int32 index
+    assert bench.compulsory_bytes(N, Ep, D, D) == 8 * N * D + 4 * Ep + 4 * (N + 1)
+    doc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    for k in ("gat_fused_rows_kernel", "fused_conv_kernel"):
+        assert doc["products"][k]["hbm_read_bytes"] > 0 and doc["products"][k]["round"] == "r02"
+        t, src = bench.traffic_from_profiles("products", k)
+        assert t == doc["products"][k]["hbm_read_bytes"] + doc["products"][k]["hbm_write_bytes"] and src["round"] == "r02"
