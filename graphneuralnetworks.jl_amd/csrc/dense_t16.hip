@@ -1,12 +1,15 @@
 // dense_t16.hip — the dense feature contractions of the layer bodies (see dense.hip for the list of reference call sites) for
 // the shapes the hot path actually has: every segment's K a multiple of 4 and at most 128, any Dout that is a multiple of 4.
-// One persistent 1024-thread block per CU; W^T lives in LDS as the operand image of mfma16.h; each WAVE owns 16-node tiles:
+// One persistent block per CU (1024 threads; 768 when eight column blocks need more than 128 VGPRs); W^T lives in LDS as the
+// operand image of mfma16.h; each WAVE owns 16-node tiles:
 //   7-8 16-byte loads per lane straight from the row-major feature matrix into MFMA operand registers (no LDS staging of x),
 //   K/4 x NCB v_mfma_f32_16x16x4_f32 with the A operands coming from the image by ds_read_b128, bias + activation on the
 //   accumulators, one 16-byte store per accumulator straight to the output row (no LDS staging of the result either).
 // Per 16-node tile at 100 => 100: 7 loads, 49 LDS reads, 175 MFMAs, 7 stores, ~60 VALU — against ~1 100 non-MFMA instructions
-// per 200 MFMAs in the LDS-staged 32x32x2 kernel this replaces on these shapes (profiles/README.md, round 1).  Four waves per
-// SIMD (<= 128 VGPRs): while one wave waits for its rows the other three keep the matrix pipe busy; no barrier after the image.
+// per 200 MFMAs in the LDS-staged 32x32x2 kernel this replaces on these shapes (profiles/README.md, round 1).  Three or four
+// waves per SIMD, the next tile's rows in flight during the current tile's MFMAs, a two-deep register pipeline of the A-operand
+// reads; no barrier after the image.  Measured: matrix pipe 74-79 % busy at the 2.25 GHz the chip holds under this load
+// (1 380 W of the 1 400 W socket limit), 89-126 TF by shape (profiles/README.md, round 2).
 #include <algorithm>
 
 #include "mfma16.h"

@@ -5,7 +5,8 @@
 // without the (N, D) aggregate ever going to HBM: round 1 wrote it (4 N D bytes) and the dense kernel read it back.
 //
 // One persistent block per CU; W^T (both segments) lives in LDS as the operand image of mfma16.h.  Each WAVE takes 16-row
-// tiles from a device-wide ticket (rows differ 100x in length: a static split leaves a tail) and for each tile
+// tiles — the first 7/8 dealt statically, the last 1/8 from a device-wide ticket (rows differ 100x in length: a purely
+// static split leaves a tail; a purely ticketed one is bound by the atomic) — and for each tile
 //   1. walks its 16 destination rows exactly like csr_rows_kernel (csr_reduce.h: one lane group per row, U = 8 sixteen-byte
 //      row loads in flight, adds in original edge order => the aggregate is BIT-IDENTICAL to the unfused kernel's) and puts
 //      the finished rows into a wave-private 16 x D LDS tile (padded stride: the later ds_read_b128 are conflict-free);
@@ -15,8 +16,9 @@
 //      W1 * x_i, by 16-byte loads of x_i straight from HBM), A operands from the W image; bias + activation on the
 //      accumulators; one 16-byte store per accumulator to the output row.
 // No workgroup barrier after the image is built; the only cross-lane hand-off is inside a wave (LDS tile).  The kernel stays
-// HBM-bound on the row gather: the MFMA phase of a tile (175 MFMAs = 5 600 cycles at 100 => 100) is ~5 % of the tile's
-// gather time and overlaps with the other waves' gathers.
+// bound by the row gather (cache-line requests: DESIGN.md section 5): the MFMA phase of a tile (175 MFMAs = 5 600 cycles at
+// 100 => 100) is ~5 % of the tile's gather time and overlaps with the other waves' gathers.  Used by default only where it
+// removes an HBM round trip (aggregate >= 128 MiB) and there is no root term: see gnnmp_fused_conv_f32 below.
 #include <algorithm>
 
 #include "csr_reduce.h"
