@@ -45,7 +45,8 @@ enum Knob {
     KNOB_FUSED_WAVES = 14,     // fused_conv_kernel: 0 = auto (as many waves as LDS holds tiles for, <= 16), > 0 = cap, < 0 = never fuse
     KNOB_ROW_ORDER = 15,       // rows by decreasing length in the row kernels that share a wave between rows: 0 (default) = never,
                                // 1 = when the gathered matrix exceeds the Infinity Cache, 2 = always (use_row_order)
-    KNOB_COUNT = 16
+    KNOB_SOFTMAX_ROWS = 16,    // one-pass narrow-row softmax (softmax_rows.hip): 0 = auto, < 0 = the three-step kernels on every row
+    KNOB_COUNT = 17
 };
 int knob(int k);
 int device_cus();   // compute units of the current device, queried once (hipDeviceGetAttribute costs microseconds per call)

@@ -65,7 +65,9 @@ __global__ void __launch_bounds__(t16_max_threads<NCB>()) dense_t16_kernel(const
     const int64_t ntiles = (a.N + 15) >> 4;
     const int64_t stride = (int64_t)gridDim.x * a.waves;
     const bool has_bias = a.bias != nullptr;
-    int64_t tile = (int64_t)blockIdx.x * a.waves + wave;
+    // wave-major hand-out: round r gives tile r * stride + wave * gridDim.x + block, so the last, partial round spreads over
+    // every CU (block-major put all of it on the first blocks: 48 against 36 tiles per CU on the arxiv shape)
+    int64_t tile = (int64_t)wave * gridDim.x + blockIdx.x;
     if (tile >= ntiles) return;
     if constexpr (KQ1 >= 0) {
         // Compile-time K.  A software pipeline over "phases" (tile, segment): while a phase's MFMAs run, the NEXT phase's rows

@@ -391,11 +391,17 @@ int run_reduce(gnnmp_graph_t *p, const int32_t *idx, int aggr, const float *x, c
 // softmax over the rows of a plan in the reference's three steps (utils.jl:84-97 / :49-72): max_ = scatter(max, e, t),
 // den = scatter(+, exp.(e .- max_[t]), t) (edge order), alpha = num ./ den.  Every step is the balanced row-group walk
 // (chunked long rows), so a 17 000-edge hub costs what 17 000 edges cost, not a serial tail.
+int softmax_rows_try(gnnmp_graph_t *p, const float *e, float *alpha, int64_t D, float den_add, float *partial, float *mx, float *den,
+                     hipStream_t stream);  // softmax_rows.hip
+
 int run_softmax(gnnmp_graph_t *p, const float *e, float *alpha, int64_t D, float den_add, hipStream_t stream) {
     if (p->n_dst == 0 || p->n_total == 0 || D == 0) return GNNMP_OK;
     const size_t nd = (size_t)p->n_dst * (size_t)D, pc = (size_t)p->n_chunks * (size_t)D;
     if (int rc = ensure_workspace(p, pc + 2 * nd)) return rc;
     float *mx = p->ws + pc, *den = mx + nd;
+    // narrow rows: one pass over the rows the plan does not split, a wave per chunk on those it does (softmax_rows.hip)
+    const int rc1 = softmax_rows_try(p, e, alpha, D, den_add, p->ws, mx, den, stream);
+    if (rc1 != 1) return rc1;
     if (int rc = run_reduce(p, p->eid, GNNMP_MAX, e, nullptr, nullptr, nullptr, nullptr, nullptr, mx, D, stream)) return rc;
     if (int rc = run_reduce(p, p->eid, GNNMP_SUM, e, nullptr, nullptr, nullptr, nullptr, nullptr, den, D, stream, nullptr, mx))
         return rc;
@@ -432,7 +438,7 @@ int run_softmax(gnnmp_graph_t *p, const float *e, float *alpha, int64_t D, float
 }
 
 // fold plan->ws ([n_chunks][D] partial sums written by another kernel in the same virtual-row layout) into out's long rows
-int run_combine_sum(gnnmp_graph_t *p, float *out, int64_t D, hipStream_t stream) {
+int run_combine(gnnmp_graph_t *p, float *out, int64_t D, int aggr, hipStream_t stream) {
     if (p->n_long == 0) return GNNMP_OK;
     ReduceArgs a = {};
     a.rowptr = p->rowptr;
@@ -447,14 +453,23 @@ int run_combine_sum(gnnmp_graph_t *p, float *out, int64_t D, hipStream_t stream)
     const int G = 1 << a.log2g;
     const int tiles = (int)(((D + vec - 1) / vec + G - 1) / G);
     dim3 grid((unsigned)a.n_long, (unsigned)tiles);
-    switch (vec) {
-        case 4: csr_combine_kernel<4, OP_SUM><<<grid, 256, 0, stream>>>(a); break;
-        case 2: csr_combine_kernel<2, OP_SUM><<<grid, 256, 0, stream>>>(a); break;
-        default: csr_combine_kernel<1, OP_SUM><<<grid, 256, 0, stream>>>(a); break;
+    if (aggr == GNNMP_MAX) {
+        switch (vec) {
+            case 4: csr_combine_kernel<4, OP_MAX><<<grid, 256, 0, stream>>>(a); break;
+            case 2: csr_combine_kernel<2, OP_MAX><<<grid, 256, 0, stream>>>(a); break;
+            default: csr_combine_kernel<1, OP_MAX><<<grid, 256, 0, stream>>>(a); break;
+        }
+    } else {
+        switch (vec) {
+            case 4: csr_combine_kernel<4, OP_SUM><<<grid, 256, 0, stream>>>(a); break;
+            case 2: csr_combine_kernel<2, OP_SUM><<<grid, 256, 0, stream>>>(a); break;
+            default: csr_combine_kernel<1, OP_SUM><<<grid, 256, 0, stream>>>(a); break;
+        }
     }
     GNNMP_LAUNCH_CHECK("csr_combine_kernel");
     return GNNMP_OK;
 }
+int run_combine_sum(gnnmp_graph_t *p, float *out, int64_t D, hipStream_t stream) { return run_combine(p, out, D, GNNMP_SUM, stream); }
 
 // ---- degree / norm ------------------------------------------------------------------------------
 __global__ void degree_count_kernel(const int32_t *rowptr, int64_t n, float *deg) {
