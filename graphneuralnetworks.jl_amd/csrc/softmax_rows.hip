@@ -52,6 +52,14 @@ struct SmxBatch {
 
 constexpr int SMX_IT = 8;   // items (edge, lane-of-edge) per lane and batch
 
+// The max of a softmax needs no Julia `max` (common.h: jl_max, ~8 instructions): the sign of a zero maximum cancels in
+// e - max, and a NaN in the row makes every weight of the row NaN whether the maximum carries it (the reference) or skips it
+// (v_max_f32) — exp(NaN - m) poisons the denominator either way.  One instruction.
+template <int OP>
+__device__ __forceinline__ float smx_apply(float x, float y) {
+    return OP == OP_MAX ? fmaxf(x, y) : x + y;
+}
+
 // fold LDS rows [st, st + len) into acc, 8 reads in flight; every lane of the group calls it
 template <int VEC, int OP>
 __device__ __forceinline__ void smx_fold(const float *vals, int Dp, int f0, int st, int len, float (&acc)[VEC]) {
@@ -63,7 +71,7 @@ __device__ __forceinline__ void smx_fold(const float *vals, int Dp, int f0, int 
         for (int u = 0; u < 8; ++u) {
             if (t + u < len) {
 #pragma unroll
-                for (int q = 0; q < VEC; ++q) acc[q] = op_apply<OP>(acc[q], v[u][q]);
+                for (int q = 0; q < VEC; ++q) acc[q] = smx_apply<OP>(acc[q], v[u][q]);
             }
         }
     }
@@ -343,7 +351,7 @@ __global__ void __launch_bounds__(256) softmax_chunk_kernel(const SmxArgs a) {
             if (i < nitems && active) {
                 if (MODE == 0) {
 #pragma unroll
-                    for (int q = 0; q < VEC; ++q) acc[q] = op_apply<OP_MAX>(acc[q], x[k][q]);
+                    for (int q = 0; q < VEC; ++q) acc[q] = fmaxf(acc[q], x[k][q]);
                 } else {
 #pragma unroll
                     for (int q = 0; q < VEC; ++q) x[k][q] = expf(x[k][q] - rm[q]);
@@ -367,7 +375,7 @@ __global__ void __launch_bounds__(256) softmax_chunk_kernel(const SmxArgs a) {
         // the lanes that hold the same features (same lane-of-edge) meet: xor butterfly over the group index
         for (int d = G; d < 64; d <<= 1) {
 #pragma unroll
-            for (int q = 0; q < VEC; ++q) acc[q] = op_apply<OP_MAX>(acc[q], __shfl_xor(acc[q], d, 64));
+            for (int q = 0; q < VEC; ++q) acc[q] = fmaxf(acc[q], __shfl_xor(acc[q], d, 64));
         }
     }
     if (MODE <= 1 && grp == 0 && active) Vec<VEC>::store(a.partial + (int64_t)v * a.D + f0, acc);

@@ -133,3 +133,26 @@ def test_one_destination_one_edge_and_no_edges(gm):
     assert torch.equal(z.cpu(), torch.ones(1, 2))
     g0 = gm.GNNGraph(dev(np.zeros(0, np.int64)), dev(np.zeros(0, np.int64)), num_nodes=4)
     assert gm.softmax_edge_neighbors(g0, torch.empty((0, 8), device="cuda")).shape == (0, 8)
+
+
+def test_nan_logit_poisons_its_destination_only(gm, oracle):
+    """the kernels fold the maximum with v_max_f32 (a NaN is skipped, not carried): the weights must still be what the
+    reference's NaN-carrying max gives — NaN on every edge of the destination (and channel) that holds the NaN, untouched
+    elsewhere — on batch rows, rows longer than a batch and rows the plan splits"""
+    import torch
+    rng = np.random.default_rng(21)
+    n, E = 400, 9000
+    s, t = hub_graph(rng, n, E, (300, 700))
+    e = rng.standard_normal((len(s), 8)).astype(np.float32)
+    bad_edges = [3, 17, int(np.flatnonzero(t == 6)[5]), int(np.flatnonzero(t == 17)[100])]   # 6, 17: the hubs
+    for k, ed in enumerate(bad_edges):
+        e[ed, k % 8] = np.nan
+    g = gm.GNNGraph(dev(s), dev(t), num_nodes=n)
+    new, old = both_paths(gm, lambda: gm.softmax_edge_neighbors(g, dev(e)))
+    ref = oracle.softmax_edge_neighbors(t, n, e)
+    got = new.cpu().numpy()
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    assert np.array_equal(np.isnan(old.cpu().numpy()), np.isnan(ref))
+    ok = ~np.isnan(ref)
+    np.testing.assert_allclose(got[ok], ref[ok], rtol=2e-6, atol=1e-30)
+    assert np.isnan(ref).sum() >= len(bad_edges)
