@@ -38,7 +38,7 @@ enum Knob {
                               // first version spilled — 270 VGPRs — and was slower: see dense.hip).
     KNOB_GAT_FAST_EXP = 8,   // retired: the one-pass attention kernel always uses v_exp_f32 now (gat_fused.hip, gexp)
     KNOB_GRADW_SLABS = 9,    // ΔW kernel: slabs per CU (0 = auto)
-    KNOB_GRADW_RP = 10,      // ΔW kernel: row pairs loaded per batch (0 = auto, else 2|4|8)
+    KNOB_GRADW_RP = 10,      // ΔW kernel: 0 = the 16x16x4 kernel, < 0 = the round-1 32x32x2 kernel (A/B runs)
     KNOB_GRADW_MIN_ROWS = 11,  // ΔW kernel: rows-per-slab floor (0 = auto: ~3 slabs per CU on small inputs, 512 on large)
     KNOB_DENSE_T16_WAVES = 12, // dense_t16_kernel: waves per block (0 = auto, else 1..16)
     KNOB_T16_DEBUG = 13,       // dense_t16_kernel phase ablation (experiments only): 1 = no stores, 2 = no x loads

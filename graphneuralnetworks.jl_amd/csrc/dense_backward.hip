@@ -15,6 +15,7 @@
 namespace gnnmp {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __global__ void __launch_bounds__(256) act_grad_kernel(const float *dy, const float *y, int act, float *dz,
                                                        int64_t n) {
@@ -185,6 +186,133 @@ __global__ void __launch_bounds__(256) dense_gradw_kernel(const GradWArgs a) {
     }
 }
 
+// ---- ΔW on v_mfma_f32_16x16x4_f32 ------------------------------------------------------------------------------------------
+// The 32x32x2 kernel above pads 100 x 100 to 128 x 128 (61 % of its MFMAs useful) and feeds each 64-cycle MFMA with two
+// 4-byte loads per lane.  With 16 x 16 tiles 100 x 100 is 7 x 7 tiles (80 % useful), and the reduction index of one MFMA step
+// is FOUR rows: lane (i, q) supplies Δz[n + q][o0 + 16 a + i] and x[n + q][k0 + 16 b + i] — both operands still straight from the
+// row-major matrices in HBM (64-byte segments of four rows per load instruction), no LDS.  A wave owns up to 8 x 4 tiles
+// (128 ΔW rows x 64 ΔW columns, 128 accumulator registers); the waves of a block share the Δz rows and split the columns of
+// ΔW; a block reduces one slab of rows into its partial.  NB batches of four rows are in flight in a register ring.
+struct GradW16Args {
+    const float *dz;   // [N][Dout]
+    const float *x;    // [N][K]
+    float *part;       // [slabs][Dout][K]
+    float *part_db;    // [slabs][Dout] column sums of Δz (Δb), or null
+    int64_t N;
+    int64_t rows_per_slab;   // multiple of 4
+    int Dout, K;
+    int tiles_per_wave;      // k-tiles (16 columns of ΔW) per wave, <= TK
+};
+
+template <int TO, int TK, int NB, int WPE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) dense_gradw16_kernel(const GradW16Args a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int o0 = (int)blockIdx.y * 128;
+    const int k0 = ((int)blockIdx.z * (int)(blockDim.x >> 6) + wave) * 16 * a.tiles_per_wave;
+    if (k0 >= a.K) return;
+    const int nto = min(TO, (a.Dout - o0 + 15) >> 4);
+    const int ntk = min(a.tiles_per_wave, (a.K - k0 + 15) >> 4);
+    // columns that do not exist read column 0 of the row instead (valid memory); their accumulator rows / columns are never
+    // stored.  No select on the loaded values: see the note in dense_gradw_kernel.
+    int ocol[TO], kcol[TK];
+#pragma unroll
+    for (int t = 0; t < TO; ++t) ocol[t] = (o0 + 16 * t + i < a.Dout) ? o0 + 16 * t + i : 0;
+#pragma unroll
+    for (int t = 0; t < TK; ++t) kcol[t] = (k0 + 16 * t + i < a.K) ? k0 + 16 * t + i : 0;
+    f32x4 acc[TO][TK];
+#pragma unroll
+    for (int t = 0; t < TO; ++t)
+#pragma unroll
+        for (int u = 0; u < TK; ++u) acc[t][u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    // Δb rides along: the first wave of the first column block already holds every Δz value of the slab in its A operands
+    const bool do_db = a.part_db != nullptr && wave == 0 && blockIdx.z == 0;
+    float dbacc[TO];
+#pragma unroll
+    for (int t = 0; t < TO; ++t) dbacc[t] = 0.0f;
+    const int64_t n0 = (int64_t)blockIdx.x * a.rows_per_slab;
+    const int64_t n1 = min(a.N, n0 + a.rows_per_slab);
+    if (n0 < n1) {
+        const int64_t nfull = (n1 - n0) >> 2;               // full batches of four rows
+        auto mfma_batch = [&](const float (&av)[TO], const float (&bv)[TK]) {
+#pragma unroll
+            for (int t = 0; t < TO; ++t) {
+                if (t < nto) {
+#pragma unroll
+                    for (int u = 0; u < TK; ++u)
+                        if (u < ntk) acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv[u], acc[t][u], 0, 0, 0);
+                }
+            }
+            if (do_db) {
+#pragma unroll
+                for (int t = 0; t < TO; ++t) dbacc[t] = dbacc[t] + av[t];
+            }
+        };
+        if (nfull > 0) {
+            float av[NB][TO], bv[NB][TK];
+            // batches past the last full one re-read it (never consumed); tiles past nto / ntk read column 0 (never used)
+            auto load_batch = [&](int slot, int64_t b) {
+                const int64_t row = n0 + 4 * (b < nfull ? b : nfull - 1) + q;
+                const float *pa = a.dz + row * a.Dout;
+                const float *pb = a.x + row * a.K;
+#pragma unroll
+                for (int t = 0; t < TO; ++t) av[slot][t] = pa[ocol[t]];
+#pragma unroll
+                for (int t = 0; t < TK; ++t) bv[slot][t] = pb[kcol[t]];
+            };
+#pragma unroll
+            for (int s = 0; s < NB - 1; ++s) load_batch(s, s);
+            for (int64_t b0 = 0; b0 < nfull; b0 += NB) {
+#pragma unroll
+                for (int s = 0; s < NB; ++s) {
+                    load_batch((s + NB - 1) % NB, b0 + s + NB - 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (b0 + s < nfull) mfma_batch(av[s], bv[s]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        if (n0 + 4 * nfull < n1) {   // the ragged last batch: rows past the end re-read the last row with weight 0
+            const int64_t row = n0 + 4 * nfull + q;
+            const float m = row < n1 ? 1.0f : 0.0f;
+            const float *pa = a.dz + min(row, n1 - 1) * a.Dout;
+            const float *pb = a.x + min(row, n1 - 1) * a.K;
+            float av[TO], bv[TK];
+#pragma unroll
+            for (int t = 0; t < TO; ++t) av[t] = pa[ocol[t]] * m;
+#pragma unroll
+            for (int t = 0; t < TK; ++t) bv[t] = pb[kcol[t]] * m;
+            mfma_batch(av, bv);
+        }
+    }
+    if (do_db) {   // rows n + q, q = 0..3, of every batch sit in four lane groups: fold them in a fixed order
+#pragma unroll
+        for (int t = 0; t < TO; ++t) {
+            float v = dbacc[t];
+            v = v + __shfl_xor(v, 16, 64);
+            v = v + __shfl_xor(v, 32, 64);
+            if (q == 0 && o0 + 16 * t + i < a.Dout) a.part_db[(int64_t)blockIdx.x * a.Dout + o0 + 16 * t + i] = v;
+        }
+    }
+    // C/D layout: col = lane & 15, row = 4 (lane >> 4) + reg
+    float *part = a.part + (int64_t)blockIdx.x * a.Dout * a.K;
+#pragma unroll
+    for (int t = 0; t < TO; ++t) {
+        if (t >= nto) continue;
+#pragma unroll
+        for (int u = 0; u < TK; ++u) {
+            if (u >= ntk) continue;
+            const int col = k0 + 16 * u + i;
+            if (col >= a.K) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = o0 + 16 * t + 4 * q + r;
+                if (row < a.Dout) part[(int64_t)row * a.K + col] = acc[t][u][r];
+            }
+        }
+    }
+}
+
 static int gradw_slabs(int64_t N) {
     const int cus = device_cus();
     // rows per slab floor.  A wave is latency-bound per batch of row pairs (~1.2 us), so a block's time is proportional to
@@ -222,7 +350,8 @@ int gnnmp_act_grad_f32(const float *dy, const float *y, int act, float *dz, int6
 
 int64_t gnnmp_dense_grad_workspace(int64_t N, int64_t Dout, int64_t K) {
     if (N <= 0 || Dout <= 0 || K <= 0) return 0;
-    return ((int64_t)gradw_slabs(N) + FOLD_GROUPS) * std::max(Dout * K, Dout);
+    const int64_t slabs = gradw_slabs(N);
+    return (slabs + FOLD_GROUPS) * std::max(Dout * K, Dout) + slabs * Dout;   // ΔW partials + fold scratch, Δb partials
 }
 
 int gnnmp_dense_grad_w_f32(const float *dz, const float *x, int64_t N, int64_t Dout, int64_t K, float *dW,
@@ -241,12 +370,41 @@ int gnnmp_dense_grad_w_f32(const float *dz, const float *x, int64_t N, int64_t D
         return fail(GNNMP_EINVAL, "dense_grad_w: workspace too small (%lld < %lld floats)", (long long)workspace_floats,
                     (long long)gnnmp_dense_grad_workspace(N, Dout, K));
     int64_t rps = (N + slabs - 1) / slabs;
-    rps = (rps + 1) & ~(int64_t)1;                               // even: row pairs never straddle slabs
+    rps = (rps + 3) & ~(int64_t)3;                               // multiple of 4: the four rows of an MFMA step never straddle slabs
     // a slab length that is a multiple of 64 rows puts every slab's stream at the same offset of the HBM channel
     // interleave when the row size is a power of two too (245 760 x 128: all blocks camp on two channels, 221 us for a
     // job that takes 118 us at 169 343 rows): de-tune it.  Slabs past the end of the input are empty (n0 >= N).
-    if ((rps & 63) == 0) rps += 2;
+    if ((rps & 63) == 0) rps += 4;
+    bool db_done = false;
     if (dW) {
+        if (knob(KNOB_GRADW_RP) >= 0) {
+            GradW16Args a;
+            a.dz = dz;
+            a.x = x;
+            a.part = workspace;
+            a.part_db = db ? workspace + ((int64_t)slabs + FOLD_GROUPS) * std::max(Dout * K, Dout) : nullptr;
+            db_done = db != nullptr;
+            a.N = N;
+            a.rows_per_slab = rps;
+            a.Dout = (int)Dout;
+            a.K = (int)K;
+            // 16 x 16 tiles of ΔW per wave: 8 x 4 (128 rows x 64 columns, 128 accumulator registers), two waves per SIMD; the
+            // waves of a block share the Δz rows and split the columns.  (ONE wave per SIMD holding all of a 7 x 7 or 8 x 7-tile
+            // ΔW in AGPRs — equal work for every wave — was slower: 756 vs 723 us at 100 x 100, 889 vs 807 us at 128 x 100; one
+            // wave does not cover its own load latency.  Alternating which wave of a block takes the short share of a 4 + 3 column
+            // split changed nothing either.)
+            const int ktiles = (int)((K + 15) / 16);
+            const int kwaves_all = (ktiles + 3) / 4;
+            const int waves = std::min(4, kwaves_all);
+            const int kblocks = (kwaves_all + waves - 1) / waves;
+            a.tiles_per_wave = (ktiles + kblocks * waves - 1) / (kblocks * waves);
+            dim3 grid((unsigned)slabs, (unsigned)((Dout + 127) / 128), (unsigned)kblocks);
+            if ((Dout + 15) / 16 <= 7)
+                dense_gradw16_kernel<7, 4, 6, 2><<<grid, 64 * waves, 0, stream>>>(a);
+            else
+                dense_gradw16_kernel<8, 4, 4, 2><<<grid, 64 * waves, 0, stream>>>(a);
+            GNNMP_LAUNCH_CHECK("dense_gradw16_kernel");
+        } else {
         GradWArgs a;
         a.dz = dz;
         a.x = x;
@@ -256,16 +414,16 @@ int gnnmp_dense_grad_w_f32(const float *dz, const float *x, int64_t N, int64_t D
         a.Dout = (int)Dout;
         a.K = (int)K;
         dim3 grid((unsigned)slabs, (unsigned)((Dout + 127) / 128), (unsigned)((K + 127) / 128));
-        switch (knob(KNOB_GRADW_RP)) {
-            case 4: dense_gradw_kernel<4><<<grid, 256, 0, stream>>>(a); break;
-            case 8: dense_gradw_kernel<8><<<grid, 256, 0, stream>>>(a); break;
-            default: dense_gradw_kernel<2><<<grid, 256, 0, stream>>>(a); break;   // fewest registers, most waves: 1.55 ms
-        }
+        dense_gradw_kernel<2><<<grid, 256, 0, stream>>>(a);
         GNNMP_LAUNCH_CHECK("dense_gradw_kernel");
+        }
         const int64_t len = Dout * K;
         if (int rc = fold_partials(workspace, slabs, len, dW, workspace + (int64_t)slabs * len, stream)) return rc;
     }
-    if (db) {
+    if (db && db_done) {
+        const float *pdb = workspace + ((int64_t)slabs + FOLD_GROUPS) * std::max(Dout * K, Dout);
+        if (int rc = fold_partials(pdb, slabs, Dout, db, workspace + (int64_t)slabs * Dout * K, stream)) return rc;
+    } else if (db) {
         colsum_partial_kernel<<<(unsigned)slabs, 256, 0, stream>>>(dz, N, (int)Dout, rps, workspace);
         GNNMP_LAUNCH_CHECK("colsum_partial_kernel");
         if (int rc = fold_partials(workspace, slabs, Dout, db, workspace + (int64_t)slabs * Dout, stream)) return rc;

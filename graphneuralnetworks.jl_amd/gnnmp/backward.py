@@ -191,17 +191,15 @@ class _GCNConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, g, sigma, add_self_loops):
-        from .layers import _inv_sqrt, bias_act, dense
+        from .layers import bias_act, dense, fused_conv, gcn_norm_cache
         lib = L.load()
         plan = g.plan(add_self_loops)
-        d = torch.empty(g.num_nodes, dtype=torch.float32, device=g.device)
-        L.check(lib.gnnmp_degree_f32(plan.handle, None, L.ptr(d), L.stream_ptr()))
-        c = _inv_sqrt(d)
+        c, c_slot, _ = gcn_norm_cache(g, add_self_loops)          # degree, 1/sqrt and slot order: once per graph
 
         def P(h):
             out = torch.empty((plan.n_dst, h.shape[1]), dtype=torch.float32, device=h.device)
-            L.check(lib.gnnmp_propagate_f32(plan.handle, L.COPY_XJ, L.SUM, L.ptr(h), None, L.ptr(c), L.ptr(c), L.ptr(out),
-                                            h.shape[1], L.stream_ptr()))
+            L.check(lib.gnnmp_propagate_slots_f32(plan.handle, L.SUM, L.ptr(h), None, L.ptr(c_slot), L.ptr(c), L.ptr(out),
+                                                  h.shape[1], L.stream_ptr()))
             return out
 
         Dout, Din = weight.shape
@@ -212,14 +210,20 @@ class _GCNConvFn(torch.autograd.Function):
             y = bias_act(p, bias, sigma)
             ctx.save_for_backward(x, weight, y, c)
         else:
-            agg = P(x)
-            y = dense(agg, weight, bias, sigma)
+            # the aggregate is the ΔW operand of the backward: the fused kernel hands it out next to the layer output
+            r = fused_conv(plan, L.SUM, x, weight, bias, sigma, ss_slot=c_slot, scale_dst=c, return_aggregate=True)
+            if r is not None:
+                y, agg = r
+            else:
+                agg = P(x)
+                y = dense(agg, weight, bias, sigma)
             ctx.save_for_backward(agg, weight, y, c)
         ctx.g, ctx.sigma, ctx.loops, ctx.w_first, ctx.has_bias = g, sigma, add_self_loops, Dout < Din, bias is not None
         return y
 
     @staticmethod
     def backward(ctx, dy):
+        from .layers import fused_conv
         saved, weight, y, c = ctx.saved_tensors
         g = ctx.g
         dz = act_grad(dy.contiguous(), y, ctx.sigma)
@@ -236,7 +240,13 @@ class _GCNConvFn(torch.autograd.Function):
         else:
             agg = saved
             dW, db = dense_grad_w(dz, agg, need_b=ctx.has_bias)
-            dx = PT(dense_grad_x(dz, weight)) if ctx.needs_input_grad[0] else None
+            dx = None
+            if ctx.needs_input_grad[0]:
+                # Δx = PT(Δz * W) = PT(Δz) * W (the propagate acts on rows, W on columns): aggregate-then-transform on the
+                # plan of the reversed edges, one kernel, W read as stored
+                dx = fused_conv(plan_transposed(g, ctx.loops), L.SUM, dz, weight, scale_src=c, scale_dst=c, w_layout=1)
+                if dx is None:
+                    dx = PT(dense_grad_x(dz, weight))
         return dx, dW, (db if ctx.has_bias else None), None, None, None
 
 

@@ -59,15 +59,21 @@ def dense(x, W, bias=None, sigma=None, x2=None, W2=None):
 
 
 def fused_conv(plan, aggr, xj, W_agg, bias=None, sigma=None, xi=None, W_root=None, w=None, scale_src=None, w_slot=None,
-               ss_slot=None, scale_dst=None, return_aggregate=False):
+               ss_slot=None, scale_dst=None, return_aggregate=False, w_layout=0):
     """act(W_root * xi + W_agg * A + bias) with A = the plan's aggregation of xj (same arguments as gnnmp_propagate_f32 /
     gnnmp_propagate_slots_f32), in ONE kernel: A stays in LDS (csrc/fused_conv.hip).  Returns None when the shape is outside
     the kernel's envelope (the caller then runs propagate + dense); with return_aggregate the pre-GEMM aggregate comes back
-    too (bit-identical to the unfused propagate: tests)."""
+    too (bit-identical to the unfused propagate: tests).  w_layout = 1: W_agg is [D, Dout] and the product is A * W_agg (the
+    adjoint's `Δz * W` with the layer's own [Dout, Din] matrix, no transposed copy); not with a root term."""
     xf = _flat(xj)
     D = xf.shape[1]
-    Dout = W_agg.shape[0]
-    assert W_agg.shape[1] == D and W_agg.stride(1) == 1
+    if w_layout:
+        assert xi is None
+        Dout = W_agg.shape[1]
+        assert W_agg.shape[0] == D and W_agg.stride(1) == 1
+    else:
+        Dout = W_agg.shape[0]
+        assert W_agg.shape[1] == D and W_agg.stride(1) == 1
     D1 = 0
     if xi is not None:
         xi = _flat(xi)
@@ -80,7 +86,7 @@ def fused_conv(plan, aggr, xj, W_agg, bias=None, sigma=None, xi=None, W_root=Non
     lib = L.load()
     rc = lib.gnnmp_fused_conv_f32(plan.handle, aggr, L.ptr(xf), L.ptr(w), L.ptr(scale_src), L.ptr(w_slot), L.ptr(ss_slot),
                                   L.ptr(scale_dst), D, L.ptr(xi), D1, L.ptr(W_root), 0 if W_root is None else W_root.stride(0),
-                                  L.ptr(W_agg), W_agg.stride(0), 0, L.ptr(b), code, L.ptr(out), Dout, L.ptr(agg), L.stream_ptr())
+                                  L.ptr(W_agg), W_agg.stride(0), int(w_layout), L.ptr(b), code, L.ptr(out), Dout, L.ptr(agg), L.stream_ptr())
     if rc == L.EUNSUPPORTED:
         return None
     L.check(rc)

@@ -154,3 +154,42 @@ def test_many_launches_start_from_a_zeroed_ticket(gm):
     for _ in range(100):
         assert torch.equal(gm.fused_conv(plan, L.SUM, xa, Wa), ya)
         assert torch.equal(gm.fused_conv(plan, L.MEAN, xb, Wb), yb)
+
+
+@pytest.mark.parametrize("Din,Dout", [(100, 100), (16, 128), (128, 128), (12, 20)])
+def test_gcn_layer_adjoint_through_the_fused_kernels(gm, oracle, Din, Dout):
+    """gcn_conv_ad with the fused kernel forced (module fixture): the forward hands out the aggregate next to the output, the
+    backward forms Δx = PT(Δz) * W as ONE aggregate-then-transform on the plan of the reversed edges (w_layout = 1).  Against
+    the oracle's composition of NNlib's rules (FD-pinned on CPU), hubs above the split threshold included."""
+    import torch
+    from gnnmp.backward import gcn_conv_ad
+    rng = np.random.default_rng(Din * 7 + Dout)
+    s, t, n = hub_graph(rng, n=1500, E=20000, hub_edges=(600, 90))
+    x = rng.standard_normal((n, Din)).astype(np.float32)
+    r = rng.standard_normal((n, Dout)).astype(np.float32)
+    g = gm.GNNGraph(dev(s), dev(t), num_nodes=n)
+    l = gm.GCNConv((Din, Dout), "relu", seed=5)
+    l.bias = dev(rng.standard_normal(Dout).astype(np.float32) * 0.1)
+    W0, b0 = l.weight.cpu().numpy(), l.bias.cpu().numpy()
+    xt = dev(x).requires_grad_(True)
+    l.weight.requires_grad_(True)
+    l.bias.requires_grad_(True)
+    y = gcn_conv_ad(l, g, xt)
+    ref_y = oracle.gcn_conv(s, t, n, x, W0, b0, "relu")
+    assert np.linalg.norm(y.detach().cpu().numpy() - ref_y) <= 1e-5 * np.linalg.norm(ref_y)
+    (y * dev(r)).sum().backward()
+    dx, dW, db = oracle.grad_gcn_conv(s, t, n, x, W0, b0, "relu", r)
+    for got, ref in ((xt.grad, dx), (l.weight.grad, dW), (l.bias.grad, db)):
+        assert np.linalg.norm(got.cpu().numpy() - ref) <= 2e-5 * np.linalg.norm(ref)
+    # and the same gradients as the unfused composition
+    gm.tune(14, -1)
+    try:
+        x2 = dev(x).requires_grad_(True)
+        l.weight.grad = None
+        l.bias.grad = None
+        y2 = gcn_conv_ad(l, g, x2)
+        (y2 * dev(r)).sum().backward()
+    finally:
+        gm.tune(14, 16)
+    close(xt.grad.cpu().numpy(), x2.grad.cpu().numpy(), 2e-5)
+    close(y.detach().cpu().numpy(), y2.detach().cpu().numpy())

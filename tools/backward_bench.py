@@ -35,6 +35,12 @@ from gnnmp.backward import dense_grad_w, dense_grad_x, act_grad, gcn_conv_ad
 W = torch.randn((100, D), device="cuda") * 0.1
 dz = torch.randn((N, 100), device="cuda")
 tw = t(lambda: dense_grad_w(dz, x))
+L_ = __import__("gnnmp")._lib.load()
+L_.gnnmp_tune(10, -1); tw_old = t(lambda: dense_grad_w(dz, x)); L_.gnnmp_tune(10, 0)
+print(f"dW+db 2.4M x 100 x 100: 16x16x4 kernel {tw:.3f} ms, round-1 32x32x2 kernel {tw_old:.3f} ms")
+dz128 = torch.randn((N, 128), device="cuda")
+tw128 = t(lambda: dense_grad_w(dz128, x))
+print(f"dW+db 2.4M x 128 x 100: {tw128:.3f} ms ({2*N*128*D/tw128/1e9:.1f} TF)")
 tx = t(lambda: dense_grad_x(dz, W))
 ta = t(lambda: act_grad(dz, dz, "relu"))
 print(f"dense adjoints 2.4M x 100 => 100: dW+db {tw:.3f} ms ({2*N*100*D/tw/1e9:.1f} TF) | dX {tx:.3f} ms | act_grad {ta:.3f} ms")
