@@ -525,6 +525,40 @@ def main():
         extras["sage_products"] = {"E": E, "layer_ms_mean": t_sm, "layer_ms_sum": t_ss,
                                    "edges_per_s_mean": E / t_sm * 1e3, "edges_per_s_sum": E / t_ss * 1e3}
         del out_p, out_g, Wx, sage
+        # SURVEY §8f "next" rows on the same graph: the standalone neighbourhood softmax (a20) and the training step of the two
+        # headline layers (f1: forward + backward through the HIP adjoints)
+        from gnnmp.backward import gat_conv_ad, gcn_conv_ad
+        e8 = torch.randn((E, H), device="cuda")
+        t_sx = layer_time(lambda: gnnmp.softmax_edge_neighbors(g, e8), 5)
+        del e8
+        xr = x.clone().requires_grad_(True)
+        dyg = torch.randn((N, D), device="cuda")
+        dya = torch.randn((N, H * C), device="cuda")
+        for prm in (gcn.weight, gcn.bias, gat.dense_x_weight, gat.a, gat.bias):
+            prm.requires_grad_(True)
+
+        def train(fn, l, dy):
+            def f():
+                fn(l, g, xr).backward(dy)
+                xr.grad = None
+            return f
+
+        def median_time(fn, iters=5):   # two warm-ups (the first calls build the reversed-edge plans and grow the allocator)
+            fn(); fn()
+            torch.cuda.synchronize()
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+            for a_, b_ in ev:
+                a_.record(); fn(); b_.record()
+            torch.cuda.synchronize()
+            return sorted(a_.elapsed_time(b_) for a_, b_ in ev)[iters // 2]
+
+        t_tg = median_time(train(gcn_conv_ad, gcn, dyg))
+        t_ta = median_time(train(gat_conv_ad, gat, dya))
+        for prm in (gcn.weight, gcn.bias, gat.dense_x_weight, gat.a, gat.bias):
+            prm.requires_grad_(False)
+            prm.grad = None
+        extras["next_rows"] = {"softmax_edge_neighbors_h8_ms": t_sx, "gcn_fwd_bwd_ms": t_tg, "gat_fwd_bwd_ms": t_ta}
+        del xr, dyg, dya
         # configs 2 and 3: arxiv shape
         Na, Da = synth.ARXIV["N"], synth.ARXIV["D"]
         sa, ta = synth.arxiv_like()
