@@ -480,6 +480,81 @@ static int launch_wlds(const DenseWArgs &w, size_t lds_bytes, int col_tiles, int
     GNNMP_LAUNCH_CHECK("dense_wlds_kernel");
     return GNNMP_OK;
 }
+// ---- narrow outputs (a classifier head: Dense(128 => 2) after the pool) ---------------------------------------------------
+// Dout <= 8: no matrix core has anything to do (a 16-wide tile would be 7/8 padding and the whole product is a few MFLOP); the
+// MFMA kernels above spend their time staging W.  Eight lanes per row: lane l of the group reads the row's float4s l, l + 8, ...
+// (128 contiguous bytes per group and step), multiplies them into Dout running dot products against W read through L1 (every
+// group reads the same few KB), the eight partial sums meet in a DPP butterfly, lane 0 adds the bias and stores.
+template <int NOUT>
+__global__ void __launch_bounds__(256) dense_narrow_kernel(const float *__restrict__ x1, const float *__restrict__ W1, int K1,
+                                                           int64_t sj1, int64_t sk1, const float *__restrict__ x2,
+                                                           const float *__restrict__ W2, int K2, int64_t sj2, int64_t sk2,
+                                                           const float *__restrict__ bias, int act, float *__restrict__ out,
+                                                           int64_t N, int Dout) {
+    const int lane8 = threadIdx.x & 7;
+    const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+    const int64_t r = row < N ? row : N - 1;
+    float acc[NOUT];
+#pragma unroll
+    for (int j = 0; j < NOUT; ++j) acc[j] = 0.0f;
+    auto segment = [&](const float *x, const float *W, int K, int64_t sj, int64_t sk) {
+        const float *xr = x + r * K;
+        for (int k = 4 * lane8; k < K; k += 32) {
+            const float4 v = *reinterpret_cast<const float4 *>(xr + k);
+#pragma unroll
+            for (int j = 0; j < NOUT; ++j) {
+                if (j < Dout) {
+                    const float *w = W + (int64_t)j * sj + (int64_t)k * sk;
+                    acc[j] = acc[j] + v.x * w[0];
+                    acc[j] = acc[j] + v.y * w[sk];
+                    acc[j] = acc[j] + v.z * w[2 * sk];
+                    acc[j] = acc[j] + v.w * w[3 * sk];
+                }
+            }
+        }
+    };
+    segment(x1, W1, K1, sj1, sk1);
+    if (K2 > 0) segment(x2, W2, K2, sj2, sk2);
+#pragma unroll
+    for (int j = 0; j < NOUT; ++j) {
+        float v = acc[j];
+        v = v + __shfl_xor(v, 1, 64);
+        v = v + __shfl_xor(v, 2, 64);
+        v = v + __shfl_xor(v, 4, 64);
+        acc[j] = v;
+    }
+    if (lane8 == 0 && row < N) {
+#pragma unroll
+        for (int j = 0; j < NOUT; ++j) {
+            if (j < Dout) {
+                float v = acc[j];
+                if (bias) v = v + bias[j];
+                if (act == GNNMP_ACT_RELU) v = v < 0.0f ? 0.0f : v;
+                out[row * Dout + j] = v;
+            }
+        }
+    }
+}
+
+// Returns GNNMP_OK if it launched, 1 if the shape is not one this kernel takes.
+static int dense_narrow_try(const float *x1, const float *W1, int64_t D1, int64_t ldw1, const float *x2, const float *W2,
+                            int64_t D2, int64_t ldw2, int w_layout, const float *bias, int act, float *out, int64_t N,
+                            int64_t Dout, hipStream_t stream) {
+    if (Dout > 8 || (D1 & 3) || (D2 & 3) || D1 > 4096 || D2 > 4096) return 1;
+    if ((reinterpret_cast<uintptr_t>(x1) & 15) || (D2 > 0 && (reinterpret_cast<uintptr_t>(x2) & 15))) return 1;
+    const int64_t sj1 = w_layout == 0 ? ldw1 : 1, sk1 = w_layout == 0 ? 1 : ldw1;
+    const int64_t sj2 = w_layout == 0 ? ldw2 : 1, sk2 = w_layout == 0 ? 1 : ldw2;
+    const unsigned nb = (unsigned)((N * 8 + 255) / 256);
+    if (Dout <= 2)
+        dense_narrow_kernel<2><<<nb, 256, 0, stream>>>(x1, W1, (int)D1, sj1, sk1, x2, W2, (int)D2, sj2, sk2, bias, act, out, N, (int)Dout);
+    else if (Dout <= 4)
+        dense_narrow_kernel<4><<<nb, 256, 0, stream>>>(x1, W1, (int)D1, sj1, sk1, x2, W2, (int)D2, sj2, sk2, bias, act, out, N, (int)Dout);
+    else
+        dense_narrow_kernel<8><<<nb, 256, 0, stream>>>(x1, W1, (int)D1, sj1, sk1, x2, W2, (int)D2, sj2, sk2, bias, act, out, N, (int)Dout);
+    GNNMP_LAUNCH_CHECK("dense_narrow_kernel");
+    return GNNMP_OK;
+}
+
 int dense_t16_try(const float *x1, const float *W1, int64_t D1, int64_t ldw1, const float *x2, const float *W2, int64_t D2,
                   int64_t ldw2, int w_layout, const float *bias, int act, float *out, int64_t N, int64_t Dout,
                   hipStream_t stream);   // dense_t16.hip
@@ -501,6 +576,10 @@ extern "C" int gnnmp_dense_f32(const float *x1, const float *W1, int64_t D1, int
     {
         // the shapes of the hot path (K a multiple of 4, <= 128 per segment): operands straight from HBM, 16x16x4 MFMAs
         const int rc = dense_t16_try(x1, W1, D1, ldw1, x2, W2, D2, ldw2, w_layout, bias, act, out, N, Dout, stream);
+        if (rc != 1) return rc;
+    }
+    if (knob(KNOB_DENSE_GENERIC) == 0) {
+        const int rc = dense_narrow_try(x1, W1, D1, ldw1, x2, W2, D2, ldw2, w_layout, bias, act, out, N, Dout, stream);
         if (rc != 1) return rc;
     }
     DenseArgs a;

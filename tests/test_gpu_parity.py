@@ -487,7 +487,9 @@ def test_size_checks_raise_assertion_error(gm, gold):
 # dense (MFMA) kernel
 # ---------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("N,Din,Dout", [(1, 3, 5), (130, 100, 100), (1000, 128, 128), (257, 1433, 64), (300, 16, 130),
-                                         (513, 200, 256), (64, 7, 2)])
+                                         (513, 200, 256), (64, 7, 2),
+                                         # narrow outputs (dense_narrow_kernel: classifier heads): Dout <= 8, K a multiple of 4
+                                         (8192, 128, 2), (1001, 64, 7), (3, 4, 1), (777, 100, 8), (50, 36, 3), (129, 128, 4)])
 def test_dense_vs_float64(gm, N, Din, Dout):
     rng = np.random.default_rng(N + Din)
     x = rng.standard_normal((N, Din)).astype(np.float32)

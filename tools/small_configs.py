@@ -54,3 +54,9 @@ else:
                            gnnmp.GlobalPool("mean"), gnnmp.Dense((128, 2), seed=23))
     print("batched: nodes", gb.num_nodes, "edges", gb.num_edges)
     measure(lambda: model(gb, gb.x), "config-5 step")
+    l1, l2, pool, head = model.layers
+    h1 = l1(gb, gb.x); h2 = l2(gb, h1); u = pool(gb, h2)
+    measure(lambda: l1(gb, gb.x), "  GraphConv(16=>128)")
+    measure(lambda: l2(gb, h1), "  GraphConv(128=>128)")
+    measure(lambda: pool(gb, h2), "  GlobalPool(mean)")
+    measure(lambda: head(u), "  Dense(128=>2)")
