@@ -21,6 +21,11 @@
  *     plan with a row longer than GNNMP_LONG_ROW at a larger D than before grows a plan-owned
  *     workspace with hipMalloc).  gnnmp_plan_create synchronises `stream` (it is graph prep, done
  *     once per graph, outside the timed path).
+ *   - a plan carries scratch of its own (the partials of split rows, the tile ticket of the fused layer kernel, cached
+ *     orderings): calls that take the SAME plan must be ordered on ONE stream (or by events) — two streams may run
+ *     different plans, or read-only queries of one plan, concurrently, but not two compute calls on one plan.  The
+ *     reference has the same shape: one GNNGraph, one task.  Host threads: the library keeps no global mutable state
+ *     besides the tuning knobs (gnnmp_tune, experiments only) and the thread-local error string.
  *   - return value: 0 = ok, negative = gnnmp_status; nothing throws, nothing aborts.
  *     gnnmp_last_error() gives a thread-local message for the last failing call.
  *   - determinism: no entry point except *_atomic_* uses floating-point atomics.  Per-destination
