@@ -123,6 +123,36 @@ def test_gat_full_size_convexity(gm, products):
     assert torch.equal(l(g, v.repeat(N, 1)), y)
 
 
+def test_softmax_edge_neighbors_full_size(gm, oracle, products):
+    """softmax_edge_neighbors (utils.jl:84-97) on all 61.9 M edge rows, H = 8 and H = 1: the one-pass narrow-row kernels are
+    bit-identical to the three-step kernels (knob 16 < 0), every destination with an edge sums to one, and 3000 sampled
+    destinations match the oracle's restatement on their own edges"""
+    import torch
+    s, t, g, N = products["s"], products["t"], products["g"], products["N"]
+    E = len(s)
+    rng = np.random.default_rng(12)
+    rows = np.sort(rng.choice(N, 3000, replace=False)) + 1
+    sel = np.flatnonzero(np.isin(t, rows))
+    tmap = np.zeros(N + 1, np.int64)
+    tmap[rows] = np.arange(1, len(rows) + 1)
+    tdev = torch.from_numpy(t - 1).cuda()
+    has = torch.from_numpy(np.bincount(t - 1, minlength=N) > 0).cuda()
+    for H in (8, 1):
+        e = torch.randn((E, H), device="cuda") * 2.0
+        a = gm.softmax_edge_neighbors(g, e)
+        gm.tune(16, -1)
+        try:
+            a3 = gm.softmax_edge_neighbors(g, e)
+        finally:
+            gm.tune(16, 0)
+        assert torch.equal(a, a3)
+        sums = torch.zeros((N, H), dtype=torch.float64, device="cuda").index_add_(0, tdev, a.double())
+        assert float((sums[has] - 1.0).abs().max()) < 1e-5
+        ref = oracle.softmax_edge_neighbors(tmap[t[sel]], len(rows), e[torch.from_numpy(sel).cuda()].cpu().numpy())
+        np.testing.assert_allclose(a[torch.from_numpy(sel).cuda()].cpu().numpy(), ref, rtol=1e-5, atol=1e-12)
+        del e, a, a3, sums
+
+
 def test_batched_model_config5_vs_oracle(gm, oracle):
     """config 5 at G = 512: GNNChain(GraphConv(16=>128,relu), GraphConv(128=>128,relu), GlobalPool(mean), Dense(128=>2))"""
     import torch
