@@ -1,0 +1,52 @@
+// gather_probe.hip — how fast can the chip fetch random ROWS of a row-major fp32 matrix, with nothing else to do?
+// Each lane group of G lanes (16 bytes per lane: a row of 4 G floats) walks a list of random row ids and adds the rows into
+// registers, U row loads in flight; one 16-byte store per lane at the end.  No index broadcast, no order, no epilogue: this is
+// the ceiling the propagate / attention kernels are measured against (profiles/README.md).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+template <int U>
+__global__ void __launch_bounds__(256) gather_probe_kernel(const float *__restrict__ x, const int32_t *__restrict__ ids,
+                                                           int64_t n_ids, int log2g, int row_floats, int per_group,
+                                                           float *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int G = 1 << log2g;
+    const int lig = lane & (G - 1);
+    const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> log2g;
+    const int64_t beg = group * per_group;
+    if (beg >= n_ids) return;
+    const int64_t end = beg + per_group < n_ids ? beg + per_group : n_ids;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool active = 4 * lig < row_floats;
+    for (int64_t p = beg; p < end; p += U) {
+        int c[U];
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) c[u] = ids[p + u < end ? p + u : end - 1];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (active) v[u] = *reinterpret_cast<const float4 *>(x + (int64_t)c[u] * row_floats + 4 * lig);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (active && p + u < end) {
+                acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w;
+            }
+        }
+    }
+    if (active) *reinterpret_cast<float4 *>(out + group * row_floats + 4 * lig) = acc;
+}
+
+extern "C" int gather_probe(const float *x, const int32_t *ids, int64_t n_ids, int log2g, int row_floats, int per_group, int U,
+                            float *out, void *stream) {
+    const int64_t groups = (n_ids + per_group - 1) / per_group;
+    const int64_t threads = groups << log2g;
+    const unsigned blocks = (unsigned)((threads + 255) / 256);
+    hipStream_t s = (hipStream_t)stream;
+    switch (U) {
+        case 4: gather_probe_kernel<4><<<blocks, 256, 0, s>>>(x, ids, n_ids, log2g, row_floats, per_group, out); break;
+        case 8: gather_probe_kernel<8><<<blocks, 256, 0, s>>>(x, ids, n_ids, log2g, row_floats, per_group, out); break;
+        case 16: gather_probe_kernel<16><<<blocks, 256, 0, s>>>(x, ids, n_ids, log2g, row_floats, per_group, out); break;
+        default: return -1;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
