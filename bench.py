@@ -510,6 +510,30 @@ def main():
     MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32, 64 FLOP/clk/SIMD
     t_dg, _ = event_time(lambda: gnnmp.dense(out_p, gcn.weight, gcn.bias, "relu"), iters)
     t_da, _ = event_time(lambda: gnnmp.dense(x, gat.dense_x_weight), iters)
+    # the bare ceiling of this box: a kernel that only fetches E' random rows into registers (tools/ubench/gather_probe.hip),
+    # 26 rows per lane group (the mean in-degree) and 208; the step's two gather kernels are to be read against these
+    if rank == 0 and not args.no_extras:
+        try:
+            import ctypes
+            probe = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "ubench", "libgather_probe.so"))
+            probe.gather_probe.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
+                                           ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+            ids = torch.randint(0, N, (Ep,), device="cuda", dtype=torch.int32)
+            ceil = {}
+            for Dp in (D, H * C):
+                xp = torch.randn((N, Dp), device="cuda")
+                for per in (26, 208):
+                    outp = torch.empty(((Ep + per - 1) // per, Dp), device="cuda")
+                    ceil[f"D{Dp}_rows{per}_ms"] = event_time(
+                        lambda: probe.gather_probe(xp.data_ptr(), ids.data_ptr(), Ep, 5, Dp, per, 8, outp.data_ptr(),
+                                                   torch.cuda.current_stream().cuda_stream), 5)[0]
+                del xp, outp
+            del ids
+            ceil["note"] = ("ms to fetch E' uniformly random rows of an N x D matrix into registers and nothing else; "
+                            "compare kernels.gcn_fused_layer (D=%d) and kernels.gat_aggregate (D=%d)" % (D, H * C))
+            extras["gather_ceiling"] = ceil
+        except OSError as e:
+            extras["gather_ceiling"] = {"note": f"tools/ubench/libgather_probe.so not built: {e}"}
     extras["dense"] = {
         "kernel": "dense kernels (fp32 MFMA)", "peak_TFs": MFMA_F32_PEAK_TF,
         "gcn_W_x": {"shape": f"{N}x{D}=>{D}", "ms": t_dg, "TFs": 2.0 * N * D * D / t_dg / 1e9,
