@@ -59,6 +59,7 @@ def test_edge_softmax_matches_three_steps_and_oracle(gm, oracle, H, n, E, hubs):
     ed = dev(e)
     new, old = both_paths(gm, lambda: gm.softmax_edge_neighbors(g, ed))
     assert torch.equal(new, old)
+    assert torch.equal(new, gm.softmax_edge_neighbors(g, ed))       # no atomics anywhere: run-to-run identical
     ref = oracle.softmax_edge_neighbors(t, n, e)                    # 1-based, like the graph
     np.testing.assert_allclose(new.cpu().numpy(), ref, rtol=2e-6, atol=1e-12)
     # every destination with an edge sums to one
