@@ -8,6 +8,7 @@
 //   rs_hist    every wave counts its tile's digits in a private 256-entry LDS table (ds_add), writes them DIGIT-MAJOR
 //              (counts[digit][tile]) so that one flat exclusive scan yields every (digit, tile) pair's first output slot;
 //   scan       reduce-then-scan over 4 096-element chunks (wave shuffles + one LDS hop);
+//   (passes whose digit is the same in every key are dropped beforehand: rs_varying_bits)
 //   rs_scatter every wave walks its tile again 64 elements at a time IN ORDER: the lanes holding equal digits are found with 8
 //              ballots (one per digit bit), a lane's rank among them is a popcount of the lower lanes — no sorting network, no
 //              atomics — and the digit's running slot lives in an LDS table.  The four wave tiles of a block are first put into
@@ -41,10 +42,18 @@ __global__ void __launch_bounds__(64 * RS_WPB) rs_hist(const K *__restrict__ key
     for (int k = 0; k < 4; ++k) h[w][lane + 64 * k] = 0;
     wave_lds_sync();
     const size_t base = tile * RS_WT;
-#pragma unroll 4
+    // the whole tile's keys first (32 independent loads per lane in flight), then the LDS counting: with the load inside the
+    // counting loop every step paid a memory round trip (182 us per pass of 62 M 64-bit keys)
+    K kreg[RS_WT / 64];
+#pragma unroll
     for (int s = 0; s < RS_WT / 64; ++s) {
         const size_t i = base + (size_t)s * 64 + lane;
-        if (i < n) atomicAdd(&h[w][(int)((keys[i] >> shift) & 255)], 1u);
+        kreg[s] = i < n ? keys[i] : (K)0;
+    }
+#pragma unroll
+    for (int s = 0; s < RS_WT / 64; ++s) {
+        const size_t i = base + (size_t)s * 64 + lane;
+        if (i < n) atomicAdd(&h[w][(int)((kreg[s] >> shift) & 255)], 1u);
     }
     wave_lds_sync();
 #pragma unroll
@@ -114,11 +123,22 @@ __global__ void __launch_bounds__(64 * RS_WPB) rs_scatter(const K *__restrict__ 
     if (tile < n_tiles) {
         const size_t base = tile * RS_WT;
         const uint64_t lower = (1ull << lane) - 1ull;
+        // the tile's keys (and payloads) into registers first: 32 (64) independent loads per lane in flight.  With the load inside
+        // the ranking loop every one of its 32 steps waited for memory between two LDS barriers (575 us per pass of 62 M keys).
+        K kreg[RS_WT / 64];
+        uint32_t vreg[PAIRS ? RS_WT / 64 : 1];
+#pragma unroll
+        for (int s = 0; s < RS_WT / 64; ++s) {
+            const size_t i = base + (size_t)s * 64 + lane;
+            kreg[s] = i < n ? keys[i] : (K)0;
+            if (PAIRS) vreg[PAIRS ? s : 0] = i < n ? vals[i] : 0u;
+        }
+#pragma unroll
         for (int s = 0; s < RS_WT / 64; ++s) {
             const size_t i = base + (size_t)s * 64 + lane;
             const bool valid = i < n;
-            const K key = valid ? keys[i] : (K)0;
-            const uint32_t val = (PAIRS && valid) ? vals[i] : 0u;
+            const K key = kreg[s];
+            const uint32_t val = PAIRS ? vreg[PAIRS ? s : 0] : 0u;
             const int d = (int)((key >> shift) & 255);
             uint64_t same = __ballot(valid);
 #pragma unroll
@@ -262,10 +282,19 @@ int exclusive_scan_u32(const uint32_t *in, uint32_t *out, size_t n, hipStream_t 
 }
 
 // ---- the sort ---------------------------------------------------------------------------------------------------------
-// digit_start[d] = first output slot of digit d (= offsets[d][tile 0]); a pass whose digit is the same for every key
-// (one bucket holds all n: the zero bytes of a packed (s, t) pair, the high byte of a 22-bit destination) moves nothing
-__global__ void rs_digit_starts(const uint32_t *__restrict__ offsets, size_t n_tiles, uint32_t *__restrict__ starts) {
-    starts[threadIdx.x] = offsets[(size_t)threadIdx.x * n_tiles];
+// OR over all keys of (key XOR key[0]): the bits that are not the same in every key.  A pass whose eight bits are all constant
+// moves nothing and is skipped — known before the first pass, from ONE read of the keys and one host round trip (the first
+// version found out per pass, from that pass's scanned histogram: a histogram, a scan and a stream synchronisation for every
+// dead byte of a packed (s, t) pair or of a 22-bit destination).
+template <class K>
+__global__ void __launch_bounds__(256) rs_varying_bits(const K *__restrict__ keys, size_t n, unsigned long long *__restrict__ out) {
+    const K k0 = keys[0];
+    unsigned long long v = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        v |= (unsigned long long)(keys[i] ^ k0);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v |= __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicOr(out, v);
 }
 
 template <class K, bool PAIRS>
@@ -277,12 +306,12 @@ static int radix_sort_impl(const K *keys_in, K *keys_out, const uint32_t *vals_i
     const size_t n_tiles = (n + RS_WT - 1) / RS_WT;
     const size_t m = 256 * n_tiles;
     K *ktmp = nullptr;
-    uint32_t *vtmp = nullptr, *counts = nullptr, *sums = nullptr, *starts = nullptr;
-    uint32_t hstarts[256];
+    uint32_t *vtmp = nullptr, *counts = nullptr, *sums = nullptr;
+    unsigned long long *dvary = nullptr, hvary = 0;
     int rc = GNNMP_OK;
     hipError_t e = hipMalloc((void **)&counts, sizeof(uint32_t) * m);
+    if (e == hipSuccess) e = hipMalloc((void **)&dvary, sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc((void **)&sums, sizeof(uint32_t) * scan_blocks(m));
-    if (e == hipSuccess) e = hipMalloc((void **)&starts, sizeof(uint32_t) * 256);
     if (e == hipSuccess) e = hipMalloc((void **)&ktmp, sizeof(K) * n);
     if (e == hipSuccess && PAIRS) e = hipMalloc((void **)&vtmp, sizeof(uint32_t) * n);
     if (e != hipSuccess) rc = hip_fail(e, "hipMalloc(radix sort temporaries)");
@@ -293,22 +322,23 @@ static int radix_sort_impl(const K *keys_in, K *keys_out, const uint32_t *vals_i
                                             (int)scatter_lds);
         if (ea != hipSuccess && rc == GNNMP_OK) rc = hip_fail(ea, "hipFuncSetAttribute(rs_scatter)");
     }
+    if (rc == GNNMP_OK) {
+        e = hipMemsetAsync(dvary, 0, sizeof(unsigned long long), stream);
+        if (e == hipSuccess) {
+            const unsigned vb = (unsigned)std::min<size_t>((n + 255) / 256, (size_t)device_cus() * 8);
+            rs_varying_bits<K><<<vb, 256, 0, stream>>>(keys_in, n, dvary);
+            e = hipMemcpyAsync(&hvary, dvary, sizeof(hvary), hipMemcpyDeviceToHost, stream);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) rc = hip_fail(e, "radix sort: varying bits");
+    }
     const K *ksrc = keys_in;
     const uint32_t *vsrc = vals_in;
     for (int p = 0; p < passes && rc == GNNMP_OK; ++p) {
         const int shift = begin_bit + 8 * p;
+        if (((hvary >> shift) & 255ull) == 0) continue;    // every key has the same digit here: nothing moves
         rs_hist<K><<<blocks, 64 * RS_WPB, 0, stream>>>(ksrc, n, shift, counts, n_tiles);
         exclusive_scan_enqueue<uint32_t>(counts, counts, m, sums, stream);
-        rs_digit_starts<<<1, 256, 0, stream>>>(counts, n_tiles, starts);
-        e = hipMemcpyAsync(hstarts, starts, sizeof(hstarts), hipMemcpyDeviceToHost, stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(stream);
-        if (e != hipSuccess) { rc = hip_fail(e, "radix sort pass"); break; }
-        bool trivial = false;                              // some digit holds every key <=> its bucket is [0, n)
-        for (int d = 0; d < 256 && !trivial; ++d) {
-            const size_t lo = hstarts[d], hi = d + 1 < 256 ? (size_t)hstarts[d + 1] : n;
-            trivial = lo == 0 && hi == n;
-        }
-        if (trivial) continue;
         // destination: whichever of (out, tmp) does not hold the current source
         K *kdst = (ksrc == keys_out) ? ktmp : keys_out;
         uint32_t *vdst = (ksrc == keys_out) ? vtmp : vals_out;
@@ -329,7 +359,7 @@ static int radix_sort_impl(const K *keys_in, K *keys_out, const uint32_t *vals_i
     }
     if (counts) (void)hipFree(counts);
     if (sums) (void)hipFree(sums);
-    if (starts) (void)hipFree(starts);
+    if (dvary) (void)hipFree(dvary);
     if (ktmp) (void)hipFree(ktmp);
     if (vtmp) (void)hipFree(vtmp);
     return rc;

@@ -26,6 +26,8 @@ CMD="python $REPO/tools/small_configs.py batched"
 run batched_kernel_stats --kernel-trace --stats
 CMD="python $REPO/tools/backward_bench.py"
 run backward_kernel_stats --kernel-trace --stats
+CMD="python $REPO/tools/next_rows_bench.py --quick"
+run next_rows_kernel_stats --kernel-trace --stats
 if [ -z "$QUICK" ]; then
 CMD="$BENCH --steps 3 --warmup 1"
 run pmc_rd --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_32B_sum
