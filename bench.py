@@ -618,7 +618,7 @@ def main():
                                f"GCNConv({D}=>{D},relu) fwd + GATConv({D}=>{C},heads={H},relu) fwd per step; "
                                f"edges counted = 2*E' per GPU",
                    "parallelism": f"replicas x{world} (independent feature batches, no collective)",
-                   "index": "Int64 1-based COO as held by GNNGraph; plan = int32 dst-sorted CSR built once"},
+                   "index": "Int64 1-based COO as held by GNNGraph; plan = dst-sorted CSR (4-byte slots) built once"},
         "roofline": roofline,
         "extras": extras,
     }

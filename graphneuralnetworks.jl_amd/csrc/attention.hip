@@ -45,7 +45,7 @@ __global__ void __launch_bounds__(256) gat_node_scores_kernel(const float *Wx, c
 
 // ---- fused edge softmax + weighted aggregate -----------------------------------------------------
 struct GatArgs {
-    const int32_t *rowptr;
+    const uint32_t *rowptr;
     const int32_t *col;
     const int32_t *eid;
     const float *Wx;     // [n_src][D], D = H*C
@@ -68,13 +68,13 @@ struct GatArgs {
 
 // pass 1: running max of the row's logits (per lane: the lane's head)
 template <int U>
-__device__ __forceinline__ float gat_pass_max(const GatArgs &a, int beg, int end, int lig, int gbase,
+__device__ __forceinline__ float gat_pass_max(const GatArgs &a, uint32_t beg, uint32_t end, int lig, int gbase,
                                               int G, int h, float sd) {
     float mx = -__builtin_inff();
-    for (int base = beg; base < end; base += G) {
-        const int p = base + lig;
+    for (uint32_t base = beg; base < end; base += G) {   // slots are unsigned 32-bit (csr_reduce.h)
+        const uint32_t p = base + lig;
         const int c = p < end ? a.col[p] : 0;
-        const int n = min(G, end - base);
+        const int n = (int)min((uint32_t)G, end - base);
         for (int j = 0; j < n; j += U) {
             float s[U];
 #pragma unroll
@@ -91,13 +91,13 @@ __device__ __forceinline__ float gat_pass_max(const GatArgs &a, int beg, int end
 }
 // pass 2: denominator, summed in edge order
 template <int U>
-__device__ __forceinline__ float gat_pass_den(const GatArgs &a, int beg, int end, int lig, int gbase,
+__device__ __forceinline__ float gat_pass_den(const GatArgs &a, uint32_t beg, uint32_t end, int lig, int gbase,
                                               int G, int h, float sd, float mx) {
     float den = 0.0f;
-    for (int base = beg; base < end; base += G) {
-        const int p = base + lig;
+    for (uint32_t base = beg; base < end; base += G) {   // slots are unsigned 32-bit (csr_reduce.h)
+        const uint32_t p = base + lig;
         const int c = p < end ? a.col[p] : 0;
-        const int n = min(G, end - base);
+        const int n = (int)min((uint32_t)G, end - base);
         for (int j = 0; j < n; j += U) {
             float s[U];
 #pragma unroll
@@ -114,18 +114,18 @@ __device__ __forceinline__ float gat_pass_den(const GatArgs &a, int beg, int end
 }
 // pass 3: acc += (num/den) * Wx[col]
 template <int VEC, int U>
-__device__ __forceinline__ void gat_pass_acc(const GatArgs &a, int beg, int end, int lig, int gbase,
+__device__ __forceinline__ void gat_pass_acc(const GatArgs &a, uint32_t beg, uint32_t end, int lig, int gbase,
                                              int G, int h, int f0, bool active, float sd, float mx,
                                              float den, float acc[VEC]) {
     const bool write_alpha = a.alpha_out != nullptr && active && (f0 % a.C == 0);
-    for (int base = beg; base < end; base += G) {
-        const int p = base + lig;
-        int c = 0, e = 0;
+    for (uint32_t base = beg; base < end; base += G) {
+        const uint32_t p = base + lig;
+        int c = 0, e = 0;                      // e: original edge position, an unsigned 32-bit value carried in an int
         if (p < end) {
             c = a.col[p];
             if (a.alpha_out) e = a.eid[p];
         }
-        const int n = min(G, end - base);
+        const int n = (int)min((uint32_t)G, end - base);
         for (int j = 0; j < n; j += U) {
             float v[U][VEC];
             float s[U];
@@ -148,7 +148,7 @@ __device__ __forceinline__ void gat_pass_acc(const GatArgs &a, int beg, int end,
                 if (j + u < n) {
                     const float num = expf(leaky_relu(sd + s[u], a.slope) - mx);
                     const float al = num / den;
-                    if (write_alpha) a.alpha_out[(int64_t)ej[u] * a.H + h] = al;
+                    if (write_alpha) a.alpha_out[(int64_t)(uint32_t)ej[u] * a.H + h] = al;
 #pragma unroll
                     for (int q = 0; q < VEC; ++q) {
                         const float b = al * v[u][q];  // β = α .* Wxj   (conv.jl:140)
@@ -190,8 +190,8 @@ __global__ void __launch_bounds__(256) gat_rows_kernel(const GatArgs a) {
     const int f0 = ((int)blockIdx.y * G + lig) * VEC;
     const bool active = f0 < a.D;
     const int h = active ? f0 / a.C : 0;
-    const int beg = a.rowptr[row];
-    const int end = a.rowptr[row + 1];
+    const uint32_t beg = a.rowptr[row];
+    const uint32_t end = a.rowptr[row + 1];
     if (end - beg > a.long_thresh) return;
     const float sd = a.sdst[(int64_t)row * a.H + h];
     const float mx = gat_pass_max<U>(a, beg, end, lig, gbase, G, h, sd);
@@ -217,12 +217,12 @@ __global__ void __launch_bounds__(1024) gat_long_rows_kernel(const GatArgs a) {
     const int f0 = ((int)blockIdx.y * G + lig) * VEC;
     const bool active = f0 < a.D;
     const int h = active ? f0 / a.C : 0;
-    const int beg = a.rowptr[row];
-    const int end = a.rowptr[row + 1];
-    const int len = end - beg;
-    const int part = (len + NG - 1) / NG;
-    const int pb = min(beg + q * part, end);
-    const int pe = min(pb + part, end);
+    const uint32_t beg = a.rowptr[row];
+    const uint32_t end = a.rowptr[row + 1];
+    const uint32_t len = end - beg;
+    const uint32_t part = (len + NG - 1) / NG;
+    const uint32_t pb = (uint32_t)min((uint64_t)beg + (uint64_t)q * part, (uint64_t)end);
+    const uint32_t pe = (uint32_t)min((uint64_t)pb + part, (uint64_t)end);
     const float sd = a.sdst[(int64_t)row * a.H + h];
 
     float mx = gat_pass_max<U>(a, pb, pe, lig, gbase, G, h, sd);

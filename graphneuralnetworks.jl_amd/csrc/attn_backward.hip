@@ -19,8 +19,10 @@
 namespace gnnmp {
 
 struct AttnBwdArgs {
-    const int32_t *rowptr, *col;
-    const int32_t *chunk_row, *chunk_beg, *chunk_end;
+    const uint32_t *rowptr;
+    const int32_t *col;
+    const int32_t *chunk_row;
+    const uint32_t *chunk_beg, *chunk_end;
     const int32_t *long_rows, *long_cptr;
     int n_chunks, n_long, n_rows, long_thresh;
     const float *Q, *K, *V;   // [n_dst][D], [n_src][D], [n_src][D]
@@ -38,7 +40,7 @@ struct AttnBwdArgs {
 
 __device__ __forceinline__ float lrelu_a(float x, float slope) { return x > 0.0f ? x : x * slope; }
 
-__device__ __forceinline__ bool attn_virtual_row(const AttnBwdArgs &a, int &v, bool &is_chunk, int &row, int &beg, int &end,
+__device__ __forceinline__ bool attn_virtual_row(const AttnBwdArgs &a, int &v, bool &is_chunk, int &row, uint32_t &beg, uint32_t &end,
                                                  int &lig, int &gbase, int &G) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -99,7 +101,8 @@ __device__ __forceinline__ void attn_dst_finalize(const AttnBwdArgs &a, int row,
 template <int VEC, int U, int LPH, int MODE>
 __global__ void __launch_bounds__(256) attn_bwd_dst_kernel(const AttnBwdArgs a) {
     constexpr int NA = Acc1<MODE>::N;
-    int v, row, beg, end, lig, gbase, G;
+    int v, row, lig, gbase, G;
+    uint32_t beg, end;
     bool is_chunk;
     if (!attn_virtual_row(a, v, is_chunk, row, beg, end, lig, gbase, G)) return;
     const int f0 = lig * VEC;
@@ -128,10 +131,10 @@ __global__ void __launch_bounds__(256) attn_bwd_dst_kernel(const AttnBwdArgs a) 
     for (int k = 0; k < NA; ++k)
 #pragma unroll
         for (int q = 0; q < VEC; ++q) acc[k][q] = 0.0f;
-    for (int base = beg; base < end; base += G) {
-        const int p = base + lig;
+    for (uint32_t base = beg; base < end; base += G) {   // slots are unsigned 32-bit (csr_reduce.h)
+        const uint32_t p = base + lig;
         const int c = p < end ? a.col[p] : 0;
-        const int n = min(G, end - base);
+        const int n = (int)min((uint32_t)G, end - base);
         for (int j = 0; j < n; j += U) {
             float kv[U][VEC];                                   // K_j
             float vv[MODE == GNNMP_ATTN_DOT ? U : 1][VEC];      // V_j when it is a different array
@@ -254,7 +257,8 @@ __device__ __forceinline__ void attn_src_store(const AttnBwdArgs &a, int row, in
 
 template <int VEC, int U, int LPH, int MODE>
 __global__ void __launch_bounds__(256) attn_bwd_src_kernel(const AttnBwdArgs a) {
-    int v, row, beg, end, lig, gbase, G;
+    int v, row, lig, gbase, G;
+    uint32_t beg, end;
     bool is_chunk;
     if (!attn_virtual_row(a, v, is_chunk, row, beg, end, lig, gbase, G)) return;
     const int f0 = lig * VEC;
@@ -278,10 +282,10 @@ __global__ void __launch_bounds__(256) attn_bwd_src_kernel(const AttnBwdArgs a) 
     float dk[VEC], dv[VEC];
 #pragma unroll
     for (int q = 0; q < VEC; ++q) dk[q] = dv[q] = 0.0f;
-    for (int base = beg; base < end; base += G) {
-        const int p = base + lig;
+    for (uint32_t base = beg; base < end; base += G) {   // slots are unsigned 32-bit (csr_reduce.h)
+        const uint32_t p = base + lig;
         const int c = p < end ? a.col[p] : 0;
-        const int n = min(G, end - base);
+        const int n = (int)min((uint32_t)G, end - base);
         for (int j = 0; j < n; j += U) {
             float dd[U][VEC], qq[U][VEC];
             float4 ln[U];

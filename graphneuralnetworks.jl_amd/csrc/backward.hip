@@ -48,11 +48,14 @@ __global__ void __launch_bounds__(256) edge_dot_kernel(const float *a, const flo
 // chunk for split rows) and stays in registers, only b[col_p] is gathered per edge — half the traffic of the COO-order
 // kernel above (measured 12.0 -> see DESIGN.md).  Results are written back in ORIGINAL edge order through eid.
 struct EdgeDotRowsArgs {
-    const int32_t *rowptr, *col, *eid;
-    const int32_t *chunk_row, *chunk_beg, *chunk_end;
+    const uint32_t *rowptr;
+    const int32_t *col, *eid;
+    const int32_t *chunk_row;
+    const uint32_t *chunk_beg, *chunk_end;
     const float *a, *b;
     float *out;
-    int n_chunks, long_thresh, n_edges;
+    int n_chunks, long_thresh;
+    uint32_t n_edges;
     int D, n_rows, log2g, waves;
 };
 template <int VEC, int U>
@@ -67,7 +70,8 @@ __global__ void __launch_bounds__(256) edge_dot_rows_kernel(const EdgeDotRowsArg
     const int64_t v64 = ((int64_t)blockIdx.x * a.waves + wave) * rpw + grp;
     if (v64 >= (int64_t)a.n_rows + a.n_chunks) return;
     const int v = (int)v64;
-    int row, beg, end;
+    int row;
+    uint32_t beg, end;
     if (v < a.n_chunks) {
         row = a.chunk_row[v];
         beg = a.chunk_beg[v];
@@ -84,14 +88,15 @@ __global__ void __launch_bounds__(256) edge_dot_rows_kernel(const EdgeDotRowsArg
 #pragma unroll
     for (int q = 0; q < VEC; ++q) av[q] = 0.0f;
     if (active) Vec<VEC>::load(a.a + (int64_t)row * a.D + f0, av);
-    for (int base = beg; base < end; base += G) {
-        const int p = base + lig;
-        int c = 0, e = 0;
+    for (uint32_t base = beg; base < end; base += G) {
+        const uint32_t p = base + lig;
+        int c = 0;
+        uint32_t e = 0;
         if (p < end) {
             c = a.col[p];
-            e = a.eid[p];
+            e = (uint32_t)a.eid[p];
         }
-        const int n = min(G, end - base);
+        const int n = (int)min((uint32_t)G, end - base);
         float mine = 0.0f;                         // lane lig keeps the result of slot base + lig
         for (int j = 0; j < n; j += U) {
             float bv[U][VEC];
@@ -119,14 +124,15 @@ __global__ void __launch_bounds__(256) edge_dot_rows_kernel(const EdgeDotRowsArg
 }
 
 struct MaxMinGradArgs {
-    const int32_t *rowptr;  // transposed plan: row j = source node, slots = the edges j -> i in original order
+    const uint32_t *rowptr;  // transposed plan: row j = source node, slots = the edges j -> i in original order
     const int32_t *col;     // destination i of each slot
     const float *x;         // [n_src][D] forward input
     const float *y;         // [n_dst][D] forward output (max / min over incoming messages)
     const float *dy;        // [n_dst][D]
     float *dx;              // [n_src][D]
     float *partial;         // [n_chunks][D] (rows of the transposed plan longer than its threshold are split)
-    const int32_t *chunk_row, *chunk_beg, *chunk_end;
+    const int32_t *chunk_row;
+    const uint32_t *chunk_beg, *chunk_end;
     int n_chunks, long_thresh;
     int D, n_rows, log2g, waves;
 };
@@ -145,7 +151,8 @@ __global__ void __launch_bounds__(256) maxmin_grad_kernel(const MaxMinGradArgs a
     if (v64 >= (int64_t)a.n_rows + a.n_chunks) return;
     const int v = (int)v64;
     const bool is_chunk = v < a.n_chunks;
-    int row, beg, end;
+    int row;
+    uint32_t beg, end;
     if (is_chunk) {
         row = a.chunk_row[v];
         beg = a.chunk_beg[v];
@@ -162,10 +169,10 @@ __global__ void __launch_bounds__(256) maxmin_grad_kernel(const MaxMinGradArgs a
 #pragma unroll
     for (int q = 0; q < VEC; ++q) { xv[q] = 0.0f; acc[q] = 0.0f; }
     if (active) Vec<VEC>::load(a.x + (int64_t)row * a.D + f0, xv);
-    for (int base = beg; base < end; base += G) {
-        const int p = base + lig;
+    for (uint32_t base = beg; base < end; base += G) {   // slots are unsigned 32-bit (csr_reduce.h)
+        const uint32_t p = base + lig;
         const int c = p < end ? a.col[p] : 0;
-        const int n = min(G, end - base);
+        const int n = (int)min((uint32_t)G, end - base);
         for (int j = 0; j < n; j += U) {
             float yv[U][VEC], dv[U][VEC];
 #pragma unroll
@@ -243,7 +250,7 @@ int gnnmp_edge_dot_plan_f32(gnnmp_graph_t *plan, const float *a_dst, const float
     a.out = out;
     a.n_chunks = plan->n_chunks;
     a.long_thresh = plan->long_thresh;
-    a.n_edges = (int)plan->n_edges;
+    a.n_edges = (uint32_t)plan->n_edges;
     a.D = (int)D;
     a.n_rows = (int)plan->n_dst;
     a.log2g = 0;

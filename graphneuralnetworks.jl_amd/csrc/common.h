@@ -193,17 +193,17 @@ __device__ __forceinline__ int xcd_remap_after(int b, int nbc, int cpx) {
 struct gnnmp_graph {
     int64_t n_src = 0, n_dst = 0, n_edges = 0, n_total = 0;
     int self_loops = 0;
-    int32_t *rowptr = nullptr;  // [n_dst + 1]
-    int32_t *col = nullptr;     // [n_total] 0-based source of each slot
-    int32_t *eid = nullptr;     // [n_total] 0-based original edge position of each slot
+    uint32_t *rowptr = nullptr;  // [n_dst + 1]  UNSIGNED: a plan may hold 2^31 <= E' < 2^32 - 65536 slots
+    int32_t *col = nullptr;     // [n_total] 0-based source of each slot (n_src < 2^31)
+    int32_t *eid = nullptr;     // [n_total] 0-based original edge position of each slot, to be read as UNSIGNED 32 bits
     // rows longer than long_thresh (sorted ascending) are cut into n_chunks balanced chunks of at most
     // long_thresh slots; the row kernels process chunks like ordinary (virtual) rows into a partial buffer and a
     // small combine kernel folds the partials of each long row in chunk order.
     int32_t *long_rows = nullptr;   // [n_long]
     int32_t *long_cptr = nullptr;   // [n_long + 1] chunk range of each long row
     int32_t *chunk_row = nullptr;   // [n_chunks]
-    int32_t *chunk_beg = nullptr;   // [n_chunks]
-    int32_t *chunk_end = nullptr;   // [n_chunks]
+    uint32_t *chunk_beg = nullptr;   // [n_chunks] (slots: unsigned 32-bit)
+    uint32_t *chunk_end = nullptr;   // [n_chunks]
     int n_long = 0;
     int n_chunks = 0;
     int long_thresh = GNNMP_LONG_ROW;

@@ -8,7 +8,7 @@
 namespace gnnmp {
 
 struct ReduceArgs {
-    const int32_t *rowptr;
+    const uint32_t *rowptr;
     const int32_t *row_order; // [n_rows] rows by decreasing length, or null (common.h: gnnmp_graph::row_order)
     const int32_t *idx;      // per slot: source row of x to read (plan->col, or plan->eid for scatter)
     const int32_t *eid;      // per slot: original edge position (weights lookup); unused unless w
@@ -29,14 +29,15 @@ struct ReduceArgs {
     const float *sd;         // [n_dst] nullable
     float *out;              // [n_dst][D]
     float *partial;          // [n_chunks][D]
-    const int32_t *chunk_row, *chunk_beg, *chunk_end;
+    const int32_t *chunk_row;
+    const uint32_t *chunk_beg, *chunk_end;
     const int32_t *long_rows, *long_cptr;
     int n_chunks;
     int n_long;
     int D;
     int n_rows;
     int n_src;               // rows of x (XCD-remap heuristic)
-    int n_edges;             // weights exist for eid < n_edges; others are 1
+    uint32_t n_edges;        // weights exist for eid < n_edges; others are 1 (edge positions are unsigned 32-bit)
     int log2g;
     int mean;
     int long_thresh;
@@ -91,7 +92,7 @@ __device__ __forceinline__ float cg_act(float x, int act) {
 
 // reduce slots [beg, end) of one destination into acc[VEC]; all lanes of the group call this together.
 template <int VEC, int OP, bool SCALED, int U, bool EMAT = false, bool EXPSUB = false, int GATED = 0>
-__device__ __forceinline__ void reduce_range(const ReduceArgs &a, int beg, int end, int lig,
+__device__ __forceinline__ void reduce_range(const ReduceArgs &a, uint32_t beg, uint32_t end, int lig,
                                              int gbase, int G, int f0, bool active,
                                              float acc[VEC], int row = 0) {
     float sub[VEC];
@@ -107,18 +108,21 @@ __device__ __forceinline__ void reduce_range(const ReduceArgs &a, int beg, int e
         Vec<VEC>::load(a.gate_i + (int64_t)row * 2 * a.D + a.D + f0, sub2);              // dense_s's share of x_i
     }
     const int64_t ldx = GATED ? 2 * (int64_t)a.D : (int64_t)a.D;
-    for (int base = beg; base < end; base += G) {
-        const int p = base + lig;
-        int c = 0, ev = 0;
+    // Slots are UNSIGNED 32-bit (a plan holds fewer than 2^32 - 65536 of them): the walk costs what it cost with int32 slots.
+    // (A 64-bit rowptr was tried first: 64-bit loop counters cost the VALU-sensitive attention kernel 7 % on the products shape,
+    // and with per-row base pointers instead the row kernels went from 78 to 90 VGPRs — 6 -> 5 waves per SIMD, arxiv shape +4 %.)
+    for (uint32_t base = beg; base < end; base += G) {
+        const uint32_t p = base + lig;
+        uint32_t c = 0, ev = 0;     // row ids: sources (< 2^31) or, for _scatter, edge positions (< 2^32)
         float wv = 1.0f, sv = 1.0f;
         if (p < end) {
-            c = a.idx[p];
-            if (EMAT) ev = a.eid[p];
+            c = (uint32_t)a.idx[p];
+            if (EMAT) ev = (uint32_t)a.eid[p];
             if (SCALED) {
                 if (a.w_slot) {
                     wv = a.w_slot[p];
                 } else if (a.w) {
-                    const int e = a.eid[p];
+                    const uint32_t e = (uint32_t)a.eid[p];
                     if (e < a.n_edges) wv = a.w[e];
                 }
                 if (a.ss_slot)
@@ -127,7 +131,7 @@ __device__ __forceinline__ void reduce_range(const ReduceArgs &a, int beg, int e
                     sv = a.ss[c];
             }
         }
-        const int n = min(G, end - base);
+        const int n = (int)min((uint32_t)G, end - base);
         for (int j = 0; j < n; j += U) {
             float v[U][VEC];
             float gb[GATED ? U : 1][VEC];
@@ -135,12 +139,12 @@ __device__ __forceinline__ void reduce_range(const ReduceArgs &a, int beg, int e
             float em2[(EMAT && GATED == 2) ? U : 1][VEC];
             float wj[U], sj[U];
             // every cross-lane broadcast of the batch first (one LDS round trip), then the row loads back to back
-            int cjs[U], ejs[EMAT ? U : 1];
+            uint32_t cjs[U], ejs[EMAT ? U : 1];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int jj = min(j + u, n - 1);
-                cjs[u] = __shfl(c, gbase + jj, 64);
-                if (EMAT) ejs[EMAT ? u : 0] = __shfl(ev, gbase + jj, 64);
+                cjs[u] = (uint32_t)__shfl((int)c, gbase + jj, 64);
+                if (EMAT) ejs[EMAT ? u : 0] = (uint32_t)__shfl((int)ev, gbase + jj, 64);
                 if (SCALED) {
                     wj[u] = __shfl(wv, gbase + jj, 64);
                     sj[u] = __shfl(sv, gbase + jj, 64);
@@ -148,11 +152,11 @@ __device__ __forceinline__ void reduce_range(const ReduceArgs &a, int beg, int e
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int cj = cjs[u];
+                const uint32_t cj = cjs[u];
                 if (EMAT) {
                     // e .* xj with e (D, E'): the edge's own row of factors, by original edge position; self loops the
                     // plan added carry no features and weigh 1
-                    const int ej = ejs[EMAT ? u : 0];
+                    const uint32_t ej = ejs[EMAT ? u : 0];
                     if (GATED == 2) {   // the edge's share of both pre-activations (additive: absent = 0)
                         if (active && (j + u < n) && ej < a.n_edges) {
                             Vec<VEC>::load(a.emat + (int64_t)ej * 2 * a.D + f0, em[EMAT ? u : 0]);
@@ -211,7 +215,7 @@ __device__ __forceinline__ void reduce_range(const ReduceArgs &a, int beg, int e
 
 // mean division and the destination scaling of one finished row (no store)
 template <int VEC, int OP>
-__device__ __forceinline__ void finalize_row(const ReduceArgs &a, int row, int len, float acc[VEC]) {
+__device__ __forceinline__ void finalize_row(const ReduceArgs &a, int row, uint32_t len, float acc[VEC]) {
     if (OP == OP_SUM && a.mean) {
         // NNlib scatter(mean): dst = 0 .+ safe_div.(sum, count); count == 0 keeps the sum (0)
         const float cnt = (float)len;
@@ -226,7 +230,7 @@ __device__ __forceinline__ void finalize_row(const ReduceArgs &a, int row, int l
 }
 // ... and the store to out[out_row] (out_row = row, or the compact slot of a split row: ReduceArgs::compact_long)
 template <int VEC, int OP>
-__device__ __forceinline__ void finalize_store(const ReduceArgs &a, int row, int len, int f0,
+__device__ __forceinline__ void finalize_store(const ReduceArgs &a, int row, uint32_t len, int f0,
                                                bool active, float acc[VEC], int out_row = -1) {
     finalize_row<VEC, OP>(a, row, len, acc);
     if (active) Vec<VEC>::store(a.out + (int64_t)(out_row < 0 ? row : out_row) * a.D + f0, acc);

@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(1024) fused_conv_kernel(const FusedArgs a) {
 #pragma unroll
             for (int v = 0; v < VEC; ++v) acc[v] = op_identity<OP>();
             if (row < r.n_rows) {
-                const int beg = r.rowptr[row], end = r.rowptr[row + 1];
+                const uint32_t beg = r.rowptr[row], end = r.rowptr[row + 1];
                 if (end - beg > r.long_thresh) {
                     if (active) Vec<VEC>::load(a.agg_long + (int64_t)long_slot(r.long_rows, r.n_long, row) * D + f0, acc);
                 } else {
@@ -271,7 +271,7 @@ extern "C" int gnnmp_fused_conv_f32(gnnmp_graph_t *p, int aggr, const float *xj,
     r.D = (int)D;
     r.n_rows = (int)p->n_dst;
     r.n_src = (int)p->n_src;
-    r.n_edges = (int)p->n_edges;
+    r.n_edges = (uint32_t)p->n_edges;
     r.mean = (aggr == GNNMP_MEAN);
     r.long_thresh = p->long_thresh;
     r.log2g = pick_log2g((D + 3) / 4);

@@ -22,8 +22,10 @@
 namespace gnnmp {
 
 struct GatBwdArgs {
-    const int32_t *rowptr, *col;
-    const int32_t *chunk_row, *chunk_beg, *chunk_end;
+    const uint32_t *rowptr;
+    const int32_t *col;
+    const int32_t *chunk_row;
+    const uint32_t *chunk_beg, *chunk_end;
     const int32_t *long_rows, *long_cptr;
     int n_chunks, n_long, n_rows, long_thresh;
     const float *Wx_src;  // [n_src][D]
@@ -44,7 +46,7 @@ struct GatBwdArgs {
 __device__ __forceinline__ float lrelu_b(float x, float slope) { return x > 0.0f ? x : x * slope; }
 
 // decode the virtual row of this lane group; false = nothing to do
-__device__ __forceinline__ bool virtual_row(const GatBwdArgs &a, int &v, bool &is_chunk, int &row, int &beg, int &end,
+__device__ __forceinline__ bool virtual_row(const GatBwdArgs &a, int &v, bool &is_chunk, int &row, uint32_t &beg, uint32_t &end,
                                             int &lig, int &gbase, int &G) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -72,7 +74,8 @@ __device__ __forceinline__ bool virtual_row(const GatBwdArgs &a, int &v, bool &i
 
 template <int VEC, int U, int LPH>
 __global__ void __launch_bounds__(256) gat_bwd_dst_kernel(const GatBwdArgs a) {
-    int v, row, beg, end, lig, gbase, G;
+    int v, row, lig, gbase, G;
+    uint32_t beg, end;
     bool is_chunk;
     if (!virtual_row(a, v, is_chunk, row, beg, end, lig, gbase, G)) return;
     const int f0 = lig * VEC;
@@ -103,10 +106,10 @@ __global__ void __launch_bounds__(256) gat_bwd_dst_kernel(const GatBwdArgs a) {
     // branch-free body: the U loads, the 2U dot products, their butterflies and the U exponentials are independent
     // chains the scheduler interleaves; slots past the end of the row re-read the last edge and get α = 0
     float S1 = 0.0f, S2 = 0.0f, S3 = 0.0f;
-    for (int base = beg; base < end; base += G) {
-        const int p = base + lig;
+    for (uint32_t base = beg; base < end; base += G) {   // slots are unsigned 32-bit (csr_reduce.h)
+        const uint32_t p = base + lig;
         const int c = p < end ? a.col[p] : 0;
-        const int n = min(G, end - base);
+        const int n = (int)min((uint32_t)G, end - base);
         for (int j = 0; j < n; j += U) {
             float w[U][VEC];
 #pragma unroll
@@ -197,7 +200,8 @@ __device__ __forceinline__ void gat_bwd_src_store(const GatBwdArgs &a, int row, 
 
 template <int VEC, int U, int LPH>
 __global__ void __launch_bounds__(256) gat_bwd_src_kernel(const GatBwdArgs a) {
-    int v, row, beg, end, lig, gbase, G;
+    int v, row, lig, gbase, G;
+    uint32_t beg, end;
     bool is_chunk;
     if (!virtual_row(a, v, is_chunk, row, beg, end, lig, gbase, G)) return;
     const int f0 = lig * VEC;
@@ -224,10 +228,10 @@ __global__ void __launch_bounds__(256) gat_bwd_src_kernel(const GatBwdArgs a) {
     float acc[VEC], dss = 0.0f;
 #pragma unroll
     for (int q = 0; q < VEC; ++q) acc[q] = 0.0f;
-    for (int base = beg; base < end; base += G) {
-        const int p = base + lig;
+    for (uint32_t base = beg; base < end; base += G) {   // slots are unsigned 32-bit (csr_reduce.h)
+        const uint32_t p = base + lig;
         const int c = p < end ? a.col[p] : 0;
-        const int n = min(G, end - base);
+        const int n = (int)min((uint32_t)G, end - base);
         for (int j = 0; j < n; j += U) {
             float dv[U][VEC];
             float4 ln[U];

@@ -29,7 +29,7 @@
 namespace gnnmp {
 
 struct GatFusedArgs {
-    const int32_t *rowptr;
+    const uint32_t *rowptr;
     const int32_t *row_order;   // [n_rows] rows by decreasing length, or null: virtual row v -> destination (see common.h)
     const int32_t *col;
     const float *Wx_src;  // K [n_src][D]
@@ -42,7 +42,8 @@ struct GatFusedArgs {
     float *out;           // [n_dst][D]
     float *partial;       // [n_chunks][D + 2*D/VEC]
     float *stats;         // [n_dst][H][2] = (running max m, denominator) of every destination, or null (saved for the adjoint)
-    const int32_t *chunk_row, *chunk_beg, *chunk_end;
+    const int32_t *chunk_row;
+    const uint32_t *chunk_beg, *chunk_end;
     const int32_t *long_rows, *long_cptr;
     int n_chunks, n_long;
     int H, C, D;
@@ -110,7 +111,7 @@ __device__ __forceinline__ void gat_batch(const GatFusedArgs &a, int c, int ev, 
     if (edge_term) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int ej = __shfl(ev, gbase + min(j + u, n - 1), 64);
+            const uint32_t ej = (uint32_t)__shfl(ev, gbase + min(j + u, n - 1), 64);   // edge positions are unsigned 32-bit
             es[u] = a.escore[(int64_t)ej * a.H + r.h];
         }
     }
@@ -164,17 +165,17 @@ __device__ __forceinline__ void gat_batch(const GatFusedArgs &a, int c, int ev, 
 // for what is left, ONE batch of the smallest width in {U/4, U/2, U} that holds it: a row of 9 edges costs 8 + 2 slots, not
 // 16 (on the products shape a third of the rows are shorter than two batches: padded batches were 12 % of all issue slots).
 template <int VEC, int U, int LPH, int MODE, bool OFF24>
-__device__ __forceinline__ void gat_online_range(const GatFusedArgs &a, int beg, int end, int lig,
+__device__ __forceinline__ void gat_online_range(const GatFusedArgs &a, uint32_t beg, uint32_t end, int lig,
                                                  int gbase, int G, int fc, const LaneRow<VEC> &r,
                                                  float &m, float &den, float acc[VEC]) {
-    for (int base = beg; base < end; base += G) {
-        const int p = base + lig;
+    for (uint32_t base = beg; base < end; base += G) {   // slots are unsigned 32-bit (see csr_reduce.h: reduce_range)
+        const uint32_t p = base + lig;
         const int c = p < end ? a.col[p] : 0;
         // edge features (gat_conv with dense_e): the edge's share of the logit, a_e . We_k, precomputed per edge and head,
         // is fetched by original edge position (uniform branch: absent for the headline layer)
         constexpr bool edge_term = MODE == ATTN_GAT_EDGE;
         const int ev = (edge_term && p < end) ? a.eid[p] : 0;
-        const int n = min(G, end - base);
+        const int n = (int)min((uint32_t)G, end - base);
         int j = 0;
         for (; j + U <= n; j += U) gat_batch<VEC, U, LPH, MODE, OFF24>(a, c, ev, gbase, j, n, fc, r, m, den, acc);
         const int rem = n - j;
@@ -220,7 +221,8 @@ __global__ void __launch_bounds__(256) gat_fused_rows_kernel(const GatFusedArgs 
     const int f0 = ((int)blockIdx.y * G + lig) * VEC;
     const bool active = f0 < a.D;
     const bool is_chunk = v < a.n_chunks;
-    int row, beg, end;
+    int row;
+    uint32_t beg, end;
     if (is_chunk) {
         row = a.chunk_row[v];
         beg = a.chunk_beg[v];

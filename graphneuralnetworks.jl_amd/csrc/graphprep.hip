@@ -130,7 +130,7 @@ __device__ __forceinline__ double uniform01(uint64_t seed, uint64_t node, uint64
     return (double)(r >> 11) * (1.0 / 9007199254740992.0);
 }
 
-__global__ void sample_counts_kernel(const int32_t *rowptr, const void *nodes, int idx_bytes, int base, int64_t M,
+__global__ void sample_counts_kernel(const uint32_t *rowptr, const void *nodes, int idx_bytes, int base, int64_t M,
                                      int64_t n_rows, int64_t K, int replace, int64_t *counts, int *bad) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M) return;
@@ -140,7 +140,7 @@ __global__ void sample_counts_kernel(const int32_t *rowptr, const void *nodes, i
         counts[i] = 0;
         return;
     }
-    const int64_t d = rowptr[v + 1] - rowptr[v];
+    const int64_t d = (int64_t)(rowptr[v + 1] - rowptr[v]);
     // sampling.jl:73-78: replace ? (K > 0 ? K : d) : (K > 0 ? min(d, K) : d); nothing can be drawn from an empty list
     // replace = 2: picks with replacement but only min(d, K) of them — NeighborLoader's rand(neighbors, min(K, d)), samplers.jl:60-61
     counts[i] = d == 0 ? 0 : (K > 0 ? (replace == 1 ? K : (d < K ? d : K)) : d);
@@ -148,30 +148,30 @@ __global__ void sample_counts_kernel(const int32_t *rowptr, const void *nodes, i
 
 // one thread per seed node.  Without replacement: Knuth's selection sampling (Algorithm S) over the row — every k-subset
 // equally likely, chosen edges stay in original edge order.  With replacement: k independent uniform picks.
-__global__ void sample_fill_kernel(const int32_t *rowptr, const int32_t *eid, const void *nodes, int idx_bytes, int base,
+__global__ void sample_fill_kernel(const uint32_t *rowptr, const int32_t *eid, const void *nodes, int idx_bytes, int base,
                                    int64_t M, int64_t K, int replace, uint64_t seed, const int64_t *offsets,
                                    void *eids_out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M) return;
     const int64_t v = load_index(nodes, i, idx_bytes, base);
-    const int beg = rowptr[v], d = rowptr[v + 1] - beg;
+    const int64_t beg = rowptr[v], d = (int64_t)rowptr[v + 1] - beg;
     const int64_t o = offsets[i], k = offsets[i + 1] - o;
     if (k == 0) return;
     if (replace) {
         for (int64_t j = 0; j < k; ++j) {
-            const int pick = min(d - 1, (int)(uniform01(seed, (uint64_t)i, (uint64_t)j) * d));
-            store_index(eids_out, o + j, idx_bytes, (int64_t)eid[beg + pick] + base);
+            const int64_t pick = min(d - 1, (int64_t)(uniform01(seed, (uint64_t)i, (uint64_t)j) * (double)d));
+            store_index(eids_out, o + j, idx_bytes, (int64_t)(uint32_t)eid[beg + pick] + base);
         }
         return;
     }
-    if ((int64_t)d > 2 * k * k) {
+    if (d > 2 * k * k) {
         // Hub seed, few picks: Floyd's algorithm — a uniformly random k-subset of the d slots in k draws (not d): for
         // j = d-k .. d-1 draw r in [0, j]; take r unless it is already chosen, then take j (never chosen before).  The
         // chosen slots are kept sorted in the output (insertion, O(k) each), so the result is in original edge order like
         // the selection sampling below; O(k^2) instead of O(d) keeps a 17 000-edge seed from being the kernel.
         for (int64_t c = 0; c < k; ++c) {
-            const int j = d - (int)k + (int)c;
-            const int r = min(j, (int)(uniform01(seed, (uint64_t)i, (uint64_t)c) * (double)(j + 1)));
+            const int64_t j = d - k + c;
+            const int64_t r = min(j, (int64_t)(uniform01(seed, (uint64_t)i, (uint64_t)c) * (double)(j + 1)));
             int64_t lo = 0, hi = c;                    // first position with slot >= r among the c sorted picks
             while (lo < hi) {
                 const int64_t mid = (lo + hi) >> 1;
@@ -179,24 +179,24 @@ __global__ void sample_fill_kernel(const int32_t *rowptr, const int32_t *eid, co
             }
             const bool taken = lo < c && load_index(eids_out, o + lo, idx_bytes, 0) == r;
             if (taken) {
-                store_index(eids_out, o + c, idx_bytes, (int64_t)j);        // j exceeds every earlier pick: append
+                store_index(eids_out, o + c, idx_bytes, j);        // j exceeds every earlier pick: append
             } else {
                 for (int64_t q = c; q > lo; --q)
                     store_index(eids_out, o + q, idx_bytes, load_index(eids_out, o + q - 1, idx_bytes, 0));
-                store_index(eids_out, o + lo, idx_bytes, (int64_t)r);
+                store_index(eids_out, o + lo, idx_bytes, r);
             }
         }
         for (int64_t c = 0; c < k; ++c) {
-            const int p = (int)load_index(eids_out, o + c, idx_bytes, 0);
-            store_index(eids_out, o + c, idx_bytes, (int64_t)eid[beg + p] + base);
+            const int64_t p = load_index(eids_out, o + c, idx_bytes, 0);
+            store_index(eids_out, o + c, idx_bytes, (int64_t)(uint32_t)eid[beg + p] + base);
         }
         return;
     }
     int64_t chosen = 0;
-    for (int p = 0; p < d && chosen < k; ++p) {
+    for (int64_t p = 0; p < d && chosen < k; ++p) {
         // take slot p with probability (k - chosen) / (d - p)
         if (uniform01(seed, (uint64_t)i, (uint64_t)p) * (double)(d - p) < (double)(k - chosen)) {
-            store_index(eids_out, o + chosen, idx_bytes, (int64_t)eid[beg + p] + base);
+            store_index(eids_out, o + chosen, idx_bytes, (int64_t)(uint32_t)eid[beg + p] + base);
             ++chosen;
         }
     }
@@ -246,7 +246,7 @@ __global__ void unique_write_kernel(const void *cand, int idx_bytes, int base, i
 
 // induced_subgraph(graph, nodes) — GNNGraphs/src/sampling.jl:173-203: for every listed node (in list order) its incoming
 // edges (in edge order) whose source is listed too, relabelled by list position.
-__global__ void induced_count_kernel(const int32_t *rowptr, const int32_t *col, const int32_t *map, const void *nodes,
+__global__ void induced_count_kernel(const uint32_t *rowptr, const int32_t *col, const int32_t *map, const void *nodes,
                                      int idx_bytes, int base, int64_t M, int64_t *counts) {
     // one WAVE per listed node, 64 slots of its row at a time (a thread per node walked a 17 000-edge hub alone: tens of
     // milliseconds per mini-batch); the kept slots are counted with a ballot
@@ -258,16 +258,16 @@ __global__ void induced_count_kernel(const int32_t *rowptr, const int32_t *col, 
         return;
     }
     const int64_t v = load_index(nodes, i, idx_bytes, base);
-    const int beg = rowptr[v], end = rowptr[v + 1];
+    const int64_t beg = rowptr[v], end = rowptr[v + 1];
     int64_t c = 0;
-    for (int p0 = beg; p0 < end; p0 += 64) {
-        const int p = p0 + lane;
+    for (int64_t p0 = beg; p0 < end; p0 += 64) {
+        const int64_t p = p0 + lane;
         const bool keep = p < end && map[col[min(p, end - 1)]] != 0;
         c += __popcll(__ballot(keep));
     }
     if (lane == 0) counts[i] = c;
 }
-__global__ void induced_fill_kernel(const int32_t *rowptr, const int32_t *col, const int32_t *eid, const int32_t *map,
+__global__ void induced_fill_kernel(const uint32_t *rowptr, const int32_t *col, const int32_t *eid, const int32_t *map,
                                     const void *nodes, int idx_bytes, int base, int64_t M, const int64_t *offsets,
                                     void *s_out, void *t_out, void *eid_out) {
     // one wave per listed node; a kept slot's output position = edges kept before it in the row (ballot prefix): in-edge
@@ -276,11 +276,11 @@ __global__ void induced_fill_kernel(const int32_t *rowptr, const int32_t *col, c
     const int lane = threadIdx.x & 63;
     if (i >= M) return;
     const int64_t v = load_index(nodes, i, idx_bytes, base);
-    const int beg = rowptr[v], end = rowptr[v + 1];
+    const int64_t beg = rowptr[v], end = rowptr[v + 1];
     int64_t o = offsets[i];
-    for (int p0 = beg; p0 < end; p0 += 64) {
-        const int p = p0 + lane;
-        const int pc = min(p, end - 1);
+    for (int64_t p0 = beg; p0 < end; p0 += 64) {
+        const int64_t p = p0 + lane;
+        const int64_t pc = min(p, end - 1);
         const int32_t m = map[col[pc]];
         const bool keep = p < end && m != 0;
         const unsigned long long mask = __ballot(keep);
@@ -288,7 +288,7 @@ __global__ void induced_fill_kernel(const int32_t *rowptr, const int32_t *col, c
             const int64_t at = o + __popcll(mask & ((1ull << lane) - 1ull));
             store_index(s_out, at, idx_bytes, (int64_t)m - 1 + base);
             store_index(t_out, at, idx_bytes, i + base);
-            store_index(eid_out, at, idx_bytes, (int64_t)eid[pc] + base);
+            store_index(eid_out, at, idx_bytes, (int64_t)(uint32_t)eid[pc] + base);
         }
         o += __popcll(mask);
     }

@@ -61,10 +61,10 @@ int ensure_ticket(gnnmp_graph *p, hipStream_t stream) {
     return GNNMP_OK;
 }
 
-__global__ void plan_degree_keys(const int32_t *rowptr, int64_t n, int maxdeg, uint32_t *keys, uint32_t *vals) {
+__global__ void plan_degree_keys(const uint32_t *rowptr, int64_t n, uint32_t maxdeg, uint32_t *keys, uint32_t *vals) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    keys[i] = (uint32_t)(maxdeg - (rowptr[i + 1] - rowptr[i]));   // ascending key = descending length
+    keys[i] = maxdeg - (rowptr[i + 1] - rowptr[i]);   // ascending key = descending length
     vals[i] = (uint32_t)i;
 }
 
@@ -76,12 +76,12 @@ int ensure_row_order(gnnmp_graph *p, hipStream_t stream) {
     int rc = GNNMP_OK;
     hipError_t e = hipSuccess;
     unsigned bits = 1;
-    while (bits < 32 && ((int64_t)1 << bits) <= p->max_degree) ++bits;
+    while (bits < 32 && ((int64_t)1 << bits) <= p->max_degree) ++bits;   // max_degree <= E' < 2^32
     if ((e = hipMalloc((void **)&kin, 4 * n)) != hipSuccess || (e = hipMalloc((void **)&kout, 4 * n)) != hipSuccess ||
         (e = hipMalloc((void **)&vin, 4 * n)) != hipSuccess || (e = hipMalloc((void **)&order, 4 * n)) != hipSuccess) {
         rc = hip_fail(e, "hipMalloc(row order)");
     } else {
-        plan_degree_keys<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(p->rowptr, p->n_dst, (int)p->max_degree, kin, vin);
+        plan_degree_keys<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(p->rowptr, p->n_dst, (uint32_t)p->max_degree, kin, vin);
         rc = radix_sort_pairs_u32(kin, kout, vin, reinterpret_cast<uint32_t *>(order), n, 0, (int)bits, stream);   // syncs the stream
     }
     if (kin) (void)hipFree(kin);
@@ -121,7 +121,7 @@ __global__ void plan_fill_keys(const void *src, const void *dst, int idx_bytes, 
 }
 
 // rowptr[i] = first slot whose key >= i  (binary search in the sorted keys); rowptr[n_dst] = Etot
-__global__ void plan_rowptr(const uint32_t *keys, int64_t Etot, int64_t n_dst, int32_t *rowptr) {
+__global__ void plan_rowptr(const uint32_t *keys, int64_t Etot, int64_t n_dst, uint32_t *rowptr) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i > n_dst) return;
     int64_t lo = 0, hi = Etot;
@@ -132,7 +132,7 @@ __global__ void plan_rowptr(const uint32_t *keys, int64_t Etot, int64_t n_dst, i
         else
             hi = mid;
     }
-    rowptr[i] = (int32_t)lo;
+    rowptr[i] = (uint32_t)lo;
 }
 
 // col[p] = 0-based source of the edge in slot p
@@ -145,22 +145,26 @@ __global__ void plan_col(const void *src, int idx_bytes, int base, int64_t E, in
     col[p] = (int32_t)s;
 }
 
-// collect rows longer than `thresh` as (row, beg, end) triples; meta[0] = count (atomic), meta[1] = max degree
-__global__ void plan_long_rows(const int32_t *rowptr, int64_t n_dst, int thresh, int32_t *list,
-                               int cap, int *meta) {
+// collect rows longer than `thresh` as (row, beg, end) triples; *count = how many (atomic), *maxdeg = max degree
+__global__ void plan_long_rows(const uint32_t *rowptr, int64_t n_dst, int thresh, int64_t *list,
+                               int cap, int *count, unsigned long long *maxdeg) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_dst) return;
-    const int beg = rowptr[i], end = rowptr[i + 1];
-    const int len = end - beg;
-    atomicMax(&meta[1], len);
+    const int64_t beg = rowptr[i], end = rowptr[i + 1];
+    const int64_t len = end - beg;
+    if (len > 0) atomicMax(maxdeg, (unsigned long long)len);
     if (len > thresh) {
-        int pos = atomicAdd(&meta[0], 1);
+        int pos = atomicAdd(count, 1);
         if (pos < cap) {
-            list[3 * pos] = (int32_t)i;
+            list[3 * pos] = i;
             list[3 * pos + 1] = beg;
             list[3 * pos + 2] = end;
         }
     }
+}
+__global__ void widen_u32_kernel(const uint32_t *in, int64_t n, int64_t *out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (int64_t)in[i];
 }
 
 // out[p] = v[col[p]] (by == 0, node vector) or v[eid[p]] with 1.0 for plan-added self loops (by == 1, edge vector)
@@ -168,7 +172,7 @@ __global__ void slot_gather_kernel(const int32_t *idx, const float *v, int64_t E
                                    float *out) {
     int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= Etot) return;
-    const int64_t k = idx[p];
+    const int64_t k = (uint32_t)idx[p];   // source ids (< 2^31) or edge positions (< 2^32): unsigned either way
     out[p] = k < n_valid ? v[k] : 1.0f;
 }
 
@@ -274,8 +278,10 @@ int gnnmp_plan_create(gnnmp_graph_t **out, const void *src, const void *dst, int
         return fail(GNNMP_EINVAL, "plan_create: add_self_loops needs n_src == n_dst (%lld vs %lld)",
                     (long long)n_src, (long long)n_dst);
     const int64_t Etot = n_edges + (add_self_loops ? n_dst : 0);
-    if (Etot >= (int64_t)INT32_MAX || n_src >= (int64_t)INT32_MAX || n_dst >= (int64_t)INT32_MAX)
-        return fail(GNNMP_EUNSUPPORTED, "plan_create: E' = %lld / N = %lld exceed the int32 plan format",
+    // slots and edge positions are UNSIGNED 32-bit, node ids signed 32-bit; 65 536 slots of headroom so that no slot counter of
+    // a kernel (base += G, p0 += 4, off += cap ...) can wrap
+    if (Etot >= (int64_t)GNNMP_MAX_SLOTS || n_src >= (int64_t)INT32_MAX || n_dst >= (int64_t)INT32_MAX)
+        return fail(GNNMP_EUNSUPPORTED, "plan_create: E' = %lld (limit 2^32 - 65536) / N = %lld (limit 2^31 - 2) exceed the plan format",
                     (long long)Etot, (long long)std::max(n_src, n_dst));
 
     gnnmp_graph_t *p = new gnnmp_graph_t();
@@ -296,8 +302,8 @@ int gnnmp_plan_create(gnnmp_graph_t **out, const void *src, const void *dst, int
     }
 
     uint32_t *keys_in = nullptr, *keys_out = nullptr, *vals_in = nullptr;
-    int *flags = nullptr;  // [0] bad index, [1] long count, [2] max degree
-    int32_t *long_tmp = nullptr;
+    int *flags = nullptr;  // [0] bad index, [1] long count; [2..3] = one unsigned long long: max degree
+    int64_t *long_tmp = nullptr;
     int rc = GNNMP_OK;
     const int BS = 256;
     const size_t epad = (size_t)std::max<int64_t>(Etot, 1);
@@ -311,7 +317,7 @@ int gnnmp_plan_create(gnnmp_graph_t **out, const void *src, const void *dst, int
         }                                               \
     } while (0)
 
-    PLAN_HIP(hipMalloc((void **)&p->rowptr, sizeof(int32_t) * (size_t)(n_dst + 1)));
+    PLAN_HIP(hipMalloc((void **)&p->rowptr, sizeof(uint32_t) * (size_t)(n_dst + 1)));
     PLAN_HIP(hipMalloc((void **)&p->col, sizeof(int32_t) * epad));
     PLAN_HIP(hipMalloc((void **)&p->eid, sizeof(int32_t) * epad));
     PLAN_HIP(hipMalloc((void **)&flags, sizeof(int) * 4));
@@ -352,36 +358,45 @@ int gnnmp_plan_create(gnnmp_graph_t **out, const void *src, const void *dst, int
     {
         // long rows: at most Etot / thresh of them
         int cap = (int)std::min<int64_t>(Etot / std::max(1, p->long_thresh) + 1, n_dst + 1);
-        PLAN_HIP(hipMalloc((void **)&long_tmp, sizeof(int32_t) * 3 * (size_t)std::max(cap, 1)));
+        PLAN_HIP(hipMalloc((void **)&long_tmp, sizeof(int64_t) * 3 * (size_t)std::max(cap, 1)));
         if (n_dst > 0) {
-            plan_long_rows<<<nblocks(n_dst, BS), BS, 0, stream>>>(p->rowptr, n_dst, p->long_thresh,
-                                                                  long_tmp, cap, flags + 1);
+            plan_long_rows<<<nblocks(n_dst, BS), BS, 0, stream>>>(p->rowptr, n_dst, p->long_thresh, long_tmp, cap, flags + 1,
+                                                                  reinterpret_cast<unsigned long long *>(flags + 2));
             PLAN_HIP(hipGetLastError());
         }
-        int meta[2] = {0, 0};
-        PLAN_HIP(hipMemcpyAsync(meta, flags + 1, sizeof(int) * 2, hipMemcpyDeviceToHost, stream));
+        int meta[3] = {0, 0, 0};
+        PLAN_HIP(hipMemcpyAsync(meta, flags + 1, sizeof(int) * 3, hipMemcpyDeviceToHost, stream));
         PLAN_HIP(hipStreamSynchronize(stream));
-        p->max_degree = meta[1];
+        {
+            unsigned long long md;
+            memcpy(&md, meta + 1, sizeof(md));
+            p->max_degree = (int64_t)md;
+        }
         p->n_long = std::min(meta[0], cap);
         if (p->n_long > 0) {
-            struct Tri { int32_t row, beg, end; };
+            struct Tri { int64_t row, beg, end; };
             std::vector<Tri> h((size_t)p->n_long);
             PLAN_HIP(hipMemcpy(h.data(), long_tmp, sizeof(Tri) * h.size(), hipMemcpyDeviceToHost));
             // atomics filled the list in arbitrary order: make it canonical (ascending row)
             std::sort(h.begin(), h.end(), [](const Tri &a, const Tri &b) { return a.row < b.row; });
-            std::vector<int32_t> rows, cptr, crow, cbeg, cend;
+            std::vector<int32_t> rows, cptr, crow;
+            std::vector<uint32_t> cbeg, cend;
             cptr.push_back(0);
             for (const Tri &t : h) {
-                const int len = t.end - t.beg;
-                const int nch = (len + p->long_thresh - 1) / p->long_thresh;
-                const int csz = (len + nch - 1) / nch;  // balanced chunks, each <= long_thresh slots
-                for (int c = 0; c < nch; ++c) {
-                    crow.push_back(t.row);
-                    cbeg.push_back(t.beg + c * csz);
-                    cend.push_back(std::min(t.beg + (c + 1) * csz, t.end));
+                const int64_t len = t.end - t.beg;
+                const int64_t nch = (len + p->long_thresh - 1) / p->long_thresh;
+                const int64_t csz = (len + nch - 1) / nch;  // balanced chunks, each <= long_thresh slots
+                for (int64_t c = 0; c < nch; ++c) {
+                    crow.push_back((int32_t)t.row);
+                    cbeg.push_back((uint32_t)(t.beg + c * csz));
+                    cend.push_back((uint32_t)std::min(t.beg + (c + 1) * csz, t.end));
                 }
-                rows.push_back(t.row);
+                rows.push_back((int32_t)t.row);
                 cptr.push_back((int32_t)crow.size());
+            }
+            if (crow.size() >= (size_t)INT32_MAX) {
+                rc = fail(GNNMP_EUNSUPPORTED, "plan_create: %zu chunks of split rows exceed the int32 chunk index", crow.size());
+                goto done;
             }
             p->n_chunks = (int)crow.size();
             auto upload = [&](int32_t **dst, const std::vector<int32_t> &v) -> hipError_t {
@@ -393,8 +408,14 @@ int gnnmp_plan_create(gnnmp_graph_t **out, const void *src, const void *dst, int
             PLAN_HIP(upload(&p->long_rows, rows));
             PLAN_HIP(upload(&p->long_cptr, cptr));
             PLAN_HIP(upload(&p->chunk_row, crow));
-            PLAN_HIP(upload(&p->chunk_beg, cbeg));
-            PLAN_HIP(upload(&p->chunk_end, cend));
+            auto upload_u = [&](uint32_t **dst, const std::vector<uint32_t> &v) -> hipError_t {
+                hipError_t e = hipMalloc((void **)dst, sizeof(uint32_t) * v.size());
+                if (e != hipSuccess) return e;
+                p->bytes += (int64_t)(sizeof(uint32_t) * v.size());
+                return hipMemcpy(*dst, v.data(), sizeof(uint32_t) * v.size(), hipMemcpyHostToDevice);
+            };
+            PLAN_HIP(upload_u(&p->chunk_beg, cbeg));
+            PLAN_HIP(upload_u(&p->chunk_end, cend));
         }
     }
 
@@ -445,15 +466,31 @@ int gnnmp_plan_export(const gnnmp_graph_t *p, int32_t *rowptr, int32_t *col, int
                       gnnmp_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!p) return fail(GNNMP_EINVAL, "plan_export: null plan");
-    if (rowptr)
-        GNNMP_HIP(hipMemcpyAsync(rowptr, p->rowptr, sizeof(int32_t) * (size_t)(p->n_dst + 1),
-                                 hipMemcpyDeviceToDevice, stream));
+    if (p->n_total > (int64_t)INT32_MAX)
+        return fail(GNNMP_EUNSUPPORTED, "plan_export: E' = %lld does not fit int32 rowptr / eid (use gnnmp_plan_export64)",
+                    (long long)p->n_total);
+    if (rowptr)   // fewer than 2^31 slots: the unsigned values ARE the int32 values
+        GNNMP_HIP(hipMemcpyAsync(rowptr, p->rowptr, sizeof(int32_t) * (size_t)(p->n_dst + 1), hipMemcpyDeviceToDevice, stream));
     if (col && p->n_total > 0)
         GNNMP_HIP(hipMemcpyAsync(col, p->col, sizeof(int32_t) * (size_t)p->n_total,
                                  hipMemcpyDeviceToDevice, stream));
     if (eid && p->n_total > 0)
         GNNMP_HIP(hipMemcpyAsync(eid, p->eid, sizeof(int32_t) * (size_t)p->n_total,
                                  hipMemcpyDeviceToDevice, stream));
+    return GNNMP_OK;
+}
+
+int gnnmp_plan_export64(const gnnmp_graph_t *p, int64_t *rowptr, int32_t *col, uint32_t *eid, gnnmp_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!p) return fail(GNNMP_EINVAL, "plan_export64: null plan");
+    if (rowptr) {
+        widen_u32_kernel<<<nblocks(p->n_dst + 1, 256), 256, 0, stream>>>(p->rowptr, p->n_dst + 1, rowptr);
+        GNNMP_LAUNCH_CHECK("widen_u32_kernel");
+    }
+    if (col && p->n_total > 0)
+        GNNMP_HIP(hipMemcpyAsync(col, p->col, sizeof(int32_t) * (size_t)p->n_total, hipMemcpyDeviceToDevice, stream));
+    if (eid && p->n_total > 0)
+        GNNMP_HIP(hipMemcpyAsync(eid, p->eid, sizeof(uint32_t) * (size_t)p->n_total, hipMemcpyDeviceToDevice, stream));
     return GNNMP_OK;
 }
 

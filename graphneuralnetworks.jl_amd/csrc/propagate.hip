@@ -46,9 +46,9 @@ __global__ void __launch_bounds__(256) csr_rows_kernel(const ReduceArgs a) {
     }
     int row = v - a.n_chunks;
     if (a.row_order) row = a.row_order[row];
-    const int beg = a.rowptr[row];
-    const int end = a.rowptr[row + 1];
-    if (end - beg > a.long_thresh) return;  // split row: its chunks are virtual rows, folded by csr_combine_kernel
+    const uint32_t beg = a.rowptr[row];
+    const uint32_t end = a.rowptr[row + 1];
+    if (end - beg > (uint32_t)a.long_thresh) return;  // split row: its chunks are virtual rows, folded by csr_combine_kernel
     reduce_range<VEC, OP, SCALED, U, EMAT, EXPSUB, GATED>(a, beg, end, lig, gbase, G, f0, active, acc, row);
     finalize_store<VEC, OP>(a, row, end - beg, f0, active, acc);
 }
@@ -69,7 +69,8 @@ __global__ void __launch_bounds__(256) softmax_write_kernel(const ReduceArgs a) 
     const int v = (int)v64;
     const int f0 = ((int)blockIdx.y * G + lig) * VEC;
     const bool active = f0 < a.D;
-    int row, beg, end;
+    int row;
+    uint32_t beg, end;
     if (v < a.n_chunks) {
         row = a.chunk_row[v];
         beg = a.chunk_beg[v];
@@ -92,16 +93,16 @@ __global__ void __launch_bounds__(256) softmax_write_kernel(const ReduceArgs a) 
         for (int q = 0; q < VEC; ++q) den[q] = den[q] + a.den_add;
     }
     float *outp = a.out;
-    for (int base = beg; base < end; base += G) {
-        const int p = base + lig;
+    for (uint32_t base = beg; base < end; base += G) {   // slots are unsigned 32-bit (csr_reduce.h)
+        const uint32_t p = base + lig;
         const int c = p < end ? a.idx[p] : 0;
-        const int n = min(G, end - base);
+        const int n = (int)min((uint32_t)G, end - base);
         for (int j = 0; j < n; j += U) {
             float x[U][VEC];
-            int cj[U];
+            uint32_t cj[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                cj[u] = __shfl(c, gbase + min(j + u, n - 1), 64);
+                cj[u] = (uint32_t)__shfl(c, gbase + min(j + u, n - 1), 64);
                 if (active) Vec<VEC>::load(a.x + (int64_t)cj[u] * a.D + f0, x[u]);
             }
 #pragma unroll
@@ -182,7 +183,8 @@ __global__ void __launch_bounds__(256) nn_rows_kernel(const ReduceArgs a, const 
     const int v = (int)v64;
     const int o = (int)blockIdx.y * G + lig;
     const bool active = o < a.D;
-    int row = 0, beg, end;
+    int row = 0;
+    uint32_t beg, end;
     const bool is_chunk = v < a.n_chunks;
     if (is_chunk) {
         beg = a.chunk_beg[v];
@@ -199,15 +201,16 @@ __global__ void __launch_bounds__(256) nn_rows_kernel(const ReduceArgs a, const 
     // the kernel ran at a third of the HBM rate); messages are still formed per edge and folded in edge order.  Slots past
     // the end re-read the last edge and are not folded.
     constexpr int EB = 4;
-    for (int p0 = beg; p0 < end; p0 += EB) {
+    for (uint32_t p0 = beg; p0 < end; p0 += EB) {
         const float *wk[EB], *xr[EB];
         bool ok[EB];
 #pragma unroll
         for (int u = 0; u < EB; ++u) {
-            const int p = min(p0 + u, end - 1);
-            const int cj = a.idx[p], ej = a.eid[p];
+            const uint32_t p = min(p0 + u, end - 1);
+            const int cj = a.idx[p];
+            const uint32_t ej = (uint32_t)a.eid[p];
             ok[u] = p0 + u < end && ej < a.n_edges;          // a self loop the plan added: no edge features, no message
-            wk[u] = we + (int64_t)min(ej, a.n_edges - 1) * a.D * Din + oc;
+            wk[u] = we + (int64_t)(a.n_edges ? min(ej, a.n_edges - 1) : 0u) * a.D * Din + oc;
             xr[u] = a.x + (int64_t)cj * Din;
         }
         float m[EB];
@@ -362,7 +365,7 @@ int run_reduce(gnnmp_graph_t *p, const int32_t *idx, int aggr, const float *x, c
     a.D = (int)D;
     a.n_rows = long_only ? 0 : (int)p->n_dst;
     a.n_src = (int)p->n_src;
-    a.n_edges = (int)p->n_edges;
+    a.n_edges = (uint32_t)p->n_edges;
     a.mean = (aggr == GNNMP_MEAN);
     a.long_thresh = p->long_thresh;
     a.cpx = 0;
@@ -472,45 +475,45 @@ int run_combine(gnnmp_graph_t *p, float *out, int64_t D, int aggr, hipStream_t s
 int run_combine_sum(gnnmp_graph_t *p, float *out, int64_t D, hipStream_t stream) { return run_combine(p, out, D, GNNMP_SUM, stream); }
 
 // ---- degree / norm ------------------------------------------------------------------------------
-__global__ void degree_count_kernel(const int32_t *rowptr, int64_t n, float *deg) {
+__global__ void degree_count_kernel(const uint32_t *rowptr, int64_t n, float *deg) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) deg[i] = 0.0f + (float)(rowptr[i + 1] - rowptr[i]);
 }
 // weighted in-degree: one thread per destination, weights added in original edge order
 // (zeros(T,N) .+ scatter(+, w, t) — GNNGraphs/src/query.jl:359-369)
-__global__ void degree_weighted_kernel(const int32_t *rowptr, const int32_t *eid, const float *w,
-                                       int64_t n, int n_edges, float *deg, int long_thresh) {
+__global__ void degree_weighted_kernel(const uint32_t *rowptr, const int32_t *eid, const float *w,
+                                       int64_t n, uint32_t n_edges, float *deg, int long_thresh) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const int beg = rowptr[i], end = rowptr[i + 1];
+    const int64_t beg = rowptr[i], end = rowptr[i + 1];
     if (end - beg > long_thresh) return;   // split rows: degree_long_kernel (a 17 000-edge hub made this thread a 5.6 ms tail)
     float acc = 0.0f;
-    int p = beg;
+    int64_t p = beg;
     for (; p + 8 <= end; p += 8) {
         float v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int e = eid[p + u];
+            const uint32_t e = (uint32_t)eid[p + u];
             v[u] = e < n_edges ? w[e] : 1.0f;
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) acc = acc + v[u];
     }
     for (; p < end; ++p) {
-        const int e = eid[p];
+        const uint32_t e = (uint32_t)eid[p];
         acc = acc + (e < n_edges ? w[e] : 1.0f);
     }
     deg[i] = 0.0f + acc;
 }
 // weighted in-degree of the split rows: one block per long row, threads stride over its slots, fixed-shape LDS tree
-__global__ void __launch_bounds__(256) degree_long_kernel(const int32_t *rowptr, const int32_t *eid, const float *w,
-                                                          const int32_t *long_rows, int n_edges, float *deg) {
+__global__ void __launch_bounds__(256) degree_long_kernel(const uint32_t *rowptr, const int32_t *eid, const float *w,
+                                                          const int32_t *long_rows, uint32_t n_edges, float *deg) {
     __shared__ float red[256];
     const int row = long_rows[blockIdx.x];
-    const int beg = rowptr[row], end = rowptr[row + 1];
+    const int64_t beg = rowptr[row], end = rowptr[row + 1];
     float acc = 0.0f;
-    for (int p = beg + (int)threadIdx.x; p < end; p += 256) {
-        const int e = eid[p];
+    for (int64_t p = beg + (int)threadIdx.x; p < end; p += 256) {
+        const uint32_t e = (uint32_t)eid[p];
         acc = acc + (e < n_edges ? w[e] : 1.0f);
     }
     red[threadIdx.x] = acc;
@@ -616,7 +619,7 @@ int gnnmp_propagate_nn_f32(gnnmp_graph_t *p, int aggr, const float *xj, const fl
     a.D = (int)Dout;
     a.n_rows = (int)p->n_dst;
     a.n_src = (int)p->n_src;
-    a.n_edges = (int)p->n_edges;
+    a.n_edges = (uint32_t)p->n_edges;
     a.mean = (aggr == GNNMP_MEAN);
     a.long_thresh = p->long_thresh;
     a.waves = 4;
@@ -676,10 +679,10 @@ int gnnmp_degree_f32(gnnmp_graph_t *plan, const float *w, float *deg, gnnmp_stre
     const unsigned nb = (unsigned)((plan->n_dst + 255) / 256);
     if (w) {
         degree_weighted_kernel<<<nb, 256, 0, stream>>>(plan->rowptr, plan->eid, w, plan->n_dst,
-                                                        (int)plan->n_edges, deg, plan->long_thresh);
+                                                        (uint32_t)plan->n_edges, deg, plan->long_thresh);
         if (plan->n_long > 0)
             degree_long_kernel<<<(unsigned)plan->n_long, 256, 0, stream>>>(plan->rowptr, plan->eid, w, plan->long_rows,
-                                                                            (int)plan->n_edges, deg);
+                                                                            (uint32_t)plan->n_edges, deg);
     } else
         degree_count_kernel<<<nb, 256, 0, stream>>>(plan->rowptr, plan->n_dst, deg);
     GNNMP_LAUNCH_CHECK("degree kernel");

@@ -22,7 +22,8 @@
 namespace gnnmp {
 
 struct SmxArgs {
-    const int32_t *rowptr, *eid;
+    const uint32_t *rowptr;
+    const int32_t *eid;
     const float *e;
     float *alpha;
     int D, n_rows, log2g, long_thresh;
@@ -32,7 +33,8 @@ struct SmxArgs {
     int wave_bytes;   // LDS per wave
     float den_add;
     // the plan's split rows (softmax_chunk_kernel)
-    const int32_t *chunk_row, *chunk_beg, *chunk_end;
+    const int32_t *chunk_row;
+    const uint32_t *chunk_beg, *chunk_end;
     int n_chunks;
     float *partial;       // [n_chunks][D]
     const float *mx;      // [n_rows][D] (split rows only)
@@ -46,8 +48,9 @@ __device__ __forceinline__ void smx_wave_sync() {
 }
 
 struct SmxBatch {
-    int r, nb, sb, ns;   // first row (wave-relative), rows, first slot, slots; nb = 0: none left.  nb = 1 and ns > cap: a row
-                         // longer than a batch
+    int r, nb;           // first row (wave-relative), rows; nb = 0: none left
+    uint32_t sb;         // first slot (slots are unsigned 32-bit)
+    int ns;              // slots (nb = 1 and ns > cap: a row longer than a batch; never more than long_thresh)
 };
 
 constexpr int SMX_IT = 8;   // items (edge, lane-of-edge) per lane and batch
@@ -87,8 +90,8 @@ __global__ void __launch_bounds__(256) softmax_rows_lds_kernel(const SmxArgs a) 
     float *vals = reinterpret_cast<float *>(base);           // [cap][Dp]
     float *rmx = vals + (size_t)a.cap * Dp;                   // [RB][Dp]
     float *rden = rmx + RB * Dp;                              // [RB][Dp]
-    int *wrp = reinterpret_cast<int *>(rden + RB * Dp);       // [rw + 1] the wave's row pointers (68 reserved)
-    int *seid = wrp + 68;                                     // [cap] original edge position of a slot
+    uint32_t *wrp = reinterpret_cast<uint32_t *>(rden + RB * Dp);   // [rw + 1] the wave's row pointers (68 reserved)
+    int *seid = reinterpret_cast<int *>(wrp + 68);            // [cap] original edge position of a slot (unsigned 32-bit)
     unsigned char *srow = reinterpret_cast<unsigned char *>(seid + a.cap);   // [cap] batch-relative row of a slot
     const int64_t r0l = ((int64_t)blockIdx.x * a.waves + wave) * a.rw;
     if (r0l >= a.n_rows) return;
@@ -104,20 +107,20 @@ __global__ void __launch_bounds__(256) softmax_rows_lds_kernel(const SmxArgs a) 
     // row ends the batch before it and is stepped over: softmax_chunk_kernel has it); a row longer than cap comes alone
     auto find = [&](int r) -> SmxBatch {
         while (r < nr) {
-            const int sb = wrp[r];
+            const uint32_t sb = wrp[r];
             const int ci = min(r + lane + 1, nr);
-            const int hi = wrp[ci];
-            const bool ok = lane < RB && r + lane + 1 <= nr && hi - sb <= a.cap && hi - wrp[ci - 1] <= a.long_thresh;
+            const uint32_t hi = wrp[ci];
+            const bool ok = lane < RB && r + lane + 1 <= nr && hi - sb <= (uint32_t)a.cap && hi - wrp[ci - 1] <= (uint32_t)a.long_thresh;
             const unsigned long long m = __ballot(ok);
             const int nb = (~m == 0ull) ? 64 : __builtin_ctzll(~m);
-            if (nb > 0) return SmxBatch{r, nb, sb, wrp[r + nb] - sb};
-            const int len0 = wrp[r + 1] - sb;
-            if (len0 <= a.long_thresh) return SmxBatch{r, 1, sb, len0};
+            if (nb > 0) return SmxBatch{r, nb, sb, (int)(wrp[r + nb] - sb)};
+            const uint32_t len0 = wrp[r + 1] - sb;
+            if (len0 <= (uint32_t)a.long_thresh) return SmxBatch{r, 1, sb, (int)len0};
             ++r;
         }
         return SmxBatch{nr, 0, 0, 0};
     };
-    auto load_eids = [&](int sb, int ns, int (&c)[IT]) {
+    auto load_eids = [&](uint32_t sb, int ns, int (&c)[IT]) {
         const int nitems = min(ns, a.cap) << a.log2g;
 #pragma unroll
         for (int k = 0; k < IT; ++k) {
@@ -130,7 +133,7 @@ __global__ void __launch_bounds__(256) softmax_rows_lds_kernel(const SmxArgs a) 
 #pragma unroll
         for (int k = 0; k < IT; ++k) {
             const int i = k * 64 + lane;
-            if (i < nitems && active) Vec<VEC>::load(a.e + (int64_t)c[k] * a.D + f0, v[k]);
+            if (i < nitems && active) Vec<VEC>::load(a.e + (int64_t)(uint32_t)c[k] * a.D + f0, v[k]);
         }
     };
     // registers -> LDS (rows and edge positions of one batch)
@@ -174,7 +177,7 @@ __global__ void __launch_bounds__(256) softmax_rows_lds_kernel(const SmxArgs a) 
                 Vec<VEC>::load(rden + j * Dp + f0, dq);
 #pragma unroll
                 for (int q = 0; q < VEC; ++q) v[q] = v[q] / dq[q];
-                Vec<VEC>::store(a.alpha + (int64_t)c * a.D + f0, v);
+                Vec<VEC>::store(a.alpha + (int64_t)(uint32_t)c * a.D + f0, v);
             }
         }
     };
@@ -190,7 +193,8 @@ __global__ void __launch_bounds__(256) softmax_rows_lds_kernel(const SmxArgs a) 
     load_rows(cur.ns, ca, rows);
     load_eids(nxt.sb, nxt.ns, cb);
     while (true) {
-        const int r = cur.r, nb = cur.nb, sb = cur.sb;
+        const int r = cur.r, nb = cur.nb;
+        const uint32_t sb = cur.sb;
         const bool big = cur.ns > a.cap;
         const int ns = min(cur.ns, a.cap);
         // A: the batch's edge rows (and positions), out of the registers they arrived in; then the next batch's rows and the
@@ -207,7 +211,7 @@ __global__ void __launch_bounds__(256) softmax_rows_lds_kernel(const SmxArgs a) 
 #pragma unroll
             for (int k = 0; k < IT; ++k) rid[k] = 0;
             for (int j = 1; j < nb; ++j) {
-                const int st = wrp[r + j] - sb;   // same address in every lane: an LDS broadcast
+                const int st = (int)(wrp[r + j] - sb);   // same address in every lane: an LDS broadcast
 #pragma unroll
                 for (int k = 0; k < IT; ++k) rid[k] += (lane + 64 * k >= st) ? 1 : 0;
             }
@@ -218,8 +222,8 @@ __global__ void __launch_bounds__(256) softmax_rows_lds_kernel(const SmxArgs a) 
         smx_wave_sync();
         const bool rowlane = grp < nb && active;
         if (!big) {
-            const int st = rowlane ? wrp[r + grp] - sb : 0;
-            const int len = rowlane ? wrp[r + grp + 1] - wrp[r + grp] : 0;
+            const int st = rowlane ? (int)(wrp[r + grp] - sb) : 0;
+            const int len = rowlane ? (int)(wrp[r + grp + 1] - wrp[r + grp]) : 0;
             const int nitems = ns << a.log2g;
             // B: max_ of every row of the batch
             float acc[VEC];
@@ -310,7 +314,8 @@ __global__ void __launch_bounds__(256) softmax_chunk_kernel(const SmxArgs a) {
     const int G = 1 << a.log2g, Dp = G * VEC;
     const int v = (int)blockIdx.x * a.waves + wave;
     if (v >= a.n_chunks) return;
-    const int row = a.chunk_row[v], beg = a.chunk_beg[v], end = a.chunk_end[v];
+    const int row = a.chunk_row[v];
+    const uint32_t beg = a.chunk_beg[v], end = a.chunk_end[v];
     const int lig = lane & (G - 1), grp = lane >> a.log2g;
     const int f0 = lig * VEC;
     const bool active = f0 < a.D;
@@ -330,8 +335,8 @@ __global__ void __launch_bounds__(256) softmax_chunk_kernel(const SmxArgs a) {
             for (int q = 0; q < VEC; ++q) rd[q] = rd[q] + a.den_add;
         }
     }
-    for (int off = beg; off < end; off += a.cap) {
-        const int n = min(a.cap, end - off);
+    for (uint32_t off = beg; off < end; off += a.cap) {
+        const int n = (int)min((uint32_t)a.cap, end - off);
         const int nitems = n << a.log2g;
         int c[IT];
         float x[IT][VEC];
@@ -343,7 +348,7 @@ __global__ void __launch_bounds__(256) softmax_chunk_kernel(const SmxArgs a) {
 #pragma unroll
         for (int k = 0; k < IT; ++k) {
             const int i = k * 64 + lane;
-            if (i < nitems && active) Vec<VEC>::load(a.e + (int64_t)c[k] * a.D + f0, x[k]);
+            if (i < nitems && active) Vec<VEC>::load(a.e + (int64_t)(uint32_t)c[k] * a.D + f0, x[k]);
         }
 #pragma unroll
         for (int k = 0; k < IT; ++k) {
@@ -360,7 +365,7 @@ __global__ void __launch_bounds__(256) softmax_chunk_kernel(const SmxArgs a) {
                     } else {
 #pragma unroll
                         for (int q = 0; q < VEC; ++q) x[k][q] = x[k][q] / rd[q];
-                        Vec<VEC>::store(a.alpha + (int64_t)c[k] * a.D + f0, x[k]);
+                        Vec<VEC>::store(a.alpha + (int64_t)(uint32_t)c[k] * a.D + f0, x[k]);
                     }
                 }
             }

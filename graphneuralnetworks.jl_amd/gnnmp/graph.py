@@ -67,12 +67,21 @@ class Plan:
         return self._h
 
     def export(self):
-        """(rowptr, col, eid) int32 device tensors — the plan's bit-exact index outputs"""
+        """(rowptr, col, eid) int32 device tensors — the plan's bit-exact index outputs (plans of fewer than 2^31 slots)"""
         rowptr = torch.empty(self.n_dst + 1, dtype=torch.int32, device=self.device)
         col = torch.empty(self.n_total, dtype=torch.int32, device=self.device)
         eid = torch.empty(self.n_total, dtype=torch.int32, device=self.device)
         L.check(self._lib.gnnmp_plan_export(self._h, L.ptr(rowptr), L.ptr(col), L.ptr(eid), L.stream_ptr()))
         return rowptr, col, eid
+
+    def export64(self):
+        """(rowptr int64, col int32, eid as int64) — the arrays as stored, at any plan size; eid is held as unsigned 32-bit on the
+        device and widened here (torch has no uint32 arithmetic)"""
+        rowptr = torch.empty(self.n_dst + 1, dtype=torch.int64, device=self.device)
+        col = torch.empty(self.n_total, dtype=torch.int32, device=self.device)
+        eid = torch.empty(self.n_total, dtype=torch.int32, device=self.device)
+        L.check(self._lib.gnnmp_plan_export64(self._h, L.ptr(rowptr), L.ptr(col), L.ptr(eid), L.stream_ptr()))
+        return rowptr, col, eid.to(torch.int64) & 0xFFFFFFFF
 
     def __del__(self):
         try:

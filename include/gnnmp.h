@@ -54,7 +54,7 @@ typedef enum {
     GNNMP_EBOUNDS = -2,      /* index outside 1..N (validate != 0 only)                    */
     GNNMP_EALLOC = -3,       /* hipMalloc failed                                           */
     GNNMP_ELAUNCH = -4,      /* kernel launch / HIP runtime error                          */
-    GNNMP_EUNSUPPORTED = -5  /* valid request outside the build's envelope (e.g. E' >= 2^31) */
+    GNNMP_EUNSUPPORTED = -5  /* valid request outside the build's envelope (e.g. E' >= 2^32 - 65536) */
 } gnnmp_status;
 
 /* aggregation operator — the `aggr` argument of propagate / aggregate_neighbors / reduce_nodes
@@ -85,6 +85,9 @@ typedef enum {
  * (~4e-5 * E', so that no single sequential row can become the kernel's tail) and reported by gnnmp_plan_info
  * (info[7]); rows of at most GNNMP_MIN_LONG_ROW edges are never split. */
 #define GNNMP_LONG_ROW 512
+/* a plan holds fewer than this many slots (edges + added self loops): slots and edge positions are unsigned 32-bit values, with
+ * headroom so that no slot counter inside a kernel can wrap */
+#define GNNMP_MAX_SLOTS 4294901760LL /* 2^32 - 65536 */
 #define GNNMP_MIN_LONG_ROW 64
 
 int gnnmp_version(void);
@@ -103,9 +106,11 @@ const char *gnnmp_last_error(void);
  *                  edges, exactly like transform.jl:12-28 (never de-duplicates).  E' = n_edges + n.
  *   validate != 0: check 1 <= s <= n_src, 1 <= t <= n_dst on the device (GNNGraphs/src/convert.jl:47-54)
  *                  and return GNNMP_EBOUNDS instead of building.
- * The plan stores: rowptr[n_dst+1], col[E'] (0-based source of each slot), eid[E'] (0-based original
- * edge position of each slot; self loops are n_edges + i).  Slots of one destination keep the original
- * edge order (stable sort).
+ * The plan stores: rowptr[n_dst+1] (unsigned 32-bit), col[E'] (0-based source of each slot, int32), eid[E'] (0-based original
+ * edge position of each slot, unsigned 32-bit; self loops are n_edges + i).  Slots of one destination keep the original
+ * edge order (stable sort).  Limits: n_src, n_dst < 2^31 - 1 and E' < GNNMP_MAX_SLOTS = 2^32 - 65536 (COO_T admits any
+ * Integer, GNNGraphs/src/abstracttypes.jl:1: the INDEX type may be Int64 at any size; the COUNT of edges of one plan is
+ * bounded by the 32-bit slots); beyond that GNNMP_EUNSUPPORTED.
  * ---------------------------------------------------------------------------------------------- */
 int gnnmp_plan_create(gnnmp_graph_t **out, const void *src, const void *dst, int idx_bytes,
                       int index_base, int64_t n_src, int64_t n_dst, int64_t n_edges,
@@ -115,9 +120,12 @@ int gnnmp_plan_destroy(gnnmp_graph_t *plan);
  * info[4]=max in-degree info[5]=number of split (long) rows info[6]=bytes of device memory held */
 int gnnmp_plan_info(const gnnmp_graph_t *plan, int64_t info[8]);
 /* copy the plan's index arrays into caller device buffers (any may be NULL): int32 rowptr[n_dst+1],
- * col[E'], eid[E'] — bit-exact index outputs, used by the parity tests. */
+ * col[E'], eid[E'] — bit-exact index outputs, used by the parity tests.  GNNMP_EUNSUPPORTED when E' >= 2^31 (the values do
+ * not fit int32): gnnmp_plan_export64 hands out rowptr widened to int64 and eid as the unsigned values they are, at any size. */
 int gnnmp_plan_export(const gnnmp_graph_t *plan, int32_t *rowptr, int32_t *col, int32_t *eid,
                       gnnmp_stream_t stream);
+int gnnmp_plan_export64(const gnnmp_graph_t *plan, int64_t *rowptr, int32_t *col, uint32_t *eid,
+                        gnnmp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Index ops (bit-exact)

@@ -6,7 +6,9 @@ size-independent properties with an exact expected value:
     representable integer sum, which torch's int64 index_add_ over (s mod 1024) gives independently;
   * attention over neighbours that all carry the same value v returns v (softmax weights sum to one), whatever the logits.
 
-The plan itself is int32 by design: a graph with 2^31 or more edges / nodes must be REFUSED, not wrapped."""
+A plan holds node ids as int32 and slots / edge positions as unsigned 32-bit values: 2^31 or more NODES and 2^32 - 65536 or more
+SLOTS must be REFUSED, not wrapped — and a graph of more than 2^31 edges (COO_T admits any Integer,
+GNNGraphs/src/abstracttypes.jl:1) must WORK: the last test builds one and checks it through exact properties."""
 import numpy as np
 import pytest
 
@@ -143,7 +145,102 @@ def test_plan_refuses_what_int32_cannot_index(gm):
     h = ctypes.c_void_p()
     rc = lib.gnnmp_plan_create(ctypes.byref(h), L.ptr(s), L.ptr(s), 8, 1, 2**31, 2**31, 4, 0, 0, L.stream_ptr())
     assert rc != 0 and not h.value
-    rc = lib.gnnmp_plan_create(ctypes.byref(h), L.ptr(s), L.ptr(s), 8, 1, 4, 4, 2**31 + 5, 0, 0, L.stream_ptr())
-    assert rc != 0 and not h.value
-    rc = lib.gnnmp_plan_create(ctypes.byref(h), L.ptr(s), L.ptr(s), 8, 1, 2**31 - 2, 2**31 - 2, 4, 1, 0, L.stream_ptr())
-    assert rc != 0 and not h.value                        # E + n self loops does not fit either
+    rc = lib.gnnmp_plan_create(ctypes.byref(h), L.ptr(s), L.ptr(s), 8, 1, 4, 4, 2**32 + 5, 0, 0, L.stream_ptr())
+    assert rc == L.EUNSUPPORTED and not h.value
+    rc = lib.gnnmp_plan_create(ctypes.byref(h), L.ptr(s), L.ptr(s), 8, 1, 4, 4, 2**32 - 65536, 0, 0, L.stream_ptr())
+    assert rc == L.EUNSUPPORTED and not h.value           # GNNMP_MAX_SLOTS: headroom so that no slot counter can wrap
+    rc = lib.gnnmp_plan_create(ctypes.byref(h), L.ptr(s), L.ptr(s), 8, 1, 2**31 - 2, 2**31 - 2, 2**31 + 10, 1, 0, L.stream_ptr())
+    assert rc == L.EUNSUPPORTED and not h.value           # E + n self loops does not fit either
+
+
+@pytest.mark.gpu
+def test_graph_with_more_than_2_pow_31_edges(gm):
+    """E = 2^31 + 4097 edges on 2^23 nodes (Int32 index arrays: 17 GB; the plan: another 17 GB; mean in-degree 256: rows the
+    plan does not split, plus one 100 000-edge hub on the LAST node, whose chunks straddle slot 2^31): slots and edge positions
+    pass 2^31, so every signed-32-bit assumption about them would wrap.  Checked through exact properties:
+      * rowptr ends at E, row lengths = in-degrees, edge positions are a permutation (checksum) and increase inside a row
+        (stability) on a window that straddles slot 2^31;
+      * aggregate_neighbors(+) of per-edge integers whose LAST rows (edge positions beyond 2^31) are distinctive = torch's
+        int64 index_add_  (the _scatter path: rows addressed by edge position);
+      * propagate(copy_xj, +) column = out-degree-weighted integer sum; propagate(w_mul_xj) reads w by edge position;
+      * softmax_edge_neighbors sums to one per destination and is invariant to the three-step / one-pass split."""
+    import torch
+    n, E = 1 << 23, (1 << 31) + 4097
+    free, _ = torch.cuda.mem_get_info()
+    if free < 120 * (1 << 30):
+        pytest.skip("needs ~100 GB of device memory")
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    s = torch.randint(1, n + 1, (E,), device="cuda", generator=gen, dtype=torch.int32)
+    t = torch.randint(1, n + 1, (E,), device="cuda", generator=gen, dtype=torch.int32)
+    t[1_000_000:1_100_000] = n                                  # the hub: its slots are the last ones of the plan
+    g = gm.GNNGraph(s, t, num_nodes=n)
+    p = g.plan(False)
+    assert p.n_total == E and p.n_edges == E and p.n_long >= 1
+    rowptr, col, eid = p.export64()
+    assert int(rowptr[0]) == 0 and int(rowptr[-1]) == E
+    indeg = torch.zeros(n, dtype=torch.int64, device="cuda")
+    outdeg = torch.zeros(n, dtype=torch.int64, device="cuda")
+    CH = 1 << 28
+    for a in range(0, E, CH):                                   # chunked: int64 copies of 2^31 indices would be 17 GB each
+        indeg += torch.bincount(t[a:a + CH].long() - 1, minlength=n)
+        outdeg += torch.bincount(s[a:a + CH].long() - 1, minlength=n)
+    assert torch.equal(rowptr[1:] - rowptr[:-1], indeg)
+    assert p.max_degree == int(indeg.max())
+    tot = 0
+    for a in range(0, E, CH):
+        tot += int(eid[a:a + CH].sum())
+    assert tot == E * (E - 1) // 2                                # a permutation of 0 .. E-1
+    assert int(eid.max()) == E - 1 and int(eid.min()) == 0
+    # stability + grouping around slot 2^31: inside a row edge positions increase, and every slot's destination is its row
+    lo, hi = (1 << 31) - 50_000, E
+    row_of = torch.searchsorted(rowptr, torch.arange(lo, hi, device="cuda"), right=True) - 1
+    w_eid = eid[lo:hi]
+    assert torch.equal(t[w_eid].long() - 1, row_of)
+    assert torch.equal(s[w_eid].long() - 1, col[lo:hi].long())
+    same = row_of[1:] == row_of[:-1]
+    assert bool((w_eid[1:][same] > w_eid[:-1][same]).all())
+    del rowptr, col, eid, w_eid, row_of
+    torch.cuda.empty_cache()
+
+    # _scatter: one value per edge, the last 4097 edges (positions >= 2^31) carry 1000
+    e = torch.ones((E, 1), dtype=torch.float32, device="cuda")
+    e[1 << 31:] = 1000.0
+    got = gm.aggregate_neighbors(g, "+", e)[:, 0]
+    want = indeg.clone()
+    want.index_add_(0, t[1 << 31:].long() - 1, torch.full((E - (1 << 31),), 999, dtype=torch.int64, device="cuda"))
+    assert int(want.max()) < 2**24
+    assert torch.equal(got, want.float())
+    # the neighbourhood softmax of the same rows: one pass == three steps, every destination with an edge sums to one
+    a1 = gm.softmax_edge_neighbors(g, e)
+    gm.tune(16, -1)
+    try:
+        a3 = gm.softmax_edge_neighbors(g, e)
+    finally:
+        gm.tune(16, 0)
+    assert torch.equal(a1, a3)
+    del a3
+    sums = torch.zeros(n, dtype=torch.float64, device="cuda")
+    for a in range(0, E, CH):
+        sums.index_add_(0, t[a:a + CH].long() - 1, a1[a:a + CH, 0].double())
+    assert float((sums[indeg > 0] - 1.0).abs().max()) < 1e-4
+    del a1, sums
+    torch.cuda.empty_cache()
+
+    # propagate: x[j] = j mod 8 in all 4 columns -> exact integer sums
+    val = torch.arange(n, device="cuda") % 8
+    x = val.float()[:, None].expand(n, 4).contiguous()
+    y = gm.propagate(gm.copy_xj, g, "+", xj=x)
+    want = torch.zeros(n, dtype=torch.int64, device="cuda")
+    for a in range(0, E, CH):
+        want.index_add_(0, t[a:a + CH].long() - 1, val[s[a:a + CH].long() - 1])
+    assert int(want.max()) < 2**24
+    assert torch.equal(y[:, 0], want.float()) and torch.equal(y[:, 3], want.float())
+    ymax = gm.propagate(gm.copy_xj, g, "max", xj=x)
+    assert float(ymax[indeg > 64].min()) == 7.0                    # 64 uniform draws of 0..7 miss the 7 with probability 2e-4
+    # w_mul_xj: weights by edge position, the positions beyond 2^31 weigh 3, the rest 1
+    w = e[:, 0].clone()
+    w[1 << 31:] = 3.0
+    gw = gm.set_edge_weight(g, w)
+    yw = gm.propagate(gm.w_mul_xj, gw, "+", xj=x)
+    want.index_add_(0, t[1 << 31:].long() - 1, 2 * val[s[1 << 31:].long() - 1])
+    assert torch.equal(yw[:, 1], want.float())
