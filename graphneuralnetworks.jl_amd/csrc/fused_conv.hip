@@ -111,15 +111,22 @@ __global__ void __launch_bounds__(1024) fused_conv_kernel(const FusedArgs a) {
         }
         if (t >= ntiles) break;
         const int row0 = t * 16;
+        // the tile's 17 row pointers in one coalesced load (lane l holds rowptr[row0 + l]); each row then takes its bounds from
+        // two lanes instead of starting with a dependent load of its own (not with a row order: those rows are not adjacent)
+        const uint32_t rp = (!r.row_order && lane <= 16) ? r.rowptr[min(row0 + lane, r.n_rows)] : 0u;
         // ---- 1. the 16 rows of the tile, rpw at a time ----
-        for (int rr = grp; rr < 16; rr += rpw) {
+        for (int rr0 = 0; rr0 < 16; rr0 += rpw) {
+            const int rr = rr0 + grp;
+            // every lane of the wave takes part in the two exchanges (a lane group past the tile's 16th row reads lane 16)
+            const uint32_t rb = (uint32_t)__shfl((int)rp, min(rr, 16), 64), re = (uint32_t)__shfl((int)rp, min(rr + 1, 16), 64);
+            if (rr >= 16) continue;
             int row = row0 + rr;
             if (r.row_order && row < r.n_rows) row = r.row_order[row];
             float acc[VEC];
 #pragma unroll
             for (int v = 0; v < VEC; ++v) acc[v] = op_identity<OP>();
             if (row < r.n_rows) {
-                const uint32_t beg = r.rowptr[row], end = r.rowptr[row + 1];
+                const uint32_t beg = r.row_order ? r.rowptr[row] : rb, end = r.row_order ? r.rowptr[row + 1] : re;
                 if (end - beg > r.long_thresh) {
                     if (active) Vec<VEC>::load(a.agg_long + (int64_t)long_slot(r.long_rows, r.n_long, row) * D + f0, acc);
                 } else {
