@@ -244,3 +244,23 @@ def test_graph_with_more_than_2_pow_31_edges(gm):
     yw = gm.propagate(gm.w_mul_xj, gw, "+", xj=x)
     want.index_add_(0, t[1 << 31:].long() - 1, 2 * val[s[1 << 31:].long() - 1])
     assert torch.equal(yw[:, 1], want.float())
+    del y, ymax, yw, w, gw, e
+    torch.cuda.empty_cache()
+    # the one-pass attention kernel and the fused aggregate-then-transform layer walk the same unsigned slots: attention over
+    # neighbours that all carry the same row returns that row; the GCN layer equals propagate + dense on the same plan
+    l = gm.GATConv((4, 4), None, heads=1, bias=False, add_self_loops=False, seed=3)
+    l.dense_x_weight = torch.eye(4, device="cuda")
+    v = torch.tensor([0.5, -1.0, 2.0, 0.25], device="cuda")
+    ya = l(g, v.repeat(n, 1))
+    assert float((ya[indeg > 0] - v[None, :]).abs().max()) < 1e-5
+    gm.tune(14, 16)
+    try:
+        gcn = gm.GCNConv((4, 4), "relu", add_self_loops=False, seed=4)
+        yf = gcn(g, x)
+    finally:
+        gm.tune(14, -1)
+    try:
+        yu = gcn(g, x)
+    finally:
+        gm.tune(14, 0)
+    assert float((yf - yu).abs().max()) <= 1e-5 * float(yu.abs().max())
