@@ -28,6 +28,8 @@ struct ReduceArgs {
     const float *ss_slot;    // [E'] slot order, nullable (takes precedence over ss)
     const float *sd;         // [n_dst] nullable
     float *out;              // [n_dst][D]
+    const float *bias;       // [D] or null: added to the finished row (after the destination scaling) ...
+    int bias_relu;           // ... and then relu, if set: the layer epilogue σ.(x .+ b) of gcn_conv's W-first branch (conv.jl:36-40,71)
     float *partial;          // [n_chunks][D]
     const int32_t *chunk_row;
     const uint32_t *chunk_beg, *chunk_end;
@@ -233,6 +235,14 @@ template <int VEC, int OP>
 __device__ __forceinline__ void finalize_store(const ReduceArgs &a, int row, uint32_t len, int f0,
                                                bool active, float acc[VEC], int out_row = -1) {
     finalize_row<VEC, OP>(a, row, len, acc);
+    if (a.bias && active) {
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) acc[q] = acc[q] + a.bias[f0 + q];
+    }
+    if (a.bias_relu) {
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) acc[q] = acc[q] < 0.0f ? 0.0f : acc[q];
+    }
     if (active) Vec<VEC>::store(a.out + (int64_t)(out_row < 0 ? row : out_row) * a.D + f0, acc);
 }
 

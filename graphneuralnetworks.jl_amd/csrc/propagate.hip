@@ -325,7 +325,8 @@ static int dispatch_op(const ReduceArgs &a, int op, bool scaled, hipStream_t s) 
 int run_reduce(gnnmp_graph_t *p, const int32_t *idx, int aggr, const float *x, const float *w,
                const float *ss, const float *w_slot, const float *ss_slot, const float *sd, float *out,
                int64_t D, hipStream_t stream, const float *emat = nullptr, const float *rowsub = nullptr,
-               const float *gate_i = nullptr, int gated = 1, int act = 0, int long_only = 0) {
+               const float *gate_i = nullptr, int gated = 1, int act = 0, int long_only = 0, const float *bias = nullptr,
+               int bias_relu = 0) {
     // long_only: reduce ONLY the split rows (their chunk virtual rows + the combine) and write row long_rows[r], finalised, to
     // out[r] — a compact [n_long][D] buffer the fused kernel reads instead of walking those rows (the caller sized the
     // workspace and passes out inside it)
@@ -354,6 +355,8 @@ int run_reduce(gnnmp_graph_t *p, const int32_t *idx, int aggr, const float *x, c
     a.ss_slot = ss_slot;
     a.sd = sd;
     a.out = out;
+    a.bias = bias;
+    a.bias_relu = bias_relu;
     a.partial = p->ws;
     a.chunk_row = p->chunk_row;
     a.chunk_beg = p->chunk_beg;
@@ -658,6 +661,19 @@ int gnnmp_propagate_slots_f32(gnnmp_graph_t *plan, int aggr, const float *xj, co
         return fail(GNNMP_EINVAL, "propagate_slots: null xj/out");
     return run_reduce(plan, plan->col, aggr, xj, nullptr, nullptr, w_slot, ss_slot, scale_dst, out, D,
                       (hipStream_t)stream);
+}
+
+int gnnmp_propagate_slots_act_f32(gnnmp_graph_t *plan, int aggr, const float *xj, const float *w_slot, const float *ss_slot,
+                                  const float *scale_dst, const float *bias, int act, float *out, int64_t D,
+                                  gnnmp_stream_t stream) {
+    if (!plan) return fail(GNNMP_EINVAL, "propagate_slots_act: null plan");
+    if (int rc = check_aggr(aggr, "propagate_slots_act")) return rc;
+    if (act != GNNMP_ACT_IDENTITY && act != GNNMP_ACT_RELU) return fail(GNNMP_EINVAL, "propagate_slots_act: bad act %d", act);
+    if (D < 0 || D > (1 << 20)) return fail(GNNMP_EINVAL, "propagate_slots_act: bad D %lld", (long long)D);
+    if (plan->n_dst > 0 && D > 0 && (!out || (!xj && plan->n_total > 0)))
+        return fail(GNNMP_EINVAL, "propagate_slots_act: null xj/out");
+    return run_reduce(plan, plan->col, aggr, xj, nullptr, nullptr, w_slot, ss_slot, scale_dst, out, D, (hipStream_t)stream, nullptr,
+                      nullptr, nullptr, 1, 0, 0, bias, act == GNNMP_ACT_RELU ? 1 : 0);
 }
 
 int gnnmp_scatter_f32(gnnmp_graph_t *plan, int aggr, const float *m, float *out, int64_t D,

@@ -25,7 +25,7 @@ SYMBOLS = (
     "gnnmp_sort_edge_index", "gnnmp_is_bidirected", "gnnmp_has_self_loops", "gnnmp_sample_neighbors",
     "gnnmp_unique_append", "gnnmp_induced_subgraph",
     "gnnmp_gather_f32", "gnnmp_edge_sub_f32", "gnnmp_scatter_f32", "gnnmp_scatter_atomic_f32",
-    "gnnmp_propagate_f32", "gnnmp_propagate_emul_f32", "gnnmp_propagate_gated_f32", "gnnmp_propagate_slots_f32", "gnnmp_plan_slot_gather_f32",
+    "gnnmp_propagate_f32", "gnnmp_propagate_emul_f32", "gnnmp_propagate_gated_f32", "gnnmp_propagate_slots_f32", "gnnmp_propagate_slots_act_f32", "gnnmp_plan_slot_gather_f32",
     "gnnmp_degree_f32", "gnnmp_inv_sqrt_f32",
     "gnnmp_edge_softmax_f32", "gnnmp_segment_softmax_f32", "gnnmp_gat_node_scores_f32", "gnnmp_gat_aggregate_f32", "gnnmp_gat_conv_f32",
     "gnnmp_gat_conv_edge_f32", "gnnmp_gat_conv_stats_f32", "gnnmp_gat_conv_grad_f32", "gnnmp_attn_conv_f32",
@@ -83,6 +83,7 @@ def load():
         "gnnmp_propagate_emul_f32": [vp, i, vp, vp, vp, i64, vp],
         "gnnmp_propagate_gated_f32": [vp, i, vp, vp, vp, i64, vp],
         "gnnmp_propagate_slots_f32": [vp, i, vp, vp, vp, vp, vp, i64, vp],
+        "gnnmp_propagate_slots_act_f32": [vp, i, vp, vp, vp, vp, vp, i, vp, i64, vp],
         "gnnmp_plan_slot_gather_f32": [vp, i, vp, vp, vp],
         "gnnmp_gat_conv_f32": [vp, vp, vp, vp, f, vp, i, vp, i64, i64, vp],
         "gnnmp_gat_conv_edge_f32": [vp, vp, vp, vp, vp, f, vp, i, vp, i64, i64, vp],

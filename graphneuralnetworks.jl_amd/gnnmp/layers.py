@@ -187,6 +187,13 @@ def gcn_conv(l, g: GNNGraph, x, edge_weight=None, norm_fn=None, conv_weight=None
     if c_slot is not None:
         xf = _flat(x)
         out = torch.empty((plan.n_dst, xf.shape[1]), dtype=torch.float32, device=x.device)
+        if Dout < Din:
+            # W came first: bias and σ ride in the row kernel's epilogue (conv.jl:71), no separate pass over (N, Dout)
+            code, post = _act_code(l.sigma)
+            b = None if l.bias is None or l.bias is False else l.bias.contiguous()
+            L.check(lib.gnnmp_propagate_slots_act_f32(plan.handle, L.SUM, L.ptr(xf), L.ptr(w_slot), L.ptr(c_slot), L.ptr(c),
+                                                      L.ptr(b), code, L.ptr(out), xf.shape[1], L.stream_ptr()))
+            return post(out) if post is not None else out
         L.check(lib.gnnmp_propagate_slots_f32(plan.handle, L.SUM, L.ptr(xf), L.ptr(w_slot), L.ptr(c_slot), L.ptr(c),
                                               L.ptr(out), xf.shape[1], L.stream_ptr()))
         x = out

@@ -265,6 +265,13 @@ int gnnmp_propagate_nn_f32(gnnmp_graph_t *plan, int aggr, const float *xj, const
 int gnnmp_propagate_slots_f32(gnnmp_graph_t *plan, int aggr, const float *xj, const float *w_slot,
                               const float *ss_slot, const float *scale_dst, float *out, int64_t D,
                               gnnmp_stream_t stream);
+/* the same with the layer epilogue of gcn_conv's W-first branch in the row kernel: out = act.(A .+ bias), A = what
+ * gnnmp_propagate_slots_f32 returns — `x = l.weight * x` before the convolution when Dout < Din, then `σ.(x .+ l.bias)` after it
+ * (GNNlib/src/layers/conv.jl:36-40,71).  bias: [D] or NULL; act: GNNMP_ACT_IDENTITY | GNNMP_ACT_RELU.  Bit-identical to
+ * gnnmp_propagate_slots_f32 followed by gnnmp_bias_act_f32, one pass over (N, D) less. */
+int gnnmp_propagate_slots_act_f32(gnnmp_graph_t *plan, int aggr, const float *xj, const float *w_slot, const float *ss_slot,
+                                  const float *scale_dst, const float *bias, int act, float *out, int64_t D,
+                                  gnnmp_stream_t stream);
 /* out_slot[p] = v[col_p] (by = 0: v is a node vector of n_src entries) or v[eid_p] (by = 1: v is an edge vector of
  * n_edges entries in original order; plan-added self loops get 1.0).  out_slot has E' entries. */
 int gnnmp_plan_slot_gather_f32(gnnmp_graph_t *plan, int by, const float *v, float *out_slot,

@@ -152,3 +152,37 @@ def test_arxiv_size_gcn_vs_reference_fast_path(gm, oracle):
     got = l(g, dev(x)).cpu().numpy()
     ref = oracle.gcn_conv(s, t, N, x, l.weight.cpu().numpy(), l.bias.cpu().numpy(), "relu", fast_path=True)
     close(got, ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Din,Dout,sigma,bias", [(40, 8, "relu", True), (1433, 64, "relu", True), (100, 64, None, True),
+                                                  (33, 7, "relu", False), (16, 4, None, False)])
+def test_gcn_w_first_epilogue_in_the_row_kernel(gm, oracle, Din, Dout, sigma, bias):
+    """Dout < Din: `x = W * x` before the convolution, `σ.(x .+ b)` after it (conv.jl:36-40,71).  The bias and the relu ride in
+    the row kernel (gnnmp_propagate_slots_act_f32): bit-identical to propagate_slots + bias_act, within 1e-5 of the oracle —
+    hubs above the split threshold included (their rows are finished by the combine kernel)."""
+    import torch
+    from gnnmp import _lib as L
+    from gnnmp.layers import bias_act, dense, gcn_norm_cache
+    rng = np.random.default_rng(Din + Dout)
+    n, E = 2000, 30000
+    s = rng.integers(1, n + 1, E)
+    t = np.concatenate([rng.integers(1, n + 1, E - 900), np.full(900, 7)])
+    x = rng.standard_normal((n, Din)).astype(np.float32)
+    g = gm.GNNGraph(dev(s), dev(t), num_nodes=n)
+    l = gm.GCNConv((Din, Dout), sigma, bias=bias, seed=3)
+    if bias:
+        l.bias = dev((rng.standard_normal(Dout) * 0.3).astype(np.float32))
+    y = l(g, dev(x))
+    ref = oracle.gcn_conv(s, t, n, x, l.weight.cpu().numpy(), l.bias.cpu().numpy() if bias else None, sigma)
+    got = y.cpu().numpy()
+    assert np.linalg.norm(got - ref) <= 1e-5 * np.linalg.norm(ref)
+    # the unfused composition on the same plan: same bits
+    lib = L.load()
+    plan = g.plan(True)
+    c, c_slot, _ = gcn_norm_cache(g, True)
+    h = dense(dev(x), l.weight)
+    agg = torch.empty_like(h)
+    L.check(lib.gnnmp_propagate_slots_f32(plan.handle, L.SUM, L.ptr(h), None, L.ptr(c_slot), L.ptr(c), L.ptr(agg), Dout,
+                                          L.stream_ptr()))
+    assert torch.equal(y, bias_act(agg, l.bias, sigma))
