@@ -138,6 +138,11 @@ def load():
         fn.restype = i
     L.gnnmp_dense_grad_workspace.argtypes = [i64, i64, i64]
     L.gnnmp_dense_grad_workspace.restype = i64
+    # GNNMP_KNOBS="0=1,5=2": tuning knobs applied at load (test runs that force the narrow-vector / other template variants of
+    # every kernel: `GNNMP_KNOBS=0=1 python -m pytest tests -m gpu`)
+    for kv in filter(None, os.environ.get("GNNMP_KNOBS", "").split(",")):
+        k, v = kv.split("=")
+        check(L.gnnmp_tune(int(k), int(v)))
     _lib = L
     return L
 

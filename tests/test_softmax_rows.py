@@ -61,7 +61,7 @@ def test_edge_softmax_matches_three_steps_and_oracle(gm, oracle, H, n, E, hubs):
     assert torch.equal(new, old)
     assert torch.equal(new, gm.softmax_edge_neighbors(g, ed))       # no atomics anywhere: run-to-run identical
     ref = oracle.softmax_edge_neighbors(t, n, e)                    # 1-based, like the graph
-    np.testing.assert_allclose(new.cpu().numpy(), ref, rtol=2e-6, atol=1e-12)
+    np.testing.assert_allclose(new.cpu().numpy(), ref, rtol=5e-6, atol=1e-12)   # split rows fold chunk partials: order differs from the oracle
     # every destination with an edge sums to one
     z = np.zeros((n, H), np.float64)
     np.add.at(z, t - 1, new.cpu().numpy().astype(np.float64))
