@@ -325,9 +325,11 @@ int gnnmp_plan_create(gnnmp_graph_t **out, const void *src, const void *dst, int
     p->bytes = (int64_t)(sizeof(int32_t) * ((size_t)(n_dst + 1) + 2 * epad));
 
     if (Etot > 0) {
-        PLAN_HIP(hipMalloc((void **)&keys_in, sizeof(uint32_t) * epad));
-        PLAN_HIP(hipMalloc((void **)&keys_out, sizeof(uint32_t) * epad));
-        PLAN_HIP(hipMalloc((void **)&vals_in, sizeof(uint32_t) * epad));
+        // one allocation for the three key / value arrays of the sort
+        const size_t piece = (sizeof(uint32_t) * epad + 255) & ~(size_t)255;
+        PLAN_HIP(hipMalloc((void **)&keys_in, 3 * piece));
+        keys_out = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(keys_in) + piece);
+        vals_in = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(keys_in) + 2 * piece);
         plan_fill_keys<<<nblocks(Etot, BS), BS, 0, stream>>>(src, dst, idx_bytes, index_base,
                                                              n_edges, Etot, n_src, n_dst, keys_in,
                                                              vals_in, flags);
@@ -420,9 +422,7 @@ int gnnmp_plan_create(gnnmp_graph_t **out, const void *src, const void *dst, int
     }
 
 done:
-    if (keys_in) (void)hipFree(keys_in);
-    if (keys_out) (void)hipFree(keys_out);
-    if (vals_in) (void)hipFree(vals_in);
+    if (keys_in) (void)hipFree(keys_in);   // keys_out and vals_in live in the same allocation
     if (flags) (void)hipFree(flags);
     if (long_tmp) (void)hipFree(long_tmp);
 #undef PLAN_HIP
