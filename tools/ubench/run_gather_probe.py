@@ -37,3 +37,20 @@ for N in (2_449_029, 169_343):
                 print(f"N={N:8d} D={D:3d} rows/group={per_group:3d} U={U:2d}: {ms:6.3f} ms  {n_ids * lines / ms / 1e6:5.1f} G lines/s  "
                       f"{n_ids * D * 4 / ms / 1e9:5.2f} TB/s of rows", flush=True)
         del x
+
+
+# persistent lane groups: 26 rows per list, waves loop over lists (with / without prefetch of the next list's first ids)
+lib.gather_probe_persistent.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                        ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+N = 2_449_029
+ids = torch.randint(0, N, (n_ids,), device="cuda", dtype=torch.int32)
+for D in (128, 100):
+    x = torch.randn((N, D), device="cuda")
+    out = torch.empty(((n_ids + 25) // 26, D), device="cuda")
+    for blocks_per_cu in (4, 6, 8, 16):
+        for pf in (0, 1):
+            ms = med(lambda: lib.gather_probe_persistent(x.data_ptr(), ids.data_ptr(), n_ids, 5, D, 26, pf, 256 * blocks_per_cu,
+                                                         out.data_ptr(), torch.cuda.current_stream().cuda_stream))
+            print(f"persistent D={D:3d} 26 rows/list blocks/CU={blocks_per_cu:2d} prefetch={pf}: {ms:6.3f} ms  "
+                  f"{n_ids * 4 / ms / 1e6:5.1f} G lines/s", flush=True)
+    del x, out
