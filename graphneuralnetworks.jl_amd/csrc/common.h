@@ -46,7 +46,10 @@ enum Knob {
     KNOB_ROW_ORDER = 15,       // rows by decreasing length in the row kernels that share a wave between rows: 0 (default) = never,
                                // 1 = when the gathered matrix exceeds the Infinity Cache, 2 = always (use_row_order)
     KNOB_SOFTMAX_ROWS = 16,    // one-pass narrow-row softmax (softmax_rows.hip): 0 = auto, < 0 = the three-step kernels on every row
-    KNOB_COUNT = 17
+    KNOB_DENSE_SPLIT = 17,     // split-bf16 dense core (msplit.h, dense_split.hip): 0 = auto (on for its shapes), < 0 = the fp32-MFMA
+                               // kernels of rounds 1-2 on every shape
+    KNOB_CHAIN = 18,           // fused GraphConv chain kernel (graph_chain.hip): 0 = auto, < 0 = never (layer-by-layer path)
+    KNOB_COUNT = 19
 };
 int knob(int k);
 int device_cus();   // compute units of the current device, queried once (hipDeviceGetAttribute costs microseconds per call)

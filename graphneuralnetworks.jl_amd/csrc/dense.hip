@@ -555,6 +555,9 @@ static int dense_narrow_try(const float *x1, const float *W1, int64_t D1, int64_
     return GNNMP_OK;
 }
 
+int dense_split_try(const float *x1, const float *W1, int64_t D1, int64_t ldw1, const float *x2, const float *W2, int64_t D2,
+                    int64_t ldw2, int w_layout, const float *bias, int act, float *out, int64_t N, int64_t Dout,
+                    hipStream_t stream);   // dense_split.hip
 int dense_t16_try(const float *x1, const float *W1, int64_t D1, int64_t ldw1, const float *x2, const float *W2, int64_t D2,
                   int64_t ldw2, int w_layout, const float *bias, int act, float *out, int64_t N, int64_t Dout,
                   hipStream_t stream);   // dense_t16.hip
@@ -573,6 +576,12 @@ extern "C" int gnnmp_dense_f32(const float *x1, const float *W1, int64_t D1, int
     if (act != GNNMP_ACT_IDENTITY && act != GNNMP_ACT_RELU) return fail(GNNMP_EINVAL, "dense: bad act %d", act);
     if (N == 0) return GNNMP_OK;
     if (!x1 || !W1 || !out || (D2 > 0 && (!x2 || !W2))) return fail(GNNMP_EINVAL, "dense: null pointer");
+    {
+        // round 3: the split-bf16 core (three exact bf16 planes per operand, six bf16 MFMAs per product: fp32-class accuracy at
+        // 2.7x the fp32-MFMA rate) for every shape whose W image fits LDS
+        const int rc = dense_split_try(x1, W1, D1, ldw1, x2, W2, D2, ldw2, w_layout, bias, act, out, N, Dout, stream);
+        if (rc != 1) return rc;
+    }
     {
         // the shapes of the hot path (K a multiple of 4, <= 128 per segment): operands straight from HBM, 16x16x4 MFMAs
         const int rc = dense_t16_try(x1, W1, D1, ldw1, x2, W2, D2, ldw2, w_layout, bias, act, out, N, Dout, stream);

@@ -32,6 +32,7 @@ SYMBOLS = (
     "gnnmp_attn_conv_grad_f32",
     "gnnmp_bias_act_f32",
     "gnnmp_segment_pool_f32", "gnnmp_segment_bounds", "gnnmp_segment_pool_ptr_f32", "gnnmp_dense_f32", "gnnmp_fused_conv_f32",
+    "gnnmp_graphconv_chain_scratch_floats", "gnnmp_graphconv_chain_f32",
     "gnnmp_edge_dot_f32", "gnnmp_edge_dot_plan_f32", "gnnmp_propagate_maxmin_grad_f32",
     "gnnmp_head_mean_f32", "gnnmp_head_mean_grad_f32", "gnnmp_add_f32", "gnnmp_axpy_f32", "gnnmp_mul_rows_f32", "gnnmp_is_sorted",
     "gnnmp_act_grad_f32", "gnnmp_dense_grad_workspace", "gnnmp_dense_grad_w_f32",
@@ -123,6 +124,8 @@ def load():
         "gnnmp_propagate_maxmin_grad_f32": [vp, vp, vp, vp, vp, i64, vp],
         "gnnmp_act_grad_f32": [vp, vp, i, vp, i64, vp],
         "gnnmp_dense_grad_w_f32": [vp, vp, i64, i64, i64, vp, vp, vp, i64, vp],
+        "gnnmp_graphconv_chain_f32": [vp, vp, i64, vp, i, ctypes.POINTER(i64), ctypes.POINTER(vp), ctypes.POINTER(vp),
+                                      ctypes.POINTER(vp), ctypes.POINTER(i), i, i, vp, vp, i64, vp, vp, vp],
         "gnnmp_tune": [i, i],
     }
     for name, args in sig.items():
@@ -138,6 +141,12 @@ def load():
         fn.restype = i
     L.gnnmp_dense_grad_workspace.argtypes = [i64, i64, i64]
     L.gnnmp_dense_grad_workspace.restype = i64
+    try:
+        L.gnnmp_graphconv_chain_scratch_floats.argtypes = [i64, i, ctypes.POINTER(i64), i64]
+        L.gnnmp_graphconv_chain_scratch_floats.restype = i64
+    except AttributeError:
+        if not os.environ.get("GNNMP_LIB"):
+            raise
     # GNNMP_KNOBS="0=1,5=2": tuning knobs applied at load (test runs that force the narrow-vector / other template variants of
     # every kernel: `GNNMP_KNOBS=0=1 python -m pytest tests -m gpu`)
     for kv in filter(None, os.environ.get("GNNMP_KNOBS", "").split(",")):

@@ -426,11 +426,90 @@ class GNNChain:
 
     def __init__(self, *layers):
         self.layers = layers
+        self._fused = None
 
     def __call__(self, g, x):
+        y = graphconv_chain(self, g, x)      # the whole chain in one kernel when it is GraphConv* -> GlobalPool -> Dense
+        if y is not None:
+            return y
         for l in self.layers:
             x = l(x) if isinstance(l, Dense) or not _takes_graph(l) else l(g, x)
         return x
+
+
+def _chain_pattern(layers):
+    """(convs, pool, head) if `layers` is GraphConv, ..., GraphConv, GlobalPool(+ | mean), Dense(identity) — the graph-classification
+    chain of examples/graph_classification_tudataset.jl:79-82 — inside the fused kernel's envelope; else None."""
+    if len(layers) < 3 or not isinstance(layers[-1], Dense) or not isinstance(layers[-2], GlobalPool):
+        return None
+    convs, pool, head = layers[:-2], layers[-2], layers[-1]
+    if not (1 <= len(convs) <= 4) or not all(isinstance(c, GraphConv) for c in convs):
+        return None
+    if pool.aggr not in ("+", "sum", "mean") or head.sigma not in (None, "identity") or head.weight.shape[0] > 8:
+        return None
+    aggr = convs[0].aggr
+    if aggr not in ("+", "sum", "mean") or any(c.aggr != aggr for c in convs):
+        return None
+    if any(c.sigma not in _ACT or c.weight1.shape[0] > 128 or c.weight1.shape[0] % 4 or c.weight1.shape[1] % 4 for c in convs):
+        return None
+    if any(convs[k + 1].weight1.shape[1] != convs[k].weight1.shape[0] for k in range(len(convs) - 1)):
+        return None
+    if head.weight.shape[1] != convs[-1].weight1.shape[0]:
+        return None
+    return convs, pool, head
+
+
+def graphconv_chain(model, g: GNNGraph, x):
+    """GNNChain(GraphConv..., GlobalPool, Dense) on a batched graph through gnnmp_graphconv_chain_f32 (csrc/graph_chain.hip): one
+    launch, layer outputs never leave the workgroup that owns the member graphs.  Returns None when the chain or the graph is not
+    of that form (the caller runs it layer by layer)."""
+    import ctypes
+    if g.graph_indicator is None or x is None or x.dim() != 2 or x.dtype != torch.float32:
+        return None
+    pat = _chain_pattern(model.layers)
+    if pat is None:
+        return None
+    convs, pool, head = pat
+    if x.shape[1] != convs[0].weight1.shape[1] or x.shape[0] < 32:
+        return None
+    check_num_nodes(g, x)
+    lib = L.load()
+    nl = len(convs)
+    # the ctypes argument block only changes when a weight tensor is replaced: cached on the model
+    tensors = [t for c in convs for t in (c.weight1, c.weight2, c.bias)] + [head.weight, head.bias]
+    key = tuple((0 if t is None or t is False else t.data_ptr()) for t in tensors) + tuple(c.sigma for c in convs)
+    if model._fused is None or model._fused[0] != key:
+        keep = [t.contiguous() if isinstance(t, torch.Tensor) else None for t in tensors]
+        i64, vp = ctypes.c_int64, ctypes.c_void_p
+        dims = (i64 * (nl + 1))(convs[0].weight1.shape[1], *[c.weight1.shape[0] for c in convs])
+        wr = (vp * nl)(*[keep[3 * k].data_ptr() for k in range(nl)])
+        wa = (vp * nl)(*[keep[3 * k + 1].data_ptr() for k in range(nl)])
+        bs = (vp * nl)(*[(keep[3 * k + 2].data_ptr() if keep[3 * k + 2] is not None else None) for k in range(nl)])
+        act = (ctypes.c_int * nl)(*[_ACT[c.sigma] for c in convs])
+        model._fused = (key, keep, dims, wr, wa, bs, act)
+    _, keep, dims, wr, wa, bs, act = model._fused
+    N, G = g.num_nodes, g.num_graphs
+    sp = g._cache.get("node_ptr")
+    if sp is None:
+        gi = g.graph_indicator
+        sp = torch.empty(G + 1, dtype=torch.int64, device=x.device)
+        L.check(lib.gnnmp_segment_bounds(L.ptr(gi), 8 if gi.dtype == torch.int64 else 4, g.index_base, N, G, L.ptr(sp), L.stream_ptr()))
+        g._cache["node_ptr"] = sp
+    nout = head.weight.shape[0]
+    need = lib.gnnmp_graphconv_chain_scratch_floats(N, nl, dims, nout)
+    scratch = g._cache.get("chain_scratch")
+    if scratch is None or scratch.numel() < need:
+        scratch = torch.empty(need, dtype=torch.float32, device=x.device)
+        g._cache["chain_scratch"] = scratch
+    out = torch.empty((G, nout), dtype=torch.float32, device=x.device)
+    xc = x.contiguous()
+    rc = lib.gnnmp_graphconv_chain_f32(g.plan(False).handle, L.ptr(sp), G, L.ptr(xc), nl, dims, wr, wa, bs, act,
+                                       aggr_code(convs[0].aggr), aggr_code(pool.aggr), L.ptr(keep[-2]), L.ptr(keep[-1]), nout,
+                                       L.ptr(scratch), L.ptr(out), L.stream_ptr())
+    if rc == L.EUNSUPPORTED:
+        return None
+    L.check(rc)
+    return out
 
 
 def _takes_graph(l):

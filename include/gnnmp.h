@@ -468,12 +468,44 @@ int gnnmp_segment_pool_ptr_f32(int aggr, const float *x, const int64_t *seg_ptr,
  * weight is C row-major [Din][Dout]; pass w_layout = 1 for that, 0 for C row-major [Dout][Din]).
  * Covers `weight * x` (conv.jl:39,69), `weight1*xi .+ weight2*m` (conv.jl:106),
  * `weight * vcat(xi, m)` (conv.jl:281; W1 = first Din columns, W2 = last Din, given by ldw) and
- * `dense_x` (conv.jl:127).  fp32 in, fp32 accumulate on v_mfma_f32_32x32x2_f32 (exact fp32).
+ * `dense_x` (conv.jl:127).  fp32 in, fp32 out.  Round 3: every operand is split EXACTLY into three bf16 planes and the six
+ * significant plane products run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (csrc/msplit.h: error against float64 in the
+ * class of an fp32 fma chain, measured lower; non-finite operands are recomputed with fp32 fma loops); shapes whose weight planes
+ * do not fit LDS, K % 4 != 0 or Dout % 32 far from full take the fp32 MFMA kernels of rounds 1-2 (v_mfma_f32_16x16x4_f32 /
+ * 32x32x2_f32, an exact fp32 fma chain).
  * ldw1/ldw2: leading dimension (elements between consecutive rows of the stored matrix).
  * ---------------------------------------------------------------------------------------------- */
 int gnnmp_dense_f32(const float *x1, const float *W1, int64_t D1, int64_t ldw1, const float *x2,
                     const float *W2, int64_t D2, int64_t ldw2, int w_layout, const float *bias,
                     int act, float *out, int64_t N, int64_t Dout, gnnmp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * A whole graph-classification forward in ONE kernel (BASELINE.json config 5):
+ *   GNNChain(GraphConv(d0 => d1, σ1; aggr), ..., GraphConv(d_{L-1} => d_L, σL; aggr), GlobalPool(pool_aggr), Dense(d_L => nout))
+ *   model: examples/graph_classification_tudataset.jl:79-82; layer body σ.(W1*x_i .+ W2*aggr_j x_j .+ b) GNNlib/src/layers/conv.jl:102-108;
+ *   pooling reduce_nodes(aggr, g, x) GNNlib/src/layers/pool.jl:3-5, utils.jl:12-16; head Flux.Dense.
+ * on a batched GNNGraph (MLUtils.batch, GNNGraphs/src/transform.jl:682-709): member graphs are contiguous row ranges and no edge
+ * crosses them, so a workgroup owns a run of whole graphs and walks the chain without any inter-workgroup traffic; layer outputs
+ * live in `scratch` (L2-resident, never read by another workgroup), the last layer is folded straight into per-row head outputs,
+ * and only the (G, nout) result is written for the caller.  Contractions run on the split-bf16 MFMA core (fp32-class accuracy).
+ *   plan      : plan of the batched graph's (s, t) WITHOUT self loops
+ *   seg_ptr   : DEVICE int64 [G + 1], seg_ptr[k] = first node of member graph k (gnnmp_segment_bounds)
+ *   dims      : HOST int64 [n_layers + 1] = d0 .. dL;  W_root / W_agg / bias : HOST arrays of n_layers DEVICE pointers
+ *               (weight1 / weight2 [d_l][d_{l-1}] C row-major, i.e. Julia's (out, in) matrices transposed in memory; bias entries may
+ *               be NULL, `bias` itself may be NULL);  act : HOST int [n_layers] (gnnmp_act: IDENTITY | RELU)
+ *   aggr, pool_aggr : GNNMP_SUM | GNNMP_MEAN;  W_head [nout][dL] row-major, b_head [nout] or NULL
+ *   scratch   : DEVICE, at least gnnmp_graphconv_chain_scratch_floats(N, n_layers, dims, nout) floats, 16-byte aligned
+ *   out       : DEVICE [G][nout]
+ * Envelope: n_layers <= 4, every d a multiple of 4, d1..dL <= 128, nout <= 8; outside it (or with max / min aggregation) the call
+ * returns GNNMP_EUNSUPPORTED without touching `out` and the caller runs the chain layer by layer (gnnmp_propagate_f32 +
+ * gnnmp_dense_f32 + gnnmp_segment_pool_ptr_f32).  The pooled-then-Dense order of the reference and the Dense-then-pooled order used
+ * here agree to rounding (both are linear); the per-row aggregates have the bits of gnnmp_propagate_f32's.
+ * ---------------------------------------------------------------------------------------------- */
+int64_t gnnmp_graphconv_chain_scratch_floats(int64_t N, int n_layers, const int64_t *dims, int64_t nout);
+int gnnmp_graphconv_chain_f32(gnnmp_graph_t *plan, const int64_t *seg_ptr, int64_t G, const float *x, int n_layers,
+                              const int64_t *dims, const float *const *W_root, const float *const *W_agg,
+                              const float *const *bias, const int *act, int aggr, int pool_aggr, const float *W_head,
+                              const float *b_head, int64_t nout, float *scratch, float *out, gnnmp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Aggregate-then-transform in one kernel — the layer bodies whose dense product FOLLOWS the aggregation:

@@ -1,0 +1,222 @@
+"""graph_chain_kernel (csrc/graph_chain.hip): GNNChain(GraphConv..., GlobalPool, Dense) on a batched graph in ONE launch — BASELINE.json
+config 5 (examples/graph_classification_tudataset.jl:79-82).  Checked against the CPU oracle's layer-by-layer composition
+(graph_conv GNNlib/src/layers/conv.jl:102-108, global_pool layers/pool.jl:3-5) within north_star's 1e-5, against the library's own
+layer-by-layer path (knob 18 = -1), at the FULL config-5 size G = 8192, and on the shapes that leave the fast lanes of the kernel:
+member graphs of 1..70 nodes, isolated nodes, hubs with more than four in-neighbours, mean aggregation, + pooling, one and three
+layers, Dout < 128, Din not a multiple of 16, non-finite features."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gm():
+    import torch
+    assert torch.cuda.is_available()
+    import gnnmp
+    gnnmp.load()
+    return gnnmp
+
+
+def random_members(G, rng, nmin=1, nmax=70, hubs=True):
+    """member graphs with uneven sizes and degrees: (s, t, n) 1-based local numbering, directed edges, some isolated nodes, some hubs"""
+    out = []
+    for _ in range(G):
+        n = int(rng.integers(nmin, nmax + 1))
+        m = int(rng.integers(0, 5 * n + 1))
+        s = rng.integers(0, n, m)
+        t = rng.integers(0, n, m)
+        if hubs and n > 8 and rng.random() < 0.3:              # one node collects 5..n in-edges
+            k = int(rng.integers(5, n + 1))
+            s = np.concatenate([s, rng.integers(0, n, k)])
+            t = np.concatenate([t, np.full(k, int(rng.integers(0, n)))])
+        out.append((s.astype(np.int64) + 1, t.astype(np.int64) + 1, n))
+    return out
+
+
+def oracle_chain(oracle, members, xs, convs, pool_aggr, head):
+    s, t, gi, n = oracle.batch(members)
+    h = np.concatenate(xs)
+    for c in convs:
+        h = oracle.graph_conv(s, t, n, h, c.weight1.cpu().numpy(), c.weight2.cpu().numpy(),
+                              None if c.bias is None else c.bias.cpu().numpy(), c.sigma, c.aggr)
+    p = oracle.global_pool(pool_aggr, gi, h, len(members))
+    ref = oracle.matmul(head.weight.cpu().numpy(), p)
+    if head.bias is not None:
+        ref = ref + head.bias.cpu().numpy()[None, :]
+    return ref
+
+
+def build(gm, dims, nout, aggr, pool, sigma="relu", bias=True, seed=21):
+    import torch
+    convs = [gm.GraphConv((dims[k], dims[k + 1]), sigma, aggr=aggr, bias=bias, seed=seed + 2 * k) for k in range(len(dims) - 1)]
+    head = gm.Dense((dims[-1], nout), seed=seed + 50)
+    g = torch.Generator(device="cpu"); g.manual_seed(seed)
+    for c in convs:                                            # non-zero biases (the constructors start them at zero)
+        if c.bias is not None:
+            c.bias = (torch.rand(c.bias.shape, generator=g) - 0.5).cuda()
+    head.bias = (torch.rand(head.bias.shape, generator=g) - 0.5).cuda()
+    return gm.GNNChain(*convs, gm.GlobalPool(pool), head)
+
+
+def run_both(gm, model, g):
+    from gnnmp import layers
+    assert layers._chain_pattern(model.layers) is not None
+    y = model(g, g.x)
+    gm.tune(18, -1)
+    try:
+        y_layers = model(g, g.x)
+    finally:
+        gm.tune(18, 0)
+    return y, y_layers
+
+
+def close(y, ref, tag, k=1.0):
+    y = np.asarray(y, np.float64); ref = np.asarray(ref, np.float64)
+    assert y.shape == ref.shape, tag
+    assert np.linalg.norm(y - ref) <= k * 1e-5 * np.linalg.norm(ref) + 1e-30, (tag, np.linalg.norm(y - ref) / np.linalg.norm(ref))
+    assert np.abs(y - ref).max() <= k * 1e-5 * np.abs(ref).max() + 1e-30, (tag, np.abs(y - ref).max() / np.abs(ref).max())
+
+
+def test_fused_kernel_is_taken(gm):
+    """the chain really goes through gnnmp_graphconv_chain_f32 (one launch), not through the layer-by-layer fallback"""
+    import torch
+    from gnnmp import synth
+    members = synth.batched_graphs(G=64, seed=5)
+    xs = [np.random.default_rng(1).standard_normal((n, 16), dtype=np.float32) for _, _, n in members]
+    g = gm.batch_arrays(members, xs)
+    model = build(gm, (16, 128, 128), 2, "+", "mean")
+    calls = []
+    from gnnmp import _lib as L
+    lib = L.load()
+    real = lib.gnnmp_graphconv_chain_f32
+
+    class Spy:
+        def __call__(self, *a):
+            rc = real(*a)
+            calls.append(rc)
+            return rc
+    try:
+        lib.gnnmp_graphconv_chain_f32 = Spy()
+        model(g, g.x)
+    finally:
+        lib.gnnmp_graphconv_chain_f32 = real
+    assert calls == [0]
+
+
+@pytest.mark.parametrize("G", [64, 512])
+def test_config5_shape_vs_oracle_and_layers(gm, oracle, G):
+    from gnnmp import synth
+    members = synth.batched_graphs(G=G, seed=9)
+    rng = np.random.default_rng(1)
+    xs = [rng.standard_normal((n, 16), dtype=np.float32) for _, _, n in members]
+    g = gm.batch_arrays(members, xs)
+    model = build(gm, (16, 128, 128), 2, "+", "mean")
+    y, yl = run_both(gm, model, g)
+    ref = oracle_chain(oracle, members, xs, model.layers[:2], "mean", model.layers[-1])
+    close(y.cpu().numpy(), ref, "fused vs oracle")
+    close(yl.cpu().numpy(), ref, "layers vs oracle")
+    import torch
+    assert torch.equal(model(g, g.x), y), "not run-to-run identical"
+
+
+def test_config5_full_size_vs_oracle(gm, oracle):
+    """BASELINE.json config 5 as bench.py runs it: G = 8192, N ~ 245 k, GraphConv(16=>128,relu), GraphConv(128=>128,relu),
+    GlobalPool(mean), Dense(128=>2) — every logit against the CPU oracle"""
+    from gnnmp import synth
+    G = 8192
+    members = synth.batched_graphs(G=G)
+    rng = np.random.default_rng(4)
+    xs = [rng.standard_normal((n, 16), dtype=np.float32) for _, _, n in members]
+    g = gm.batch_arrays(members, xs)
+    model = gm.GNNChain(gm.GraphConv((16, 128), "relu", seed=21), gm.GraphConv((128, 128), "relu", seed=22),
+                        gm.GlobalPool("mean"), gm.Dense((128, 2), seed=23))
+    y, yl = run_both(gm, model, g)
+    ref = oracle_chain(oracle, members, xs, model.layers[:2], "mean", model.layers[-1])
+    close(y.cpu().numpy(), ref, "fused vs oracle, G = 8192")
+    close(yl.cpu().numpy(), ref, "layers vs oracle, G = 8192")
+
+
+CASES = [  # dims, nout, aggr, pool, sigma, bias
+    ((16, 128, 128), 2, "mean", "+", "relu", True),
+    ((16, 128), 2, "+", "mean", "relu", True),                 # one layer: it is also the last
+    ((16, 64, 128, 32), 8, "+", "mean", "relu", True),         # three layers, Dout < 128, nout = 8
+    ((20, 36, 128), 1, "mean", "mean", None, False),           # Din % 16 != 0: root and aggregate passes; no σ, no bias
+    ((128, 128, 128), 3, "+", "+", "relu", True),              # first layer already needs two passes
+    ((4, 8), 2, "+", "mean", "relu", True),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "x".join(map(str, c[0])) + f"_{c[2]}_{c[3]}")
+@pytest.mark.parametrize("seed", [0, 1])
+def test_irregular_batches(gm, oracle, case, seed):
+    dims, nout, aggr, pool, sigma, bias = case
+    rng = np.random.default_rng(100 + seed)
+    members = random_members(150, rng)
+    xs = [rng.standard_normal((n, dims[0]), dtype=np.float32) for _, _, n in members]
+    g = gm.batch_arrays(members, xs)
+    model = build(gm, dims, nout, aggr, pool, sigma, bias, seed=31 + seed)
+    y, yl = run_both(gm, model, g)
+    ref = oracle_chain(oracle, members, xs, model.layers[:-2], pool, model.layers[-1])
+    close(y.cpu().numpy(), ref, f"fused vs oracle {case}", k=2.0 if len(dims) > 3 else 1.0)
+    close(y.cpu().numpy(), yl.cpu().numpy(), f"fused vs layers {case}", k=2.0)
+
+
+def test_sharded_equals_unsharded_bit_for_bit(gm):
+    """member graphs are independent units and a row's arithmetic does not depend on where its tile falls: any regrouping of the
+    batch (gnnmp.parallel shards by graph) reproduces the same logits bit for bit"""
+    import torch
+    from gnnmp import synth
+    from gnnmp.parallel import shard_by_size
+    G = 300
+    members = synth.batched_graphs(G=G, seed=2)
+    rng = np.random.default_rng(3)
+    xs = [rng.standard_normal((n, 16), dtype=np.float32) for _, _, n in members]
+    model = build(gm, (16, 128, 128), 2, "+", "mean")
+    g = gm.batch_arrays(members, xs)
+    y = model(g, g.x)
+    shards = shard_by_size([m[2] for m in members], 3)
+    merged = torch.empty_like(y)
+    for r in range(3):
+        gr = gm.batch_arrays([members[i] for i in shards[r]], [xs[i] for i in shards[r]])
+        merged[torch.as_tensor(shards[r], device="cuda")] = model(gr, gr.x)
+    assert torch.equal(merged, y)
+
+
+def test_non_finite_features_take_the_exact_path(gm):
+    """an Inf / NaN feature makes the accumulators of its tile NaN on the split-bf16 core; the kernel re-scans the pass and redoes
+    such tiles with fp32 fma loops: the affected graphs' logits are non-finite exactly where the layer-by-layer path's are, every
+    other graph is untouched"""
+    import torch
+    from gnnmp import synth
+    G = 200
+    members = synth.batched_graphs(G=G, seed=4)
+    rng = np.random.default_rng(5)
+    xs = [rng.standard_normal((n, 16), dtype=np.float32) for _, _, n in members]
+    xs[17][3, 2] = np.inf
+    xs[101][0, 0] = np.nan
+    xs[150][5] = -np.inf
+    g = gm.batch_arrays(members, xs)
+    model = build(gm, (16, 128, 128), 2, "+", "mean")
+    y, yl = run_both(gm, model, g)
+    bad = (~torch.isfinite(y).all(1)).nonzero().flatten().tolist()
+    assert bad == (~torch.isfinite(yl).all(1)).nonzero().flatten().tolist() == [17, 101, 150]
+    good = torch.isfinite(y).all(1)
+    close(y[good].cpu().numpy(), yl[good].cpu().numpy(), "finite graphs")
+    assert torch.equal(torch.isnan(y), torch.isnan(yl))
+
+
+def test_outside_the_envelope_falls_back(gm, oracle):
+    """max aggregation, a wide layer, a non-batched graph: gnnmp_graphconv_chain_f32 says GNNMP_EUNSUPPORTED (or the host does not
+    even ask) and the chain runs layer by layer with the same result contract"""
+    rng = np.random.default_rng(8)
+    members = random_members(40, rng, nmin=5, nmax=30, hubs=False)
+    xs = [rng.standard_normal((n, 16), dtype=np.float32) for _, _, n in members]
+    g = gm.batch_arrays(members, xs)
+    for dims, aggr in (((16, 128), "max"), ((16, 256, 128), "+")):
+        model = build(gm, dims, 2, aggr, "mean")
+        y = model(g, g.x)
+        ref = oracle_chain(oracle, members, xs, model.layers[:-2], "mean", model.layers[-1])
+        finite = np.isfinite(ref).all(1)
+        close(y.cpu().numpy()[finite], ref[finite], f"fallback {dims} {aggr}")
