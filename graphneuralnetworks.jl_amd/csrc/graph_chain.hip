@@ -453,7 +453,14 @@ extern "C" int64_t gnnmp_graphconv_chain_scratch_floats(int64_t N, int n_layers,
     return N * (d0 + d1 + nout) + 16;
 }
 
-extern "C" int gnnmp_graphconv_chain_f32(gnnmp_graph_t *p, const int64_t *seg_ptr, int64_t G, const float *x, int n_layers,
+namespace gnnmp {
+int graph_chain2_try(gnnmp_graph_t *p, const gnnmp_chain_jobs_t *J, const int64_t *seg_ptr, int64_t G, const float *x, int n_layers,
+                     const int64_t *dims, const float *const *W_root, const float *const *W_agg, const float *const *bias,
+                     const int *act, int aggr, int pool_aggr, const float *W_head, const float *b_head, int64_t nout, float *out,
+                     hipStream_t stream);   // graph_chain2.hip
+}
+
+extern "C" int gnnmp_graphconv_chain_f32(gnnmp_graph_t *p, const gnnmp_chain_jobs_t *jobs, const int64_t *seg_ptr, int64_t G, const float *x, int n_layers,
                                          const int64_t *dims, const float *const *W_root, const float *const *W_agg,
                                          const float *const *bias, const int *act, int aggr, int pool_aggr, const float *W_head,
                                          const float *b_head, int64_t nout, float *scratch, float *out, gnnmp_stream_t stream_) {
@@ -470,6 +477,15 @@ extern "C" int gnnmp_graphconv_chain_f32(gnnmp_graph_t *p, const int64_t *seg_pt
     if (knob(KNOB_CHAIN) < 0 || n_layers > CHAIN_MAX_LAYERS || nout > 8 || aggr > GNNMP_MEAN || pool_aggr > GNNMP_MEAN ||
         p->n_dst >= (int64_t)1 << 31 || p->n_dst < 32)
         return fail(GNNMP_EUNSUPPORTED, "graphconv_chain: outside the fused kernel's envelope");
+    for (int l = 0; l < n_layers; ++l)
+        if (!W_root[l] || !W_agg[l] || (act[l] != GNNMP_ACT_IDENTITY && act[l] != GNNMP_ACT_RELU))
+            return fail(GNNMP_EUNSUPPORTED, "graphconv_chain: layer %d outside the fused kernels' envelope", l);
+    {
+        // two layers 16 => 128 => 128 on member graphs of at most 64 nodes: the wave-per-graph kernel, nothing through memory
+        const int rc = graph_chain2_try(p, jobs, seg_ptr, G, x, n_layers, dims, W_root, W_agg, bias, act, aggr, pool_aggr, W_head, b_head,
+                                        nout, out, stream);
+        if (rc != 1) return rc;
+    }
     ChainArgs a = {};
     a.rowptr = p->rowptr;
     a.col = p->col;

@@ -32,7 +32,8 @@ SYMBOLS = (
     "gnnmp_attn_conv_grad_f32",
     "gnnmp_bias_act_f32",
     "gnnmp_segment_pool_f32", "gnnmp_segment_bounds", "gnnmp_segment_pool_ptr_f32", "gnnmp_dense_f32", "gnnmp_fused_conv_f32",
-    "gnnmp_graphconv_chain_scratch_floats", "gnnmp_graphconv_chain_f32",
+    "gnnmp_graphconv_chain_scratch_floats", "gnnmp_graphconv_chain_f32", "gnnmp_chain_jobs_create", "gnnmp_chain_jobs_destroy",
+    "gnnmp_chain_jobs_info",
     "gnnmp_edge_dot_f32", "gnnmp_edge_dot_plan_f32", "gnnmp_propagate_maxmin_grad_f32",
     "gnnmp_head_mean_f32", "gnnmp_head_mean_grad_f32", "gnnmp_add_f32", "gnnmp_axpy_f32", "gnnmp_mul_rows_f32", "gnnmp_is_sorted",
     "gnnmp_act_grad_f32", "gnnmp_dense_grad_workspace", "gnnmp_dense_grad_w_f32",
@@ -124,7 +125,10 @@ def load():
         "gnnmp_propagate_maxmin_grad_f32": [vp, vp, vp, vp, vp, i64, vp],
         "gnnmp_act_grad_f32": [vp, vp, i, vp, i64, vp],
         "gnnmp_dense_grad_w_f32": [vp, vp, i64, i64, i64, vp, vp, vp, i64, vp],
-        "gnnmp_graphconv_chain_f32": [vp, vp, i64, vp, i, ctypes.POINTER(i64), ctypes.POINTER(vp), ctypes.POINTER(vp),
+        "gnnmp_chain_jobs_create": [ctypes.POINTER(vp), vp, i64, vp],
+        "gnnmp_chain_jobs_destroy": [vp],
+        "gnnmp_chain_jobs_info": [vp, ctypes.POINTER(i64)],
+        "gnnmp_graphconv_chain_f32": [vp, vp, vp, i64, vp, i, ctypes.POINTER(i64), ctypes.POINTER(vp), ctypes.POINTER(vp),
                                       ctypes.POINTER(vp), ctypes.POINTER(i), i, i, vp, vp, i64, vp, vp, vp],
         "gnnmp_tune": [i, i],
     }

@@ -437,6 +437,26 @@ class GNNChain:
         return x
 
 
+class ChainJobs:
+    """gnnmp_chain_jobs_t of a batched graph (csrc/graph_chain2.hip): its member graphs packed into wave jobs of <= 64 rows"""
+
+    def __init__(self, seg_ptr, G):
+        import ctypes
+        self.handle = ctypes.c_void_p()
+        L.check(L.load().gnnmp_chain_jobs_create(ctypes.byref(self.handle), L.ptr(seg_ptr), G, L.stream_ptr()))
+        info = (ctypes.c_int64 * 5)()
+        L.check(L.load().gnnmp_chain_jobs_info(self.handle, info))
+        self.njobs, self.G, self.N, self.max_graph, self.fill = info[0], info[1], info[2], info[3], info[4] / 1000.0
+
+    def __del__(self):
+        try:
+            if self.handle:
+                L.load().gnnmp_chain_jobs_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
 def _chain_pattern(layers):
     """(convs, pool, head) if `layers` is GraphConv, ..., GraphConv, GlobalPool(+ | mean), Dense(identity) — the graph-classification
     chain of examples/graph_classification_tudataset.jl:79-82 — inside the fused kernel's envelope; else None."""
@@ -496,6 +516,10 @@ def graphconv_chain(model, g: GNNGraph, x):
         L.check(lib.gnnmp_segment_bounds(L.ptr(gi), 8 if gi.dtype == torch.int64 else 4, g.index_base, N, G, L.ptr(sp), L.stream_ptr()))
         g._cache["node_ptr"] = sp
     nout = head.weight.shape[0]
+    jobs = g._cache.get("chain_jobs")
+    if jobs is None:
+        jobs = ChainJobs(sp, G)      # member graphs packed into wave jobs: a constant of the batch, like its plan
+        g._cache["chain_jobs"] = jobs
     need = lib.gnnmp_graphconv_chain_scratch_floats(N, nl, dims, nout)
     scratch = g._cache.get("chain_scratch")
     if scratch is None or scratch.numel() < need:
@@ -503,7 +527,7 @@ def graphconv_chain(model, g: GNNGraph, x):
         g._cache["chain_scratch"] = scratch
     out = torch.empty((G, nout), dtype=torch.float32, device=x.device)
     xc = x.contiguous()
-    rc = lib.gnnmp_graphconv_chain_f32(g.plan(False).handle, L.ptr(sp), G, L.ptr(xc), nl, dims, wr, wa, bs, act,
+    rc = lib.gnnmp_graphconv_chain_f32(g.plan(False).handle, jobs.handle, L.ptr(sp), G, L.ptr(xc), nl, dims, wr, wa, bs, act,
                                        aggr_code(convs[0].aggr), aggr_code(pool.aggr), L.ptr(keep[-2]), L.ptr(keep[-1]), nout,
                                        L.ptr(scratch), L.ptr(out), L.stream_ptr())
     if rc == L.EUNSUPPORTED:

@@ -502,7 +502,19 @@ int gnnmp_dense_f32(const float *x1, const float *W1, int64_t D1, int64_t ldw1, 
  * here agree to rounding (both are linear); the per-row aggregates have the bits of gnnmp_propagate_f32's.
  * ---------------------------------------------------------------------------------------------- */
 int64_t gnnmp_graphconv_chain_scratch_floats(int64_t N, int n_layers, const int64_t *dims, int64_t nout);
-int gnnmp_graphconv_chain_f32(gnnmp_graph_t *plan, const int64_t *seg_ptr, int64_t G, const float *x, int n_layers,
+/* Optional per-batch constant (like the plan): the member graphs packed into wave jobs of at most 64 rows (best fit decreasing), which
+ * lets the chain 16 => 128 => 128 run with a WAVE per group of whole member graphs and no intermediate in memory at all
+ * (csrc/graph_chain2.hip: layer 1's accumulators are layer 2's operands, neighbours are summed through a 4 KB LDS stage, the two
+ * 64-column halves of layer 2 go to different workgroups and meet in one atomic add per logit — two addends, order-independent).
+ * Built once per batched graph from the DEVICE seg_ptr; synchronises `stream` (graph prep).  A batch with a member graph of more than
+ * 64 nodes, or without any, yields a handle without jobs: the chain then runs on the general kernel.  info[0] = jobs, [1] = member
+ * graphs, [2] = rows, [3] = largest member graph, [4] = per-mille of the MFMA tiles' rows that are real rows. */
+typedef struct gnnmp_chain_jobs gnnmp_chain_jobs_t;
+int gnnmp_chain_jobs_create(gnnmp_chain_jobs_t **out, const int64_t *seg_ptr, int64_t G, gnnmp_stream_t stream);
+int gnnmp_chain_jobs_destroy(gnnmp_chain_jobs_t *jobs);
+int gnnmp_chain_jobs_info(const gnnmp_chain_jobs_t *jobs, int64_t *info);
+/* jobs: NULL or the handle of THIS batch (gnnmp_chain_jobs_create on the same seg_ptr) */
+int gnnmp_graphconv_chain_f32(gnnmp_graph_t *plan, const gnnmp_chain_jobs_t *jobs, const int64_t *seg_ptr, int64_t G, const float *x, int n_layers,
                               const int64_t *dims, const float *const *W_root, const float *const *W_agg,
                               const float *const *bias, const int *act, int aggr, int pool_aggr, const float *W_head,
                               const float *b_head, int64_t nout, float *scratch, float *out, gnnmp_stream_t stream);

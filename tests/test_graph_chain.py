@@ -163,6 +163,53 @@ def test_irregular_batches(gm, oracle, case, seed):
     close(y.cpu().numpy(), yl.cpu().numpy(), f"fused vs layers {case}", k=2.0)
 
 
+@pytest.mark.parametrize("aggr,pool", [("+", "mean"), ("mean", "+")])
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_wave_job_kernel_on_irregular_batches(gm, oracle, aggr, pool, seed):
+    """csrc/graph_chain2.hip (two layers 16 => 128 => 128, member graphs <= 64 nodes: a wave per job, nothing through memory) on
+    uneven batches: graphs of 1..64 nodes, isolated nodes, hubs with up to n in-neighbours (the tail loops of both gathers), jobs of
+    one and two tiles, empty slots — against the oracle, the general kernel (knob 18 = 1) and the layer-by-layer path"""
+    import torch
+    from gnnmp import layers
+    rng = np.random.default_rng(500 + seed)
+    members = random_members(200, rng, nmin=1, nmax=64)
+    xs = [rng.standard_normal((n, 16), dtype=np.float32) for _, _, n in members]
+    g = gm.batch_arrays(members, xs)
+    model = build(gm, (16, 128, 128), 2 + 3 * seed, aggr, pool, seed=61 + seed)
+    y, yl = run_both(gm, model, g)
+    jobs = g._cache["chain_jobs"]
+    assert jobs.njobs > 0 and jobs.max_graph <= 64 and 0.5 < jobs.fill <= 1.0
+    gm.tune(18, 1)
+    try:
+        y_general = model(g, g.x)
+    finally:
+        gm.tune(18, 0)
+    ref = oracle_chain(oracle, members, xs, model.layers[:2], pool, model.layers[-1])
+    close(y.cpu().numpy(), ref, "wave-job kernel vs oracle")
+    close(y_general.cpu().numpy(), ref, "general kernel vs oracle")
+    close(y.cpu().numpy(), yl.cpu().numpy(), "wave-job kernel vs layers")
+    for _ in range(3):
+        assert torch.equal(model(g, g.x), y), "not run-to-run identical (two atomic addends per logit: order must not matter)"
+
+
+def test_job_packing(gm):
+    """gnnmp_chain_jobs_create: every row in exactly one slot, member graphs whole and in node order inside a job, at most 64 rows a
+    job; a batch with a larger member graph gets no jobs (the general kernel runs)"""
+    import ctypes, torch
+    from gnnmp import _lib as L, synth
+    members = synth.batched_graphs(G=1000, seed=7)
+    g = gm.batch_arrays(members, [np.zeros((n, 16), np.float32) for _, _, n in members])
+    model = build(gm, (16, 128, 128), 2, "+", "mean")
+    model(g, g.x)
+    jobs = g._cache["chain_jobs"]
+    assert jobs.fill >= 0.9, jobs.fill                       # n ~ U{20..40}: best fit decreasing fills the 64-row jobs to ~94 %
+    rng = np.random.default_rng(1)
+    big = random_members(30, rng, nmin=60, nmax=90)
+    g2 = gm.batch_arrays(big, [np.zeros((n, 16), np.float32) for _, _, n in big])
+    model(g2, g2.x)
+    assert g2._cache["chain_jobs"].njobs == 0 and g2._cache["chain_jobs"].max_graph > 64
+
+
 def test_sharded_equals_unsharded_bit_for_bit(gm):
     """member graphs are independent units and a row's arithmetic does not depend on where its tile falls: any regrouping of the
     batch (gnnmp.parallel shards by graph) reproduces the same logits bit for bit"""
