@@ -272,16 +272,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, W
                 }
             }
         }
-        if (n0 + 4 * nfull < n1) {   // the ragged last batch: rows past the end re-read the last row with weight 0
+        if (n0 + 4 * nfull < n1) {   // the ragged last batch: rows past the end re-read the last row and are replaced by zeros
             const int64_t row = n0 + 4 * nfull + q;
-            const float m = row < n1 ? 1.0f : 0.0f;
+            const bool in = row < n1;   // a SELECT, not a multiplication by 0: 0 * Inf = NaN would poison whole rows / columns of ΔW and Δb
+                                        // when the last row holds a non-finite value; outside the pipelined loop it costs nothing
             const float *pa = a.dz + min(row, n1 - 1) * a.Dout;
             const float *pb = a.x + min(row, n1 - 1) * a.K;
             float av[TO], bv[TK];
 #pragma unroll
-            for (int t = 0; t < TO; ++t) av[t] = pa[ocol[t]] * m;
+            for (int t = 0; t < TO; ++t) av[t] = in ? pa[ocol[t]] : 0.0f;
 #pragma unroll
-            for (int t = 0; t < TK; ++t) bv[t] = pb[kcol[t]] * m;
+            for (int t = 0; t < TK; ++t) bv[t] = in ? pb[kcol[t]] : 0.0f;
             mfma_batch(av, bv);
         }
     }

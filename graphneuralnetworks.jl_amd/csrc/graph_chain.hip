@@ -36,7 +36,8 @@ constexpr int CHAIN_THREADS = 512;   // 8 waves, 256 VGPRs: no spill in the tile
 
 struct ChainLayer {
     const float *W_root, *W_agg, *bias;
-    int64_t ldr, lda;   // elements between consecutive rows of W_root / W_agg ([Dout][Din] row-major)
+    int64_t sj, sk;     // W(j, k) of W_root / W_agg at [j * sj + k * sk]: C row-major [Dout][Din] (sj = Din, sk = 1) or Julia's (Dout, Din)
+                        // column-major as stored (sj = 1, sk = Dout)
     int Din, Dout, act;
     int parts;          // 1: root and aggregate positions in one pass; 2: one pass each (the pre-activation is parked in between)
 };
@@ -49,8 +50,8 @@ struct ChainArgs {
     ChainLayer L[CHAIN_MAX_LAYERS];
     int n_layers;
     int mean_aggr, pool_mean;
-    const float *W_head;      // [nout][D_L] row-major, ld = ldh
-    int64_t ldh;
+    const float *W_head;      // W_head(o, c) at [o * hsj + c * hsk]
+    int64_t hsj, hsk;
     const float *b_head;
     int nout;
     float *h[2];              // scratch: layer l writes h[l & 1]
@@ -302,7 +303,7 @@ __device__ __noinline__ void chain_redo(const ChainArgs a, const ChainLayer ly, 
         const int32_t *colidx = a.col;
         if (part == 1) {   // the parked pre-activation of this tile may itself be the NaN: redo the root pass's product first
             WCat wr = w;
-            wr.W[0] = ly.W_root; wr.sj[0] = ly.ldr;
+            wr.W[0] = ly.W_root;
             split_exact_tile(CHAIN_NCB, wr, 0, dout, h, [=](int c) { return xr[c]; },
                              [=](int colq, float sv) { if (row_ok) out_row[colq] = sv; });
         }
@@ -393,7 +394,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) graph_chain_kernel(const ChainA
     const int dl = a.L[a.n_layers - 1].Dout;
     for (int i = tid; i < 8 * DP; i += nthreads) {
         const int o = i / DP, c = i - o * DP;
-        head[i] = (o < a.nout && c < dl) ? a.W_head[(int64_t)o * a.ldh + c] : 0.0f;
+        head[i] = (o < a.nout && c < dl) ? a.W_head[(int64_t)o * a.hsj + (int64_t)c * a.hsk] : 0.0f;
     }
     __syncthreads();
     if (ctl->r1 > ctl->r0) {   // (block-uniform: a block without rows only takes part in nothing)
@@ -405,8 +406,8 @@ __global__ void __launch_bounds__(CHAIN_THREADS) graph_chain_kernel(const ChainA
             const int src_ld = l == 0 ? ly.Din : a.ldh_buf[(l - 1) & 1], dst_ld = a.ldh_buf[l & 1];
             const bool last = l + 1 == a.n_layers;
             WCat w;
-            w.W[0] = ly.W_root; w.sj[0] = ly.ldr; w.sk[0] = 1; w.K[0] = ly.Din;
-            w.W[1] = ly.W_agg; w.sj[1] = ly.lda; w.sk[1] = 1; w.K[1] = ly.Din;
+            w.W[0] = ly.W_root; w.sj[0] = ly.sj; w.sk[0] = ly.sk; w.K[0] = ly.Din;
+            w.W[1] = ly.W_agg; w.sj[1] = ly.sj; w.sk[1] = ly.sk; w.K[1] = ly.Din;
             if (ly.parts == 1) {
                 if (ly.Din == 16)
                     chain_pass<Pass<16, true, true>, FULLCOLS>(a, ly, w, 0, last, src, src_ld, hdst, dst_ld, img, bias4, head, ctl, phase++, tid, nthreads);
@@ -415,7 +416,7 @@ __global__ void __launch_bounds__(CHAIN_THREADS) graph_chain_kernel(const ChainA
             } else {
                 WCat wr = w, wa = w;
                 wr.K[1] = 0;
-                wa.W[0] = ly.W_agg; wa.sj[0] = ly.lda; wa.K[1] = 0;
+                wa.W[0] = ly.W_agg; wa.K[1] = 0;
                 if (ly.Din == 128) {
                     chain_pass<Pass<128, true, false>, FULLCOLS>(a, ly, wr, 0, last, src, src_ld, hdst, dst_ld, img, bias4, head, ctl, phase++, tid, nthreads);
                     chain_pass<Pass<128, false, true>, FULLCOLS>(a, ly, wa, 1, last, src, src_ld, hdst, dst_ld, img, bias4, head, ctl, phase++, tid, nthreads);
@@ -456,18 +457,20 @@ extern "C" int64_t gnnmp_graphconv_chain_scratch_floats(int64_t N, int n_layers,
 namespace gnnmp {
 int graph_chain2_try(gnnmp_graph_t *p, const gnnmp_chain_jobs_t *J, const int64_t *seg_ptr, int64_t G, const float *x, int n_layers,
                      const int64_t *dims, const float *const *W_root, const float *const *W_agg, const float *const *bias,
-                     const int *act, int aggr, int pool_aggr, const float *W_head, const float *b_head, int64_t nout, float *out,
-                     hipStream_t stream);   // graph_chain2.hip
+                     const int *act, int w_layout, int aggr, int pool_aggr, const float *W_head, const float *b_head, int64_t nout,
+                     float *out, hipStream_t stream);   // graph_chain2.hip
 }
 
 extern "C" int gnnmp_graphconv_chain_f32(gnnmp_graph_t *p, const gnnmp_chain_jobs_t *jobs, const int64_t *seg_ptr, int64_t G, const float *x, int n_layers,
                                          const int64_t *dims, const float *const *W_root, const float *const *W_agg,
-                                         const float *const *bias, const int *act, int aggr, int pool_aggr, const float *W_head,
+                                         const float *const *bias, const int *act, int w_layout, int aggr, int pool_aggr,
+                                         const float *W_head,
                                          const float *b_head, int64_t nout, float *scratch, float *out, gnnmp_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!p) return fail(GNNMP_EINVAL, "graphconv_chain: null plan");
     if (n_layers < 1 || !dims || !W_root || !W_agg || !act) return fail(GNNMP_EINVAL, "graphconv_chain: bad layer list");
     if (G < 0 || nout < 1) return fail(GNNMP_EINVAL, "graphconv_chain: bad size");
+    if (w_layout != 0 && w_layout != 1) return fail(GNNMP_EINVAL, "graphconv_chain: bad w_layout %d", w_layout);
     if (aggr < GNNMP_SUM || aggr > GNNMP_MIN || pool_aggr < GNNMP_SUM || pool_aggr > GNNMP_MIN)
         return fail(GNNMP_EINVAL, "graphconv_chain: bad aggr");
     if (p->n_src != p->n_dst) return fail(GNNMP_EINVAL, "graphconv_chain: the plan is not a square graph");
@@ -482,8 +485,8 @@ extern "C" int gnnmp_graphconv_chain_f32(gnnmp_graph_t *p, const gnnmp_chain_job
             return fail(GNNMP_EUNSUPPORTED, "graphconv_chain: layer %d outside the fused kernels' envelope", l);
     {
         // two layers 16 => 128 => 128 on member graphs of at most 64 nodes: the wave-per-graph kernel, nothing through memory
-        const int rc = graph_chain2_try(p, jobs, seg_ptr, G, x, n_layers, dims, W_root, W_agg, bias, act, aggr, pool_aggr, W_head, b_head,
-                                        nout, out, stream);
+        const int rc = graph_chain2_try(p, jobs, seg_ptr, G, x, n_layers, dims, W_root, W_agg, bias, act, w_layout, aggr, pool_aggr, W_head,
+                                        b_head, nout, out, stream);
         if (rc != 1) return rc;
     }
     ChainArgs a = {};
@@ -507,7 +510,8 @@ extern "C" int gnnmp_graphconv_chain_f32(gnnmp_graph_t *p, const gnnmp_chain_job
                         (long long)din, (long long)dout);
         ChainLayer &ly = a.L[l];
         ly.W_root = W_root[l]; ly.W_agg = W_agg[l]; ly.bias = bias ? bias[l] : nullptr;
-        ly.ldr = ly.lda = din;
+        ly.sj = w_layout ? 1 : din;
+        ly.sk = w_layout ? dout : 1;
         ly.Din = (int)din; ly.Dout = (int)dout; ly.act = act[l];
         const size_t budget = 160 * 1024 - 128 - 8 * CHAIN_DP * 4 - CHAIN_DP * 4 - 256;
         ly.parts = ((din & 15) == 0 && split_img_bytes((int)(2 * din), CHAIN_DP) <= budget) ? 1 : 2;
@@ -521,7 +525,8 @@ extern "C" int gnnmp_graphconv_chain_f32(gnnmp_graph_t *p, const gnnmp_chain_job
     if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(scratch) & 15))
         return fail(GNNMP_EUNSUPPORTED, "graphconv_chain: unaligned feature matrix");
     a.W_head = W_head;
-    a.ldh = dims[n_layers];
+    a.hsj = w_layout ? 1 : dims[n_layers];
+    a.hsk = w_layout ? nout : 1;
     a.b_head = b_head;
     a.nout = (int)nout;
     a.h[0] = scratch;

@@ -54,6 +54,7 @@ struct Chain2Args {
     const int64_t *seg_ptr;
     const float *x;
     const float *W1r, *W1a, *b1, *W2r, *W2a, *b2, *Wh, *bh;
+    int lay;            // 0: weights C row-major [Dout][Din]; 1: Julia (Dout, Din) column-major as stored, W(j, k) at [k * Dout + j]
     int nout, act1, act2, mean_aggr, pool_mean;
     float *out;
     int32_t *bad;       // [0] = count, [1], [2] = job tickets of the slabs, [3..] = job * 2 + slab
@@ -90,8 +91,8 @@ __device__ void chain2_exact_job(const Chain2Args &a, int slab, const int32_t *j
         }
         for (int f = 0; f < C2_D1; ++f) {
             float s = 0.0f;
-            for (int c = 0; c < C2_D0; ++c) s = fmaf(a.W1r[f * C2_D0 + c], xr[c], s);
-            for (int c = 0; c < C2_D0; ++c) s = fmaf(a.W1a[f * C2_D0 + c], xa[c], s);
+            for (int c = 0; c < C2_D0; ++c) s = fmaf(a.W1r[a.lay ? c * C2_D1 + f : f * C2_D0 + c], xr[c], s);
+            for (int c = 0; c < C2_D0; ++c) s = fmaf(a.W1a[a.lay ? c * C2_D1 + f : f * C2_D0 + c], xa[c], s);
             h[f] = c2_act(s + (a.b1 ? a.b1[f] : 0.0f), a.act1);
         }
     };
@@ -110,10 +111,10 @@ __device__ void chain2_exact_job(const Chain2Args &a, int slab, const int32_t *j
     for (int c = 0; c < C2_SLAB; ++c) {
         const int f2 = C2_SLAB * slab + c;
         float s = 0.0f;
-        for (int f = 0; f < C2_D1; ++f) s = fmaf(a.W2r[f2 * C2_D1 + f], hi[f], s);
-        for (int f = 0; f < C2_D1; ++f) s = fmaf(a.W2a[f2 * C2_D1 + f], hs[f], s);
+        for (int f = 0; f < C2_D1; ++f) s = fmaf(a.W2r[a.lay ? f * C2_D2 + f2 : f2 * C2_D1 + f], hi[f], s);
+        for (int f = 0; f < C2_D1; ++f) s = fmaf(a.W2a[a.lay ? f * C2_D2 + f2 : f2 * C2_D1 + f], hs[f], s);
         const float v = c2_act(s + (a.b2 ? a.b2[f2] : 0.0f), a.act2);
-        for (int o = 0; o < a.nout; ++o) z[o] = fmaf(a.Wh[o * C2_D2 + f2], v, z[o]);
+        for (int o = 0; o < a.nout; ++o) z[o] = fmaf(a.Wh[a.lay ? f2 * a.nout + o : o * C2_D2 + f2], v, z[o]);
     }
     for (int o = 0; o < a.nout; ++o) zst[lane * 8 + o] = z[o];
 }
@@ -166,16 +167,18 @@ __global__ void __launch_bounds__(C2_THREADS) graph_chain2_kernel(const Chain2Ar
     const int slab = blockIdx.y, n0 = C2_SLAB * slab;
     {
         WCat w1;
-        w1.W[0] = a.W1r; w1.W[1] = a.W1a; w1.sj[0] = w1.sj[1] = C2_D0; w1.sk[0] = w1.sk[1] = 1; w1.K[0] = w1.K[1] = C2_D0;
+        w1.W[0] = a.W1r; w1.W[1] = a.W1a; w1.K[0] = w1.K[1] = C2_D0;
+        w1.sj[0] = w1.sj[1] = a.lay ? 1 : C2_D0; w1.sk[0] = w1.sk[1] = a.lay ? C2_D1 : 1;
         split_fill_image(img1, 2, C2_D1, w1, 0, C2_D1, tid, C2_THREADS);
         WCat w2;
-        w2.W[0] = a.W2r; w2.W[1] = a.W2a; w2.sj[0] = w2.sj[1] = C2_D1; w2.sk[0] = w2.sk[1] = 1; w2.K[0] = w2.K[1] = C2_D1;
+        w2.W[0] = a.W2r; w2.W[1] = a.W2a; w2.K[0] = w2.K[1] = C2_D1;
+        w2.sj[0] = w2.sj[1] = a.lay ? 1 : C2_D1; w2.sk[0] = w2.sk[1] = a.lay ? C2_D2 : 1;
         split_fill_image(img2, 16, C2_SLAB, w2, n0, C2_SLAB, tid, C2_THREADS);
         split_fill_bias(bias1, C2_D1, a.b1, 0, C2_D1, tid, C2_THREADS);
         split_fill_bias(bias2, C2_SLAB, a.b2, n0, C2_SLAB, tid, C2_THREADS);
         for (int i = tid; i < 8 * C2_SLAB; i += C2_THREADS) {
             const int o = i / C2_SLAB, c = i - o * C2_SLAB;
-            head[i] = o < a.nout ? a.Wh[o * C2_D2 + n0 + c] : 0.0f;
+            head[i] = o < a.nout ? a.Wh[a.lay ? (n0 + c) * a.nout + o : o * C2_D2 + n0 + c] : 0.0f;
         }
     }
     __syncthreads();
@@ -512,8 +515,8 @@ namespace gnnmp {
 // Returns GNNMP_OK if it launched, 1 if the chain / the batch is outside this kernel's envelope (graph_chain.hip's kernel runs).
 int graph_chain2_try(gnnmp_graph_t *p, const gnnmp_chain_jobs_t *J, const int64_t *seg_ptr, int64_t G, const float *x, int n_layers,
                      const int64_t *dims, const float *const *W_root, const float *const *W_agg, const float *const *bias,
-                     const int *act, int aggr, int pool_aggr, const float *W_head, const float *b_head, int64_t nout, float *out,
-                     hipStream_t stream) {
+                     const int *act, int w_layout, int aggr, int pool_aggr, const float *W_head, const float *b_head, int64_t nout,
+                     float *out, hipStream_t stream) {
     if (!J || J->njobs <= 0 || J->has_empty || J->G != G || J->N != p->n_dst) return 1;
     if (n_layers != 2 || dims[0] != C2_D0 || dims[1] != C2_D1 || dims[2] != C2_D2 || nout > 8) return 1;
     if (knob(KNOB_CHAIN) == 1) return 1;    // 1 = the general kernel only (A/B runs)
@@ -530,6 +533,7 @@ int graph_chain2_try(gnnmp_graph_t *p, const gnnmp_chain_jobs_t *J, const int64_
     a.W2r = W_root[1]; a.W2a = W_agg[1]; a.b2 = bias ? bias[1] : nullptr;
     a.Wh = W_head; a.bh = b_head;
     a.nout = (int)nout;
+    a.lay = w_layout;
     a.act1 = act[0]; a.act2 = act[1];
     a.mean_aggr = aggr == GNNMP_MEAN;
     a.pool_mean = pool_aggr == GNNMP_MEAN;

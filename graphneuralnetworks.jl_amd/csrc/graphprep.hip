@@ -398,14 +398,16 @@ int gnnmp_sample_neighbors(gnnmp_graph_t *plan, const void *nodes, int idx_bytes
     int *flag = nullptr;
     int hflag = 0;
     int64_t tot = 0;
-    PREP_HIP(prep_alloc((void **)&counts, sizeof(int64_t) * (size_t)(n_nodes + 1)));
+    // (+ the scan's block sums behind the counts: one pooled block, no allocation or synchronisation inside the scan)
+    const size_t counts_elems = (size_t)(n_nodes + 1) + exclusive_scan_workspace((size_t)(n_nodes + 1));
+    PREP_HIP(prep_alloc((void **)&counts, sizeof(int64_t) * counts_elems));
     PREP_HIP(prep_alloc((void **)&flag, sizeof(int)));
     PREP_HIP(hipMemsetAsync(flag, 0, sizeof(int), stream));
     PREP_HIP(hipMemsetAsync(counts + n_nodes, 0, sizeof(int64_t), stream));
     sample_counts_kernel<<<nb(n_nodes), 256, 0, stream>>>(plan->rowptr, nodes, idx_bytes, index_base, n_nodes, plan->n_dst,
                                                           K, replace, counts, flag);
     PREP_HIP(hipGetLastError());
-    PREP_G(exclusive_scan_i64(counts, offsets, (size_t)(n_nodes + 1), stream));
+    PREP_G(exclusive_scan_i64(counts, offsets, (size_t)(n_nodes + 1), stream, counts + n_nodes + 1));
     PREP_HIP(hipMemcpyAsync(&tot, offsets + n_nodes, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
     PREP_HIP(hipMemcpyAsync(&hflag, flag, sizeof(int), hipMemcpyDeviceToHost, stream));
     PREP_HIP(hipStreamSynchronize(stream));
@@ -429,7 +431,7 @@ int gnnmp_sample_neighbors(gnnmp_graph_t *plan, const void *nodes, int idx_bytes
         PREP_HIP(hipGetLastError());
     }
 done:
-    prep_free(counts, sizeof(int64_t) * (size_t)(n_nodes + 1));
+    prep_free(counts, sizeof(int64_t) * ((size_t)(n_nodes + 1) + exclusive_scan_workspace((size_t)(n_nodes + 1))));
     prep_free(flag, sizeof(int));
     return rc;
 }
@@ -450,7 +452,7 @@ int gnnmp_unique_append(int32_t *map, int32_t *first, int64_t n_nodes, const voi
     int *bad = nullptr;
     int hbad = 0;
     int64_t tot = 0;
-    PREP_HIP(prep_alloc((void **)&flags, sizeof(int64_t) * (size_t)(n_cand + 1)));
+    PREP_HIP(prep_alloc((void **)&flags, sizeof(int64_t) * ((size_t)(n_cand + 1) + exclusive_scan_workspace((size_t)(n_cand + 1)))));
     PREP_HIP(prep_alloc((void **)&pos, sizeof(int64_t) * (size_t)(n_cand + 1)));
     PREP_HIP(prep_alloc((void **)&bad, sizeof(int)));
     PREP_HIP(hipMemsetAsync(bad, 0, sizeof(int), stream));
@@ -458,7 +460,7 @@ int gnnmp_unique_append(int32_t *map, int32_t *first, int64_t n_nodes, const voi
     unique_min_kernel<<<nb(n_cand), 256, 0, stream>>>(cand, idx_bytes, index_base, n_cand, n_nodes, map, first);
     unique_flag_kernel<<<nb(n_cand + 1), 256, 0, stream>>>(cand, idx_bytes, index_base, n_cand, n_nodes, map, first, flags);
     PREP_HIP(hipGetLastError());
-    PREP_G(exclusive_scan_i64(flags, pos, (size_t)(n_cand + 1), stream));
+    PREP_G(exclusive_scan_i64(flags, pos, (size_t)(n_cand + 1), stream, flags + n_cand + 1));
     unique_write_kernel<<<nb(n_cand), 256, 0, stream>>>(cand, idx_bytes, index_base, n_cand, flags, pos, set_size, map,
                                                         list_out);
     PREP_HIP(hipGetLastError());
@@ -468,7 +470,7 @@ int gnnmp_unique_append(int32_t *map, int32_t *first, int64_t n_nodes, const voi
     if (hbad) rc = fail(GNNMP_EBOUNDS, "unique_append: a node is outside 1..%lld", (long long)n_nodes);
     *n_new = tot;
 done:
-    prep_free(flags, sizeof(int64_t) * (size_t)(n_cand + 1));
+    prep_free(flags, sizeof(int64_t) * ((size_t)(n_cand + 1) + exclusive_scan_workspace((size_t)(n_cand + 1))));
     prep_free(pos, sizeof(int64_t) * (size_t)(n_cand + 1));
     prep_free(bad, sizeof(int));
     return rc;
@@ -490,11 +492,13 @@ int gnnmp_induced_subgraph(gnnmp_graph_t *plan, const int32_t *map, const void *
     int rc = GNNMP_OK;
     int64_t *counts = nullptr;
     int64_t tot = 0;
-    PREP_HIP(prep_alloc((void **)&counts, sizeof(int64_t) * (size_t)(n_nodes + 1)));
+    // (+ the scan's block sums behind the counts: one pooled block, no allocation or synchronisation inside the scan)
+    const size_t counts_elems = (size_t)(n_nodes + 1) + exclusive_scan_workspace((size_t)(n_nodes + 1));
+    PREP_HIP(prep_alloc((void **)&counts, sizeof(int64_t) * counts_elems));
     induced_count_kernel<<<nb((n_nodes + 1) * 64), 256, 0, stream>>>(plan->rowptr, plan->col, map, nodes, idx_bytes, index_base,
                                                               n_nodes, counts);
     PREP_HIP(hipGetLastError());
-    PREP_G(exclusive_scan_i64(counts, offsets, (size_t)(n_nodes + 1), stream));
+    PREP_G(exclusive_scan_i64(counts, offsets, (size_t)(n_nodes + 1), stream, counts + n_nodes + 1));
     PREP_HIP(hipMemcpyAsync(&tot, offsets + n_nodes, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
     PREP_HIP(hipStreamSynchronize(stream));
     *total = tot;
@@ -514,7 +518,7 @@ int gnnmp_induced_subgraph(gnnmp_graph_t *plan, const int32_t *map, const void *
         PREP_HIP(hipGetLastError());
     }
 done:
-    prep_free(counts, sizeof(int64_t) * (size_t)(n_nodes + 1));
+    prep_free(counts, sizeof(int64_t) * ((size_t)(n_nodes + 1) + exclusive_scan_workspace((size_t)(n_nodes + 1))));
     return rc;
 }
 

@@ -225,8 +225,9 @@ __global__ void __launch_bounds__(1024) scan_block_sums(T *__restrict__ sums, si
 }
 
 template <class T>
-__global__ void __launch_bounds__(256) scan_apply(const T *__restrict__ in, size_t n, const T *__restrict__ block_offsets,
-                                                  T *__restrict__ out) {
+// (in and out may be the SAME array — the radix passes scan their digit table in place — so neither carries __restrict__: every
+// thread reads its 16 elements into registers before it stores any, and without the qualifier the compiler has to keep it so)
+__global__ void __launch_bounds__(256) scan_apply(const T *in, size_t n, const T *__restrict__ block_offsets, T *out) {
     __shared__ T ws[4];
     const size_t base = (size_t)blockIdx.x * SC_CHUNK;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -262,8 +263,14 @@ static void exclusive_scan_enqueue(const T *in, T *out, size_t n, T *sums, hipSt
     scan_apply<T><<<(unsigned)nb, 256, 0, stream>>>(in, n, sums, out);
 }
 template <class T>
-static int exclusive_scan_impl(const T *in, T *out, size_t n, hipStream_t stream) {
+static int exclusive_scan_impl(const T *in, T *out, size_t n, hipStream_t stream, T *ws) {
     if (n == 0) return GNNMP_OK;
+    if (ws) {   // the caller's (pooled) block-sum scratch: three launches, no allocation, no synchronisation
+        exclusive_scan_enqueue<T>(in, out, n, ws, stream);
+        hipError_t e0 = hipGetLastError();
+        if (e0 != hipSuccess) return hip_fail(e0, "exclusive_scan");
+        return GNNMP_OK;
+    }
     T *sums = nullptr;
     GNNMP_HIP(hipMalloc((void **)&sums, sizeof(T) * scan_blocks(n)));
     exclusive_scan_enqueue<T>(in, out, n, sums, stream);
@@ -274,11 +281,12 @@ static int exclusive_scan_impl(const T *in, T *out, size_t n, hipStream_t stream
     return GNNMP_OK;
 }
 
-int exclusive_scan_i64(const int64_t *in, int64_t *out, size_t n, hipStream_t stream) {
-    return exclusive_scan_impl<int64_t>(in, out, n, stream);
+size_t exclusive_scan_workspace(size_t n) { return scan_blocks(n); }
+int exclusive_scan_i64(const int64_t *in, int64_t *out, size_t n, hipStream_t stream, int64_t *ws) {
+    return exclusive_scan_impl<int64_t>(in, out, n, stream, ws);
 }
-int exclusive_scan_u32(const uint32_t *in, uint32_t *out, size_t n, hipStream_t stream) {
-    return exclusive_scan_impl<uint32_t>(in, out, n, stream);
+int exclusive_scan_u32(const uint32_t *in, uint32_t *out, size_t n, hipStream_t stream, uint32_t *ws) {
+    return exclusive_scan_impl<uint32_t>(in, out, n, stream, ws);
 }
 
 // ---- the sort ---------------------------------------------------------------------------------------------------------

@@ -33,7 +33,7 @@ SYMBOLS = (
     "gnnmp_bias_act_f32",
     "gnnmp_segment_pool_f32", "gnnmp_segment_bounds", "gnnmp_segment_pool_ptr_f32", "gnnmp_dense_f32", "gnnmp_fused_conv_f32",
     "gnnmp_graphconv_chain_scratch_floats", "gnnmp_graphconv_chain_f32", "gnnmp_chain_jobs_create", "gnnmp_chain_jobs_destroy",
-    "gnnmp_chain_jobs_info",
+    "gnnmp_chain_jobs_info", "gnnmp_shard_by_size", "gnnmp_allgather_f32",
     "gnnmp_edge_dot_f32", "gnnmp_edge_dot_plan_f32", "gnnmp_propagate_maxmin_grad_f32",
     "gnnmp_head_mean_f32", "gnnmp_head_mean_grad_f32", "gnnmp_add_f32", "gnnmp_axpy_f32", "gnnmp_mul_rows_f32", "gnnmp_is_sorted",
     "gnnmp_act_grad_f32", "gnnmp_dense_grad_workspace", "gnnmp_dense_grad_w_f32",
@@ -125,11 +125,13 @@ def load():
         "gnnmp_propagate_maxmin_grad_f32": [vp, vp, vp, vp, vp, i64, vp],
         "gnnmp_act_grad_f32": [vp, vp, i, vp, i64, vp],
         "gnnmp_dense_grad_w_f32": [vp, vp, i64, i64, i64, vp, vp, vp, i64, vp],
+        "gnnmp_shard_by_size": [ctypes.POINTER(i64), i64, i, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(i64), ctypes.POINTER(i64)],
+        "gnnmp_allgather_f32": [vp, vp, vp, i64, vp],
         "gnnmp_chain_jobs_create": [ctypes.POINTER(vp), vp, i64, vp],
         "gnnmp_chain_jobs_destroy": [vp],
         "gnnmp_chain_jobs_info": [vp, ctypes.POINTER(i64)],
         "gnnmp_graphconv_chain_f32": [vp, vp, vp, i64, vp, i, ctypes.POINTER(i64), ctypes.POINTER(vp), ctypes.POINTER(vp),
-                                      ctypes.POINTER(vp), ctypes.POINTER(i), i, i, vp, vp, i64, vp, vp, vp],
+                                      ctypes.POINTER(vp), ctypes.POINTER(i), i, i, i, vp, vp, i64, vp, vp, vp],
         "gnnmp_tune": [i, i],
     }
     for name, args in sig.items():
@@ -153,10 +155,10 @@ def load():
             raise
     # GNNMP_KNOBS="0=1,5=2": tuning knobs applied at load (test runs that force the narrow-vector / other template variants of
     # every kernel: `GNNMP_KNOBS=0=1 python -m pytest tests -m gpu`)
+    _lib = L
     for kv in filter(None, os.environ.get("GNNMP_KNOBS", "").split(",")):
         k, v = kv.split("=")
-        check(L.gnnmp_tune(int(k), int(v)))
-    _lib = L
+        tune(int(k), int(v))
     return L
 
 
@@ -183,6 +185,19 @@ def ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+KNOB_DEFAULTS = {1: -1, 3: 1, 7: 17}      # every other knob starts at 0 (csrc/plan.cpp g_knobs)
+_knobs = {}
+
+
+def knob(k: int) -> int:
+    """the value last set through tune() (or the library's default)"""
+    return _knobs.get(k, KNOB_DEFAULTS.get(k, 0))
+
+
 def tune(knob: int, value: int):
     """perf-experiment hook (csrc/common.h Knob); not part of the drop-in surface"""
     check(load().gnnmp_tune(knob, value))
+    _knobs[knob] = int(value)
+    if knob == 14:                       # the host mirror of fused_conv's gating follows the knob (gnnmp/layers.py)
+        from . import layers
+        layers._KNOB14[0] = int(value)

@@ -81,9 +81,15 @@ def fused_conv(plan, aggr, xj, W_agg, bias=None, sigma=None, xi=None, W_root=Non
         assert W_root.shape == (Dout, D1) and W_root.stride(1) == 1
     code, post = _act_code(sigma)
     b = None if bias is None or bias is False else bias.contiguous()
+    lib = L.load()
+    # the library's default gating, mirrored here so that the shapes it would refuse anyway cost neither two throw-away allocations nor a
+    # failed call with a formatted error string: with knob 14 at its default the kernel fuses only a layer without a root term
+    # whose aggregate exceeds 128 MiB (csrc/fused_conv.hip); knob 14 > 0 forces it, < 0 disables it
+    k14 = _knob14()
+    if k14 < 0 or (k14 == 0 and (D1 > 0 or plan.n_dst * D * 4 < (128 << 20))):
+        return None
     out = torch.empty((plan.n_dst, Dout), dtype=torch.float32, device=xf.device)
     agg = torch.empty((plan.n_dst, D), dtype=torch.float32, device=xf.device) if return_aggregate else None
-    lib = L.load()
     rc = lib.gnnmp_fused_conv_f32(plan.handle, aggr, L.ptr(xf), L.ptr(w), L.ptr(scale_src), L.ptr(w_slot), L.ptr(ss_slot),
                                   L.ptr(scale_dst), D, L.ptr(xi), D1, L.ptr(W_root), 0 if W_root is None else W_root.stride(0),
                                   L.ptr(W_agg), W_agg.stride(0), int(w_layout), L.ptr(b), code, L.ptr(out), Dout, L.ptr(agg), L.stream_ptr())
@@ -92,6 +98,13 @@ def fused_conv(plan, aggr, xj, W_agg, bias=None, sigma=None, xi=None, W_root=Non
     L.check(rc)
     out = post(out) if post is not None else out
     return (out, agg) if return_aggregate else out
+
+
+_KNOB14 = [0]
+
+
+def _knob14():
+    return _KNOB14[0]
 
 
 def bias_act(x, bias, sigma):
@@ -527,7 +540,7 @@ def graphconv_chain(model, g: GNNGraph, x):
         g._cache["chain_scratch"] = scratch
     out = torch.empty((G, nout), dtype=torch.float32, device=x.device)
     xc = x.contiguous()
-    rc = lib.gnnmp_graphconv_chain_f32(g.plan(False).handle, jobs.handle, L.ptr(sp), G, L.ptr(xc), nl, dims, wr, wa, bs, act,
+    rc = lib.gnnmp_graphconv_chain_f32(g.plan(False).handle, jobs.handle, L.ptr(sp), G, L.ptr(xc), nl, dims, wr, wa, bs, act, 0,
                                        aggr_code(convs[0].aggr), aggr_code(pool.aggr), L.ptr(keep[-2]), L.ptr(keep[-1]), nout,
                                        L.ptr(scratch), L.ptr(out), L.stream_ptr())
     if rc == L.EUNSUPPORTED:

@@ -3,12 +3,17 @@
 A batched GNNGraph is block-diagonal (MLUtils.batch, GNNGraphs/src/transform.jl:682-709): no edge crosses member graphs,
 so member graphs are independent units.  One process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI on
 ROCm, "gloo" in the CPU tests):
-  1. `shard_by_size` deals the member graphs to ranks, largest first, round-robin — balances nodes and edges;
+  1. `shard_by_size` deals the member graphs to ranks, largest first, in a snake — balances nodes and edges (the same table
+     comes out of the C ABI: gnnmp_shard_by_size, include/gnnmp.h);
   2. every rank batches ITS graphs locally (local node offsets, local graph_indicator) and runs the whole forward,
      including GlobalPool, producing (G_r, nout) logits;
   3. ONE all-gather of the per-shard logits (padded to the largest shard; a few KB per rank: latency-bound, so a single
-     collective and no bucketing), then a permutation back to the caller's graph order.
+     collective and no bucketing), then ONE index_select back to the caller's graph order.
 Weights are replicated and read-only; there is no all-reduce, no halo exchange, nothing else on the data path.
+
+Everything that depends only on the sharding — the padded send buffer, the receive buffer, the inverse permutation — lives in a
+`ShardPlan` built once; a step does a device copy, the collective and a gather: no host -> device copy, no allocation besides
+the result (round 2 rebuilt index tensors from Python lists on every step: host-bound at 8 ranks).
 The reference has no distributed code at all: this is the build's own design for north_star's
 "shard by graph ... all-gather of per-shard logits".
 """
@@ -33,26 +38,50 @@ def shard_by_size(sizes: Sequence[int], world: int) -> List[List[int]]:
     return shards
 
 
+class ShardPlan:
+    """The static part of the graph-parallel step for one sharding: who owns which member graph, and the buffers / index that put
+    the all-gathered (world * gmax, nout) block back into graph order."""
+
+    def __init__(self, shards: List[List[int]], rank: int, world: int, nout: int, device, dtype=torch.float32, dist=None):
+        assert len(shards) == world
+        self.shards, self.rank, self.world, self.nout = shards, rank, world, nout
+        self.n_local = len(shards[rank])
+        self.n_total = sum(len(s) for s in shards)
+        self.gmax = max((len(s) for s in shards), default=0)
+        # row of graph g in the gathered block: rank * gmax + position inside the rank's (ascending) shard — built ONCE
+        inv = torch.empty(self.n_total, dtype=torch.long)
+        for r, s in enumerate(shards):
+            if s:
+                inv[torch.as_tensor(s, dtype=torch.long)] = r * self.gmax + torch.arange(len(s), dtype=torch.long)
+        self.inv = inv.to(device)
+        self.send = torch.zeros((self.gmax, nout), dtype=dtype, device=device)
+        self.recv = torch.empty((world * self.gmax, nout), dtype=dtype, device=device)
+        self.dist = dist if world > 1 else None
+        # one flat collective where the backend has it (RCCL does; so does gloo in current torch), else the list form on views
+        self._flat = True
+        self._views = [self.recv[r * self.gmax:(r + 1) * self.gmax] for r in range(world)]
+
+    def gather(self, local_out: torch.Tensor) -> torch.Tensor:
+        """all-gather the (G_r, nout) outputs of every rank; rows back in the original graph order.  Device work only."""
+        assert local_out.shape == (self.n_local, self.nout), (tuple(local_out.shape), self.n_local, self.nout)
+        if self.dist is None:
+            return local_out              # one rank: its ascending shard is the graph order
+        self.send[: self.n_local].copy_(local_out)
+        if self._flat:
+            try:
+                self.dist.all_gather_into_tensor(self.recv, self.send)           # the only collective on the path
+            except (RuntimeError, NotImplementedError, AttributeError):
+                self._flat = False
+        if not self._flat:
+            self.dist.all_gather(self._views, self.send)
+        return self.recv.index_select(0, self.inv)
+
+
 def gather_shard_outputs(local_out: torch.Tensor, shards: List[List[int]], rank: int, world: int, dist=None) -> torch.Tensor:
-    """all-gather the (G_r, nout) outputs of every rank and put the rows back in the original graph order."""
-    n_total = sum(len(s) for s in shards)
-    nout = local_out.shape[1]
-    assert local_out.shape[0] == len(shards[rank])
-    if world == 1 or dist is None:
-        gathered = [local_out]
-    else:
-        gmax = max(len(s) for s in shards)
-        pad = torch.zeros((gmax, nout), dtype=local_out.dtype, device=local_out.device)
-        pad[: local_out.shape[0]] = local_out
-        buf = [torch.empty_like(pad) for _ in range(world)]
-        dist.all_gather(buf, pad)                      # the only collective on the path
-        gathered = [buf[r][: len(shards[r])] for r in range(world)]
-    out = torch.empty((n_total, nout), dtype=local_out.dtype, device=local_out.device)
-    for r in range(len(gathered)):
-        if len(shards[r]):
-            idx = torch.as_tensor(shards[r], dtype=torch.long, device=local_out.device)
-            out[idx] = gathered[r]
-    return out
+    """One-off form (builds a ShardPlan for this call): all-gather the per-rank outputs, rows in graph order.  Steps that repeat
+    should hold a ShardPlan and call its gather()."""
+    plan = ShardPlan(shards, rank, world, local_out.shape[1], local_out.device, local_out.dtype, dist)
+    return plan.gather(local_out)
 
 
 def graph_parallel_forward(member_graphs: Sequence, forward_local: Callable, rank: int, world: int, dist=None,

@@ -94,7 +94,8 @@ function plan(g::GNNGraph{<:COO_T}; self_loops::Bool = false, transposed::Bool =
     lock(PLANS_LOCK) do
         ent = get(PLANS, key, nothing)
         if ent === nothing || !(@atomic ent.alive)
-            length(PLANS) > 256 && filter!(kv -> (@atomic kv.second.alive), PLANS)   # drop the plans of collected graphs
+            filter!(kv -> (@atomic kv.second.alive), PLANS)   # every miss drops the plans of collected graphs: a plan holds device
+                                                                 # memory (0.5 GB at the products size) that must not wait for 256 entries
             p = transposed ? Plan(t, s, g.num_nodes, g.num_nodes, self_loops) : Plan(s, t, g.num_nodes, g.num_nodes, self_loops)
             ent = PlanEntry(p, true)
             let ent = ent
@@ -448,6 +449,101 @@ function attention(g::GNNGraph{<:COO_T}, mode::Int, K::AnyROCMatrix{Float32}; Q 
                                               Cint(relu)::Cint, devptr(out)::Ptr{Cvoid}, C_NULL::Ptr{Cvoid},
                                               heads::Int64, (size(K, 1) ÷ heads)::Int64, stream_ptr()::Ptr{Cvoid})::Cint)
     return out
+end
+
+# ---- a whole graph-classification forward in one launch: GNNChain(GraphConv..., GlobalPool, Dense) ------------------------------
+# examples/graph_classification_tudataset.jl:79-82 on a batched GNNGraph (MLUtils.batch, GNNGraphs/src/transform.jl:682-709).  The layer
+# objects are read through their field names only (weight1, weight2, bias, σ, aggr — GraphNeuralNetworks/src/layers/conv.jl:226-245 —
+# and Flux.Dense's weight, bias), so this extension of GNNlib needs no dependency on the Flux front-end; a front-end method
+# `(c::GNNChain)(g::GNNGraph, x::AnyROCMatrix)` can try `graphconv_chain` first and fall back to its layer loop on `nothing`.
+# Julia's (out, in) weight matrices are passed AS STORED (w_layout = 1).  Forward only (inference / evaluation): no rrule.
+mutable struct ChainJobs
+    handle::Ptr{Cvoid}
+    function ChainJobs(seg_ptr::ROCVector{Int64}, G::Int)
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        check(@ccall libgnnmp.gnnmp_chain_jobs_create(h::Ptr{Ptr{Cvoid}}, devptr(seg_ptr)::Ptr{Cvoid}, G::Int64,
+                                                      stream_ptr()::Ptr{Cvoid})::Cint)
+        j = new(h[])
+        finalizer(j -> (@ccall libgnnmp.gnnmp_chain_jobs_destroy(j.handle::Ptr{Cvoid})::Cint), j)
+        return j
+    end
+end
+function chain_jobs_info(j::ChainJobs)
+    info = zeros(Int64, 5)
+    check(@ccall libgnnmp.gnnmp_chain_jobs_info(j.handle::Ptr{Cvoid}, info::Ptr{Int64})::Cint)
+    return (jobs = info[1], graphs = info[2], rows = info[3], max_graph = info[4], fill = info[5] / 1000)
+end
+# first node of every member graph (0-based rows, G + 1 entries) from the sorted indicator `batch` builds
+function segment_bounds(g::GNNGraph)
+    gi = GNNGraphs.graph_indicator(g)
+    sp = ROCVector{Int64}(undef, g.num_graphs + 1)
+    check(@ccall libgnnmp.gnnmp_segment_bounds(devptr(gi)::Ptr{Cvoid}, sizeof(eltype(gi))::Cint, 1::Cint, g.num_nodes::Int64,
+                                               g.num_graphs::Int64, devptr(sp)::Ptr{Cvoid}, stream_ptr()::Ptr{Cvoid})::Cint)
+    return sp
+end
+# per-batch constants, cached like the plans (identity of the indicator vector)
+const CHAIN_CACHE = Dict{UInt, Tuple{ROCVector{Int64}, ChainJobs}}()
+function chain_constants(g::GNNGraph)
+    key = objectid(GNNGraphs.graph_indicator(g))
+    lock(PLANS_LOCK) do
+        get!(CHAIN_CACHE, key) do
+            sp = segment_bounds(g)
+            (sp, ChainJobs(sp, g.num_graphs))
+        end
+    end
+end
+@non_differentiable chain_constants(::Any...)
+
+function graphconv_chain(convs::Tuple, pool_aggr, head_weight::ROCMatrix{Float32}, head_bias, g::GNNGraph{<:COO_T},
+                         x::AnyROCMatrix{Float32})
+    check_num_nodes(g, x)
+    L = length(convs)
+    aggr = convs[1].aggr
+    (aggr === (+) || aggr === mean) && (pool_aggr === (+) || pool_aggr === mean) || return nothing
+    all(c -> c.aggr === aggr && act_code(c.σ) !== nothing, convs) || return nothing
+    dims = Int64[size(x, 1); [size(c.weight1, 1) for c in convs]...]
+    nout = size(head_weight, 1)
+    sp, jobs = chain_constants(g)
+    nfloats = @ccall libgnnmp.gnnmp_graphconv_chain_scratch_floats(g.num_nodes::Int64, L::Cint, dims::Ptr{Int64}, nout::Int64)::Int64
+    nfloats < 0 && return nothing
+    scratch = ROCVector{Float32}(undef, nfloats)
+    out = similar(x, nout, g.num_graphs)
+    wr = Ptr{Cvoid}[devptr(c.weight1) for c in convs]
+    wa = Ptr{Cvoid}[devptr(c.weight2) for c in convs]
+    bs = Ptr{Cvoid}[c.bias isa AbstractArray ? devptr(c.bias) : C_NULL for c in convs]
+    acts = Cint[act_code(c.σ) for c in convs]
+    hb = head_bias isa AbstractArray ? head_bias : nothing
+    GC.@preserve convs head_weight hb scratch begin
+        st = @ccall libgnnmp.gnnmp_graphconv_chain_f32(plan(g).handle::Ptr{Cvoid}, jobs.handle::Ptr{Cvoid}, devptr(sp)::Ptr{Cvoid},
+                  g.num_graphs::Int64, devptr(x)::Ptr{Cvoid}, L::Cint, dims::Ptr{Int64}, wr::Ptr{Ptr{Cvoid}}, wa::Ptr{Ptr{Cvoid}},
+                  bs::Ptr{Ptr{Cvoid}}, acts::Ptr{Cint}, 1::Cint, aggr_code(aggr)::Cint, aggr_code(pool_aggr)::Cint,
+                  devptr(head_weight)::Ptr{Cvoid}, devptr(hb)::Ptr{Cvoid}, nout::Int64, devptr(scratch)::Ptr{Cvoid},
+                  devptr(out)::Ptr{Cvoid}, stream_ptr()::Ptr{Cvoid})::Cint
+    end
+    st == EUNSUPPORTED && return nothing                           # outside the fused kernels' envelope: run the layers one by one
+    check(st)
+    return out
+end
+
+# ---- graph-parallel step for batched graphs (SURVEY.md §8e): shard by graph, ONE all-gather of the per-shard logits -----------------
+# Host side of the recipe in INTEGRATION.md §2b.  `sizes` = num_nodes of every member graph BEFORE batching (a host Vector{Int}).
+# Returns (rank_of, gather_index, gmax): rank_of[g] (0-based rank) owns member graph g; after the all-gather of `gmax` padded rows per
+# rank, row gather_index[g] (0-based) of the (nout, world * gmax) block is graph g.
+function shard_by_size(sizes::Vector{Int64}, world::Int)
+    G = length(sizes)
+    rank_of = Vector{Int32}(undef, G)
+    gather_index = Vector{Int64}(undef, G)
+    gmax = Ref{Int64}(0)
+    check(@ccall libgnnmp.gnnmp_shard_by_size(sizes::Ptr{Int64}, G::Int64, world::Cint, rank_of::Ptr{Int32}, gather_index::Ptr{Int64},
+                                              gmax::Ptr{Int64})::Cint)
+    return rank_of, gather_index, gmax[]
+end
+# the one collective: `comm` is the caller's RCCL communicator (an ncclComm_t as a Ptr{Cvoid}, e.g. from NCCL.jl built against RCCL);
+# send = this rank's (nout, gmax) logits (padding columns arbitrary), recv = (nout, world * gmax)
+function allgather_logits!(recv::ROCMatrix{Float32}, send::ROCMatrix{Float32}, comm::Ptr{Cvoid})
+    check(@ccall libgnnmp.gnnmp_allgather_f32(comm::Ptr{Cvoid}, devptr(send)::Ptr{Cvoid}, devptr(recv)::Ptr{Cvoid},
+                                              length(send)::Int64, stream_ptr()::Ptr{Cvoid})::Cint)
+    return recv
 end
 
 # ---- graph prep that the CUDA extension sends to the CPU (GNNGraphs/ext/GNNGraphsCUDAExt.jl:24-30) ---------------------------

@@ -480,6 +480,23 @@ int gnnmp_dense_f32(const float *x1, const float *W1, int64_t D1, int64_t ldw1, 
                     int act, float *out, int64_t N, int64_t Dout, gnnmp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Graph-parallel step for batched graphs (north_star: "shard by graph across up to 8 GPUs of one node with an
+ * RCCL-over-xGMI all-gather of per-shard logits").  A batched GNNGraph is block-diagonal (MLUtils.batch,
+ * GNNGraphs/src/transform.jl:682-709): member graphs are independent units.  One process per GPU:
+ *   1. gnnmp_shard_by_size (HOST arrays): deal the member graphs to the ranks — by decreasing size in a boustrophedon: counts +-1,
+ *      node totals within a fraction of a per cent; rank_of[g] = owner, gather_index[g] = row of graph g in the all-gathered block
+ *      (rank * gmax + position among the rank's graphs in ascending graph order), *gmax = rows per rank in the collective.
+ *   2. every rank batches ITS members (MLUtils.batch), uploads, builds its plan and runs the forward (e.g. gnnmp_graphconv_chain_f32),
+ *      writing its (G_r, nout) logits at the start of a (gmax, nout) send buffer (the padding rows are never read back).
+ *   3. gnnmp_allgather_f32: ONE ncclAllGather of gmax * nout floats per rank on the caller's communicator and stream (RCCL resolved
+ *      with dlopen at the first call; a few KB per rank: latency-bound, no bucketing), then ONE gnnmp_gather_f32 with gather_index
+ *      (uploaded once) puts the rows back in graph order.  Weights are replicated; there is no other collective on the path.
+ * The host mirror of the same design is gnnmp/parallel.py (torch.distributed, "nccl" = RCCL on ROCm).
+ * ---------------------------------------------------------------------------------------------- */
+int gnnmp_shard_by_size(const int64_t *sizes, int64_t G, int world, int32_t *rank_of, int64_t *gather_index, int64_t *gmax);
+int gnnmp_allgather_f32(void *nccl_comm, const float *send, float *recv, int64_t count, gnnmp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * A whole graph-classification forward in ONE kernel (BASELINE.json config 5):
  *   GNNChain(GraphConv(d0 => d1, σ1; aggr), ..., GraphConv(d_{L-1} => d_L, σL; aggr), GlobalPool(pool_aggr), Dense(d_L => nout))
  *   model: examples/graph_classification_tudataset.jl:79-82; layer body σ.(W1*x_i .+ W2*aggr_j x_j .+ b) GNNlib/src/layers/conv.jl:102-108;
@@ -491,9 +508,11 @@ int gnnmp_dense_f32(const float *x1, const float *W1, int64_t D1, int64_t ldw1, 
  *   plan      : plan of the batched graph's (s, t) WITHOUT self loops
  *   seg_ptr   : DEVICE int64 [G + 1], seg_ptr[k] = first node of member graph k (gnnmp_segment_bounds)
  *   dims      : HOST int64 [n_layers + 1] = d0 .. dL;  W_root / W_agg / bias : HOST arrays of n_layers DEVICE pointers
- *               (weight1 / weight2 [d_l][d_{l-1}] C row-major, i.e. Julia's (out, in) matrices transposed in memory; bias entries may
- *               be NULL, `bias` itself may be NULL);  act : HOST int [n_layers] (gnnmp_act: IDENTITY | RELU)
- *   aggr, pool_aggr : GNNMP_SUM | GNNMP_MEAN;  W_head [nout][dL] row-major, b_head [nout] or NULL
+ *               (weight1 / weight2; bias entries may be NULL, `bias` itself may be NULL);  act : HOST int [n_layers] (gnnmp_act:
+ *               IDENTITY | RELU)
+ *   w_layout  : like gnnmp_dense_f32 — 0: every weight is C row-major [out][in]; 1: Julia's (out, in) column-major matrices as stored
+ *               (weight1, weight2 and the head's weight alike)
+ *   aggr, pool_aggr : GNNMP_SUM | GNNMP_MEAN;  W_head (nout, dL) in the same layout, b_head [nout] or NULL
  *   scratch   : DEVICE, at least gnnmp_graphconv_chain_scratch_floats(N, n_layers, dims, nout) floats, 16-byte aligned
  *   out       : DEVICE [G][nout]
  * Envelope: n_layers <= 4, every d a multiple of 4, d1..dL <= 128, nout <= 8; outside it (or with max / min aggregation) the call
@@ -516,7 +535,7 @@ int gnnmp_chain_jobs_info(const gnnmp_chain_jobs_t *jobs, int64_t *info);
 /* jobs: NULL or the handle of THIS batch (gnnmp_chain_jobs_create on the same seg_ptr) */
 int gnnmp_graphconv_chain_f32(gnnmp_graph_t *plan, const gnnmp_chain_jobs_t *jobs, const int64_t *seg_ptr, int64_t G, const float *x, int n_layers,
                               const int64_t *dims, const float *const *W_root, const float *const *W_agg,
-                              const float *const *bias, const int *act, int aggr, int pool_aggr, const float *W_head,
+                              const float *const *bias, const int *act, int w_layout, int aggr, int pool_aggr, const float *W_head,
                               const float *b_head, int64_t nout, float *scratch, float *out, gnnmp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------

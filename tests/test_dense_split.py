@@ -57,11 +57,12 @@ def case(gm, N, K1, K2, Dout, act, has_bias, w_layout, seed, scale_x=1.0):
         mag = mag + b.double().abs()
     ref = torch.relu(pre) if act else pre
     y = run_dense(gm, x, W1, b, act, x2, W2, w_layout)
+    before = gm.knob(17)
     gm.tune(17, -1)
     try:
         y32 = run_dense(gm, x, W1, b, act, x2, W2, w_layout)
     finally:
-        gm.tune(17, 0)
+        gm.tune(17, before)
     e_split = float(((y.double() - ref).abs() / mag).max())
     e_f32 = float(((y32.double() - ref).abs() / mag).max())
     assert torch.equal(run_dense(gm, x, W1, b, act, x2, W2, w_layout), y), "not run-to-run identical"

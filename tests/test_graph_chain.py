@@ -64,11 +64,12 @@ def run_both(gm, model, g):
     from gnnmp import layers
     assert layers._chain_pattern(model.layers) is not None
     y = model(g, g.x)
+    before = gm.knob(18)
     gm.tune(18, -1)
     try:
         y_layers = model(g, g.x)
     finally:
-        gm.tune(18, 0)
+        gm.tune(18, before)
     return y, y_layers
 
 
@@ -179,11 +180,12 @@ def test_wave_job_kernel_on_irregular_batches(gm, oracle, aggr, pool, seed):
     y, yl = run_both(gm, model, g)
     jobs = g._cache["chain_jobs"]
     assert jobs.njobs > 0 and jobs.max_graph <= 64 and 0.5 < jobs.fill <= 1.0
+    before = gm.knob(18)
     gm.tune(18, 1)
     try:
         y_general = model(g, g.x)
     finally:
-        gm.tune(18, 0)
+        gm.tune(18, before)
     ref = oracle_chain(oracle, members, xs, model.layers[:2], pool, model.layers[-1])
     close(y.cpu().numpy(), ref, "wave-job kernel vs oracle")
     close(y_general.cpu().numpy(), ref, "general kernel vs oracle")
@@ -252,6 +254,38 @@ def test_non_finite_features_take_the_exact_path(gm):
     good = torch.isfinite(y).all(1)
     close(y[good].cpu().numpy(), yl[good].cpu().numpy(), "finite graphs")
     assert torch.equal(torch.isnan(y), torch.isnan(yl))
+
+
+@pytest.mark.parametrize("dims", [(16, 128, 128), (16, 64, 128)])
+def test_julia_weight_layout(gm, dims):
+    """w_layout = 1: Julia's (out, in) column-major weight matrices as stored (C row-major [in][out]) — what the Julia binding passes —
+    give the same logits, bit for bit, as the C row-major [out][in] matrices (both fused kernels)"""
+    import ctypes
+    import torch
+    from gnnmp import _lib as L, synth
+    from gnnmp.msgpass import aggr_code
+    lib = L.load()
+    members = synth.batched_graphs(G=200, seed=11)
+    xs = [np.random.default_rng(2).standard_normal((n, dims[0]), dtype=np.float32) for _, _, n in members]
+    g = gm.batch_arrays(members, xs)
+    model = build(gm, dims, 3, "+", "mean")
+    y = model(g, g.x)
+    convs, head = model.layers[:-2], model.layers[-1]
+    nl = len(convs)
+    i64, vp = ctypes.c_int64, ctypes.c_void_p
+    wt = [(c.weight1.t().contiguous(), c.weight2.t().contiguous()) for c in convs]      # [in][out] = Julia (out, in) as stored
+    ht = head.weight.t().contiguous()
+    cdims = (i64 * (nl + 1))(*dims)
+    wr = (vp * nl)(*[w[0].data_ptr() for w in wt])
+    wa = (vp * nl)(*[w[1].data_ptr() for w in wt])
+    bs = (vp * nl)(*[c.bias.data_ptr() for c in convs])
+    act = (ctypes.c_int * nl)(*[1] * nl)
+    out = torch.empty_like(y)
+    scratch = torch.empty(lib.gnnmp_graphconv_chain_scratch_floats(g.num_nodes, nl, cdims, 3), device="cuda")
+    L.check(lib.gnnmp_graphconv_chain_f32(g.plan(False).handle, g._cache["chain_jobs"].handle, L.ptr(g._cache["node_ptr"]), g.num_graphs,
+                                          L.ptr(g.x), nl, cdims, wr, wa, bs, act, 1, aggr_code("+"), aggr_code("mean"), L.ptr(ht),
+                                          L.ptr(head.bias), 3, L.ptr(scratch), L.ptr(out), L.stream_ptr()))
+    assert torch.equal(out, y)
 
 
 def test_outside_the_envelope_falls_back(gm, oracle):

@@ -35,7 +35,8 @@ def c_prototypes():
     return protos
 
 
-JL_KIND = {"Ptr{Cvoid}": "ptr", "Ptr{Ptr{Cvoid}}": "ptr", "Cstring": "ptr", "Cint": "i32", "Int64": "i64", "Cfloat": "f32"}
+JL_KIND = {"Ptr{Cvoid}": "ptr", "Ptr{Ptr{Cvoid}}": "ptr", "Ptr{Int64}": "ptr", "Ptr{Int32}": "ptr", "Ptr{Cint}": "ptr", "Cstring": "ptr",
+           "Cint": "i32", "Int64": "i64", "Cfloat": "f32"}
 
 
 def split_top(s):
@@ -102,3 +103,57 @@ def test_the_binding_covers_the_reference_seam():
     assert "objectid(s), objectid(t), g.num_nodes, self_loops" in src      # the cache key (round 1 keyed on s alone)
     assert "WeakKeyDict" not in "\n".join(l for l in src.splitlines() if not l.lstrip().startswith("#"))
     assert "gnnmp_fused_conv_f32" in src and "gnnmp_gat_conv_grad_f32" in src
+
+
+# ---- what a Julia parser / method table would have told us: checked statically ------------------------------------
+def test_blocks_and_brackets_balance():
+    """every function / if / for / while / let / do / begin / struct / module / try has its `end`, every bracket closes — one stray `end`
+    and the north-star drop-in does not load"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from julia_static import block_balance
+    opens, ends, stack, dsq, dpar = block_balance()
+    assert dsq == 0 and dpar == 0
+    assert opens == ends and not stack, f"{opens} block openers, {ends} ends; unclosed: {stack[-3:]}"
+    assert opens > 50
+
+
+def test_every_rrule_returns_one_tangent_per_argument():
+    """ChainRulesCore's contract: the pullback returns a tangent for the function itself and for EVERY positional argument"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from julia_static import rrules
+    rs = rrules()
+    assert len(rs) >= 7
+    for name, npos, counts in rs:
+        assert counts, f"rrule of {name}: no `return NoTangent(), ...` found in its pullback"
+        for c in counts:
+            assert c == npos + 1, f"rrule of {name}: {npos} positional arguments but a pullback return with {c} tangents"
+
+
+def test_extended_methods_exist_in_the_reference_with_that_arity():
+    """every GNNlib.f / GNNGraphs.f the extension adds a method to is a function the reference defines, callable with the same number
+    of positional arguments (tests/golden/julia_api_table.json, generated from /root/reference by tests/golden/make_julia_api_table.py:
+    names and arities only)"""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from julia_static import extended_methods
+    table = json.load(open(os.path.join(ROOT, "tests", "golden", "julia_api_table.json")))
+    ms = extended_methods()
+    assert len(ms) >= 10
+    for pkg, name, (lo, hi) in ms:
+        key = f"{pkg}.{name}"
+        assert key in table and table[key], f"{key} is not defined by the reference"
+        assert any(rlo <= hi and lo <= rhi for rlo, rhi in table[key]), f"{key}: extension arity {lo}..{hi}, reference {table[key]}"
+    if os.path.isdir("/root/reference"):            # in the build container the table must be current
+        import subprocess
+        before = json.dumps(table, sort_keys=True)
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "tests", "golden", "make_julia_api_table.py")], stdout=subprocess.DEVNULL)
+        assert json.dumps(json.load(open(os.path.join(ROOT, "tests", "golden", "julia_api_table.json"))), sort_keys=True) == before
+
+
+def test_round3_entry_points_are_bound():
+    src = open(JL).read()
+    for sym in ("gnnmp_graphconv_chain_f32", "gnnmp_chain_jobs_create", "gnnmp_shard_by_size", "gnnmp_allgather_f32", "gnnmp_segment_bounds"):
+        assert sym in src, sym
