@@ -16,9 +16,10 @@
 //     [W_root | W_agg] (96 KB) + 8 stages fit LDS for the whole launch — no image is ever swapped, there is no block barrier after the
 //     set-up and no block-level hand-off; each slab block recomputes the cheap layer 1 (48 of 240 MFMAs per tile);
 //   * bias, σ2, z = W_head[:, slab] * h2 on the accumulators, per-graph sum over the job's slots in row order (through the stage),
-//     mean, and ONE atomic add per (graph, output) and slab into the zeroed result: two addends per word — a + b is commutative, the
-//     result does not depend on which slab arrives first (run-to-run identical; tested).
-// A job that meets a non-finite operand (NaN accumulators, msplit.h) is recomputed by its wave with plain fp32 loops (cold path).
+//     mean: this slab's half of each logit, stored once; a one-block finish kernel adds the two halves and the head's bias (no
+//     floating-point atomic anywhere, no memset: two launches per call).
+// A job that meets a non-finite operand (NaN accumulators, msplit.h) is set aside and recomputed with plain fp32 loops by the finish
+// kernel (a call or the inlined loops inside the main kernel cost its job loop ~100 spilled registers).
 // Envelope: exactly two layers 16 => 128 => 128, nout <= 8, aggr and pool in {+, mean}, member graphs of at most 64 nodes; everything
 // else is graph_chain.hip's.
 #include <algorithm>
@@ -34,13 +35,14 @@ struct gnnmp_chain_jobs {
     int64_t max_graph = 0;     // largest member graph (> 64: no jobs, the general kernel runs)
     double fill = 0.0;         // rows / (32 x tiles): MFMA work spent on real rows
     int has_empty = 0;         // some member graph has no node (its logits are the head's bias: left to the general kernel)
-    int32_t *bad = nullptr;    // [3 + 2 njobs] count of set-aside jobs, the two slabs' job tickets, then (job * 2 + slab) of the jobs that met a
-                               // non-finite operand in the last call
+    int32_t *bad = nullptr;    // [3 + 2 njobs] count of set-aside jobs (reset by the finish kernel), two spare words, then (job * 2 + slab) of
+                               // the jobs that met a non-finite operand in the running call
+    float *part = nullptr;     // [2][G][8] the two slabs' halves of every logit (each word written once per call: no atomics, no memset)
 };
 
 namespace gnnmp {
 
-constexpr int C2_THREADS = 512, C2_WAVES = 8;
+constexpr int C2_MAX_WAVES = 8;
 constexpr int C2_D0 = 16, C2_D1 = 128, C2_D2 = 128, C2_SLAB = 64;
 constexpr int C2_UNITS1 = 2 * 2 * C2_D1;          // 16-byte units per plane of the W1 image (K = 32)
 constexpr int C2_UNITS2 = 16 * 2 * C2_SLAB;       // ... of one slab of [W2_root | W2_agg] (K = 256)
@@ -57,7 +59,9 @@ struct Chain2Args {
     int lay;            // 0: weights C row-major [Dout][Din]; 1: Julia (Dout, Din) column-major as stored, W(j, k) at [k * Dout + j]
     int nout, act1, act2, mean_aggr, pool_mean;
     float *out;
-    int32_t *bad;       // [0] = count, [1], [2] = job tickets of the slabs, [3..] = job * 2 + slab
+    float *part;        // [2][G][nout]
+    int G;
+    int32_t *bad;       // [0] = count, [3..] = job * 2 + slab
 };
 
 __device__ __forceinline__ float4 c2_ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
@@ -74,7 +78,7 @@ __device__ __forceinline__ void c2_wave_sync() {
 __device__ __forceinline__ int c2_stage_off(int row, int pos) { return row * 64 + ((pos ^ ((row >> 2) & 3)) << 4); }
 __device__ __forceinline__ float c2_act(float v, int act) { return (act == GNNMP_ACT_RELU && v < 0.0f) ? 0.0f : v; }
 
-// The exact path of a job: z of every slot's row with fp32 loops (this lane = slot `lane`).  Runs in graph_chain2_exact_kernel only: a call
+// The exact path of a job: z of every slot's row with fp32 loops (this lane = slot `lane`).  Runs in graph_chain2_finish_kernel only: a call
 // (or the inlined loops) inside the main kernel costs its tile loop ~100 spilled registers.
 __device__ void chain2_exact_job(const Chain2Args &a, int slab, const int32_t *jr, int lane, float *zst) {
     const int row = jr[lane];
@@ -119,7 +123,7 @@ __device__ void chain2_exact_job(const Chain2Args &a, int slab, const int32_t *j
     for (int o = 0; o < a.nout; ++o) zst[lane * 8 + o] = z[o];
 }
 
-// per-graph pooling of a job's z rows (stage: zst [64][8], gst [64] = member graph of each slot), one atomic add per logit and slab
+// per-graph pooling of a job's z rows (stage: zst [64][8], gst [64] = member graph of each slot): this slab's half of every logit
 __device__ __forceinline__ void c2_pool(const Chain2Args &a, int slab, int gid, int lane, const float *zst, const int *gst) {
     if (gid >= 0 && (lane == 0 || gst[lane - 1] != gid)) {
         // reduce_nodes(aggr, g, x) = scatter(aggr, x, graph_indicator) in node order (utils.jl:12-16); Dense and + / mean commute
@@ -128,32 +132,37 @@ __device__ __forceinline__ void c2_pool(const Chain2Args &a, int slab, int gid, 
             float s = 0.0f;
             for (int t = 0; t < cnt; ++t) s = s + zst[(lane + t) * 8 + o];
             if (a.pool_mean && cnt > 0) s = 0.0f + s / (float)cnt;
-            if (slab == 0 && a.bh) s = s + a.bh[o];
-            atomicAdd(a.out + (int64_t)gid * a.nout + o, s);     // two addends per word (one per slab): order-independent
+            a.part[((int64_t)slab * a.G + gid) * a.nout + o] = s;      // this slab's half of the logit: summed by the finish kernel
         }
     }
 }
 
-// the jobs the main kernel set aside (normally none: the launch reads one word and ends)
-__global__ void __launch_bounds__(64) graph_chain2_exact_kernel(const Chain2Args a) {
-    __shared__ float zst[64 * 8];
-    __shared__ int gst[64];
-    const int lane = threadIdx.x;
+// The second (and last) launch of a call, ONE block: the jobs the main kernel set aside (normally none) are redone with fp32 loops,
+// then out[g][o] = half of slab 0 + half of slab 1 + b_head[o] — plain loads and stores in a fixed order: no floating-point atomic, no
+// memset of the result.  It also re-arms the set-aside counter for the next call.
+__global__ void __launch_bounds__(1024) graph_chain2_finish_kernel(const Chain2Args a) {
+    __shared__ float zst[16][64 * 8];
+    __shared__ int gst[16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nbad = a.bad[0];
-    for (int i = blockIdx.x; i < nbad; i += gridDim.x) {
+    for (int i = wave; i < nbad; i += 16) {
         const int job = a.bad[3 + i] >> 1, slab = a.bad[3 + i] & 1;
         const int gid = a.job_gid[(int64_t)job * 64 + lane];
-        gst[lane] = gid;
-        chain2_exact_job(a, slab, a.job_rows + (int64_t)job * 64, lane, zst);
-        __syncthreads();
-        c2_pool(a, slab, gid, lane, zst, gst);
-        __syncthreads();
+        gst[wave][lane] = gid;
+        chain2_exact_job(a, slab, a.job_rows + (int64_t)job * 64, lane, zst[wave]);
+        c2_wave_sync();
+        c2_pool(a, slab, gid, lane, zst[wave], gst[wave]);
     }
+    __syncthreads();       // (block scope: the halves written above are read below by other waves of this block)
+    const int n = a.G * a.nout;
+    for (int i = threadIdx.x; i < n; i += 1024)
+        a.out[i] = (a.part[i] + a.part[(int64_t)n + i]) + (a.bh ? a.bh[i % a.nout] : 0.0f);
+    if (threadIdx.x == 0) a.bad[0] = 0;
 }
 
-
-
-__global__ void __launch_bounds__(C2_THREADS) graph_chain2_kernel(const Chain2Args a) {
+template <int THREADS, bool SB>
+__global__ void __launch_bounds__(THREADS) graph_chain2_kernel(const Chain2Args a) {
+    constexpr int C2_THREADS = THREADS, C2_WAVES = THREADS / 64;
     extern __shared__ __align__(16) unsigned char lds_raw[];
     u32x4 *img1 = reinterpret_cast<u32x4 *>(lds_raw);
     u32x4 *img2 = img1 + 3 * C2_UNITS1;
@@ -296,7 +305,7 @@ __global__ void __launch_bounds__(C2_THREADS) graph_chain2_kernel(const Chain2Ar
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const int kb = 2 * cb + s;
-                __builtin_amdgcn_sched_barrier(0);   // (keep hipcc from hoisting every A-operand read of the block to its top: 96 registers)
+                if (SB) __builtin_amdgcn_sched_barrier(0);   // (keep hipcc from hoisting every A-operand read of the block to its top: 96 registers)
 #pragma unroll
                 for (int T = 0; T < 2; ++T) {
                     if (T < nt) {
@@ -312,11 +321,11 @@ __global__ void __launch_bounds__(C2_THREADS) graph_chain2_kernel(const Chain2Ar
                             const SplitA wr = split_read_a(a2 + (2 * kb) * C2_SLAB + 32 * c, C2_UNITS2);
                             out[T][c] = split_mac(out[T][c], wr, b);
                         }
-                        __builtin_amdgcn_sched_barrier(0);
+                        if (SB) __builtin_amdgcn_sched_barrier(0);
                     }
                 }
                 c2_wave_sync();
-                __builtin_amdgcn_sched_barrier(0);
+                if (SB) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int T = 0; T < 2; ++T) {
                     if (T < nt) {
@@ -357,7 +366,7 @@ __global__ void __launch_bounds__(C2_THREADS) graph_chain2_kernel(const Chain2Ar
                             const SplitA wa = split_read_a(a2 + (2 * (8 + kb)) * C2_SLAB + 32 * c, C2_UNITS2);
                             out[T][c] = split_mac(out[T][c], wa, b);
                         }
-                        __builtin_amdgcn_sched_barrier(0);
+                        if (SB) __builtin_amdgcn_sched_barrier(0);
                     }
                 }
                 c2_wave_sync();   // the stage is rewritten by the next k-block
@@ -400,7 +409,7 @@ __global__ void __launch_bounds__(C2_THREADS) graph_chain2_kernel(const Chain2Ar
         gst[lane] = gid;
         c2_wave_sync();
         if (__builtin_amdgcn_ballot_w64(bad) != 0) {
-            // a non-finite operand somewhere in the job (NaN accumulators): nothing of it is added here; graph_chain2_exact_kernel redoes it
+            // a non-finite operand somewhere in the job (NaN accumulators): nothing of it is written here; graph_chain2_finish_kernel redoes it
             if (lane == 0) a.bad[3 + atomicAdd(a.bad, 1)] = job * 2 + slab;
         } else {
             c2_pool(a, slab, gid, lane, zst, gst);
@@ -486,6 +495,12 @@ extern "C" int gnnmp_chain_jobs_create(gnnmp_chain_jobs_t **out, const int64_t *
             delete J;
             return fail(GNNMP_EALLOC, "chain_jobs_create: hipMalloc failed");
         }
+        if (hipMalloc(&J->part, sizeof(float) * (size_t)2 * (size_t)G * 8) != hipSuccess) {
+            (void)hipFree(J->rows); (void)hipFree(J->gid); (void)hipFree(J->bad);
+            delete J;
+            return fail(GNNMP_EALLOC, "chain_jobs_create: hipMalloc failed");
+        }
+        GNNMP_HIP(hipMemsetAsync(J->bad, 0, 3 * sizeof(int32_t), stream));
         GNNMP_HIP(hipMemcpyAsync(J->rows, rows.data(), bytes, hipMemcpyHostToDevice, stream));
         GNNMP_HIP(hipMemcpyAsync(J->gid, gid.data(), bytes, hipMemcpyHostToDevice, stream));
         GNNMP_HIP(hipStreamSynchronize(stream));
@@ -499,6 +514,7 @@ extern "C" int gnnmp_chain_jobs_destroy(gnnmp_chain_jobs_t *J) {
     if (J->rows) (void)hipFree(J->rows);
     if (J->gid) (void)hipFree(J->gid);
     if (J->bad) (void)hipFree(J->bad);
+    if (J->part) (void)hipFree(J->part);
     delete J;
     return GNNMP_OK;
 }
@@ -539,24 +555,35 @@ int graph_chain2_try(gnnmp_graph_t *p, const gnnmp_chain_jobs_t *J, const int64_
     a.pool_mean = pool_aggr == GNNMP_MEAN;
     a.out = out;
     a.bad = J->bad;
+    a.part = J->part;
+    a.G = (int)G;
+    // knob 13 (experiments): low 2 bits = waves per block 0: 8, 1: 4 (512 VGPRs a wave), 2: 6; bit 2 = scheduling barriers around the A-operand reads
+    const int kv = knob(KNOB_T16_DEBUG);
+    const int waves = (kv & 3) == 1 ? 4 : ((kv & 3) == 2 ? 6 : 8);
+    const bool sb = (kv & 4) != 0;        // default: none (measured 191 -> 176 us at G = 8192: hipcc schedules the block better on its own)
     const size_t lds = (size_t)3 * C2_UNITS1 * 16 + (size_t)3 * C2_UNITS2 * 16 + C2_D1 * 4 + C2_SLAB * 4 + 8 * C2_SLAB * 4 +
-                       (size_t)C2_WAVES * C2_STAGE_BYTES + 16;
+                       (size_t)C2_MAX_WAVES * C2_STAGE_BYTES + 16;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&graph_chain2_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipSuccess;
+#define C2_ATTR(T, S) if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&graph_chain2_kernel<T, S>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        C2_ATTR(512, true) C2_ATTR(512, false) C2_ATTR(256, true) C2_ATTR(256, false) C2_ATTR(384, true) C2_ATTR(384, false)
+#undef C2_ATTR
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(graph_chain2_kernel)");
         attr_set = true;
     }
-    // the result is accumulated from the two slabs: start from zero (a memset node on the same stream)
-    GNNMP_HIP(hipMemsetAsync(out, 0, sizeof(float) * (size_t)G * (size_t)nout, stream));
-    GNNMP_HIP(hipMemsetAsync(J->bad, 0, 3 * sizeof(int32_t), stream));
     const int cus = device_cus();
-    const int gx = std::max(1, std::min(cus / 2, (a.njobs + C2_WAVES - 1) / C2_WAVES));
-    graph_chain2_kernel<<<dim3((unsigned)gx, 2), C2_THREADS, lds, stream>>>(a);
+    const int gx = std::max(1, std::min(cus / 2, (a.njobs + waves - 1) / waves));
+    const dim3 grid((unsigned)gx, 2);
+    if (waves == 8 && sb) graph_chain2_kernel<512, true><<<grid, 512, lds, stream>>>(a);
+    else if (waves == 8) graph_chain2_kernel<512, false><<<grid, 512, lds, stream>>>(a);
+    else if (waves == 4 && sb) graph_chain2_kernel<256, true><<<grid, 256, lds, stream>>>(a);
+    else if (waves == 4) graph_chain2_kernel<256, false><<<grid, 256, lds, stream>>>(a);
+    else if (sb) graph_chain2_kernel<384, true><<<grid, 384, lds, stream>>>(a);
+    else graph_chain2_kernel<384, false><<<grid, 384, lds, stream>>>(a);
     GNNMP_LAUNCH_CHECK("graph_chain2_kernel");
-    graph_chain2_exact_kernel<<<64, 64, 0, stream>>>(a);
-    GNNMP_LAUNCH_CHECK("graph_chain2_exact_kernel");
+    graph_chain2_finish_kernel<<<1, 1024, 0, stream>>>(a);
+    GNNMP_LAUNCH_CHECK("graph_chain2_finish_kernel");
     return GNNMP_OK;
 }
 }  // namespace gnnmp

@@ -100,28 +100,41 @@ __device__ __forceinline__ void split_fill_image(u32x4 *img, int nkb, int DP, co
     const int units = nkb * 2 * DP;
     const bool vec = w.sk[0] == 1 && (w.sj[0] & 3) == 0 && (reinterpret_cast<uintptr_t>(w.W[0]) & 15) == 0 &&
                      (w.K[1] == 0 || (w.sk[1] == 1 && (w.sj[1] & 3) == 0 && (reinterpret_cast<uintptr_t>(w.W[1]) & 15) == 0));
-    for (int idx = tid; idx < units; idx += nthreads) {
-        const int col = idx % DP, kbh = idx / DP;
-        const int c0 = (kbh >> 1) * 16 + (kbh & 1) * 4;         // 16 kb + 4 h; the second float4 sits 8 positions on
-        float4 q[2];
+    // four units per thread and round: their eight 16-byte loads are in flight together (one unit at a time made the fill a chain of
+    // ~12 dependent L2 round trips per block: ~10 us of every launch of the chain kernels)
+    constexpr int UB = 4;
+    for (int idx0 = tid; idx0 < units; idx0 += UB * nthreads) {
+        float4 q[UB][2];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int c = c0 + 8 * u;
-            q[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (col < ncols && c < kcat) {                      // K[0], K[1] multiples of 4: a float4 never straddles
-                if (vec) {
-                    const int s = c >= w.K[0];
-                    q[u] = *reinterpret_cast<const float4 *>(w.W[s] + (int64_t)(n0 + col) * w.sj[s] + (c - (s ? w.K[0] : 0)));
-                } else {
-                    q[u] = make_float4(wcat_at(w, n0 + col, c), wcat_at(w, n0 + col, c + 1), wcat_at(w, n0 + col, c + 2),
-                                       wcat_at(w, n0 + col, c + 3));
+        for (int b = 0; b < UB; ++b) {
+            const int idx = idx0 + b * nthreads;
+            const int col = idx % DP, kbh = idx / DP;
+            const int c0 = (kbh >> 1) * 16 + (kbh & 1) * 4;         // 16 kb + 4 h; the second float4 sits 8 positions on
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int c = c0 + 8 * u;
+                q[b][u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (idx < units && col < ncols && c < kcat) {        // K[0], K[1] multiples of 4: a float4 never straddles
+                    if (vec) {
+                        const int s = c >= w.K[0];
+                        q[b][u] = *reinterpret_cast<const float4 *>(w.W[s] + (int64_t)(n0 + col) * w.sj[s] + (c - (s ? w.K[0] : 0)));
+                    } else {
+                        q[b][u] = make_float4(wcat_at(w, n0 + col, c), wcat_at(w, n0 + col, c + 1), wcat_at(w, n0 + col, c + 2),
+                                              wcat_at(w, n0 + col, c + 3));
+                    }
                 }
             }
         }
-        const Split8 s = split8(q[0], q[1]);
-        img[idx] = s.p0;
-        img[units + idx] = s.p1;
-        img[2 * units + idx] = s.p2;
+#pragma unroll
+        for (int b = 0; b < UB; ++b) {
+            const int idx = idx0 + b * nthreads;
+            if (idx < units) {
+                const Split8 s = split8(q[b][0], q[b][1]);
+                img[idx] = s.p0;
+                img[units + idx] = s.p1;
+                img[2 * units + idx] = s.p2;
+            }
+        }
     }
 }
 
