@@ -169,7 +169,7 @@ __device__ __forceinline__ void chain_tile(const ChainArgs &a, const ChainLayer 
 #pragma unroll 1
                     for (int j = 4; j < degmax; ++j) {
                         const bool ok = j < nb.deg;
-                        const int m = a.col[nb.beg + (ok ? j : 0)];
+                        const int m = ok ? a.col[nb.beg + j] : rowc;    // (never col[beg] of a row without edges: for the last rows that is col[E])
                         const float4 v = ld4(src + (int64_t)m * src_ld + cc);
                         s = sel4(ok, add4(s, v), s);
                     }

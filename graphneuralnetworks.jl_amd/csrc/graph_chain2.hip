@@ -1,25 +1,30 @@
-// graph_chain2.hip — BASELINE.json config 5 with NOTHING but the features, the edge index and the logits crossing the chip's memory:
+// graph_chain2.hip — BASELINE.json config 5 with NOTHING but the features, the edge index, 8 bytes of z per row and the logits crossing
+// the chip's memory:
 //   GNNChain(GraphConv(16 => 128, σ1), GraphConv(128 => 128, σ2), GlobalPool(mean | +), Dense(128 => nout))
 //   (examples/graph_classification_tudataset.jl:79-82; layer body GNNlib/src/layers/conv.jl:102-108; pooling layers/pool.jl:3-5)
 // graph_chain.hip (the general kernel) keeps layer outputs in a block-local scratch matrix; at G = 8192 that scratch (32 blocks x ~1 MB
-// per XCD) falls out of the 4 MB L2 and the kernel runs at the fabric's speed (0.215 ms).  Here a WAVE owns whole member graphs:
-//   * a job = up to 64 rows = whole member graphs packed best-fit-decreasing on the host side of gnnmp_chain_jobs_create (94 % full
-//     at n ~ U{20..40}); the wave runs it as two 32-row MFMA tiles;
-//   * layer 1, 32 features at a time: 12 split-bf16 MFMAs per tile against the W1 planes in LDS; its B operand (x_i, and sum_j x_j
-//     gathered from the 64-byte feature rows in original edge order) is formed once per job;
-//   * those 32 features ARE the next layer's root operand: the 32x32 accumulator layout (lane = node, registers = 8 a + 4 h + b) is the
+// per XCD) falls out of the 4 MB L2 and the kernel runs at the fabric's speed (0.215 ms).  Here whole member graphs stay inside a CU:
+//   * a job = up to 64 rows = whole member graphs packed best-fit-decreasing on the host side of gnnmp_chain_jobs_create (98 % full
+//     at n ~ U{20..40}); a PAIR of waves runs it, one 32-row MFMA tile each (one wave holding both tiles needs 256 registers and
+//     spills; a tile a wave fits 168: three waves a SIMD);
+//   * layer 1, 32 features at a time: 12 split-bf16 MFMAs against the W1 planes in LDS; its B operand (x_i, and sum_j x_j gathered
+//     from the 64-byte feature rows in original edge order) is formed once per job; the job-table / rowptr / col entries of the NEXT
+//     job are fetched during this job's K loop (three dependent loads, one per pass);
+//   * those 32 features ARE the next layer's operand: the 32x32 accumulator layout (lane = node, registers = 8 a + 4 h + b) is the
 //     B-operand layout of msplit.h for k-blocks 2 cb and 2 cb + 1 — bias, σ1, split into planes, MFMA, no memory in between;
-//   * the aggregate operand sum_j h1_j: the 16 features of a k-block go to a 4 KB wave-private LDS stage (64 rows x 64 bytes, 16-byte
-//     slots XOR-swizzled by the row), every lane sums its row's in-neighbours from there in original edge order (member graphs are
-//     whole inside a job: a neighbour's slot is this row's slot + the difference of the node ids) — the adds of NNlib.scatter(+);
+//   * the aggregation of layer 2 runs AFTER its product: t_i = W2_agg h1_i is accumulated next to W2_root h1_i (one B operand, one
+//     split, for both), and sum_j t_j — the same sum as W2_agg sum_j h1_j in exact arithmetic — is formed over this block's 64 columns:
+//     8 columns at a time through the two 2 KB halves of the pair's LDS stage, every lane adding its row's in-neighbours in original
+//     edge order (member graphs are whole inside a job: a neighbour's slot is this row's slot + the difference of the node ids).  The
+//     two waves order their stage accesses with a pair of LDS event counters (see PairCtl): no block barrier after the set-up;
 //   * layer 2's 128 outputs are two 64-column slabs handled by DIFFERENT blocks (blockIdx.y): W1's planes (24 KB) + one slab of
-//     [W_root | W_agg] (96 KB) + 8 stages fit LDS for the whole launch — no image is ever swapped, there is no block barrier after the
-//     set-up and no block-level hand-off; each slab block recomputes the cheap layer 1 (48 of 240 MFMAs per tile);
-//   * bias, σ2, z = W_head[:, slab] * h2 on the accumulators, per-graph sum over the job's slots in row order (through the stage),
-//     mean: this slab's half of each logit, stored once; a one-block finish kernel adds the two halves and the head's bias (no
+//     [W_root | W_agg] (96 KB) + 6 stages fit LDS for the whole launch — no image is ever swapped; each slab block recomputes the cheap
+//     layer 1 (48 of 240 MFMAs per tile);
+//   * bias, σ2 and z = W_head[:, slab] * h2 on the accumulators; the row's z (nout floats per slab) goes to memory, and a second small
+//     launch pools the rows of every member graph in node order and adds the two slabs' halves and the head's bias (no
 //     floating-point atomic anywhere, no memset: two launches per call).
-// A job that meets a non-finite operand (NaN accumulators, msplit.h) is set aside and recomputed with plain fp32 loops by the finish
-// kernel (a call or the inlined loops inside the main kernel cost its job loop ~100 spilled registers).
+// A tile that meets a non-finite operand (NaN accumulators, msplit.h) sets its job aside; the finish kernel recomputes it with plain
+// fp32 loops (a call or the inlined loops inside the main kernel cost its job loop ~100 spilled registers).
 // Envelope: exactly two layers 16 => 128 => 128, nout <= 8, aggr and pool in {+, mean}, member graphs of at most 64 nodes; everything
 // else is graph_chain.hip's.
 #include <algorithm>
@@ -28,30 +33,29 @@
 #include "msplit.h"
 
 struct gnnmp_chain_jobs {
-    int32_t *rows = nullptr;   // [njobs][64] global row of each slot, -1 = empty
-    int32_t *gid = nullptr;    // [njobs][64] member graph of each slot, -1 = empty
+    int32_t *tab = nullptr;    // rows [njobs][64]: global row of each slot, -1 = empty
     int njobs = 0;
     int64_t G = 0, N = 0;
     int64_t max_graph = 0;     // largest member graph (> 64: no jobs, the general kernel runs)
     double fill = 0.0;         // rows / (32 x tiles): MFMA work spent on real rows
     int has_empty = 0;         // some member graph has no node (its logits are the head's bias: left to the general kernel)
-    int32_t *bad = nullptr;    // [3 + 2 njobs] count of set-aside jobs (reset by the finish kernel), two spare words, then (job * 2 + slab) of
-                               // the jobs that met a non-finite operand in the running call
-    float *part = nullptr;     // [2][G][8] the two slabs' halves of every logit (each word written once per call: no atomics, no memset)
+    int32_t *bad = nullptr;    // [3 + 4 njobs]: [0], [1] the counters of set-aside jobs of even / odd calls (each re-armed by the other parity's
+                               // finish kernel), [3..] (job * 2 + slab) of the tiles that met a non-finite operand in the running call
+    float *zrows = nullptr;    // [2][N][8] the two slabs' z of every row (each word written once per call: no atomics, no memset)
+    unsigned calls = 0;        // launches so far (host side; one stream at a time, like a plan)
 };
 
 namespace gnnmp {
 
-constexpr int C2_MAX_WAVES = 8;
 constexpr int C2_D0 = 16, C2_D1 = 128, C2_D2 = 128, C2_SLAB = 64;
 constexpr int C2_UNITS1 = 2 * 2 * C2_D1;          // 16-byte units per plane of the W1 image (K = 32)
 constexpr int C2_UNITS2 = 16 * 2 * C2_SLAB;       // ... of one slab of [W2_root | W2_agg] (K = 256)
-constexpr int C2_STAGE_BYTES = 4096;
+constexpr int C2_STAGE_BYTES = 4096;          // per pair of waves
 
 struct Chain2Args {
     const uint32_t *rowptr;
     const int32_t *col;
-    const int32_t *job_rows, *job_gid;
+    const int32_t *job_rows;
     int njobs;
     const int64_t *seg_ptr;
     const float *x;
@@ -59,9 +63,10 @@ struct Chain2Args {
     int lay;            // 0: weights C row-major [Dout][Din]; 1: Julia (Dout, Din) column-major as stored, W(j, k) at [k * Dout + j]
     int nout, act1, act2, mean_aggr, pool_mean;
     float *out;
-    float *part;        // [2][G][nout]
-    int G;
-    int32_t *bad;       // [0] = count, [3..] = job * 2 + slab
+    float *zrows;       // [2][N][nout] z = W_head[:, slab] * h2 of every row: pooled by the finish kernel
+    int G, N;
+    long long *trace;   // (GNNMP_CHAIN_TRACE builds: cycle stamps of block (0, 0))
+    int32_t *bad_count, *bad_reset, *bad_list;     // this call's counter of set-aside jobs, the next call's (re-armed), job * 2 + slab
 };
 
 __device__ __forceinline__ float4 c2_ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
@@ -74,13 +79,11 @@ __device__ __forceinline__ void c2_wave_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-// byte offset of 16-byte slot `pos` (0..3) of stage row `row`: rows 4 apart share banks, the XOR spreads them
-__device__ __forceinline__ int c2_stage_off(int row, int pos) { return row * 64 + ((pos ^ ((row >> 2) & 3)) << 4); }
 __device__ __forceinline__ float c2_act(float v, int act) { return (act == GNNMP_ACT_RELU && v < 0.0f) ? 0.0f : v; }
 
 // The exact path of a job: z of every slot's row with fp32 loops (this lane = slot `lane`).  Runs in graph_chain2_finish_kernel only: a call
 // (or the inlined loops) inside the main kernel costs its tile loop ~100 spilled registers.
-__device__ void chain2_exact_job(const Chain2Args &a, int slab, const int32_t *jr, int lane, float *zst) {
+__device__ void chain2_exact_job(const Chain2Args &a, int slab, const int32_t *jr, int lane) {
     const int row = jr[lane];
     if (row < 0) return;
     auto h1_of = [&](int r, float *h) {     // relu(W1r x_r + W1a aggr_k x_k + b1)
@@ -120,49 +123,115 @@ __device__ void chain2_exact_job(const Chain2Args &a, int slab, const int32_t *j
         const float v = c2_act(s + (a.b2 ? a.b2[f2] : 0.0f), a.act2);
         for (int o = 0; o < a.nout; ++o) z[o] = fmaf(a.Wh[a.lay ? f2 * a.nout + o : o * C2_D2 + f2], v, z[o]);
     }
-    for (int o = 0; o < a.nout; ++o) zst[lane * 8 + o] = z[o];
+    for (int o = 0; o < a.nout; ++o) a.zrows[((int64_t)slab * a.N + row) * a.nout + o] = z[o];
 }
 
-// per-graph pooling of a job's z rows (stage: zst [64][8], gst [64] = member graph of each slot): this slab's half of every logit
-__device__ __forceinline__ void c2_pool(const Chain2Args &a, int slab, int gid, int lane, const float *zst, const int *gst) {
-    if (gid >= 0 && (lane == 0 || gst[lane - 1] != gid)) {
-        // reduce_nodes(aggr, g, x) = scatter(aggr, x, graph_indicator) in node order (utils.jl:12-16); Dense and + / mean commute
-        const int cnt = (int)(a.seg_ptr[gid + 1] - a.seg_ptr[gid]);
-        for (int o = 0; o < a.nout; ++o) {
-            float s = 0.0f;
-            for (int t = 0; t < cnt; ++t) s = s + zst[(lane + t) * 8 + o];
-            if (a.pool_mean && cnt > 0) s = 0.0f + s / (float)cnt;
-            a.part[((int64_t)slab * a.G + gid) * a.nout + o] = s;      // this slab's half of the logit: summed by the finish kernel
+// reduce_nodes(aggr, g, x) = scatter(aggr, x, graph_indicator) in node order (utils.jl:12-16); Dense and + / mean commute: the logits of
+// member graph g are the pooled z rows of its nodes.  One lane per (graph, slab): the rows of a member graph are contiguous, the sum runs
+// in node order; the two slabs' halves meet through one shuffle.  No floating-point atomic, no memset of the result.
+__device__ __forceinline__ void c2_pool_graph(const Chain2Args &a, int g, int slab, int lane_in_wave) {
+    float acc[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) acc[o] = 0.0f;
+    int cnt = 0;
+    if (g < a.G) {
+        const int64_t r0 = a.seg_ptr[g], r1 = a.seg_ptr[g + 1];
+        cnt = (int)(r1 - r0);
+        const float *z = a.zrows + ((int64_t)slab * a.N + r0) * a.nout;
+        if (a.nout == 2) {
+            const float2 *z2 = reinterpret_cast<const float2 *>(z);
+            int t = 0;
+            for (; t + 8 <= cnt; t += 8) {          // eight loads in flight, the adds in row order
+                float2 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = z2[t + u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { acc[0] = acc[0] + v[u].x; acc[1] = acc[1] + v[u].y; }
+            }
+            for (; t < cnt; ++t) { const float2 v = z2[t]; acc[0] = acc[0] + v.x; acc[1] = acc[1] + v.y; }
+        } else {
+            for (int t = 0; t < cnt; ++t)
+#pragma unroll
+                for (int o = 0; o < 8; ++o)
+                    if (o < a.nout) acc[o] = acc[o] + z[(int64_t)t * a.nout + o];
         }
     }
-}
-
-// The second (and last) launch of a call, ONE block: the jobs the main kernel set aside (normally none) are redone with fp32 loops,
-// then out[g][o] = half of slab 0 + half of slab 1 + b_head[o] — plain loads and stores in a fixed order: no floating-point atomic, no
-// memset of the result.  It also re-arms the set-aside counter for the next call.
-__global__ void __launch_bounds__(1024) graph_chain2_finish_kernel(const Chain2Args a) {
-    __shared__ float zst[16][64 * 8];
-    __shared__ int gst[16][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nbad = a.bad[0];
-    for (int i = wave; i < nbad; i += 16) {
-        const int job = a.bad[3 + i] >> 1, slab = a.bad[3 + i] & 1;
-        const int gid = a.job_gid[(int64_t)job * 64 + lane];
-        gst[wave][lane] = gid;
-        chain2_exact_job(a, slab, a.job_rows + (int64_t)job * 64, lane, zst[wave]);
-        c2_wave_sync();
-        c2_pool(a, slab, gid, lane, zst[wave], gst[wave]);
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+        if (o < a.nout) {
+            float s = acc[o];
+            if (a.pool_mean && cnt > 0) s = 0.0f + s / (float)cnt;
+            const float other = __shfl_xor(s, 1, 64);            // the other slab's half (lanes 2 k, 2 k + 1)
+            if (slab == 0 && g < a.G) a.out[(int64_t)g * a.nout + o] = (s + other) + (a.bh ? a.bh[o] : 0.0f);
+        }
     }
-    __syncthreads();       // (block scope: the halves written above are read below by other waves of this block)
-    const int n = a.G * a.nout;
-    for (int i = threadIdx.x; i < n; i += 1024)
-        a.out[i] = (a.part[i] + a.part[(int64_t)n + i]) + (a.bh ? a.bh[i % a.nout] : 0.0f);
-    if (threadIdx.x == 0) a.bad[0] = 0;
+    (void)lane_in_wave;
 }
 
-template <int THREADS, bool SB>
+// The second (and last) launch of a call: the pooling.  If the main kernel set jobs aside (non-finite operands: normally none), block 0
+// alone first redoes them with fp32 loops and then pools every graph; the other blocks leave.  The counter of set-aside jobs alternates
+// between two words from call to call: this launch reads one (nobody writes it now) and re-arms the other for the next call.
+__global__ void __launch_bounds__(256) graph_chain2_finish_kernel(const Chain2Args a) {
+    const int nbad = *a.bad_count;
+    if (nbad == 0) {
+        const int i = blockIdx.x * 256 + threadIdx.x;                // (the grid covers 2 G lanes)
+        c2_pool_graph(a, i >> 1, i & 1, threadIdx.x & 63);
+    } else if (blockIdx.x == 0) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        for (int i = wave; i < nbad; i += 4)
+            chain2_exact_job(a, a.bad_list[i] & 1, a.job_rows + (int64_t)(a.bad_list[i] >> 1) * 64, lane);
+        __threadfence_block();
+        __syncthreads();       // (block scope: the rows written above are read below by other waves of this block)
+        for (int i = threadIdx.x; i < 2 * ((a.G + 127) / 128) * 128; i += 256) c2_pool_graph(a, i >> 1, i & 1, threadIdx.x & 63);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *a.bad_reset = 0;
+}
+
+// ---- wave PAIRS: one 32-row tile a wave --------------------------------------------------------------------------------------------------
+// The two tiles of a job belong to two waves (2 p, 2 p + 1: different SIMDs) that share the job's 4 KB stage.  What they exchange through
+// it — t of the other tile's rows for the neighbour sums — is ordered by a pair of LDS event counters: each
+// wave publishes the number of events it has passed (release), the other spins on it (acquire); both are resident in the same block,
+// so the spin cannot starve its partner.  The event numbers are the same in both waves at every point of the program.
+struct PairCtl {
+    int *mine;            // this wave's event counter (LDS)
+    int *theirs;          // the partner's
+    int ev;               // events passed so far: identical in both waves at every event
+};
+// LDS executes a wave's instructions in issue order, so "my stage writes (or reads), then my counter" needs no s_waitcnt in between: the
+// counter store is relaxed behind a wavefront-scope fence (compiler ordering only).  A release at workgroup scope would drain lgkmcnt
+// before every counter store: two more LDS round trips (~400 cycles each under this kernel's load) per round.
+__device__ __forceinline__ void pair_arrive(PairCtl &p) {
+    p.ev = __builtin_amdgcn_readfirstlane(p.ev) + 1;      // (kept in a scalar register: hipcc otherwise carries it per lane and spills it)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __hip_atomic_store(p.mine, p.ev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void pair_wait(const PairCtl &p, int ev_) {
+    const int ev = __builtin_amdgcn_readfirstlane(ev_);
+    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(p.theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < ev)
+        __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// what a lane needs of a job before any feature is touched: fetched for the NEXT job while this one is in its K loop (three dependent
+// global loads: job table -> rowptr -> col)
+struct JobPre {
+    int rid;            // this lane's row (-1: empty slot)
+    int first;          // the job's first row (uniform)
+    int r32;            // row of slot 32 (uniform; < 0: the job has one tile)
+    uint32_t beg;
+    int deg;
+    int m[4];           // the first four in-neighbours (the row itself past the degree)
+};
+
+#ifdef GNNMP_CHAIN_TRACE
+#define C2_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && kjob < 8) a.trace[(wave * 8 + kjob) * 8 + (i)] = clock64(); } while (0)
+#else
+#define C2_STAMP(i) do { } while (0)
+#endif
+
+template <int THREADS>
 __global__ void __launch_bounds__(THREADS) graph_chain2_kernel(const Chain2Args a) {
-    constexpr int C2_THREADS = THREADS, C2_WAVES = THREADS / 64;
+    constexpr int WAVES = THREADS / 64, PAIRS = WAVES / 2;
     extern __shared__ __align__(16) unsigned char lds_raw[];
     u32x4 *img1 = reinterpret_cast<u32x4 *>(lds_raw);
     u32x4 *img2 = img1 + 3 * C2_UNITS1;
@@ -170,251 +239,269 @@ __global__ void __launch_bounds__(THREADS) graph_chain2_kernel(const Chain2Args 
     float4 *bias2 = bias1 + C2_D1 / 4;                                      // [16]
     float *head = reinterpret_cast<float *>(bias2 + C2_SLAB / 4);           // [8][64]
     unsigned char *stages = reinterpret_cast<unsigned char *>(head + 8 * C2_SLAB);
-    int *ticket = reinterpret_cast<int *>(stages + C2_WAVES * C2_STAGE_BYTES);
-    if (threadIdx.x == 0) *ticket = 0;
+    int *events = reinterpret_cast<int *>(stages + PAIRS * C2_STAGE_BYTES);  // per wave: event counter
     const int tid = threadIdx.x;
+    if (tid < WAVES) events[tid] = 0;
     const int slab = blockIdx.y, n0 = C2_SLAB * slab;
     {
         WCat w1;
         w1.W[0] = a.W1r; w1.W[1] = a.W1a; w1.K[0] = w1.K[1] = C2_D0;
         w1.sj[0] = w1.sj[1] = a.lay ? 1 : C2_D0; w1.sk[0] = w1.sk[1] = a.lay ? C2_D1 : 1;
-        split_fill_image(img1, 2, C2_D1, w1, 0, C2_D1, tid, C2_THREADS);
+        split_fill_image(img1, 2, C2_D1, w1, 0, C2_D1, tid, THREADS);
         WCat w2;
         w2.W[0] = a.W2r; w2.W[1] = a.W2a; w2.K[0] = w2.K[1] = C2_D1;
         w2.sj[0] = w2.sj[1] = a.lay ? 1 : C2_D1; w2.sk[0] = w2.sk[1] = a.lay ? C2_D2 : 1;
-        split_fill_image(img2, 16, C2_SLAB, w2, n0, C2_SLAB, tid, C2_THREADS);
-        split_fill_bias(bias1, C2_D1, a.b1, 0, C2_D1, tid, C2_THREADS);
-        split_fill_bias(bias2, C2_SLAB, a.b2, n0, C2_SLAB, tid, C2_THREADS);
-        for (int i = tid; i < 8 * C2_SLAB; i += C2_THREADS) {
+        split_fill_image(img2, 16, C2_SLAB, w2, n0, C2_SLAB, tid, THREADS);
+        split_fill_bias(bias1, C2_D1, a.b1, 0, C2_D1, tid, THREADS);
+        split_fill_bias(bias2, C2_SLAB, a.b2, n0, C2_SLAB, tid, THREADS);
+        for (int i = tid; i < 8 * C2_SLAB; i += THREADS) {
             const int o = i / C2_SLAB, c = i - o * C2_SLAB;
             head[i] = o < a.nout ? a.Wh[a.lay ? (n0 + c) * a.nout + o : o * C2_D2 + n0 + c] : 0.0f;
         }
     }
     __syncthreads();
 
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 31, h = lane >> 5;
-    unsigned char *stage = stages + wave * C2_STAGE_BYTES;
-    float *zst = reinterpret_cast<float *>(stage);                 // [64][8] after the layers
-    int *gst = reinterpret_cast<int *>(stage + 2048);              // [64]
+    const int T = wave & 1, pr = wave >> 1;                        // this wave's tile of the pair's jobs
+    unsigned char *stage = stages + pr * C2_STAGE_BYTES;
     const u32x4 *a1 = img1 + h * C2_D1 + n;                        // + (2 kb) * 128 + 32 cb, planes C2_UNITS1 apart
     const u32x4 *a2 = img2 + h * C2_SLAB + n;                      // + (2 kb) * 64 + 32 cb2, planes C2_UNITS2 apart
+    PairCtl pc = {events + wave, events + (wave ^ 1), 0};
 
-    // Jobs: a contiguous share per block, dealt to its waves by an LDS ticket (a wave has only ~4 jobs: a static deal leaves some waves a
-    // fifth; a device-wide ticket was tried — 8 200 atomics on two words cost more than they balanced, 198 -> 227 us)
+    // Jobs: a contiguous share per block, dealt to its pairs round-robin (the jobs are packed to the same size: a ticket balances nothing,
+    // and a known next job is what lets its table entries be fetched ahead)
     const int jb0 = (int)(((int64_t)a.njobs * blockIdx.x) / gridDim.x), jb1 = (int)(((int64_t)a.njobs * (blockIdx.x + 1)) / gridDim.x);
-    for (;;) {
-        int job = 0;
-        if (lane == 0) job = jb0 + atomicAdd(ticket, 1);
-        job = __builtin_amdgcn_readfirstlane(job);
-        if (job >= jb1) break;
-        const int32_t *jr = a.job_rows + (int64_t)job * 64;
-        const int r_first = __builtin_amdgcn_readfirstlane(jr[0]);
-        const bool two = __builtin_amdgcn_readfirstlane(jr[32]) >= 0;
-        const int nt = two ? 2 : 1;
-        // ---- the job's rows, neighbours and layer-1 operands ----------------------------------------------------------------------
-        int slot[2], deg[2];
-        uint32_t locp[2][2];   // the first four neighbours' stage byte offsets at 16-byte position h, 16 bits each (position 2 + h is ^ 32)
-        float4 xq[2][4];   // layer-1 operand of each tile, fp32: [0..1] the row itself, [2..3] the sum of its neighbours (split into planes
-                           // per 32-feature block: 16 registers a tile instead of 24 — the planes spilled)
-        int degmax = 0, degmin = 1 << 30;
+    auto pre_a = [&](int job, JobPre &p) {
+        const int32_t *q = a.job_rows + (int64_t)job * 64;
+        p.rid = q[32 * T + n];
+        p.first = q[0];
+        p.r32 = q[32];
+    };
+    auto pre_b = [&](JobPre &p) {
+        const int rowc = p.rid >= 0 ? p.rid : p.first;
+        p.beg = a.rowptr[rowc];
+        p.deg = (int)(a.rowptr[rowc + 1] - p.beg);
+    };
+    auto pre_c = [&](JobPre &p) {
+        const int rowc = p.rid >= 0 ? p.rid : p.first;
 #pragma unroll
-        for (int T = 0; T < 2; ++T) {
-            if (T < nt) {
-                const int rid = jr[32 * T + n];
-                const bool valid = rid >= 0;
-                const int rowc = valid ? rid : r_first;            // empty slots mirror slot 0 (finite operands, results unused)
-                slot[T] = valid ? 32 * T + n : 0;
-                const uint32_t beg = a.rowptr[rowc];
-                deg[T] = (int)(a.rowptr[rowc + 1] - beg);
+        for (int j = 0; j < 4; ++j) p.m[j] = j < p.deg ? a.col[p.beg + j] : rowc;
+    };
+    JobPre cur = {}, nxt = {};
+    int ev_stage = 0;          // the partner's event after which the pair's stage is free again (its last read of the previous job)
+    int job = jb0 + pr;
+    if (job < jb1) { pre_a(job, cur); pre_b(cur); pre_c(cur); }
+    for (int kjob = 0; job < jb1; job += PAIRS, ++kjob) {
+        C2_STAMP(0);
+        const int job_next = min(job + PAIRS, jb1 - 1);           // (the last job of the share is fetched again: always a valid entry)
+        const bool two = __builtin_amdgcn_readfirstlane(cur.r32) >= 0;
+        if (two || T == 0) {       // (a job of at most 32 rows: the even wave alone, no event but the last)
+            // ---- this tile's rows, neighbours and layer-1 operands -------------------------------------------------------------------
+            const bool valid = cur.rid >= 0;
+            const int rowc = valid ? cur.rid : __builtin_amdgcn_readfirstlane(cur.first);   // empty slots mirror slot 0 (finite operands, results unused)
+            const int slot = valid ? 32 * T + n : 0;
+            const uint32_t beg = cur.beg;
+            const int deg = cur.deg;
+            uint32_t locp[2];      // the first four neighbours' stage byte offsets (32-byte rows, 16-byte half h), 16 bits each
+            float4 xq[4];          // [0..1] the row itself, [2..3] the sum of its neighbours
+            {
                 const float *xr = a.x + (int64_t)rowc * C2_D0;
-                xq[T][0] = c2_ld4(xr + 4 * h);
-                xq[T][1] = c2_ld4(xr + 8 + 4 * h);
+                xq[0] = c2_ld4(xr + 4 * h);
+                xq[1] = c2_ld4(xr + 8 + 4 * h);
                 float4 s0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), s1 = s0;
+                locp[0] = locp[1] = 0;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const bool ok = j < deg[T];
-                    const int m = ok ? a.col[beg + j] : rowc;
-                    const uint32_t off = (uint32_t)c2_stage_off(slot[T] + (m - rowc), h);   // the neighbour's stage row: same member graph, rows in order
-                    locp[T][j >> 1] = (j & 1) ? (locp[T][j >> 1] | (off << 16)) : off;
+                    const bool ok = j < deg;
+                    const int m = cur.m[j];
+                    const uint32_t off = (uint32_t)((slot + (m - rowc)) * 32 + 16 * h);   // same member graph, rows in order
+                    locp[j >> 1] |= off << (16 * (j & 1));
                     const float *xm = a.x + (int64_t)m * C2_D0;
                     s0 = c2_sel4(ok, c2_add4(s0, c2_ld4(xm + 4 * h)), s0);
                     s1 = c2_sel4(ok, c2_add4(s1, c2_ld4(xm + 8 + 4 * h)), s1);
                 }
 #pragma unroll 1
-                for (int j = 4; j < deg[T]; ++j) {
+                for (int j = 4; j < deg; ++j) {
                     const float *xm = a.x + (int64_t)a.col[beg + j] * C2_D0;
                     s0 = c2_add4(s0, c2_ld4(xm + 4 * h));
                     s1 = c2_add4(s1, c2_ld4(xm + 8 + 4 * h));
                 }
-                if (a.mean_aggr && deg[T] > 0) {
-                    const float cnt = (float)deg[T];
+                if (a.mean_aggr && deg > 0) {
+                    const float cnt = (float)deg;
                     s0 = make_float4(0.0f + s0.x / cnt, 0.0f + s0.y / cnt, 0.0f + s0.z / cnt, 0.0f + s0.w / cnt);
                     s1 = make_float4(0.0f + s1.x / cnt, 0.0f + s1.y / cnt, 0.0f + s1.z / cnt, 0.0f + s1.w / cnt);
                 }
-                xq[T][2] = s0;
-                xq[T][3] = s1;
-                degmax = max(degmax, deg[T]);
-                degmin = min(degmin, deg[T]);
+                xq[2] = s0;
+                xq[3] = s1;
             }
-        }
+            int degmax = deg, degmin = deg;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            degmax = max(degmax, __shfl_xor(degmax, o, 64));
-            degmin = min(degmin, __shfl_xor(degmin, o, 64));
-        }
-
-        bool bad = false;
-        f32x16 out[2][2];
-#pragma unroll
-        for (int T = 0; T < 2; ++T)
+            for (int o = 1; o < 64; o <<= 1) {
+                degmax = max(degmax, __shfl_xor(degmax, o, 64));
+                degmin = min(degmin, __shfl_xor(degmin, o, 64));
+            }
+            C2_STAMP(1);
+            bool bad = false;
+            f32x16 out[2], tacc[2];      // W2_root h1_i (the result), t_i = W2_agg h1_i (summed over the in-neighbours afterwards)
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) out[T][c][r] = 0.0f;
+                for (int r = 0; r < 16; ++r) { out[c][r] = 0.0f; tacc[c][r] = 0.0f; }
 
 #pragma unroll 1
-        for (int cb = 0; cb < 4; ++cb) {
-            // ---- layer 1, features 32 cb .. 32 cb + 31 of both tiles -------------------------------------------------------------
-            f32x16 hb[2];
+            for (int cb = 0; cb < 4; ++cb) {
+                // the next job's table entries, one dependent load per pass (consumed a pass later: their latency is covered)
+                if (cb == 0) pre_a(job_next, nxt);
+                else if (cb == 1) pre_b(nxt);
+                else if (cb == 2) pre_c(nxt);
+                // ---- layer 1, features 32 cb .. 32 cb + 31 of this tile ----------------------------------------------------------------
+                f32x16 hb;
 #pragma unroll
-            for (int T = 0; T < 2; ++T)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) hb[T][r] = 0.0f;
-            {
-                const SplitA w0 = split_read_a(a1 + 32 * cb, C2_UNITS1);                 // k-block 0: the rows themselves
-                const SplitA w1 = split_read_a(a1 + 2 * C2_D1 + 32 * cb, C2_UNITS1);     // k-block 1: sum of the neighbours
-                hb[0] = split_mac(hb[0], w0, split8(xq[0][0], xq[0][1]));
-                if (two) hb[1] = split_mac(hb[1], w0, split8(xq[1][0], xq[1][1]));
-                hb[0] = split_mac(hb[0], w1, split8(xq[0][2], xq[0][3]));
-                if (two) hb[1] = split_mac(hb[1], w1, split8(xq[1][2], xq[1][3]));
-            }
-#pragma unroll
-            for (int T = 0; T < 2; ++T) {
-                float s = 0.0f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s += hb[T][r];
-                bad |= (s != s);
-#pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    const float4 v = split_out4(hb[T], q4, bias1[8 * cb + 2 * q4 + h], a.act1);
-                    hb[T][4 * q4] = v.x; hb[T][4 * q4 + 1] = v.y; hb[T][4 * q4 + 2] = v.z; hb[T][4 * q4 + 3] = v.w;
-                }
-            }
-            // ---- layer 2, k-blocks 2 cb and 2 cb + 1: root straight from hb, aggregate through the stage -----------------------------
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int kb = 2 * cb + s;
-                if (SB) __builtin_amdgcn_sched_barrier(0);   // (keep hipcc from hoisting every A-operand read of the block to its top: 96 registers)
-#pragma unroll
-                for (int T = 0; T < 2; ++T) {
-                    if (T < nt) {
-                        const float4 q0 = make_float4(hb[T][8 * s], hb[T][8 * s + 1], hb[T][8 * s + 2], hb[T][8 * s + 3]);
-                        const float4 q1 = make_float4(hb[T][8 * s + 4], hb[T][8 * s + 5], hb[T][8 * s + 6], hb[T][8 * s + 7]);
-                        if (slot[T] == 32 * T + n) {               // (mirror lanes of empty slots do not write)
-                            *reinterpret_cast<float4 *>(stage + c2_stage_off(slot[T], h)) = q0;
-                            *reinterpret_cast<float4 *>(stage + c2_stage_off(slot[T], 2 + h)) = q1;
-                        }
-                        const Split8 b = split8(q0, q1);
-#pragma unroll
-                        for (int c = 0; c < 2; ++c) {              // one tile, one column block at a time: 12 + 12 operand registers live
-                            const SplitA wr = split_read_a(a2 + (2 * kb) * C2_SLAB + 32 * c, C2_UNITS2);
-                            out[T][c] = split_mac(out[T][c], wr, b);
-                        }
-                        if (SB) __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-                c2_wave_sync();
-                if (SB) __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int T = 0; T < 2; ++T) {
-                    if (T < nt) {
-                        // NNlib.scatter(+): dst = 0, then dst += src for the edges in order
-                        float4 s0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), s1 = s0;
-                        if (degmin >= 4) {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                s0 = c2_add4(s0, *reinterpret_cast<const float4 *>(stage + ((locp[T][j >> 1] >> (16 * (j & 1))) & 0xffff)));
-                                s1 = c2_add4(s1, *reinterpret_cast<const float4 *>(stage + (((locp[T][j >> 1] >> (16 * (j & 1))) & 0xffff) ^ 32)));
-                            }
-                        } else {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                const bool ok = j < deg[T];
-                                s0 = c2_sel4(ok, c2_add4(s0, *reinterpret_cast<const float4 *>(stage + ((locp[T][j >> 1] >> (16 * (j & 1))) & 0xffff))), s0);
-                                s1 = c2_sel4(ok, c2_add4(s1, *reinterpret_cast<const float4 *>(stage + (((locp[T][j >> 1] >> (16 * (j & 1))) & 0xffff) ^ 32))), s1);
-                            }
-                        }
-                        if (degmax > 4) {
-                            const int rowc = slot[T] == 32 * T + n ? jr[32 * T + n] : r_first;
-                            const uint32_t beg = a.rowptr[rowc];
-#pragma unroll 1
-                            for (int j = 4; j < deg[T]; ++j) {
-                                const int lj = slot[T] + (a.col[beg + j] - rowc);
-                                s0 = c2_add4(s0, *reinterpret_cast<const float4 *>(stage + c2_stage_off(lj, h)));
-                                s1 = c2_add4(s1, *reinterpret_cast<const float4 *>(stage + c2_stage_off(lj, 2 + h)));
-                            }
-                        }
-                        if (a.mean_aggr && deg[T] > 0) {
-                            const float cnt = (float)deg[T];
-                            s0 = make_float4(0.0f + s0.x / cnt, 0.0f + s0.y / cnt, 0.0f + s0.z / cnt, 0.0f + s0.w / cnt);
-                            s1 = make_float4(0.0f + s1.x / cnt, 0.0f + s1.y / cnt, 0.0f + s1.z / cnt, 0.0f + s1.w / cnt);
-                        }
-                        const Split8 b = split8(s0, s1);
-#pragma unroll
-                        for (int c = 0; c < 2; ++c) {
-                            const SplitA wa = split_read_a(a2 + (2 * (8 + kb)) * C2_SLAB + 32 * c, C2_UNITS2);
-                            out[T][c] = split_mac(out[T][c], wa, b);
-                        }
-                        if (SB) __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-                c2_wave_sync();   // the stage is rewritten by the next k-block
-            }
-        }
-        // ---- σ2, z = W_head[:, slab] * h2, per-graph pooling ---------------------------------------------------------------------------
-#pragma unroll
-        for (int T = 0; T < 2; ++T) {
-            if (T < nt) {
-                float zo[8];
-#pragma unroll
-                for (int o = 0; o < 8; ++o) zo[o] = 0.0f;
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
+                for (int r = 0; r < 16; ++r) hb[r] = 0.0f;
+                hb = split_mac(hb, split_read_a(a1 + 32 * cb, C2_UNITS1), split8(xq[0], xq[1]));                 // the rows themselves
+                hb = split_mac(hb, split_read_a(a1 + 2 * C2_D1 + 32 * cb, C2_UNITS1), split8(xq[2], xq[3]));     // sum of the neighbours
+                {
                     float s = 0.0f;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) s += out[T][c][r];
+                    for (int r = 0; r < 16; ++r) s += hb[r];
                     bad |= (s != s);
 #pragma unroll
                     for (int q4 = 0; q4 < 4; ++q4) {
-                        const int colq = 32 * c + 8 * q4 + 4 * h;
-                        const float4 v = split_out4(out[T][c], q4, bias2[colq >> 2], a.act2);
+                        const float4 v = split_out4(hb, q4, bias1[8 * cb + 2 * q4 + h], a.act1);
+                        hb[4 * q4] = v.x; hb[4 * q4 + 1] = v.y; hb[4 * q4 + 2] = v.z; hb[4 * q4 + 3] = v.w;
+                    }
+                }
+                // ---- layer 2, k-blocks 2 cb and 2 cb + 1: both products of h1_i straight from hb (the 32x32 accumulator layout IS the
+                // B-operand layout of msplit.h) -------------------------------------------------------------------------------------------
 #pragma unroll
-                        for (int o = 0; o < 8; ++o) {
-                            if (o < a.nout) {
-                                const float4 wv = *reinterpret_cast<const float4 *>(head + o * C2_SLAB + colq);
-                                zo[o] = fmaf(wv.x, v.x, fmaf(wv.y, v.y, fmaf(wv.z, v.z, fmaf(wv.w, v.w, zo[o]))));
-                            }
+                for (int s = 0; s < 2; ++s) {
+                    const int kb = 2 * cb + s;
+                    const Split8 b = split8(make_float4(hb[8 * s], hb[8 * s + 1], hb[8 * s + 2], hb[8 * s + 3]),
+                                            make_float4(hb[8 * s + 4], hb[8 * s + 5], hb[8 * s + 6], hb[8 * s + 7]));
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        out[c] = split_mac(out[c], split_read_a(a2 + (2 * kb) * C2_SLAB + 32 * c, C2_UNITS2), b);
+                        tacc[c] = split_mac(tacc[c], split_read_a(a2 + (2 * (8 + kb)) * C2_SLAB + 32 * c, C2_UNITS2), b);
+                    }
+                }
+            }
+            {
+                float s = 0.0f;
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s += tacc[c][r];
+                bad |= (s != s);
+            }
+            C2_STAMP(2);
+            // ---- sum_j t_j: 8 columns at a time through the two 2 KB halves of the pair's stage (rows of 32 bytes).  Chunk k + 1 is written
+            // before chunk k is read: a wave waits for its partner's write of a chunk a whole round after that write was due --------------
+            // events of the rounds, counted from here: W0 W1 R0 W2 R1 ... W7 R6 R7
+            const int eb = __builtin_amdgcn_readfirstlane(pc.ev);
+            // (an offset of zero hipcc cannot see through: it otherwise forms the LDS addresses of this phase once per launch, outside the
+            // job loop, keeps each in a register of its own and spills them — a scratch reload, i.e. a memory round trip, per round)
+            int opq;
+            asm volatile("v_mov_b32 %0, 0" : "=v"(opq));
+            unsigned char *stg = stage + opq;
+            auto ev_w = [&](int k) { return eb + (k == 0 ? 1 : 2 * k); };
+            auto ev_r = [&](int k) { return eb + (k == 7 ? 16 : 2 * k + 3); };
+            auto put = [&](int k) {
+                if (valid)           // (mirror lanes of empty slots do not write)
+                    *reinterpret_cast<float4 *>(stg + 2048 * (k & 1) + slot * 32 + 16 * h) =
+                        make_float4(tacc[k >> 2][4 * (k & 3)], tacc[k >> 2][4 * (k & 3) + 1], tacc[k >> 2][4 * (k & 3) + 2], tacc[k >> 2][4 * (k & 3) + 3]);
+                if (two) pair_arrive(pc);
+            };
+            if (two && ev_stage) pair_wait(pc, ev_stage);      // (an event of a whole K loop ago: falls through)
+            put(0);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (k + 1 < 8) {
+                    if (two && k >= 1) pair_wait(pc, ev_r(k - 1));      // the partner has read chunk k - 1: its half is free
+                    put(k + 1);
+                }
+                // (W(k) precedes R(k - 1) in the partner's program: after the wait above only rounds 0 and 7 have to ask for the write)
+                if (two) { if (k == 0 || k == 7) pair_wait(pc, ev_w(k)); } else c2_wave_sync();
+                const unsigned char *sb = stg + 2048 * (k & 1);
+                // NNlib.scatter(+): dst = 0, then dst += src for the edges in order
+                float4 s0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (degmin >= 4) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        s0 = c2_add4(s0, *reinterpret_cast<const float4 *>(sb + ((locp[j >> 1] >> (16 * (j & 1))) & 0xffff)));
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        s0 = c2_sel4(j < deg, c2_add4(s0, *reinterpret_cast<const float4 *>(sb + ((locp[j >> 1] >> (16 * (j & 1))) & 0xffff))), s0);
+                }
+                if (degmax > 4) {
+#pragma unroll 1
+                    for (int j = 4; j < deg; ++j)
+                        s0 = c2_add4(s0, *reinterpret_cast<const float4 *>(sb + (slot + (a.col[beg + j] - rowc)) * 32 + 16 * h));
+                }
+                if (two) pair_arrive(pc); else c2_wave_sync();     // (release: the reads above have completed)
+                if (a.mean_aggr && deg > 0) {
+                    const float cnt = (float)deg;
+                    s0 = make_float4(0.0f + s0.x / cnt, 0.0f + s0.y / cnt, 0.0f + s0.z / cnt, 0.0f + s0.w / cnt);
+                }
+                out[k >> 2][4 * (k & 3)] += s0.x; out[k >> 2][4 * (k & 3) + 1] += s0.y;
+                out[k >> 2][4 * (k & 3) + 2] += s0.z; out[k >> 2][4 * (k & 3) + 3] += s0.w;
+            }
+            C2_STAMP(3);
+            // ---- σ2, z = W_head[:, slab] * h2 ------------------------------------------------------------------------------------------
+            // (the same opaque zero: ~20 addresses here, nine of them were scratch reloads)
+            const float4 *bias2o = bias2 + opq + h;
+            const float *heado = head + 4 * (opq + h);
+            float zo[8];
+#pragma unroll
+            for (int o = 0; o < 8; ++o) zo[o] = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                float s = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s += out[c][r];
+                bad |= (s != s);
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int colq = 32 * c + 8 * q4;      // + 4 h: inside bias2o / heado
+                    const float4 v = split_out4(out[c], q4, bias2o[colq >> 2], a.act2);
+#pragma unroll
+                    for (int o = 0; o < 8; ++o) {
+                        if (o < a.nout) {
+                            const float4 wv = *reinterpret_cast<const float4 *>(heado + o * C2_SLAB + colq);
+                            zo[o] = fmaf(wv.x, v.x, fmaf(wv.y, v.y, fmaf(wv.z, v.z, fmaf(wv.w, v.w, zo[o]))));
                         }
                     }
                 }
+            }
 #pragma unroll
-                for (int o = 0; o < 8; ++o) {
-                    const float tot = zo[o] + __shfl_xor(zo[o], 32, 64);
-                    if (h == 0 && slot[T] == 32 * T + n) zst[(32 * T + n) * 8 + o] = tot;
+            for (int o = 0; o < 8; ++o) zo[o] = zo[o] + __shfl_xor(zo[o], 32, 64);
+            C2_STAMP(4);
+            // a non-finite operand somewhere in this tile (NaN accumulators): the finish kernel redoes the whole job with fp32 loops (both
+            // waves of a pair may report it: the job is then redone twice, with the same result)
+            if (__builtin_amdgcn_ballot_w64(bad) != 0) {
+                if (lane == 0) a.bad_list[atomicAdd(a.bad_count, 1)] = job * 2 + slab;
+            }
+            if (h == 0 && valid) {
+                // this slab's z of the row: pooled over the member graph, in node order, by the finish kernel
+                float *zr = a.zrows + ((int64_t)slab * a.N + rowc) * a.nout;
+                if (a.nout == 2) {
+                    *reinterpret_cast<float2 *>(zr) = make_float2(zo[0], zo[1]);
+                } else {
+#pragma unroll
+                    for (int o = 0; o < 8; ++o)
+                        if (o < a.nout) zr[o] = zo[o];
                 }
             }
-        }
-        const int gid = a.job_gid[(int64_t)job * 64 + lane];
-        gst[lane] = gid;
-        c2_wave_sync();
-        if (__builtin_amdgcn_ballot_w64(bad) != 0) {
-            // a non-finite operand somewhere in the job (NaN accumulators): nothing of it is written here; graph_chain2_finish_kernel redoes it
-            if (lane == 0) a.bad[3 + atomicAdd(a.bad, 1)] = job * 2 + slab;
+            C2_STAMP(5);
+            if (two) ev_stage = ev_r(7);
         } else {
-            c2_pool(a, slab, gid, lane, zst, gst);
+            // the odd wave of a one-tile job: nothing to compute, but the next job's entries are still due
+            pre_a(job_next, nxt); pre_b(nxt); pre_c(nxt);
         }
-        c2_wave_sync();   // the stage is reused by the next job
+        C2_STAMP(6);
+        C2_STAMP(7);
+        cur = nxt;
     }
 }
 
@@ -469,40 +556,26 @@ extern "C" int gnnmp_chain_jobs_create(gnnmp_chain_jobs_t **out, const int64_t *
         by_room[(size_t)room[(size_t)j]].push_back(j);
     }
     const int njobs = (int)members.size();
-    std::vector<int32_t> rows((size_t)njobs * 64, -1), gid((size_t)njobs * 64, -1);
+    std::vector<int32_t> tab((size_t)njobs * 64, -1);
     int64_t tiles = 0;
     for (int j = 0; j < njobs; ++j) {
         std::sort(members[(size_t)j].begin(), members[(size_t)j].end());   // rows of a job in node order
         int s = 0;
         for (int32_t g : members[(size_t)j])
-            for (int64_t r = sp[(size_t)g]; r < sp[(size_t)g + 1]; ++r, ++s) {
-                rows[(size_t)j * 64 + (size_t)s] = (int32_t)r;
-                gid[(size_t)j * 64 + (size_t)s] = g;
-            }
+            for (int64_t r = sp[(size_t)g]; r < sp[(size_t)g + 1]; ++r, ++s) tab[(size_t)j * 64 + (size_t)s] = (int32_t)r;
         tiles += s > 32 ? 2 : 1;
     }
     J->njobs = njobs;
     J->fill = tiles > 0 ? (double)J->N / (32.0 * (double)tiles) : 0.0;
     if (njobs > 0) {
-        const size_t bytes = (size_t)njobs * 64 * sizeof(int32_t);
-        if (hipMalloc(&J->rows, bytes) != hipSuccess || hipMalloc(&J->gid, bytes) != hipSuccess) {
-            if (J->rows) (void)hipFree(J->rows);
-            delete J;
-            return fail(GNNMP_EALLOC, "chain_jobs_create: hipMalloc failed");
-        }
-        if (hipMalloc(&J->bad, sizeof(int32_t) * (size_t)(3 + 2 * njobs)) != hipSuccess) {
-            (void)hipFree(J->rows); (void)hipFree(J->gid);
-            delete J;
-            return fail(GNNMP_EALLOC, "chain_jobs_create: hipMalloc failed");
-        }
-        if (hipMalloc(&J->part, sizeof(float) * (size_t)2 * (size_t)G * 8) != hipSuccess) {
-            (void)hipFree(J->rows); (void)hipFree(J->gid); (void)hipFree(J->bad);
-            delete J;
+        const size_t bytes = tab.size() * sizeof(int32_t);
+        if (hipMalloc(&J->tab, bytes) != hipSuccess || hipMalloc(&J->bad, sizeof(int32_t) * (size_t)(3 + 4 * njobs)) != hipSuccess ||
+            hipMalloc(&J->zrows, sizeof(float) * (size_t)2 * (size_t)J->N * 8) != hipSuccess) {
+            (void)gnnmp_chain_jobs_destroy(J);
             return fail(GNNMP_EALLOC, "chain_jobs_create: hipMalloc failed");
         }
         GNNMP_HIP(hipMemsetAsync(J->bad, 0, 3 * sizeof(int32_t), stream));
-        GNNMP_HIP(hipMemcpyAsync(J->rows, rows.data(), bytes, hipMemcpyHostToDevice, stream));
-        GNNMP_HIP(hipMemcpyAsync(J->gid, gid.data(), bytes, hipMemcpyHostToDevice, stream));
+        GNNMP_HIP(hipMemcpyAsync(J->tab, tab.data(), bytes, hipMemcpyHostToDevice, stream));
         GNNMP_HIP(hipStreamSynchronize(stream));
     }
     *out = J;
@@ -511,10 +584,9 @@ extern "C" int gnnmp_chain_jobs_create(gnnmp_chain_jobs_t **out, const int64_t *
 
 extern "C" int gnnmp_chain_jobs_destroy(gnnmp_chain_jobs_t *J) {
     if (!J) return GNNMP_OK;
-    if (J->rows) (void)hipFree(J->rows);
-    if (J->gid) (void)hipFree(J->gid);
+    if (J->tab) (void)hipFree(J->tab);
     if (J->bad) (void)hipFree(J->bad);
-    if (J->part) (void)hipFree(J->part);
+    if (J->zrows) (void)hipFree(J->zrows);
     delete J;
     return GNNMP_OK;
 }
@@ -526,6 +598,15 @@ extern "C" int gnnmp_chain_jobs_info(const gnnmp_chain_jobs_t *J, int64_t *info)
     info[0] = J->njobs; info[1] = J->G; info[2] = J->N; info[3] = J->max_graph; info[4] = (int64_t)(J->fill * 1000.0 + 0.5);
     return GNNMP_OK;
 }
+
+#ifdef GNNMP_CHAIN_TRACE
+static long long *g_chain_trace = nullptr;
+extern "C" int gnnmp_chain_trace(long long *host) {     // 16 waves x 8 jobs x 8 stamps
+    if (!g_chain_trace) return 1;
+    (void)hipDeviceSynchronize();
+    return hipMemcpy(host, g_chain_trace, sizeof(long long) * 16 * 8 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 2;
+}
+#endif
 
 namespace gnnmp {
 // Returns GNNMP_OK if it launched, 1 if the chain / the batch is outside this kernel's envelope (graph_chain.hip's kernel runs).
@@ -540,8 +621,7 @@ int graph_chain2_try(gnnmp_graph_t *p, const gnnmp_chain_jobs_t *J, const int64_
     Chain2Args a = {};
     a.rowptr = p->rowptr;
     a.col = p->col;
-    a.job_rows = J->rows;
-    a.job_gid = J->gid;
+    a.job_rows = J->tab;
     a.njobs = J->njobs;
     a.seg_ptr = seg_ptr;
     a.x = x;
@@ -554,35 +634,36 @@ int graph_chain2_try(gnnmp_graph_t *p, const gnnmp_chain_jobs_t *J, const int64_
     a.mean_aggr = aggr == GNNMP_MEAN;
     a.pool_mean = pool_aggr == GNNMP_MEAN;
     a.out = out;
-    a.bad = J->bad;
-    a.part = J->part;
+    const unsigned parity = const_cast<gnnmp_chain_jobs_t *>(J)->calls++ & 1u;
+    a.bad_count = J->bad + parity;
+    a.bad_reset = J->bad + (parity ^ 1u);
+    a.bad_list = J->bad + 3;
+    a.zrows = J->zrows;
+    a.N = (int)J->N;
+#ifdef GNNMP_CHAIN_TRACE
+    if (!g_chain_trace) { (void)hipMalloc(&g_chain_trace, sizeof(long long) * 16 * 8 * 8); (void)hipMemset(g_chain_trace, 0, sizeof(long long) * 16 * 8 * 8); }
+    a.trace = g_chain_trace;
+#endif
     a.G = (int)G;
-    // knob 13 (experiments): low 2 bits = waves per block 0: 8, 1: 4 (512 VGPRs a wave), 2: 6; bit 2 = scheduling barriers around the A-operand reads
-    const int kv = knob(KNOB_T16_DEBUG);
-    const int waves = (kv & 3) == 1 ? 4 : ((kv & 3) == 2 ? 6 : 8);
-    const bool sb = (kv & 4) != 0;        // default: none (measured 191 -> 176 us at G = 8192: hipcc schedules the block better on its own)
+    // knob 13 (experiments): 1 = 8 waves a block (4 pairs, up to 256 registers a wave) instead of 12 (6 pairs, 168 registers)
+    const int waves = (knob(KNOB_T16_DEBUG) & 3) == 1 ? 8 : 12;
     const size_t lds = (size_t)3 * C2_UNITS1 * 16 + (size_t)3 * C2_UNITS2 * 16 + C2_D1 * 4 + C2_SLAB * 4 + 8 * C2_SLAB * 4 +
-                       (size_t)C2_MAX_WAVES * C2_STAGE_BYTES + 16;
+                       (size_t)(waves / 2) * C2_STAGE_BYTES + 4 * 2 * (size_t)waves;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipSuccess;
-#define C2_ATTR(T, S) if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&graph_chain2_kernel<T, S>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        C2_ATTR(512, true) C2_ATTR(512, false) C2_ATTR(256, true) C2_ATTR(256, false) C2_ATTR(384, true) C2_ATTR(384, false)
-#undef C2_ATTR
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&graph_chain2_kernel<768>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&graph_chain2_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(graph_chain2_kernel)");
         attr_set = true;
     }
     const int cus = device_cus();
-    const int gx = std::max(1, std::min(cus / 2, (a.njobs + waves - 1) / waves));
+    const int gx = std::max(1, std::min(cus / 2, (a.njobs + waves / 2 - 1) / (waves / 2)));     // one block a CU: half of them per slab
     const dim3 grid((unsigned)gx, 2);
-    if (waves == 8 && sb) graph_chain2_kernel<512, true><<<grid, 512, lds, stream>>>(a);
-    else if (waves == 8) graph_chain2_kernel<512, false><<<grid, 512, lds, stream>>>(a);
-    else if (waves == 4 && sb) graph_chain2_kernel<256, true><<<grid, 256, lds, stream>>>(a);
-    else if (waves == 4) graph_chain2_kernel<256, false><<<grid, 256, lds, stream>>>(a);
-    else if (sb) graph_chain2_kernel<384, true><<<grid, 384, lds, stream>>>(a);
-    else graph_chain2_kernel<384, false><<<grid, 384, lds, stream>>>(a);
+    if (waves == 12) graph_chain2_kernel<768><<<grid, 768, lds, stream>>>(a);
+    else graph_chain2_kernel<512><<<grid, 512, lds, stream>>>(a);
     GNNMP_LAUNCH_CHECK("graph_chain2_kernel");
-    graph_chain2_finish_kernel<<<1, 1024, 0, stream>>>(a);
+    graph_chain2_finish_kernel<<<(unsigned)((2 * G + 255) / 256), 256, 0, stream>>>(a);      // a lane per (member graph, slab)
     GNNMP_LAUNCH_CHECK("graph_chain2_finish_kernel");
     return GNNMP_OK;
 }

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
-"""graph_chain2_kernel launch variants (knob 13: low 2 bits = waves per block 0: 8, 1: 4, 2: 6; bit 2 = no scheduling barriers) and the
-arxiv-size dense product over waves per block (knob 12)."""
+"""graph_chain2_kernel launch variants (knob 13, read at gnnmp_chain_jobs_create and at launch): bit 3 = 32-row jobs (one MFMA tile a
+wave; low bits 0: 16 waves a block, 1: 12, 2: 8), else 64-row jobs (low bits 0: 8 waves, 1: 4, 2: 6); bit 2 = scheduling barriers.
+usage: chain_variants.py [G] [nmin] [nmax]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "graphneuralnetworks.jl_amd")):
@@ -21,24 +22,23 @@ def t(fn, it=50):
     return ts[len(ts) // 2]
 
 
-members = synth.batched_graphs(G=8192)
+G = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+nmin = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+nmax = int(sys.argv[3]) if len(sys.argv) > 3 else 40
+members = synth.batched_graphs(G=G, nmin=nmin, nmax=nmax)
 rng = np.random.default_rng(4)
 xs = [rng.standard_normal((n, 16), dtype=np.float32) for _, _, n in members]
-g = gnnmp.batch_arrays(members, xs)
 model = gnnmp.GNNChain(gnnmp.GraphConv((16, 128), "relu", seed=21), gnnmp.GraphConv((128, 128), "relu", seed=22),
                        gnnmp.GlobalPool("mean"), gnnmp.Dense((128, 2), seed=23))
-f = lambda: model(g, g.x)
-y0 = f()
-for kv in (0, 1, 2, 4, 5, 6):
+y0 = None
+variants = [int(v) for v in os.environ.get('VARIANTS', '3,0,1,2').split(',')]
+for kv in variants:
     gnnmp.tune(13, kv)
+    g = gnnmp.batch_arrays(members, xs)          # (a fresh graph: the jobs are built under this knob value)
+    f = lambda: model(g, g.x)
     y = f()
-    print(f"chain2 knob13={kv} (waves {[8,4,6][kv & 3]}, sched barriers {'off' if kv & 4 else 'on'}): {t(f)*1e3:7.1f} us  equal {bool(torch.equal(y, y0))}", flush=True)
+    if y0 is None:
+        y0 = y
+    cj = g._cache.get("chain_jobs"); info = (cj.njobs, cj.fill) if cj is not None else None
+    print(f"chain2 knob13={kv}: {t(f)*1e3:7.1f} us  max diff {float((y - y0).abs().max()):.1e}  jobs {info}", flush=True)
 gnnmp.tune(13, 0)
-for (N, K, Dout) in [(169343, 128, 128), (245246, 128, 128)]:
-    x = torch.randn((N, K), device="cuda"); W = torch.randn((Dout, K), device="cuda") * 0.1; b = torch.randn(Dout, device="cuda")
-    fd = lambda: gnnmp.dense(x, W, b, "relu")
-    row = [f"auto {t(fd)*1e3:6.1f}"]
-    for w in (4, 5, 6, 7, 8):
-        gnnmp.tune(12, w); row.append(f"w{w} {t(fd)*1e3:6.1f}")
-    gnnmp.tune(12, 0)
-    print(f"dense {N}x{K}=>{Dout}: " + "  ".join(row), flush=True)
