@@ -74,6 +74,31 @@ __device__ __forceinline__ void store_index(void *p, int64_t k, int idx_bytes, i
 // below fp32 epsilon of the weights that matter — for 2 instructions instead of libm's 12.  exp(-inf) = 0, NaN propagates.
 // Used by the one-pass attention kernel only: in its pullbacks (one exp per edge, not VALU-bound) the same substitution
 // measured 1.6 % SLOWER on the same box, and the reference-order softmax kernels keep expf for parity of the order.
+// Attention dropout (GNNlib/src/layers/conv.jl:139: α = dropout(α, l.dropout)): the keep decision of coefficient (edge e, head h) is a
+// pure function of (seed, e, h) — e = the edge's position in the caller's edge list, plan-added self loops at E + node like
+// add_self_loops appends them — so the forward, both backward passes and any host restatement of these few lines agree
+// without any stored mask.  Two rounds of the "lowbias32" integer mixer; kept when the 32 bits are >= floor(p * 2^32).
+__host__ __device__ __forceinline__ uint32_t drop_mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+__host__ __device__ __forceinline__ uint32_t drop_bits(uint32_t seed_lo, uint32_t seed_hi, uint32_t e, uint32_t h) {
+    return drop_mix32(drop_mix32(e ^ seed_lo) ^ (h * 0x9e3779b9u + seed_hi));
+}
+struct DropArgs {
+    uint32_t thr;        // floor(p * 2^32): keep when drop_bits >= thr
+    uint32_t seed_lo, seed_hi;
+    float inv;           // 1 / (1 - p)
+};
+__host__ __forceinline__ DropArgs make_drop(float p, uint64_t seed) {
+    DropArgs d;
+    const double t = (double)p * 4294967296.0;
+    d.thr = t >= 4294967295.0 ? 0xffffffffu : (uint32_t)t;
+    d.seed_lo = (uint32_t)seed;
+    d.seed_hi = (uint32_t)(seed >> 32);
+    d.inv = 1.0f / (1.0f - p);
+    return d;
+}
 __device__ __forceinline__ float softmax_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
 
 __device__ __forceinline__ float jl_max(float x, float y) {

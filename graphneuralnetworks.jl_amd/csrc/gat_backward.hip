@@ -41,6 +41,8 @@ struct GatBwdArgs {
     int fold_dst;         // add a_d * dsd_j into dWx_j (non-bipartite: Wx_dst is Wx_src)
     int H, C, D, log2g, lph, waves;
     float slope;
+    const int32_t *eid;   // DROP: plan slot -> original edge position (of the plan the running pass walks)
+    DropArgs drop;
 };
 
 __device__ __forceinline__ float lrelu_b(float x, float slope) { return x > 0.0f ? x : x * slope; }
@@ -72,7 +74,7 @@ __device__ __forceinline__ bool virtual_row(const GatBwdArgs &a, int &v, bool &i
     return true;
 }
 
-template <int VEC, int U, int LPH>
+template <int VEC, int U, int LPH, bool DROP>
 __global__ void __launch_bounds__(256) gat_bwd_dst_kernel(const GatBwdArgs a) {
     int v, row, lig, gbase, G;
     uint32_t beg, end;
@@ -109,13 +111,19 @@ __global__ void __launch_bounds__(256) gat_bwd_dst_kernel(const GatBwdArgs a) {
     for (uint32_t base = beg; base < end; base += G) {   // slots are unsigned 32-bit (csr_reduce.h)
         const uint32_t p = base + lig;
         const int c = p < end ? a.col[p] : 0;
+        const int ev = (DROP && p < end) ? a.eid[p] : 0;
         const int n = (int)min((uint32_t)G, end - base);
         for (int j = 0; j < n; j += U) {
             float w[U][VEC];
+            float kf[DROP ? U : 1];      // keep_ij / (1 - p) of conv.jl:139's dropout (common.h drop_bits): g_ij becomes kf g_ij
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int cj = __shfl(c, gbase + min(j + u, n - 1), 64);
                 Vec<VEC>::load(a.Wx_src + (int64_t)cj * a.D + fc, w[u]);
+                if (DROP) {
+                    const uint32_t ej = (uint32_t)__shfl(ev, gbase + min(j + u, n - 1), 64);
+                    kf[DROP ? u : 0] = drop_bits(a.drop.seed_lo, a.drop.seed_hi, ej, (uint32_t)h) >= a.drop.thr ? a.drop.inv : 0.0f;
+                }
             }
             float d[U], g[U];
 #pragma unroll
@@ -139,7 +147,7 @@ __global__ void __launch_bounds__(256) gat_bwd_dst_kernel(const GatBwdArgs a) {
                 float al = expf(lrelu_b(z, a.slope) - m) * rden;
                 al = (j + u < n) ? al : 0.0f;
                 const float s = z > 0.0f ? 1.0f : a.slope;
-                const float ag = al * g[u];
+                const float ag = DROP ? al * (kf[DROP ? u : 0] * g[u]) : al * g[u];
                 S1 += ag;
                 S2 = fmaf(ag, s, S2);
                 S3 = fmaf(al, s, S3);
@@ -198,7 +206,7 @@ __device__ __forceinline__ void gat_bwd_src_store(const GatBwdArgs &a, int row, 
     if ((f0 % a.C) == 0) a.dss[(int64_t)row * a.H + h] = dss;
 }
 
-template <int VEC, int U, int LPH>
+template <int VEC, int U, int LPH, bool DROP>
 __global__ void __launch_bounds__(256) gat_bwd_src_kernel(const GatBwdArgs a) {
     int v, row, lig, gbase, G;
     uint32_t beg, end;
@@ -231,15 +239,21 @@ __global__ void __launch_bounds__(256) gat_bwd_src_kernel(const GatBwdArgs a) {
     for (uint32_t base = beg; base < end; base += G) {   // slots are unsigned 32-bit (csr_reduce.h)
         const uint32_t p = base + lig;
         const int c = p < end ? a.col[p] : 0;
+        const int ev = (DROP && p < end) ? a.eid[p] : 0;
         const int n = (int)min((uint32_t)G, end - base);
         for (int j = 0; j < n; j += U) {
             float dv[U][VEC];
             float4 ln[U];
+            float kf[DROP ? U : 1];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int ci = __shfl(c, gbase + min(j + u, n - 1), 64);
                 Vec<VEC>::load(a.dout + (int64_t)ci * a.D + fc, dv[u]);
                 ln[u] = *reinterpret_cast<const float4 *>(a.line + ((int64_t)ci * a.H + h) * 4);
+                if (DROP) {    // (the transposed plan's slots carry the same original edge positions)
+                    const uint32_t ej = (uint32_t)__shfl(ev, gbase + min(j + u, n - 1), 64);
+                    kf[DROP ? u : 0] = drop_bits(a.drop.seed_lo, a.drop.seed_hi, ej, (uint32_t)h) >= a.drop.thr ? a.drop.inv : 0.0f;
+                }
             }
             float g[U];
 #pragma unroll
@@ -256,9 +270,11 @@ __global__ void __launch_bounds__(256) gat_bwd_src_kernel(const GatBwdArgs a) {
                 float al = expf(lrelu_b(z, a.slope) - ln[u].y) * ln[u].z;
                 al = (j + u < n) ? al : 0.0f;
                 const float s = z > 0.0f ? 1.0f : a.slope;
-                dss = fmaf(al * (g[u] - ln[u].w), s, dss);
+                const float gk = DROP ? kf[DROP ? u : 0] * g[u] : g[u];
+                dss = fmaf(al * (gk - ln[u].w), s, dss);
+                const float ak = DROP ? al * kf[DROP ? u : 0] : al;
 #pragma unroll
-                for (int q = 0; q < VEC; ++q) acc[q] = fmaf(al, dv[u][q], acc[q]);
+                for (int q = 0; q < VEC; ++q) acc[q] = fmaf(ak, dv[u][q], acc[q]);
             }
         }
     }
@@ -388,7 +404,7 @@ static void fill_plan(GatBwdArgs &g, const gnnmp_graph *p) {
     g.partial = p->ws;
 }
 
-template <int VEC, int LPH>
+template <int VEC, int LPH, bool DROP>
 static int launch_gat_bwd(GatBwdArgs g, gnnmp_graph *plan, gnnmp_graph *plan_t, float *dWx_dst, float *da,
                           hipStream_t stream) {
     const int G = 1 << g.log2g;
@@ -399,14 +415,15 @@ static int launch_gat_bwd(GatBwdArgs g, gnnmp_graph *plan, gnnmp_graph *plan_t, 
     const int unroll = knob(KNOB_UNROLL);
     // ---- pass 1: destinations (forward plan)
     fill_plan(g, plan);
+    g.eid = plan->eid;
     {
         const int64_t nvirt = (int64_t)g.n_rows + g.n_chunks;
         const int64_t blocks = (nvirt + (int64_t)rpw * waves - 1) / ((int64_t)rpw * waves);
         if (blocks > 0) {
             if (unroll == 4)
-                gat_bwd_dst_kernel<VEC, 4, LPH><<<(unsigned)blocks, 64 * waves, 0, stream>>>(g);
+                gat_bwd_dst_kernel<VEC, 4, LPH, DROP><<<(unsigned)blocks, 64 * waves, 0, stream>>>(g);
             else
-                gat_bwd_dst_kernel<VEC, 8, LPH><<<(unsigned)blocks, 64 * waves, 0, stream>>>(g);
+                gat_bwd_dst_kernel<VEC, 8, LPH, DROP><<<(unsigned)blocks, 64 * waves, 0, stream>>>(g);
             GNNMP_LAUNCH_CHECK("gat_bwd_dst_kernel");
         }
         if (g.n_long > 0) {
@@ -417,6 +434,7 @@ static int launch_gat_bwd(GatBwdArgs g, gnnmp_graph *plan, gnnmp_graph *plan_t, 
     }
     // ---- pass 2: sources (transposed plan)
     fill_plan(g, plan_t);
+    g.eid = plan_t->eid;
     {
         const int64_t nvirt = (int64_t)g.n_rows + g.n_chunks;
         const int64_t blocks = (nvirt + (int64_t)rpw * waves - 1) / ((int64_t)rpw * waves);
@@ -424,9 +442,9 @@ static int launch_gat_bwd(GatBwdArgs g, gnnmp_graph *plan, gnnmp_graph *plan_t, 
             // 20 bytes of operands per lane and edge here (Δ slice + the statistics line): 4 in flight keeps 6 waves/SIMD
             // (7.0 ms on the products shape against 8.4 ms with 8 in flight at 4 waves/SIMD)
             if (unroll == 8)
-                gat_bwd_src_kernel<VEC, 8, LPH><<<(unsigned)blocks, 64 * waves, 0, stream>>>(g);
+                gat_bwd_src_kernel<VEC, 8, LPH, DROP><<<(unsigned)blocks, 64 * waves, 0, stream>>>(g);
             else
-                gat_bwd_src_kernel<VEC, 4, LPH><<<(unsigned)blocks, 64 * waves, 0, stream>>>(g);
+                gat_bwd_src_kernel<VEC, 4, LPH, DROP><<<(unsigned)blocks, 64 * waves, 0, stream>>>(g);
             GNNMP_LAUNCH_CHECK("gat_bwd_src_kernel");
         }
         if (g.n_long > 0) {
@@ -464,11 +482,12 @@ static int launch_gat_bwd(GatBwdArgs g, gnnmp_graph *plan, gnnmp_graph *plan_t, 
 
 using namespace gnnmp;
 
-extern "C" int gnnmp_gat_conv_grad_f32(gnnmp_graph_t *plan, gnnmp_graph_t *plan_t, const float *Wx_src,
-                                       const float *Wx_dst, const float *a, float negative_slope, const float *stats,
-                                       const float *dout, float *line, float *dsd, float *dss, float *dWx_src,
-                                       float *dWx_dst, float *da, int64_t H, int64_t C, gnnmp_stream_t stream_) {
+static int gat_conv_grad_impl(gnnmp_graph_t *plan, gnnmp_graph_t *plan_t, const float *Wx_src,
+                              const float *Wx_dst, const float *a, float negative_slope, float drop_p, uint64_t drop_seed,
+                              const float *stats, const float *dout, float *line, float *dsd, float *dss, float *dWx_src,
+                              float *dWx_dst, float *da, int64_t H, int64_t C, gnnmp_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    if (!(drop_p >= 0.0f && drop_p < 1.0f)) return fail(GNNMP_EINVAL, "gat_conv_grad: dropout probability %g outside [0, 1)", (double)drop_p);
     if (!plan || !plan_t) return fail(GNNMP_EINVAL, "gat_conv_grad: null plan");
     if (H <= 0 || C <= 0 || H * C > (1 << 20)) return fail(GNNMP_EINVAL, "gat_conv_grad: bad H/C");
     if (plan_t->n_dst != plan->n_src || plan_t->n_src != plan->n_dst || plan_t->n_total != plan->n_total)
@@ -521,16 +540,39 @@ extern "C" int gnnmp_gat_conv_grad_f32(gnnmp_graph_t *plan, gnnmp_graph_t *plan_
     g.lph = lph_code(lph, g.log2g);   // odd head widths sum their lanes one by one (common.h group_sum<0>)
     g.waves = 1;
     g.slope = negative_slope;
+    g.eid = nullptr;
+    g.drop = make_drop(drop_p, drop_seed);
+    if (drop_p > 0.0f) {   // the dropout variants walk the head butterfly with the run-time lane count (one instantiation per width)
+        if (vec == 4) return launch_gat_bwd<4, 0, true>(g, plan, plan_t, dWx_dst, da, stream);
+        if (vec == 2) return launch_gat_bwd<2, 0, true>(g, plan, plan_t, dWx_dst, da, stream);
+        return launch_gat_bwd<1, 0, true>(g, plan, plan_t, dWx_dst, da, stream);
+    }
     if (vec == 4) {   // the usual case (C a multiple of 4): compile-time lane count per head -> DPP butterflies
         switch (lph) {
-            case 1: return launch_gat_bwd<4, 1>(g, plan, plan_t, dWx_dst, da, stream);
-            case 2: return launch_gat_bwd<4, 2>(g, plan, plan_t, dWx_dst, da, stream);
-            case 4: return launch_gat_bwd<4, 4>(g, plan, plan_t, dWx_dst, da, stream);
-            case 8: return launch_gat_bwd<4, 8>(g, plan, plan_t, dWx_dst, da, stream);
-            case 16: return launch_gat_bwd<4, 16>(g, plan, plan_t, dWx_dst, da, stream);
-            default: return launch_gat_bwd<4, 0>(g, plan, plan_t, dWx_dst, da, stream);
+            case 1: return launch_gat_bwd<4, 1, false>(g, plan, plan_t, dWx_dst, da, stream);
+            case 2: return launch_gat_bwd<4, 2, false>(g, plan, plan_t, dWx_dst, da, stream);
+            case 4: return launch_gat_bwd<4, 4, false>(g, plan, plan_t, dWx_dst, da, stream);
+            case 8: return launch_gat_bwd<4, 8, false>(g, plan, plan_t, dWx_dst, da, stream);
+            case 16: return launch_gat_bwd<4, 16, false>(g, plan, plan_t, dWx_dst, da, stream);
+            default: return launch_gat_bwd<4, 0, false>(g, plan, plan_t, dWx_dst, da, stream);
         }
     }
-    if (vec == 2) return launch_gat_bwd<2, 0>(g, plan, plan_t, dWx_dst, da, stream);
-    return launch_gat_bwd<1, 0>(g, plan, plan_t, dWx_dst, da, stream);
+    if (vec == 2) return launch_gat_bwd<2, 0, false>(g, plan, plan_t, dWx_dst, da, stream);
+    return launch_gat_bwd<1, 0, false>(g, plan, plan_t, dWx_dst, da, stream);
+}
+
+extern "C" int gnnmp_gat_conv_grad_f32(gnnmp_graph_t *plan, gnnmp_graph_t *plan_t, const float *Wx_src,
+                                       const float *Wx_dst, const float *a, float negative_slope, const float *stats,
+                                       const float *dout, float *line, float *dsd, float *dss, float *dWx_src,
+                                       float *dWx_dst, float *da, int64_t H, int64_t C, gnnmp_stream_t stream) {
+    return gat_conv_grad_impl(plan, plan_t, Wx_src, Wx_dst, a, negative_slope, 0.0f, 0, stats, dout, line, dsd, dss, dWx_src, dWx_dst,
+                              da, H, C, stream);
+}
+extern "C" int gnnmp_gat_conv_grad_drop_f32(gnnmp_graph_t *plan, gnnmp_graph_t *plan_t, const float *Wx_src,
+                                            const float *Wx_dst, const float *a, float negative_slope, float p, uint64_t seed,
+                                            const float *stats, const float *dout, float *line, float *dsd, float *dss,
+                                            float *dWx_src, float *dWx_dst, float *da, int64_t H, int64_t C,
+                                            gnnmp_stream_t stream) {
+    return gat_conv_grad_impl(plan, plan_t, Wx_src, Wx_dst, a, negative_slope, p, seed, stats, dout, line, dsd, dss, dWx_src, dWx_dst,
+                              da, H, C, stream);
 }

@@ -59,12 +59,17 @@ struct GatFusedArgs {
     int cpx;
     int nbc;              // leading blocks (chunk virtual rows) that are not remapped
     int waves;
+    DropArgs drop;        // ATTN_GAT_DROP only
 };
 
 // internal fifth mode: GAT with the per-edge logit term (gnnmp_gat_conv_edge_f32) — a compile-time property, so the headline
 // kernel carries no trace of it (as a runtime flag both logit variants were computed and selected per edge)
 constexpr int ATTN_GAT_EDGE = 4;
-__host__ __device__ constexpr bool is_gat(int mode) { return mode == GNNMP_ATTN_GAT || mode == ATTN_GAT_EDGE; }
+// internal sixth mode: GAT with dropout on the attention coefficients (conv.jl:139; gnnmp_gat_conv_drop_f32): the numerator takes
+// keep_ij / (1 - p) * exp(l_ij - m), the denominator and the saved statistics are those of the undropped softmax
+constexpr int ATTN_GAT_DROP = 5;
+__host__ __device__ constexpr bool is_gat(int mode) { return mode == GNNMP_ATTN_GAT || mode == ATTN_GAT_EDGE || mode == ATTN_GAT_DROP; }
+__host__ __device__ constexpr bool needs_eid(int mode) { return mode == ATTN_GAT_EDGE || mode == ATTN_GAT_DROP; }
 
 __device__ __forceinline__ float lrelu(float x, float slope) { return x > 0.0f ? x : x * slope; }
 // softmax_exp (common.h): PMC showed this kernel at 84 % VALU utilisation with 9 libm exponentials per batch of 8 edges a
@@ -115,6 +120,15 @@ __device__ __forceinline__ void gat_batch(const GatFusedArgs &a, int c, int ev, 
             es[u] = a.escore[(int64_t)ej * a.H + r.h];
         }
     }
+    constexpr bool drop = MODE == ATTN_GAT_DROP;
+    float kf[drop ? U : 1];      // keep_ij / (1 - p)
+    if (drop) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t ej = (uint32_t)__shfl(ev, gbase + min(j + u, n - 1), 64);
+            kf[drop ? u : 0] = drop_bits(a.drop.seed_lo, a.drop.seed_hi, ej, (uint32_t)r.h) >= a.drop.thr ? a.drop.inv : 0.0f;
+        }
+    }
     float l[U], nn[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -155,9 +169,10 @@ __device__ __forceinline__ void gat_batch(const GatFusedArgs &a, int c, int ev, 
     for (int u = 0; u < U; ++u) {
         const float pe = gexp(l[u] - m);
         den += pe;
+        const float pw = drop ? pe * kf[drop ? u : 0] : pe;
 #pragma unroll
         for (int q = 0; q < VEC; ++q)
-            acc[q] = fmaf(pe, MODE == GNNMP_ATTN_DOT ? w[MODE == GNNMP_ATTN_DOT ? u : 0][q] : v[u][q], acc[q]);
+            acc[q] = fmaf(pw, MODE == GNNMP_ATTN_DOT ? w[MODE == GNNMP_ATTN_DOT ? u : 0][q] : v[u][q], acc[q]);
     }
 }
 
@@ -173,8 +188,7 @@ __device__ __forceinline__ void gat_online_range(const GatFusedArgs &a, uint32_t
         const int c = p < end ? a.col[p] : 0;
         // edge features (gat_conv with dense_e): the edge's share of the logit, a_e . We_k, precomputed per edge and head,
         // is fetched by original edge position (uniform branch: absent for the headline layer)
-        constexpr bool edge_term = MODE == ATTN_GAT_EDGE;
-        const int ev = (edge_term && p < end) ? a.eid[p] : 0;
+        const int ev = (needs_eid(MODE) && p < end) ? a.eid[p] : 0;
         const int n = (int)min((uint32_t)G, end - base);
         int j = 0;
         for (; j + U <= n; j += U) gat_batch<VEC, U, LPH, MODE, OFF24>(a, c, ev, gbase, j, n, fc, r, m, den, acc);
@@ -468,9 +482,13 @@ using namespace gnnmp;
 
 static int attn_conv_impl(gnnmp_graph_t *plan, int mode, const float *Q, const float *K, const float *V, const float *a,
                           float negative_slope, float scale, const float *bias, int act, float *out, float *stats,
-                          int64_t H, int64_t C, gnnmp_stream_t stream_, const float *escore = nullptr) {
+                          int64_t H, int64_t C, gnnmp_stream_t stream_, const float *escore = nullptr, float drop_p = 0.0f,
+                          uint64_t drop_seed = 0) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!plan) return fail(GNNMP_EINVAL, "attn_conv: null plan");
+    if (!(drop_p >= 0.0f && drop_p < 1.0f)) return fail(GNNMP_EINVAL, "gat_conv: dropout probability %g outside [0, 1)", (double)drop_p);
+    if (drop_p > 0.0f && (mode != GNNMP_ATTN_GAT || escore))
+        return fail(GNNMP_EUNSUPPORTED, "attention dropout: only on the GAT logit without edge features");
     if (escore && plan->self_loops)
         return fail(GNNMP_EINVAL, "gat_conv: edge features and add_self_loops cannot be combined (GNNlib/src/layers/conv.jl:120)");
     if (mode < GNNMP_ATTN_GAT || mode > GNNMP_ATTN_COS) return fail(GNNMP_EINVAL, "attn_conv: bad mode %d", mode);
@@ -494,7 +512,7 @@ static int attn_conv_impl(gnnmp_graph_t *plan, int mode, const float *Q, const f
     while ((1 << log2g) < lanes) ++log2g;   // one feature tile: the head butterfly needs the whole row in one group
     if (H == 1 && lanes <= 64) lph = 1 << log2g;   // a single head may spill over idle lanes: they carry zeros
     if (lanes > 64) {
-        if (mode != GNNMP_ATTN_GAT || stats || escore)
+        if (mode != GNNMP_ATTN_GAT || stats || escore || drop_p > 0.0f)
             return fail(GNNMP_EUNSUPPORTED,
                         "attn_conv: the one-pass kernel needs a feature row that fits one wave (H*C = %lld lanes %d > 64)",
                         (long long)(H * C), lanes);
@@ -549,6 +567,8 @@ static int attn_conv_impl(gnnmp_graph_t *plan, int mode, const float *Q, const f
     g.nbc = 0;
     g.waves = 4;
     g.off24 = plan->n_src < (1 << 24) && D < (1 << 24) && (int64_t)plan->n_src * D < (1ll << 32);
+    g.drop = make_drop(drop_p, drop_seed);
+    if (drop_p > 0.0f) return launch_mode<ATTN_GAT_DROP>(g, vec, stream);
     switch (mode) {
         case GNNMP_ATTN_GATV2: return launch_mode<GNNMP_ATTN_GATV2>(g, vec, stream);
         case GNNMP_ATTN_DOT: return launch_mode<GNNMP_ATTN_DOT>(g, vec, stream);
@@ -576,6 +596,29 @@ extern "C" int gnnmp_gat_conv_edge_f32(gnnmp_graph_t *plan, const float *Wx_src,
     if (!edge_score && plan && plan->n_edges > 0) return fail(GNNMP_EINVAL, "gat_conv_edge: null edge_score");
     return attn_conv_impl(plan, GNNMP_ATTN_GAT, Wx_dst, Wx_src, nullptr, a, negative_slope, 1.0f, bias, act, out, nullptr,
                           H, C, stream, edge_score);
+}
+extern "C" int gnnmp_gat_conv_drop_f32(gnnmp_graph_t *plan, const float *Wx_src, const float *Wx_dst, const float *a,
+                                       float negative_slope, float p, uint64_t seed, const float *bias, int act, float *out,
+                                       float *stats, int64_t H, int64_t C, gnnmp_stream_t stream) {
+    return attn_conv_impl(plan, GNNMP_ATTN_GAT, Wx_dst, Wx_src, nullptr, a, negative_slope, 1.0f, bias, act, out, stats, H, C,
+                          stream, nullptr, p, seed);
+}
+
+__global__ void __launch_bounds__(256) dropout_keep_kernel(DropArgs d, int64_t n, int H, uint8_t *keep) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * H) return;
+    const int64_t e = i / H;
+    keep[i] = drop_bits(d.seed_lo, d.seed_hi, (uint32_t)e, (uint32_t)(i - e * H)) >= d.thr ? 1 : 0;
+}
+extern "C" int gnnmp_dropout_keep_u8(uint64_t seed, float p, int64_t n_edges, int64_t H, uint8_t *keep, gnnmp_stream_t stream_) {
+    if (!(p >= 0.0f && p < 1.0f)) return fail(GNNMP_EINVAL, "dropout_keep: probability %g outside [0, 1)", (double)p);
+    if (n_edges < 0 || H <= 0 || n_edges >= ((int64_t)1 << 32)) return fail(GNNMP_EINVAL, "dropout_keep: bad size");
+    if (n_edges == 0) return GNNMP_OK;
+    if (!keep) return fail(GNNMP_EINVAL, "dropout_keep: null pointer");
+    const int64_t n = n_edges * H;
+    dropout_keep_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream_>>>(make_drop(p, seed), n_edges, (int)H, keep);
+    GNNMP_LAUNCH_CHECK("dropout_keep_kernel");
+    return GNNMP_OK;
 }
 extern "C" int gnnmp_attn_conv_f32(gnnmp_graph_t *plan, int mode, const float *Q, const float *K, const float *V,
                                    const float *a, float negative_slope, float scale, const float *bias, int act,

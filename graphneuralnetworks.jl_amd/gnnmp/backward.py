@@ -314,7 +314,7 @@ class _GATConvFn(torch.autograd.Function):
     (csrc/gat_backward.hip) + the dense adjoints."""
 
     @staticmethod
-    def forward(ctx, x, weight, a, bias, g, sigma, heads, slope, add_self_loops, concat=True):
+    def forward(ctx, x, weight, a, bias, g, sigma, heads, slope, add_self_loops, concat=True, p_drop=0.0, seed=0):
         from .layers import dense
         lib = L.load()
         plan = g.plan(add_self_loops)
@@ -327,9 +327,14 @@ class _GATConvFn(torch.autograd.Function):
         out = torch.empty((N, H * C), dtype=torch.float32, device=x.device)
         stats = torch.empty((N, H, 2), dtype=torch.float32, device=x.device)
         # concat = false: the heads are averaged BEFORE bias and σ (conv.jl:143-147), so the kernel's fused tail is off
-        L.check(lib.gnnmp_gat_conv_stats_f32(plan.handle, L.ptr(Wx), None, L.ptr(a_hc), float(slope),
-                                             L.ptr(bias) if concat else None, _act_code(sigma) if concat else L.ACT_IDENTITY,
-                                             L.ptr(out), L.ptr(stats), H, C, L.stream_ptr()))
+        if p_drop > 0.0:       # α = dropout(α, l.dropout) (conv.jl:139) inside the kernel; the mask is a function of (seed, edge, head)
+            L.check(lib.gnnmp_gat_conv_drop_f32(plan.handle, L.ptr(Wx), None, L.ptr(a_hc), float(slope), float(p_drop), int(seed),
+                                                L.ptr(bias) if concat else None, _act_code(sigma) if concat else L.ACT_IDENTITY,
+                                                L.ptr(out), L.ptr(stats), H, C, L.stream_ptr()))
+        else:
+            L.check(lib.gnnmp_gat_conv_stats_f32(plan.handle, L.ptr(Wx), None, L.ptr(a_hc), float(slope),
+                                                 L.ptr(bias) if concat else None, _act_code(sigma) if concat else L.ACT_IDENTITY,
+                                                 L.ptr(out), L.ptr(stats), H, C, L.stream_ptr()))
         if not concat:
             y = torch.empty((N, C), dtype=torch.float32, device=x.device)
             L.check(lib.gnnmp_head_mean_f32(L.ptr(out), L.ptr(bias), _act_code(sigma), L.ptr(y), N, H, C, L.stream_ptr()))
@@ -337,6 +342,7 @@ class _GATConvFn(torch.autograd.Function):
         ctx.save_for_backward(x, weight, Wx, a_hc, stats, out)
         ctx.g, ctx.sigma, ctx.H, ctx.C, ctx.slope, ctx.loops, ctx.has_bias = g, sigma, H, C, slope, add_self_loops, bias is not None
         ctx.concat = concat
+        ctx.p_drop, ctx.seed = float(p_drop), int(seed)
         return out
 
     @staticmethod
@@ -360,18 +366,29 @@ class _GATConvFn(torch.autograd.Function):
         dss = torch.empty((N, H), **f32)
         dWx = torch.empty((N, H * C), **f32)
         da_hc = torch.empty((H, 2 * C), **f32)
-        L.check(lib.gnnmp_gat_conv_grad_f32(plan.handle, plan_t.handle, L.ptr(Wx), None, L.ptr(a_hc), float(ctx.slope),
-                                            L.ptr(stats), L.ptr(dz), L.ptr(line), L.ptr(dsd), L.ptr(dss), L.ptr(dWx), None,
-                                            L.ptr(da_hc), H, C, L.stream_ptr()))
+        if ctx.p_drop > 0.0:
+            L.check(lib.gnnmp_gat_conv_grad_drop_f32(plan.handle, plan_t.handle, L.ptr(Wx), None, L.ptr(a_hc), float(ctx.slope),
+                                                     ctx.p_drop, ctx.seed, L.ptr(stats), L.ptr(dz), L.ptr(line), L.ptr(dsd),
+                                                     L.ptr(dss), L.ptr(dWx), None, L.ptr(da_hc), H, C, L.stream_ptr()))
+        else:
+            L.check(lib.gnnmp_gat_conv_grad_f32(plan.handle, plan_t.handle, L.ptr(Wx), None, L.ptr(a_hc), float(ctx.slope),
+                                                L.ptr(stats), L.ptr(dz), L.ptr(line), L.ptr(dsd), L.ptr(dss), L.ptr(dWx), None,
+                                                L.ptr(da_hc), H, C, L.stream_ptr()))
         dW = dense_grad_w(dWx, x, need_b=False)[0] if ctx.needs_input_grad[1] else None
         dx = dense_grad_x(dWx, weight) if ctx.needs_input_grad[0] else None
-        return dx, dW, da_hc.t(), db, None, None, None, None, None, None
+        return dx, dW, da_hc.t(), db, None, None, None, None, None, None, None, None
 
 
-def gat_conv_ad(l, g: GNNGraph, x):
+def gat_conv_ad(l, g: GNNGraph, x, seed=None):
     """differentiable GATConv forward (no edge features; concat = true or false): gradients w.r.t. x, l.dense_x_weight,
-    l.a, l.bias"""
+    l.a, l.bias.  l.dropout > 0: the attention coefficients are dropped (conv.jl:139) with the mask of `seed` (default: the layer's
+    next seed), in the forward and — recomputed, never stored — in the pullback."""
     check_num_nodes(g, x)
     assert getattr(l, "dense_e_weight", None) is None, "the HIP adjoint does not cover edge features"
+    p_drop = float(getattr(l, "dropout", 0.0))
+    if p_drop > 0.0:
+        if seed is None:
+            seed = l.next_seed()
+        l.last_seed = int(seed)
     return _GATConvFn.apply(x, l.dense_x_weight, l.a, l.bias, g, l.sigma, l.heads, l.negative_slope,
-                            bool(l.add_self_loops), bool(l.concat))
+                            bool(l.add_self_loops), bool(l.concat), p_drop, 0 if seed is None else int(seed))

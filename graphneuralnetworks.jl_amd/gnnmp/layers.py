@@ -15,6 +15,8 @@ from __future__ import annotations
 
 import math
 
+import numpy as np
+
 import torch
 
 from . import _lib as L
@@ -297,9 +299,18 @@ class SAGEConv:
 # ---------------------------------------------------------------------------------------------------------
 # GATConv
 # ---------------------------------------------------------------------------------------------------------
-def gat_conv(l, g: GNNGraph, x, e=None, return_alpha=False, exact_order=False):
+def dropout_keep(seed, p, n_edges, heads, device="cuda"):
+    """keep[e][h] in {0, 1} of the attention dropout (include/gnnmp.h: gnnmp_gat_conv_drop_f32): the mask the kernels recompute from
+    (seed, e, h), e = 0-based edge position with plan-added self loops at E + node"""
+    keep = torch.empty((n_edges, heads), dtype=torch.uint8, device=device)
+    L.check(L.load().gnnmp_dropout_keep_u8(int(seed), float(p), n_edges, heads, L.ptr(keep), L.stream_ptr()))
+    return keep
+
+
+def gat_conv(l, g: GNNGraph, x, e=None, return_alpha=False, exact_order=False, seed=None):
     """GNNlib/src/layers/conv.jl:112-167 (no edge features: dense_e === nothing).  dense_x GEMM -> node scores ->
-    one fused edge-softmax + weighted aggregate over the (self-looped) plan."""
+    one fused edge-softmax + weighted aggregate over the (self-looped) plan.  l.dropout > 0: `α = dropout(α, l.dropout)` (conv.jl:139)
+    inside the same kernel; `seed` (default: the layer's next seed, see GATConv.next_seed) defines the mask."""
     check_num_nodes(g, x)
     dense_e = getattr(l, "dense_e_weight", None)
     assert not (e is None and dense_e is not None), "Input edge features required for this layer"
@@ -319,7 +330,16 @@ def gat_conv(l, g: GNNGraph, x, e=None, return_alpha=False, exact_order=False):
     fuse_tail = bool(l.concat)
     b = l.bias if (fuse_tail and l.bias is not None) else None
     alpha = None
-    if e is not None:
+    p_drop = float(getattr(l, "dropout", 0.0))
+    if p_drop > 0.0:
+        # like the reference, the layer function drops whenever l.dropout > 0 (NNlib.dropout has no test mode of its own)
+        assert e is None and not (return_alpha or exact_order), "attention dropout: one-pass kernel only (no edge features / alpha output)"
+        if seed is None:
+            seed = l.next_seed()
+        l.last_seed = int(seed)
+        L.check(lib.gnnmp_gat_conv_drop_f32(plan.handle, L.ptr(Wx), None, L.ptr(a_hc), float(l.negative_slope), p_drop, int(seed),
+                                            L.ptr(b), code if fuse_tail else L.ACT_IDENTITY, L.ptr(out), None, H, C, L.stream_ptr()))
+    elif e is not None:
         # edge features (conv.jl:152-167): We = dense_e(e); the edge's share of the logit a[2C:3C, h] . We_k[:, h] is one
         # scalar per edge and head, added inside the one-pass kernel
         assert not (return_alpha or exact_order), "alpha output / reference order: not with edge features"
@@ -364,9 +384,13 @@ class GATConv:
         ein = 0
         if isinstance(cin, tuple):                         # GATConv((in, ein) => out, ...): edge features of size ein
             cin, ein = cin
-        assert dropout == 0.0, "dropout is identity in the forward/test mode this engine covers"
+        assert 0.0 <= dropout < 1.0
+        assert dropout == 0.0 or ein == 0, "attention dropout with edge features is not covered"
         if add_self_loops:
             assert ein == 0, "Using edge features and setting add_self_loops=true at the same time is not yet supported."
+        self.dropout = float(dropout)
+        self.last_seed = None
+        self._seed_rng = np.random.default_rng(None if seed is None else seed + 7)
         self.channel = (cin, cout)
         self.heads = heads
         self.concat = concat
@@ -398,6 +422,10 @@ class GATConv:
     def a_edge_hc(self):
         self.a_hc
         return self._a_edge_hc
+
+    def next_seed(self):
+        """a fresh 64-bit mask seed per call (the reference draws a fresh mask from its default RNG on every call)"""
+        return int(self._seed_rng.integers(0, 2**63 - 1))
 
     def __call__(self, g, x, e=None):
         return gat_conv(self, g, x, e)

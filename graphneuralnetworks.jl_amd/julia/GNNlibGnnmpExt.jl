@@ -424,13 +424,57 @@ function ChainRulesCore.rrule(::typeof(gat_attention), g::GNNGraph{<:COO_T}, Wx:
     return out, gat_attention_pullback
 end
 
+# `α = dropout(α, l.dropout)` (conv.jl:139) inside the same kernel: the coefficients are dropped where the weighted sum is formed, the
+# mask is a function of (seed, edge position, head) that forward and pullback both evaluate (gnnmp.h: gnnmp_gat_conv_drop_f32) — no
+# (H, E') mask or α array exists.  The seed comes from Julia's default RNG, a fresh one per call, like the reference's mask.
+attention_seed() = rand(UInt64)
+@non_differentiable attention_seed()
+function gat_attention_drop(g::GNNGraph{<:COO_T}, Wx::AnyROCMatrix{Float32}, a::ROCMatrix{Float32}, slope::Float32,
+                            heads::Int, self_loops::Bool, p::Float32, seed::UInt64)
+    out, _ = gat_attention_drop_stats(g, Wx, a, slope, heads, self_loops, p, seed, false)
+    return out
+end
+function gat_attention_drop_stats(g, Wx, a, slope, heads, self_loops, p, seed, want_stats)
+    chout = size(Wx, 1) ÷ heads
+    out = similar(Wx)
+    stats = want_stats ? similar(Wx, 2, heads, g.num_nodes) : nothing
+    check(@ccall libgnnmp.gnnmp_gat_conv_drop_f32(plan(g; self_loops).handle::Ptr{Cvoid}, devptr(Wx)::Ptr{Cvoid}, C_NULL::Ptr{Cvoid},
+              devptr(a)::Ptr{Cvoid}, slope::Cfloat, p::Cfloat, seed::UInt64, C_NULL::Ptr{Cvoid}, 0::Cint, devptr(out)::Ptr{Cvoid},
+              devptr(stats)::Ptr{Cvoid}, heads::Int64, chout::Int64, stream_ptr()::Ptr{Cvoid})::Cint)
+    return out, stats
+end
+function ChainRulesCore.rrule(::typeof(gat_attention_drop), g::GNNGraph{<:COO_T}, Wx::AnyROCMatrix{Float32},
+                              a::ROCMatrix{Float32}, slope::Float32, heads::Int, self_loops::Bool, p::Float32, seed::UInt64)
+    out, stats = gat_attention_drop_stats(g, Wx, a, slope, heads, self_loops, p, seed, true)
+    function gat_attention_drop_pullback(Δ̄)
+        Δ = convert(typeof(out), unthunk(Δ̄))
+        chout = size(Wx, 1) ÷ heads
+        N = g.num_nodes
+        ΔWx, Δa = similar(Wx), similar(a)
+        line = similar(Wx, 4, heads, N)
+        dsd, dss = similar(Wx, heads, N), similar(Wx, heads, N)
+        check(@ccall libgnnmp.gnnmp_gat_conv_grad_drop_f32(plan(g; self_loops).handle::Ptr{Cvoid},
+                  plan(g; self_loops, transposed = true).handle::Ptr{Cvoid}, devptr(Wx)::Ptr{Cvoid}, C_NULL::Ptr{Cvoid},
+                  devptr(a)::Ptr{Cvoid}, slope::Cfloat, p::Cfloat, seed::UInt64, devptr(stats)::Ptr{Cvoid}, devptr(Δ)::Ptr{Cvoid},
+                  devptr(line)::Ptr{Cvoid}, devptr(dsd)::Ptr{Cvoid}, devptr(dss)::Ptr{Cvoid}, devptr(ΔWx)::Ptr{Cvoid},
+                  C_NULL::Ptr{Cvoid}, devptr(Δa)::Ptr{Cvoid}, heads::Int64, chout::Int64, stream_ptr()::Ptr{Cvoid})::Cint)
+        return NoTangent(), NoTangent(), ΔWx, Δa, NoTangent(), NoTangent(), NoTangent(), NoTangent(), NoTangent()
+    end
+    return out, gat_attention_drop_pullback
+end
+
 function GNNlib.gat_conv(l, g::GNNGraph{<:COO_T}, x::AnyROCMatrix{Float32}, e::Nothing = nothing)
     check_num_nodes(g, x)
     @assert l.dense_e === nothing "Input edge features required for this layer"
-    l.dropout == 0 || return invoke(GNNlib.gat_conv, Tuple{Any, GNNlib.AbstractGNNGraph, Any, Nothing}, l, g, x, e)
     _, chout = l.channel
     Wx = l.dense_x(x)                                              # (C*H, N)
-    y = gat_attention(g, Wx, l.a, Float32(l.negative_slope), l.heads, l.add_self_loops)
+    if l.dropout > 0
+        (l.heads * chout) ÷ (chout % 4 == 0 ? 4 : (chout % 2 == 0 ? 2 : 1)) <= 64 ||    # rows wider than a wave: the generic path
+            return invoke(GNNlib.gat_conv, Tuple{Any, GNNlib.AbstractGNNGraph, Any, Nothing}, l, g, x, e)
+        y = gat_attention_drop(g, Wx, l.a, Float32(l.negative_slope), l.heads, l.add_self_loops, Float32(l.dropout), attention_seed())
+    else
+        y = gat_attention(g, Wx, l.a, Float32(l.negative_slope), l.heads, l.add_self_loops)
+    end
     if !l.concat
         y = reshape(mean(reshape(y, chout, l.heads, :), dims = 2), chout, :)
     end

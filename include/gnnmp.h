@@ -349,6 +349,23 @@ int gnnmp_gat_conv_stats_f32(gnnmp_graph_t *plan, const float *Wx_src, const flo
                              float negative_slope, const float *bias, int act, float *out, float *stats,
                              int64_t H, int64_t C, gnnmp_stream_t stream);
 
+/* Dropout on the attention coefficients — GNNlib/src/layers/conv.jl:139 `α = dropout(α, l.dropout)` (NNlib.dropout: every
+ * coefficient kept with probability 1 - p and scaled by 1 / (1 - p); the reference applies it whenever l.dropout > 0).  Inside the
+ * one-pass kernel: out_i = Σ_j keep_ij / (1 - p) α_ij Wx_j with α the UNdropped softmax, so the saved statistics (stats, nullable) are
+ * those of gnnmp_gat_conv_stats_f32.  No mask is stored: keep_ij[h] is a pure function of (seed, e, h) that the forward, both
+ * backward passes and a host restatement share —
+ *     mix(x):  x ^= x >> 16; x *= 0x7feb352d; x ^= x >> 15; x *= 0x846ca68b; x ^= x >> 16     (32-bit, wrapping)
+ *     keep  =  mix( mix(e ^ lo32(seed)) ^ (h * 0x9e3779b9 + hi32(seed)) )  >=  floor(p * 2^32)
+ * with e = the edge's 0-based position in the caller's edge list (plan-added self loops: E + node, the order add_self_loops appends
+ * them in) and h the 0-based head.  0 <= p < 1; p = 0 is gnnmp_gat_conv_stats_f32 / gnnmp_gat_conv_f32 exactly.  The feature row must
+ * fit one wave and there are no edge features (GNNMP_EUNSUPPORTED otherwise).  A fresh seed per call gives the reference's behaviour;
+ * the same seed must be handed to gnnmp_gat_conv_grad_drop_f32.
+ * gnnmp_dropout_keep_u8 writes that mask, keep[e][h] in {0, 1}, for n_edges edge positions (tests, or a caller that wants α .* mask). */
+int gnnmp_gat_conv_drop_f32(gnnmp_graph_t *plan, const float *Wx_src, const float *Wx_dst, const float *a,
+                            float negative_slope, float p, uint64_t seed, const float *bias, int act, float *out,
+                            float *stats, int64_t H, int64_t C, gnnmp_stream_t stream);
+int gnnmp_dropout_keep_u8(uint64_t seed, float p, int64_t n_edges, int64_t H, uint8_t *keep, gnnmp_stream_t stream);
+
 /* The same one-pass kernel for the other attention layers that share the path: GATv2Conv
  * (gatv2_conv, conv.jl:171-214), TransformerConv's attention core (transformer_conv, conv.jl:553-616) and AGNNConv
  * (agnn_conv, conv.jl:337-352).  out[i][h][:] = Σ_j softmax_{j in N(i)}(l_ij) V_j[h][:], then + bias and act.
@@ -373,6 +390,14 @@ int gnnmp_gat_conv_grad_f32(gnnmp_graph_t *plan, gnnmp_graph_t *plan_t, const fl
                             const float *a, float negative_slope, const float *stats, const float *dout,
                             float *line, float *dsd, float *dss, float *dWx_src, float *dWx_dst, float *da,
                             int64_t H, int64_t C, gnnmp_stream_t stream);
+
+/* The same pullback through the dropped coefficients of gnnmp_gat_conv_drop_f32 (same p and seed as the forward): with
+ * k_ij = keep_ij / (1 - p), g_ij = k_ij (Δ_i . Wx_j) replaces Δ_i . Wx_j and Σ_i k_ij α_ij Δ_i replaces Σ_i α_ij Δ_i; everything else,
+ * including the caller-supplied buffers, is as in gnnmp_gat_conv_grad_f32. */
+int gnnmp_gat_conv_grad_drop_f32(gnnmp_graph_t *plan, gnnmp_graph_t *plan_t, const float *Wx_src, const float *Wx_dst,
+                                 const float *a, float negative_slope, float p, uint64_t seed, const float *stats,
+                                 const float *dout, float *line, float *dsd, float *dss, float *dWx_src, float *dWx_dst,
+                                 float *da, int64_t H, int64_t C, gnnmp_stream_t stream);
 
 /* Pullback of gnnmp_attn_conv_f32 for the GATV2 and DOT logits (the GAT logit has the cheaper dedicated entry above; the
  * cosine logit has none yet: GNNMP_EUNSUPPORTED).  dout = Δ w.r.t. the aggregated (pre-bias, pre-σ) output; stats from the

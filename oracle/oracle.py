@@ -293,10 +293,28 @@ def sage_conv(s, t, n, x, weight, bias=None, sigma=None, aggr=MEAN, blas=True, f
     return _act(sigma, y)
 
 
+def dropout_keep(seed, p, n_edges, heads):
+    """The keep mask of the attention dropout as include/gnnmp.h (gnnmp_gat_conv_drop_f32) defines it — the build's own counter-based
+    generator, restated with numpy uint32 arithmetic (the reference draws its mask from Julia's task-local RNG: only the distribution,
+    Bernoulli(1 - p) per coefficient, can be matched, never the draws).  keep[e, h] in {0, 1}, e = 0-based edge position."""
+    def mix(x):
+        x = x.astype(np.uint32)
+        x ^= x >> np.uint32(16); x *= np.uint32(0x7feb352d); x ^= x >> np.uint32(15); x *= np.uint32(0x846ca68b); x ^= x >> np.uint32(16)
+        return x
+    lo, hi = np.uint32(seed & 0xffffffff), np.uint32((seed >> 32) & 0xffffffff)
+    e = np.arange(n_edges, dtype=np.uint32)[:, None]
+    h = np.arange(heads, dtype=np.uint32)[None, :]
+    with np.errstate(over="ignore"):
+        bits = mix(mix(e ^ lo) ^ (h * np.uint32(0x9e3779b9) + hi))
+    thr = min(int(float(np.float32(p)) * 4294967296.0), 0xffffffff)
+    return (bits >= np.uint32(thr)).astype(np.uint8)
+
+
 def gat_conv(s, t, n, x, dense_x_weight, a, bias=None, sigma=None, heads=1, concat=True, negative_slope=0.2,
-             add_self_loops_=True, blas=True, return_alpha=False):
+             add_self_loops_=True, blas=True, return_alpha=False, dropout=0.0, seed=0):
     """gat_conv + gat_message — GNNlib/src/layers/conv.jl:112-167.
-    dense_x_weight (C*H, Din); a (2C, H) in Julia shape, i.e. numpy [2C, H]."""
+    dense_x_weight (C*H, Din); a (2C, H) in Julia shape, i.e. numpy [2C, H].
+    dropout > 0: α = dropout(α, p) (conv.jl:139; NNlib.dropout: α .* keep ./ (1 - p)) with the mask of dropout_keep(seed, ...)."""
     s = _i64(s)
     t = _i64(t)
     x = _f32(x)
@@ -313,6 +331,9 @@ def gat_conv(s, t, n, x, dense_x_weight, a, bias=None, sigma=None, heads=1, conc
     logit = np.empty((E, H), np.float32)
     lib().orc_gat_logits(_p(Wxi), _p(Wxj), _p(a_hc), _i(E), _i(H), _i(C), ctypes.c_float(negative_slope), _p(logit))
     alpha = softmax_edge_neighbors(t, n, logit)                  # utils.jl:84-97
+    if dropout > 0.0:                                            # conv.jl:139
+        keep = dropout_keep(seed, dropout, E, H).astype(np.float32)
+        alpha = _f32(alpha * keep * np.float32(1.0 / (1.0 - np.float32(dropout))))
     beta = np.empty_like(Wxj)
     lib().orc_gat_weight_messages(_p(alpha), _p(Wxj), _i(E), _i(H), _i(C), _p(beta))
     y = scatter(SUM, beta.reshape(E, H * C), t, n).reshape(n, H, C)   # aggregate_neighbors(g, +, β)
@@ -402,7 +423,7 @@ def grad_gcn_conv(s, t, n, x, weight, bias, sigma, dy, add_self_loops_=True):
 
 
 def grad_gat_conv(s, t, n, x, dense_x_weight, a, bias, sigma, dy, heads=1, negative_slope=0.2, add_self_loops_=True,
-                  concat=True):
+                  concat=True, dropout=0.0, seed=0):
     """(Δx, ΔW, Δa, Δb) of gat_conv (concat = true, no edge features; conv.jl:112-167), composed rule by rule in the order
     Zygote walks the forward backwards: σ, bias, ∇scatter(+) (Δβ = Δ[t]), β = α .* Wxj, the softmax_edge_neighbors
     pullback  Δl = α .* (Δα - Σ_{N(i)} α Δα)  (utils.jl:84-97 is exp / scatter / gather / division, this is what their
@@ -429,15 +450,17 @@ def grad_gat_conv(s, t, n, x, dense_x_weight, a, bias, sigma, dy, heads=1, negat
     den = np.zeros((n, H))
     np.add.at(den, ti, p)
     alpha = p / den[ti]
+    # α' = dropout(α) = k .* α with the constant k = keep / (1 - p) (conv.jl:139): its rule hands Δα = k .* Δα' to the softmax pullback
+    k = dropout_keep(seed, dropout, len(ti), H).astype(np.float64) / (1.0 - float(np.float32(dropout))) if dropout > 0.0 else 1.0
     o = np.zeros((n, H, C))
-    np.add.at(o, ti, alpha[..., None] * Wxj)
+    np.add.at(o, ti, (alpha * k)[..., None] * Wxj)
     y = (o.reshape(n, H * C) if concat else o.mean(axis=1)) + (0 if bias is None else np.asarray(bias, np.float64)[None, :])
     dz = np.asarray(dy, np.float64) * (y > 0) if sigma == "relu" else np.asarray(dy, np.float64)
     db = dz.sum(0)
     delta = dz.reshape(n, H, C) if concat else np.repeat(dz[:, None, :] / H, H, axis=1)   # ∇mean(x, dims = 2)
     dbeta = delta[ti]                                             # ∇scatter(+)
-    dalpha = (dbeta * Wxj).sum(-1)
-    dWxj = alpha[..., None] * dbeta
+    dalpha = (dbeta * Wxj).sum(-1) * k
+    dWxj = (alpha * k)[..., None] * dbeta
     sa = np.zeros((n, H))
     np.add.at(sa, ti, alpha * dalpha)
     dzl = alpha * (dalpha - sa[ti]) * np.where(z > 0, 1.0, negative_slope)

@@ -36,7 +36,7 @@ def c_prototypes():
 
 
 JL_KIND = {"Ptr{Cvoid}": "ptr", "Ptr{Ptr{Cvoid}}": "ptr", "Ptr{Int64}": "ptr", "Ptr{Int32}": "ptr", "Ptr{Cint}": "ptr", "Cstring": "ptr",
-           "Cint": "i32", "Int64": "i64", "Cfloat": "f32"}
+           "Cint": "i32", "Int64": "i64", "UInt64": "i64", "Cfloat": "f32"}
 
 
 def split_top(s):
@@ -97,7 +97,7 @@ def test_the_binding_covers_the_reference_seam():
     for sym in ("GNNlib.gcn_conv", "GNNlib.gat_conv", "GNNlib.reduce_nodes", "GNNlib.softmax_edge_neighbors",
                 "GNNlib.aggregate_neighbors"):
         assert sym + "(" in src
-    for wrapped in ("fused_propagate", "dense", "gat_attention", "edge_softmax", "scatter_edges", "segment_pool",
+    for wrapped in ("fused_propagate", "dense", "gat_attention", "gat_attention_drop", "edge_softmax", "scatter_edges", "segment_pool",
                     "GNNGraphs._gather"):
         assert f"ChainRulesCore.rrule(::typeof({wrapped})" in src, f"no rrule for {wrapped}"
     assert "objectid(s), objectid(t), g.num_nodes, self_loops" in src      # the cache key (round 1 keyed on s alone)
@@ -155,5 +155,6 @@ def test_extended_methods_exist_in_the_reference_with_that_arity():
 
 def test_round3_entry_points_are_bound():
     src = open(JL).read()
-    for sym in ("gnnmp_graphconv_chain_f32", "gnnmp_chain_jobs_create", "gnnmp_shard_by_size", "gnnmp_allgather_f32", "gnnmp_segment_bounds"):
+    for sym in ("gnnmp_graphconv_chain_f32", "gnnmp_chain_jobs_create", "gnnmp_shard_by_size", "gnnmp_allgather_f32", "gnnmp_segment_bounds",
+                "gnnmp_gat_conv_drop_f32", "gnnmp_gat_conv_grad_drop_f32"):
         assert sym in src, sym
