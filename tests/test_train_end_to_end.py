@@ -30,7 +30,7 @@ def planted_partition(seed=0, n=2708, classes=7, deg_in=3.2, deg_out=0.7, D=64):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind", ["gcn", "gat"])
+@pytest.mark.parametrize("kind", ["gcn", "gat", "gat_dropout"])
 def test_full_batch_training_learns(kind):
     import torch
     import torch.nn.functional as F
@@ -50,7 +50,11 @@ def test_full_batch_training_learns(kind):
         params = [l1.weight, l1.bias, l2.weight, l2.bias, head.weight, head.bias]
         fwd = lambda: dense_ad(head, gcn_conv_ad(l2, g, gcn_conv_ad(l1, g, X)))
     else:
-        l1, head = gnnmp.GATConv((D, 8), "relu", heads=8, seed=1), gnnmp.GATConv((64, 7), None, heads=4, concat=False, seed=2)
+        # "gat_dropout": GATConv(...; dropout = 0.4) — the attention coefficients dropped with a fresh mask per step (conv.jl:139),
+        # the mask regenerated, not stored, in the pullback
+        pd = 0.4 if kind == "gat_dropout" else 0.0
+        l1 = gnnmp.GATConv((D, 8), "relu", heads=8, dropout=pd, seed=1)
+        head = gnnmp.GATConv((64, 7), None, heads=4, concat=False, dropout=pd, seed=2)
         params = [l1.dense_x_weight, l1.a, l1.bias, head.dense_x_weight, head.a, head.bias]
         fwd = lambda: gat_conv_ad(head, g, gat_conv_ad(l1, g, X))
     for p in params:
@@ -65,6 +69,8 @@ def test_full_batch_training_learns(kind):
         opt.step()
         losses.append(float(loss.detach()))
     with torch.no_grad():
+        if kind == "gat_dropout":            # evaluation without dropout (what Flux.testmode! does to the layer's dropout)
+            l1.dropout = head.dropout = 0.0
         logits = fwd()
         acc_test = float((logits[test].argmax(1) == Y[test]).float().mean())
         # the same features without the graph: a logistic-regression-strength baseline the GNN has to beat
