@@ -550,7 +550,7 @@ def main():
         except OSError as e:
             extras["gather_ceiling"] = {"note": f"tools/ubench/libgather_probe.so not built: {e}"}
     extras["dense"] = {
-        "kernel": "dense kernels (fp32 MFMA)", "peak_TFs": MFMA_F32_PEAK_TF,
+        "kernel": "dense_split_kernel (3-plane split-bf16, six bf16 MFMAs per product: 100=>128) / dense_t16_kernel (fp32 MFMA: 100=>100); TF/s of the fp32 product, rated against the fp32 matrix peak", "peak_TFs": MFMA_F32_PEAK_TF,
         "gcn_W_x": {"shape": f"{N}x{D}=>{D}", "ms": t_dg, "TFs": 2.0 * N * D * D / t_dg / 1e9,
                     "frac": 2.0 * N * D * D / t_dg / 1e9 / MFMA_F32_PEAK_TF},
         "gat_dense_x": {"shape": f"{N}x{D}=>{H * C}", "ms": t_da, "TFs": 2.0 * N * D * H * C / t_da / 1e9,

@@ -140,15 +140,15 @@ __device__ __forceinline__ void c2_pool_graph(const Chain2Args &a, int g, int sl
         const float *z = a.zrows + ((int64_t)slab * a.N + r0) * a.nout;
         if (a.nout == 2) {
             const float2 *z2 = reinterpret_cast<const float2 *>(z);
-            int t = 0;
-            for (; t + 8 <= cnt; t += 8) {          // eight loads in flight, the adds in row order
-                float2 v[8];
+            for (int t = 0; t < cnt; t += 16) {          // sixteen loads in flight (past the end: the last row again, not added), the adds in row order
+                float2 v[16];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = z2[t + u];
+                for (int u = 0; u < 16; ++u) v[u] = z2[min(t + u, cnt - 1)];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { acc[0] = acc[0] + v[u].x; acc[1] = acc[1] + v[u].y; }
+                for (int u = 0; u < 16; ++u) {
+                    if (t + u < cnt) { acc[0] = acc[0] + v[u].x; acc[1] = acc[1] + v[u].y; }
+                }
             }
-            for (; t < cnt; ++t) { const float2 v = z2[t]; acc[0] = acc[0] + v.x; acc[1] = acc[1] + v.y; }
         } else {
             for (int t = 0; t < cnt; ++t)
 #pragma unroll
