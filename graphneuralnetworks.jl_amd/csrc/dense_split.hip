@@ -256,8 +256,15 @@ static int launch_split_var(const SplitArgs &a0, hipStream_t stream) {
     const int kw = knob(KNOB_DENSE_T16_WAVES);
     if (kw >= 1 && kw <= max_waves) waves = kw;
     a.waves = waves;
-    const int64_t gx = std::min<int64_t>(cus, (ntiles + waves - 1) / waves);
-    dim3 grid((unsigned)gx, (unsigned)((a.Dout + DP - 1) / DP));
+    // Several column tiles (Dout > DP: SAGEConv's 256 columns are two): a block fills a CU (LDS), so with `cus` blocks per column tile
+    // the tiles ran one after the other and x came from HBM once per column tile.  cus / ny blocks per column tile instead: blocks
+    // (b, 0), (b, 1), ... walk the same row tiles at the same time and — linear block ids b, b + gx, ... with gx a multiple of 8 — on
+    // the same XCD, so every read of x after the first is an L2 hit (knob 13 bit 4 = the old grid, for A/B runs).
+    const int ny = (a.Dout + DP - 1) / DP;
+    int64_t bx = cus;
+    if (ny > 1 && !(knob(KNOB_T16_DEBUG) & 16)) bx = std::max<int64_t>(8, (int64_t)(cus / ny) & ~(int64_t)7);
+    const int64_t gx = std::min<int64_t>(bx, (ntiles + waves - 1) / waves);
+    dim3 grid((unsigned)gx, (unsigned)ny);
     dense_split_kernel<NCB, K0C, K1C, VAR><<<grid, 64 * waves, lds, stream>>>(a);
     GNNMP_LAUNCH_CHECK("dense_split_kernel");
     return GNNMP_OK;
