@@ -59,6 +59,7 @@ __device__ __forceinline__ float4 load_q(const RowPtr<TWO> &r, int c, int K0, in
 //   16 = no stores at all             32 = no split arithmetic (wrong numbers)                    64 = no A-operand reads
 //   128 = every tile reads rows 0..31 (operands from L1)
 //   256 = (not an experiment) every column tile is full, Dout % DP == 0: no column test in the epilogue
+//   4096 = (not an experiment) stores through a 4 KB LDS stage per wave (whole 128-byte lines): taken when the stage fits beside the image
 template <int NCB, int VAR>
 constexpr int split_threads() { return (VAR & 4) ? (NCB >= 4 ? 768 : 1024) : 512; }
 
@@ -84,6 +85,7 @@ __global__ void __launch_bounds__((split_threads<NCB, VAR>())) dense_split_kerne
     const int units = nkb * 2 * DP;
     u32x4 *img = reinterpret_cast<u32x4 *>(lds_raw);
     float4 *bias4 = reinterpret_cast<float4 *>(img + 3 * units);
+    unsigned char *stages = reinterpret_cast<unsigned char *>(bias4 + DP / 4);     // (VAR & 4096) [waves][4096]
     const int tid = threadIdx.x, nthreads = a.waves * 64;
     const int n0 = (int)blockIdx.y * DP;
     const int ncols = min(DP, a.Dout - n0);
@@ -188,6 +190,8 @@ __global__ void __launch_bounds__((split_threads<NCB, VAR>())) dense_split_kerne
         if constexpr (VAR & 16) {
         } else if constexpr (VAR & 8) {
             split_store<NCB>(acc, bias4, a.act, out_row, row <= nlast, ncols, h);
+        } else if constexpr (VAR & 4096) {
+            split_store_rows<NCB, (VAR & 256) != 0>(acc, bias4, a.act, stages + wave * 4096, a.out + n0, a.Dout, t * 32, nlast, ncols, lane);
         } else {
             split_store_all<NCB, (VAR & 256) != 0>(acc, bias4, a.act, out_row, ncols, h);
         }
@@ -231,7 +235,7 @@ template <int NCB, int K0C, int K1C, int VAR>
 static int launch_split_var(const SplitArgs &a0, hipStream_t stream) {
     SplitArgs a = a0;
     constexpr int DP = NCB * 32;
-    const size_t lds = split_img_bytes(a.nkb * 16, DP) + (size_t)DP * 4;
+    const size_t lds = split_img_bytes(a.nkb * 16, DP) + (size_t)DP * 4 + ((VAR & 4096) ? (size_t)(split_threads<NCB, VAR>() / 64) * 4096 : 0);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_split_kernel<NCB, K0C, K1C, VAR>),
@@ -281,8 +285,11 @@ static int launch_split(const SplitArgs &a, hipStream_t stream) {
         }
     }
 #endif
-    if (a.Dout % (NCB * 32) == 0) return launch_split_var<NCB, K0C, K1C, 256>(a, stream);
-    return launch_split_var<NCB, K0C, K1C, 0>(a, stream);
+    // stores through the per-wave LDS stage (whole 128-byte lines) when 8 stages fit beside the image (knob 13 bit 5 = never, for A/B runs)
+    const bool staged = split_img_bytes(a.nkb * 16, NCB * 32) + (size_t)NCB * 32 * 4 + 8 * 4096 <= 160 * 1024 && !(knob(KNOB_T16_DEBUG) & 32);
+    if (a.Dout % (NCB * 32) == 0)
+        return staged ? launch_split_var<NCB, K0C, K1C, 256 | 4096>(a, stream) : launch_split_var<NCB, K0C, K1C, 256>(a, stream);
+    return staged ? launch_split_var<NCB, K0C, K1C, 4096>(a, stream) : launch_split_var<NCB, K0C, K1C, 0>(a, stream);
 }
 
 // Returns GNNMP_OK if it launched, 1 if the shape is not one this kernel takes (the caller falls back to the fp32-MFMA kernels).
