@@ -194,6 +194,36 @@ def test_wave_job_kernel_on_irregular_batches(gm, oracle, aggr, pool, seed):
         assert torch.equal(model(g, g.x), y), "not run-to-run identical (two atomic addends per logit: order must not matter)"
 
 
+def ring_graph(n, rng, extra=0):
+    """a directed ring over n nodes (every node one in-edge, n = 1: a single isolated node) plus `extra` random edges"""
+    if n == 1:
+        return np.zeros(0, np.int64), np.zeros(0, np.int64), 1
+    s = np.arange(n); t = (s + 1) % n
+    if extra:
+        s = np.concatenate([s, rng.integers(0, n, extra)]); t = np.concatenate([t, rng.integers(0, n, extra)])
+    return s.astype(np.int64) + 1, t.astype(np.int64) + 1, n
+
+
+@pytest.mark.parametrize("sizes", [[40], [64], [32], [33, 31], [1], [64, 64, 1], [32, 32, 32], [2, 63, 17, 47, 64, 1, 1, 30]],
+                         ids=lambda v: "-".join(map(str, v)))
+@pytest.mark.parametrize("nout,sigma", [(2, "relu"), (8, None), (1, "relu")])
+def test_wave_pair_kernel_edge_sizes(gm, oracle, sizes, nout, sigma):
+    """the job shapes at the edges of the pair kernel: a batch of one graph (fewer than 32 rows goes to the layer path: the fused
+    kernels need N >= 32), a graph that fills a job exactly, one-tile jobs (the odd wave of the pair idles), a graph that straddles the
+    two tiles by one row, single-node graphs, every head width (1, 2: the vector store; 8: the wide one), with and without σ"""
+    import torch
+    rng = np.random.default_rng(sum(sizes) * 10 + nout)
+    members = [ring_graph(n, rng, extra=2 * n if n > 4 else 0) for n in sizes]
+    xs = [rng.standard_normal((n, 16), dtype=np.float32) for _, _, n in members]
+    g = gm.batch_arrays(members, xs)
+    model = build(gm, (16, 128, 128), nout, "+", "mean", sigma)
+    y, yl = run_both(gm, model, g)
+    ref = oracle_chain(oracle, members, xs, model.layers[:2], "mean", model.layers[-1])
+    close(y.cpu().numpy(), ref, f"fused vs oracle {sizes}")
+    close(yl.cpu().numpy(), ref, f"layers vs oracle {sizes}")
+    assert torch.equal(model(g, g.x), y)
+
+
 def test_job_packing(gm):
     """gnnmp_chain_jobs_create: every row in exactly one slot, member graphs whole and in node order inside a job, at most 64 rows a
     job; a batch with a larger member graph gets no jobs (the general kernel runs)"""
