@@ -500,7 +500,6 @@ __global__ void __launch_bounds__(THREADS) graph_chain2_kernel(const Chain2Args 
             pre_a(job_next, nxt); pre_b(nxt); pre_c(nxt);
         }
         C2_STAMP(6);
-        C2_STAMP(7);
         cur = nxt;
     }
 }

@@ -25,12 +25,14 @@ lib = L.load()
 lib.gnnmp_chain_trace.argtypes = [ctypes.c_void_p]
 assert lib.gnnmp_chain_trace(buf) == 0
 t = np.array(buf[:], dtype=np.int64).reshape(16, 8, 8)
-names = ["prologue", "K loop", "rounds", "sigma2/z", "zst+flag", "exchange", "pool", "end wait"]
 t0 = t[t > 0].min()
 for w in range(12):
     for k in range(8):
         r = t[w, k]
         if r[0] == 0:
             continue
-        d = [int(r[1] - r[0]), int(r[2] - r[1]), int(r[3] - r[2]), int(r[4] - r[3]), int(r[5] - r[4]), int(r[6] - r[5]), int(r[7] - r[6])]
-        print(f"wave {w:2d} job {k}: start {int(r[0] - t0):8d}  prologue {d[0]:6d}  K loop {d[1]:6d}  rounds {d[2]:6d}  z {d[3]:6d}  exch {d[4]:6d}  pool {d[5]:6d}  endwait {d[6]:6d}   total {int(r[7] - r[0]):7d}")
+        # stamps: 0 job start, 1 operands of layer 1 formed, 2 K loop done, 3 neighbour rounds done, 4 sigma2 / head done, 5 z rows stored,
+        # 6 end of the job (odd waves of one-tile jobs: the next job's prefetch)
+        d = [int(r[i + 1] - r[i]) for i in range(6)]
+        print(f"wave {w:2d} job {k}: start {int(r[0] - t0):8d}  prologue {d[0]:6d}  K loop {d[1]:6d}  rounds {d[2]:6d}  sigma2/head {d[3]:6d}  "
+              f"z store {d[4]:6d}  tail {d[5]:6d}   total {int(r[6] - r[0]):7d}")
