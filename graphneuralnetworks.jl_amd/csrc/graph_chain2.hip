@@ -455,23 +455,33 @@ __global__ void __launch_bounds__(THREADS) graph_chain2_kernel(const Chain2Args 
             float zo[8];
 #pragma unroll
             for (int o = 0; o < 8; ++o) zo[o] = 0.0f;
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
+            {
                 float s = 0.0f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s += out[c][r];
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s += out[c][r];
                 bad |= (s != s);
+            }
+            // three LDS round trips instead of twenty-four: the eight bias pieces together, then per output the eight pieces of its head
+            // row together (one uniform branch per output, not one per piece)
+            float4 v[8];
 #pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    const int colq = 32 * c + 8 * q4;      // + 4 h: inside bias2o / heado
-                    const float4 v = split_out4(out[c], q4, bias2o[colq >> 2], a.act2);
+            for (int i = 0; i < 8; ++i) v[i] = bias2o[(32 * (i >> 2) + 8 * (i & 3)) >> 2];      // (+ 4 h: inside bias2o)
 #pragma unroll
-                    for (int o = 0; o < 8; ++o) {
-                        if (o < a.nout) {
-                            const float4 wv = *reinterpret_cast<const float4 *>(heado + o * C2_SLAB + colq);
-                            zo[o] = fmaf(wv.x, v.x, fmaf(wv.y, v.y, fmaf(wv.z, v.z, fmaf(wv.w, v.w, zo[o]))));
-                        }
-                    }
+            for (int i = 0; i < 8; ++i) v[i] = split_out4(out[i >> 2], i & 3, v[i], a.act2);
+#pragma unroll
+            for (int o = 0; o < 8; ++o) {
+                if (o < a.nout) {
+                    int oo;
+                    asm volatile("v_mov_b32 %0, 0" : "=v"(oo));         // (keeps hipcc from starting every output's reads at once)
+                    const float *hr = heado + 4 * oo + o * C2_SLAB;
+                    float4 hw[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) hw[i] = *reinterpret_cast<const float4 *>(hr + 32 * (i >> 2) + 8 * (i & 3));
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        zo[o] = fmaf(hw[i].x, v[i].x, fmaf(hw[i].y, v[i].y, fmaf(hw[i].z, v[i].z, fmaf(hw[i].w, v[i].w, zo[o]))));
                 }
             }
 #pragma unroll
