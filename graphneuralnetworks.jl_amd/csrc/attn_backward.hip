@@ -36,6 +36,8 @@ struct AttnBwdArgs {
     float *partial;
     int H, C, D, log2g, lph, waves;
     float slope, scale;
+    const int32_t *eid;       // DROP: slot -> original edge position of the plan the running pass walks
+    DropArgs drop;
 };
 
 __device__ __forceinline__ float lrelu_a(float x, float slope) { return x > 0.0f ? x : x * slope; }
@@ -98,7 +100,7 @@ __device__ __forceinline__ void attn_dst_finalize(const AttnBwdArgs &a, int row,
     }
 }
 
-template <int VEC, int U, int LPH, int MODE>
+template <int VEC, int U, int LPH, int MODE, bool DROP>
 __global__ void __launch_bounds__(256) attn_bwd_dst_kernel(const AttnBwdArgs a) {
     constexpr int NA = Acc1<MODE>::N;
     int v, row, lig, gbase, G;
@@ -134,12 +136,18 @@ __global__ void __launch_bounds__(256) attn_bwd_dst_kernel(const AttnBwdArgs a) 
     for (uint32_t base = beg; base < end; base += G) {   // slots are unsigned 32-bit (csr_reduce.h)
         const uint32_t p = base + lig;
         const int c = p < end ? a.col[p] : 0;
+        const int ev = (DROP && p < end) ? a.eid[p] : 0;
         const int n = (int)min((uint32_t)G, end - base);
         for (int j = 0; j < n; j += U) {
             float kv[U][VEC];                                   // K_j
             float vv[MODE == GNNMP_ATTN_DOT ? U : 1][VEC];      // V_j when it is a different array
+            float kf[DROP ? U : 1];                             // keep_ij / (1 - p) of conv.jl:191's dropout: g_ij becomes kf g_ij
 #pragma unroll
             for (int u = 0; u < U; ++u) {
+                if (DROP) {
+                    const uint32_t ej = (uint32_t)__shfl(ev, gbase + min(j + u, n - 1), 64);
+                    kf[DROP ? u : 0] = drop_bits(a.drop.seed_lo, a.drop.seed_hi, ej, (uint32_t)h) >= a.drop.thr ? a.drop.inv : 0.0f;
+                }
                 const int cj = __shfl(c, gbase + min(j + u, n - 1), 64);
                 Vec<VEC>::load(a.K + (int64_t)cj * a.D + fc, kv[u]);
                 if (MODE == GNNMP_ATTN_DOT) Vec<VEC>::load(a.V + (int64_t)cj * a.D + fc, vv[MODE == GNNMP_ATTN_DOT ? u : 0]);
@@ -168,7 +176,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dst_kernel(const AttnBwdArgs a) 
                 if (MODE == GNNMP_ATTN_DOT) lu = lu / a.scale;
                 float al = expf(lu - m) * rden;
                 al = (j + u < n) ? al : 0.0f;
-                const float ag = al * g[u];
+                const float ag = DROP ? al * (kf[DROP ? u : 0] * g[u]) : al * g[u];
                 S1 += ag;
 #pragma unroll
                 for (int q = 0; q < VEC; ++q) {
@@ -255,7 +263,7 @@ __device__ __forceinline__ void attn_src_store(const AttnBwdArgs &a, int row, in
     }
 }
 
-template <int VEC, int U, int LPH, int MODE>
+template <int VEC, int U, int LPH, int MODE, bool DROP>
 __global__ void __launch_bounds__(256) attn_bwd_src_kernel(const AttnBwdArgs a) {
     int v, row, lig, gbase, G;
     uint32_t beg, end;
@@ -285,12 +293,18 @@ __global__ void __launch_bounds__(256) attn_bwd_src_kernel(const AttnBwdArgs a) 
     for (uint32_t base = beg; base < end; base += G) {   // slots are unsigned 32-bit (csr_reduce.h)
         const uint32_t p = base + lig;
         const int c = p < end ? a.col[p] : 0;
+        const int ev = (DROP && p < end) ? a.eid[p] : 0;
         const int n = (int)min((uint32_t)G, end - base);
         for (int j = 0; j < n; j += U) {
             float dd[U][VEC], qq[U][VEC];
             float4 ln[U];
+            float kf[DROP ? U : 1];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
+                if (DROP) {    // (the transposed plan's slots carry the same original edge positions)
+                    const uint32_t ej = (uint32_t)__shfl(ev, gbase + min(j + u, n - 1), 64);
+                    kf[DROP ? u : 0] = drop_bits(a.drop.seed_lo, a.drop.seed_hi, ej, (uint32_t)h) >= a.drop.thr ? a.drop.inv : 0.0f;
+                }
                 const int ci = __shfl(c, gbase + min(j + u, n - 1), 64);
                 Vec<VEC>::load(a.dout + (int64_t)ci * a.D + fc, dd[u]);
                 Vec<VEC>::load(a.Q + (int64_t)ci * a.D + fc, qq[u]);
@@ -319,10 +333,11 @@ __global__ void __launch_bounds__(256) attn_bwd_src_kernel(const AttnBwdArgs a) 
                 if (MODE == GNNMP_ATTN_DOT) lu = lu / a.scale;
                 float al = expf(lu - ln[u].x) * ln[u].y;
                 al = (j + u < n) ? al : 0.0f;
-                const float dl = al * (g[u] - ln[u].z);
+                const float dl = al * ((DROP ? kf[DROP ? u : 0] * g[u] : g[u]) - ln[u].z);
+                const float ak = DROP ? al * kf[DROP ? u : 0] : al;
 #pragma unroll
                 for (int q = 0; q < VEC; ++q) {
-                    dv[q] = fmaf(al, dd[u][q], dv[q]);
+                    dv[q] = fmaf(ak, dd[u][q], dv[q]);
                     if (MODE == GNNMP_ATTN_GATV2) {
                         const float s = (qq[u][q] + kj[q]) > 0.0f ? 1.0f : a.slope;
                         dk[q] = fmaf(dl * s, ca[q], dk[q]);
@@ -418,17 +433,18 @@ static void fill_plan(AttnBwdArgs &g, const gnnmp_graph *p) {
     g.partial = p->ws;
 }
 
-template <int VEC, int LPH, int MODE>
+template <int VEC, int LPH, int MODE, bool DROP>
 static int launch_attn_bwd(AttnBwdArgs g, gnnmp_graph *plan, gnnmp_graph *plan_t, float *da, hipStream_t stream) {
     const int G = 1 << g.log2g;
     const int rpw = 64 / G;
     g.waves = 1;
     fill_plan(g, plan);
+    g.eid = plan->eid;
     {
         const int64_t nvirt = (int64_t)g.n_rows + g.n_chunks;
         const int64_t blocks = (nvirt + rpw - 1) / rpw;
         if (blocks > 0) {
-            attn_bwd_dst_kernel<VEC, 4, LPH, MODE><<<(unsigned)blocks, 64, 0, stream>>>(g);
+            attn_bwd_dst_kernel<VEC, 4, LPH, MODE, DROP><<<(unsigned)blocks, 64, 0, stream>>>(g);
             GNNMP_LAUNCH_CHECK("attn_bwd_dst_kernel");
         }
         if (g.n_long > 0) {
@@ -438,11 +454,12 @@ static int launch_attn_bwd(AttnBwdArgs g, gnnmp_graph *plan, gnnmp_graph *plan_t
         }
     }
     fill_plan(g, plan_t);
+    g.eid = plan_t->eid;
     {
         const int64_t nvirt = (int64_t)g.n_rows + g.n_chunks;
         const int64_t blocks = (nvirt + rpw - 1) / rpw;
         if (blocks > 0) {
-            attn_bwd_src_kernel<VEC, 4, LPH, MODE><<<(unsigned)blocks, 64, 0, stream>>>(g);
+            attn_bwd_src_kernel<VEC, 4, LPH, MODE, DROP><<<(unsigned)blocks, 64, 0, stream>>>(g);
             GNNMP_LAUNCH_CHECK("attn_bwd_src_kernel");
         }
         if (g.n_long > 0) {
@@ -468,27 +485,30 @@ static int dispatch_attn_bwd(const AttnBwdArgs &g, int vec, int lph, gnnmp_graph
                              hipStream_t stream) {
     if (vec == 4) {
         switch (lph) {
-            case 1: return launch_attn_bwd<4, 1, MODE>(g, plan, plan_t, da, stream);
-            case 2: return launch_attn_bwd<4, 2, MODE>(g, plan, plan_t, da, stream);
-            case 4: return launch_attn_bwd<4, 4, MODE>(g, plan, plan_t, da, stream);
-            case 8: return launch_attn_bwd<4, 8, MODE>(g, plan, plan_t, da, stream);
-            case 16: return launch_attn_bwd<4, 16, MODE>(g, plan, plan_t, da, stream);
-            default: return launch_attn_bwd<4, 0, MODE>(g, plan, plan_t, da, stream);
+            case 1: return launch_attn_bwd<4, 1, MODE, false>(g, plan, plan_t, da, stream);
+            case 2: return launch_attn_bwd<4, 2, MODE, false>(g, plan, plan_t, da, stream);
+            case 4: return launch_attn_bwd<4, 4, MODE, false>(g, plan, plan_t, da, stream);
+            case 8: return launch_attn_bwd<4, 8, MODE, false>(g, plan, plan_t, da, stream);
+            case 16: return launch_attn_bwd<4, 16, MODE, false>(g, plan, plan_t, da, stream);
+            default: return launch_attn_bwd<4, 0, MODE, false>(g, plan, plan_t, da, stream);
         }
     }
-    if (vec == 2) return launch_attn_bwd<2, 0, MODE>(g, plan, plan_t, da, stream);
-    return launch_attn_bwd<1, 0, MODE>(g, plan, plan_t, da, stream);
+    if (vec == 2) return launch_attn_bwd<2, 0, MODE, false>(g, plan, plan_t, da, stream);
+    return launch_attn_bwd<1, 0, MODE, false>(g, plan, plan_t, da, stream);
 }
 
 }  // namespace gnnmp
 
 using namespace gnnmp;
 
-extern "C" int gnnmp_attn_conv_grad_f32(gnnmp_graph_t *plan, gnnmp_graph_t *plan_t, int mode, const float *Q, const float *K,
-                                        const float *V, const float *a, float negative_slope, float scale,
-                                        const float *stats, const float *dout, float *line, float *dQ, float *dK, float *dV,
-                                        float *dA, float *da, int64_t H, int64_t C, gnnmp_stream_t stream_) {
+static int attn_conv_grad_impl(gnnmp_graph_t *plan, gnnmp_graph_t *plan_t, int mode, const float *Q, const float *K,
+                               const float *V, const float *a, float negative_slope, float scale, float drop_p, uint64_t drop_seed,
+                               const float *stats, const float *dout, float *line, float *dQ, float *dK, float *dV,
+                               float *dA, float *da, int64_t H, int64_t C, gnnmp_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    if (!(drop_p >= 0.0f && drop_p < 1.0f)) return fail(GNNMP_EINVAL, "attn_conv_grad: dropout probability %g outside [0, 1)", (double)drop_p);
+    if (drop_p > 0.0f && mode != GNNMP_ATTN_GATV2)
+        return fail(GNNMP_EUNSUPPORTED, "attn_conv_grad: attention dropout only on the GATv2 logit here (GAT: gnnmp_gat_conv_grad_drop_f32)");
     if (!plan || !plan_t) return fail(GNNMP_EINVAL, "attn_conv_grad: null plan");
     if (mode != GNNMP_ATTN_GATV2 && mode != GNNMP_ATTN_DOT)
         return fail(GNNMP_EUNSUPPORTED, "attn_conv_grad: mode %d (GAT has gnnmp_gat_conv_grad_f32; the cosine logit has no pullback yet)", mode);
@@ -541,6 +561,29 @@ extern "C" int gnnmp_attn_conv_grad_f32(gnnmp_graph_t *plan, gnnmp_graph_t *plan
     g.waves = 1;
     g.slope = negative_slope;
     g.scale = scale;
+    g.eid = nullptr;
+    g.drop = make_drop(drop_p, drop_seed);
+    if (drop_p > 0.0f) {       // (the dropout variants walk the head butterfly with the run-time lane count: one instantiation per width)
+        if (vec == 4) return launch_attn_bwd<4, 0, GNNMP_ATTN_GATV2, true>(g, plan, plan_t, da, stream);
+        if (vec == 2) return launch_attn_bwd<2, 0, GNNMP_ATTN_GATV2, true>(g, plan, plan_t, da, stream);
+        return launch_attn_bwd<1, 0, GNNMP_ATTN_GATV2, true>(g, plan, plan_t, da, stream);
+    }
     if (mode == GNNMP_ATTN_GATV2) return dispatch_attn_bwd<GNNMP_ATTN_GATV2>(g, vec, lph, plan, plan_t, da, stream);
     return dispatch_attn_bwd<GNNMP_ATTN_DOT>(g, vec, lph, plan, plan_t, da, stream);
+}
+
+extern "C" int gnnmp_attn_conv_grad_f32(gnnmp_graph_t *plan, gnnmp_graph_t *plan_t, int mode, const float *Q, const float *K,
+                                        const float *V, const float *a, float negative_slope, float scale,
+                                        const float *stats, const float *dout, float *line, float *dQ, float *dK, float *dV,
+                                        float *dA, float *da, int64_t H, int64_t C, gnnmp_stream_t stream) {
+    return attn_conv_grad_impl(plan, plan_t, mode, Q, K, V, a, negative_slope, scale, 0.0f, 0, stats, dout, line, dQ, dK, dV, dA, da, H, C,
+                               stream);
+}
+extern "C" int gnnmp_attn_conv_grad_drop_f32(gnnmp_graph_t *plan, gnnmp_graph_t *plan_t, int mode, const float *Q, const float *K,
+                                             const float *V, const float *a, float negative_slope, float scale, float p,
+                                             uint64_t seed, const float *stats, const float *dout, float *line, float *dQ,
+                                             float *dK, float *dV, float *dA, float *da, int64_t H, int64_t C,
+                                             gnnmp_stream_t stream) {
+    return attn_conv_grad_impl(plan, plan_t, mode, Q, K, V, a, negative_slope, scale, p, seed, stats, dout, line, dQ, dK, dV, dA, da, H,
+                               C, stream);
 }

@@ -59,7 +59,7 @@ struct GatFusedArgs {
     int cpx;
     int nbc;              // leading blocks (chunk virtual rows) that are not remapped
     int waves;
-    DropArgs drop;        // ATTN_GAT_DROP only
+    DropArgs drop;        // ATTN_GAT_DROP / ATTN_GATV2_DROP only
 };
 
 // internal fifth mode: GAT with the per-edge logit term (gnnmp_gat_conv_edge_f32) — a compile-time property, so the headline
@@ -68,8 +68,11 @@ constexpr int ATTN_GAT_EDGE = 4;
 // internal sixth mode: GAT with dropout on the attention coefficients (conv.jl:139; gnnmp_gat_conv_drop_f32): the numerator takes
 // keep_ij / (1 - p) * exp(l_ij - m), the denominator and the saved statistics are those of the undropped softmax
 constexpr int ATTN_GAT_DROP = 5;
+constexpr int ATTN_GATV2_DROP = 6;      // the same for gatv2_conv (conv.jl:191)
 __host__ __device__ constexpr bool is_gat(int mode) { return mode == GNNMP_ATTN_GAT || mode == ATTN_GAT_EDGE || mode == ATTN_GAT_DROP; }
-__host__ __device__ constexpr bool needs_eid(int mode) { return mode == ATTN_GAT_EDGE || mode == ATTN_GAT_DROP; }
+__host__ __device__ constexpr bool is_gatv2(int mode) { return mode == GNNMP_ATTN_GATV2 || mode == ATTN_GATV2_DROP; }
+__host__ __device__ constexpr bool is_drop(int mode) { return mode == ATTN_GAT_DROP || mode == ATTN_GATV2_DROP; }
+__host__ __device__ constexpr bool needs_eid(int mode) { return mode == ATTN_GAT_EDGE || is_drop(mode); }
 
 __device__ __forceinline__ float lrelu(float x, float slope) { return x > 0.0f ? x : x * slope; }
 // softmax_exp (common.h): PMC showed this kernel at 84 % VALU utilisation with 9 libm exponentials per batch of 8 edges a
@@ -120,7 +123,7 @@ __device__ __forceinline__ void gat_batch(const GatFusedArgs &a, int c, int ev, 
             es[u] = a.escore[(int64_t)ej * a.H + r.h];
         }
     }
-    constexpr bool drop = MODE == ATTN_GAT_DROP;
+    constexpr bool drop = is_drop(MODE);
     float kf[drop ? U : 1];      // keep_ij / (1 - p)
     if (drop) {
 #pragma unroll
@@ -137,7 +140,7 @@ __device__ __forceinline__ void gat_batch(const GatFusedArgs &a, int c, int ev, 
 #pragma unroll
         for (int q = 0; q < VEC; ++q) {
             if (is_gat(MODE)) l[u] = fmaf(r.ca[q], v[u][q], l[u]);
-            if (MODE == GNNMP_ATTN_GATV2) l[u] = fmaf(r.ca[q], lrelu(r.vi[q] + v[u][q], a.slope), l[u]);
+            if (is_gatv2(MODE)) l[u] = fmaf(r.ca[q], lrelu(r.vi[q] + v[u][q], a.slope), l[u]);
             if (MODE == GNNMP_ATTN_DOT) l[u] = fmaf(r.vi[q], v[u][q], l[u]);
             if (MODE == GNNMP_ATTN_COS) {
                 l[u] = fmaf(r.vi[q], v[u][q], l[u]);
@@ -275,7 +278,7 @@ __global__ void __launch_bounds__(256) gat_fused_rows_kernel(const GatFusedArgs 
             }
             r.s0 = group_sum<LPH>(sd, a.lph);
         }
-        if (MODE == GNNMP_ATTN_GATV2) {
+        if (is_gatv2(MODE)) {
             const float *ah = a.a + (int64_t)h * a.C + c0;
 #pragma unroll
             for (int q = 0; q < VEC; ++q) r.ca[q] = active ? ah[q] : 0.0f;
@@ -487,8 +490,8 @@ static int attn_conv_impl(gnnmp_graph_t *plan, int mode, const float *Q, const f
     hipStream_t stream = (hipStream_t)stream_;
     if (!plan) return fail(GNNMP_EINVAL, "attn_conv: null plan");
     if (!(drop_p >= 0.0f && drop_p < 1.0f)) return fail(GNNMP_EINVAL, "gat_conv: dropout probability %g outside [0, 1)", (double)drop_p);
-    if (drop_p > 0.0f && (mode != GNNMP_ATTN_GAT || escore))
-        return fail(GNNMP_EUNSUPPORTED, "attention dropout: only on the GAT logit without edge features");
+    if (drop_p > 0.0f && ((mode != GNNMP_ATTN_GAT && mode != GNNMP_ATTN_GATV2) || escore))
+        return fail(GNNMP_EUNSUPPORTED, "attention dropout: only on the GAT / GATv2 logits without edge features");
     if (escore && plan->self_loops)
         return fail(GNNMP_EINVAL, "gat_conv: edge features and add_self_loops cannot be combined (GNNlib/src/layers/conv.jl:120)");
     if (mode < GNNMP_ATTN_GAT || mode > GNNMP_ATTN_COS) return fail(GNNMP_EINVAL, "attn_conv: bad mode %d", mode);
@@ -568,7 +571,8 @@ static int attn_conv_impl(gnnmp_graph_t *plan, int mode, const float *Q, const f
     g.waves = 4;
     g.off24 = plan->n_src < (1 << 24) && D < (1 << 24) && (int64_t)plan->n_src * D < (1ll << 32);
     g.drop = make_drop(drop_p, drop_seed);
-    if (drop_p > 0.0f) return launch_mode<ATTN_GAT_DROP>(g, vec, stream);
+    if (drop_p > 0.0f)
+        return mode == GNNMP_ATTN_GATV2 ? launch_mode<ATTN_GATV2_DROP>(g, vec, stream) : launch_mode<ATTN_GAT_DROP>(g, vec, stream);
     switch (mode) {
         case GNNMP_ATTN_GATV2: return launch_mode<GNNMP_ATTN_GATV2>(g, vec, stream);
         case GNNMP_ATTN_DOT: return launch_mode<GNNMP_ATTN_DOT>(g, vec, stream);
@@ -602,6 +606,13 @@ extern "C" int gnnmp_gat_conv_drop_f32(gnnmp_graph_t *plan, const float *Wx_src,
                                        float *stats, int64_t H, int64_t C, gnnmp_stream_t stream) {
     return attn_conv_impl(plan, GNNMP_ATTN_GAT, Wx_dst, Wx_src, nullptr, a, negative_slope, 1.0f, bias, act, out, stats, H, C,
                           stream, nullptr, p, seed);
+}
+
+extern "C" int gnnmp_attn_conv_drop_f32(gnnmp_graph_t *plan, int mode, const float *Q, const float *K, const float *V,
+                                        const float *a, float negative_slope, float scale, float p, uint64_t seed,
+                                        const float *bias, int act, float *out, float *stats, int64_t H, int64_t C,
+                                        gnnmp_stream_t stream) {
+    return attn_conv_impl(plan, mode, Q, K, V, a, negative_slope, scale, bias, act, out, stats, H, C, stream, nullptr, p, seed);
 }
 
 __global__ void __launch_bounds__(256) dropout_keep_kernel(DropArgs d, int64_t n, int H, uint8_t *keep) {

@@ -29,7 +29,7 @@ SYMBOLS = (
     "gnnmp_degree_f32", "gnnmp_inv_sqrt_f32",
     "gnnmp_edge_softmax_f32", "gnnmp_segment_softmax_f32", "gnnmp_gat_node_scores_f32", "gnnmp_gat_aggregate_f32", "gnnmp_gat_conv_f32",
     "gnnmp_gat_conv_edge_f32", "gnnmp_gat_conv_stats_f32", "gnnmp_gat_conv_grad_f32", "gnnmp_attn_conv_f32",
-    "gnnmp_gat_conv_drop_f32", "gnnmp_dropout_keep_u8", "gnnmp_gat_conv_grad_drop_f32",
+    "gnnmp_gat_conv_drop_f32", "gnnmp_dropout_keep_u8", "gnnmp_gat_conv_grad_drop_f32", "gnnmp_attn_conv_drop_f32", "gnnmp_attn_conv_grad_drop_f32",
     "gnnmp_attn_conv_grad_f32",
     "gnnmp_bias_act_f32",
     "gnnmp_segment_pool_f32", "gnnmp_segment_bounds", "gnnmp_segment_pool_ptr_f32", "gnnmp_dense_f32", "gnnmp_fused_conv_f32",
@@ -97,6 +97,8 @@ def load():
         "gnnmp_gat_conv_grad_f32": [vp, vp, vp, vp, vp, f, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, vp],
         "gnnmp_gat_conv_drop_f32": [vp, vp, vp, vp, f, f, u64, vp, i, vp, vp, i64, i64, vp],
         "gnnmp_dropout_keep_u8": [u64, f, i64, i64, vp, vp],
+        "gnnmp_attn_conv_drop_f32": [vp, i, vp, vp, vp, vp, f, f, f, u64, vp, i, vp, vp, i64, i64, vp],
+        "gnnmp_attn_conv_grad_drop_f32": [vp, vp, i, vp, vp, vp, vp, f, f, f, u64, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, vp],
         "gnnmp_gat_conv_grad_drop_f32": [vp, vp, vp, vp, vp, f, f, u64, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, vp],
         "gnnmp_degree_f32": [vp, vp, vp, vp],
         "gnnmp_inv_sqrt_f32": [vp, vp, i64, vp],

@@ -14,16 +14,21 @@ from .layers import dense
 from .layers_attn import ATTN_DOT, ATTN_GATV2
 
 
-def _attn_forward(plan, mode, Q, K, V, a, slope, scale, bias, act, H, C):
+def _attn_forward(plan, mode, Q, K, V, a, slope, scale, bias, act, H, C, p_drop=0.0, seed=0):
     N = plan.n_dst
     out = torch.empty((N, H * C), dtype=torch.float32, device=K.device)
     stats = torch.empty((N, H, 2), dtype=torch.float32, device=K.device)
-    L.check(L.load().gnnmp_attn_conv_f32(plan.handle, mode, L.ptr(Q), L.ptr(K), L.ptr(V), L.ptr(a), float(slope), float(scale),
-                                         L.ptr(bias), act, L.ptr(out), L.ptr(stats), H, C, L.stream_ptr()))
+    if p_drop > 0.0:
+        L.check(L.load().gnnmp_attn_conv_drop_f32(plan.handle, mode, L.ptr(Q), L.ptr(K), L.ptr(V), L.ptr(a), float(slope),
+                                                  float(scale), float(p_drop), int(seed), L.ptr(bias), act, L.ptr(out),
+                                                  L.ptr(stats), H, C, L.stream_ptr()))
+    else:
+        L.check(L.load().gnnmp_attn_conv_f32(plan.handle, mode, L.ptr(Q), L.ptr(K), L.ptr(V), L.ptr(a), float(slope), float(scale),
+                                             L.ptr(bias), act, L.ptr(out), L.ptr(stats), H, C, L.stream_ptr()))
     return out, stats
 
 
-def _attn_backward(g, loops, mode, Q, K, V, a, slope, scale, stats, dz, H, C):
+def _attn_backward(g, loops, mode, Q, K, V, a, slope, scale, stats, dz, H, C, p_drop=0.0, seed=0):
     plan, plan_t = g.plan(loops), plan_transposed(g, loops)
     N = g.num_nodes
     f32 = dict(dtype=torch.float32, device=dz.device)
@@ -33,9 +38,15 @@ def _attn_backward(g, loops, mode, Q, K, V, a, slope, scale, stats, dz, H, C):
     dV = torch.empty((N, H * C), **f32) if mode == ATTN_DOT else None
     dA = torch.empty((N, H * C), **f32) if mode == ATTN_GATV2 else None
     da = torch.empty((H, C), **f32) if mode == ATTN_GATV2 else None
-    L.check(L.load().gnnmp_attn_conv_grad_f32(plan.handle, plan_t.handle, mode, L.ptr(Q), L.ptr(K), L.ptr(V), L.ptr(a),
-                                              float(slope), float(scale), L.ptr(stats), L.ptr(dz), L.ptr(line), L.ptr(dQ),
-                                              L.ptr(dK), L.ptr(dV), L.ptr(dA), L.ptr(da), H, C, L.stream_ptr()))
+    if p_drop > 0.0:
+        L.check(L.load().gnnmp_attn_conv_grad_drop_f32(plan.handle, plan_t.handle, mode, L.ptr(Q), L.ptr(K), L.ptr(V), L.ptr(a),
+                                                       float(slope), float(scale), float(p_drop), int(seed), L.ptr(stats), L.ptr(dz),
+                                                       L.ptr(line), L.ptr(dQ), L.ptr(dK), L.ptr(dV), L.ptr(dA), L.ptr(da), H, C,
+                                                       L.stream_ptr()))
+    else:
+        L.check(L.load().gnnmp_attn_conv_grad_f32(plan.handle, plan_t.handle, mode, L.ptr(Q), L.ptr(K), L.ptr(V), L.ptr(a),
+                                                  float(slope), float(scale), L.ptr(stats), L.ptr(dz), L.ptr(line), L.ptr(dQ),
+                                                  L.ptr(dK), L.ptr(dV), L.ptr(dA), L.ptr(da), H, C, L.stream_ptr()))
     return dQ, dK, dV, da
 
 
@@ -48,7 +59,7 @@ class _GATv2ConvFn(torch.autograd.Function):
     """gatv2_conv (GNNlib/src/layers/conv.jl:171-214), e === nothing; concat = true or false"""
 
     @staticmethod
-    def forward(ctx, x, Wi, bi, Wj, a, bias, g, sigma, heads, slope, loops, concat=True):
+    def forward(ctx, x, Wi, bi, Wj, a, bias, g, sigma, heads, slope, loops, concat=True, p_drop=0.0, seed=0):
         H, C = heads, Wi.shape[0] // heads
         x = x.contiguous()
         Q = dense(x, Wi, bi)
@@ -56,7 +67,8 @@ class _GATv2ConvFn(torch.autograd.Function):
         a_hc = a.t().contiguous()                                   # (C, H) as Julia stores it -> [H][C]
         # concat = false: heads averaged before bias and σ (conv.jl:196-200): the kernel's fused tail is off
         out, stats = _attn_forward(g.plan(loops), ATTN_GATV2, Q, K, None, a_hc, slope, 1.0, bias if concat else None,
-                                   _act_code(sigma) if concat else L.ACT_IDENTITY, H, C)
+                                   _act_code(sigma) if concat else L.ACT_IDENTITY, H, C, p_drop, seed)
+        ctx.p_drop, ctx.seed = float(p_drop), int(seed)
         if not concat:
             y = torch.empty((out.shape[0], C), dtype=torch.float32, device=x.device)
             L.check(L.load().gnnmp_head_mean_f32(L.ptr(out), L.ptr(bias), _act_code(sigma), L.ptr(y), out.shape[0], H, C,
@@ -76,21 +88,28 @@ class _GATv2ConvFn(torch.autograd.Function):
             dzh = torch.empty((dz.shape[0], ctx.H * ctx.C), dtype=torch.float32, device=dz.device)
             L.check(L.load().gnnmp_head_mean_grad_f32(L.ptr(dz), L.ptr(dzh), dz.shape[0], ctx.H, ctx.C, L.stream_ptr()))
             dz = dzh
-        dQ, dK, _, da = _attn_backward(ctx.g, ctx.loops, ATTN_GATV2, Q, K, None, a_hc, ctx.slope, 1.0, stats, dz, ctx.H, ctx.C)
+        dQ, dK, _, da = _attn_backward(ctx.g, ctx.loops, ATTN_GATV2, Q, K, None, a_hc, ctx.slope, 1.0, stats, dz, ctx.H, ctx.C,
+                                       ctx.p_drop, ctx.seed)
         dWi, dbi = dense_grad_w(dQ, x, need_b=ctx.has_bi)
         dWj, _ = dense_grad_w(dK, x, need_b=False)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = _add_(dense_grad_x(dQ, Wi), dense_grad_x(dK, Wj))
-        return dx, dWi, dbi, dWj, da.t(), db, None, None, None, None, None, None
+        return dx, dWi, dbi, dWj, da.t(), db, None, None, None, None, None, None, None, None
 
 
-def gatv2_conv_ad(l, g: GNNGraph, x):
-    """differentiable GATv2Conv forward: gradients w.r.t. x, dense_i (weight, bias), dense_j weight, a, bias"""
+def gatv2_conv_ad(l, g: GNNGraph, x, seed=None):
+    """differentiable GATv2Conv forward: gradients w.r.t. x, dense_i (weight, bias), dense_j weight, a, bias.  l.dropout > 0: the
+    attention coefficients are dropped (conv.jl:191) with the mask of `seed` (default: the layer's next one), regenerated in the pullback"""
     check_num_nodes(g, x)
     assert l.dense_e is None, "the HIP adjoint does not cover edge features"
+    p_drop = float(getattr(l, "dropout", 0.0))
+    if p_drop > 0.0:
+        if seed is None:
+            seed = l.next_seed()
+        l.last_seed = int(seed)
     return _GATv2ConvFn.apply(x, l.dense_i_weight, l.dense_i_bias, l.dense_j_weight, l.a, l.bias, g, l.sigma, l.heads,
-                              l.negative_slope, bool(l.add_self_loops), bool(l.concat))
+                              l.negative_slope, bool(l.add_self_loops), bool(l.concat), p_drop, 0 if seed is None else int(seed))
 
 
 class _TransformerConvFn(torch.autograd.Function):

@@ -9,6 +9,7 @@ transformer_conv :553-629.  Constructors: GraphNeuralNetworks/src/layers/conv.jl
 """
 from __future__ import annotations
 
+import numpy as np
 import torch
 
 from . import _lib as L
@@ -20,13 +21,19 @@ ATTN_GAT, ATTN_GATV2, ATTN_DOT, ATTN_COS = 0, 1, 2, 3
 
 
 def attn_conv(plan, mode, K, Q=None, V=None, a=None, slope=0.2, scale=1.0, bias=None, act=L.ACT_IDENTITY, H=1, C=None,
-              stats=None):
-    """out[i] = Σ_j softmax_{j in N(i)}(logit_mode(Q_i, K_j)) V_j  (+ bias, act) — one pass over the plan's edges"""
+              stats=None, dropout=0.0, seed=0):
+    """out[i] = Σ_j softmax_{j in N(i)}(logit_mode(Q_i, K_j)) V_j  (+ bias, act) — one pass over the plan's edges; dropout > 0: the
+    coefficients dropped inside the kernel with the mask of `seed` (include/gnnmp.h: gnnmp_gat_conv_drop_f32)"""
     N = plan.n_dst
     C = K.shape[1] // H if C is None else C
     out = torch.empty((N, H * C), dtype=torch.float32, device=K.device)
-    L.check(L.load().gnnmp_attn_conv_f32(plan.handle, mode, L.ptr(Q), L.ptr(K), L.ptr(V), L.ptr(a), float(slope),
-                                         float(scale), L.ptr(bias), act, L.ptr(out), L.ptr(stats), H, C, L.stream_ptr()))
+    if dropout > 0.0:
+        L.check(L.load().gnnmp_attn_conv_drop_f32(plan.handle, mode, L.ptr(Q), L.ptr(K), L.ptr(V), L.ptr(a), float(slope),
+                                                  float(scale), float(dropout), int(seed), L.ptr(bias), act, L.ptr(out),
+                                                  L.ptr(stats), H, C, L.stream_ptr()))
+    else:
+        L.check(L.load().gnnmp_attn_conv_f32(plan.handle, mode, L.ptr(Q), L.ptr(K), L.ptr(V), L.ptr(a), float(slope),
+                                             float(scale), L.ptr(bias), act, L.ptr(out), L.ptr(stats), H, C, L.stream_ptr()))
     return out
 
 
@@ -44,9 +51,10 @@ def _heads_tail(out, l, N, H, C):
 # ---------------------------------------------------------------------------------------------------------
 # GATv2Conv
 # ---------------------------------------------------------------------------------------------------------
-def gatv2_conv(l, g: GNNGraph, x, e=None):
+def gatv2_conv(l, g: GNNGraph, x, e=None, seed=None):
     """conv.jl:171-214 without edge features: logα = sum(a .* leakyrelu.(Wxi + Wxj)), softmax over the neighbourhood,
-    weighted sum of Wxj, optional head mean, σ.(x .+ bias)"""
+    `α = dropout(α, l.dropout)` (:191, inside the kernel; `seed` defaults to the layer's next one), weighted sum of Wxj, optional
+    head mean, σ.(x .+ bias)"""
     check_num_nodes(g, x)
     assert e is None and l.dense_e is None, "edge features (dense_e) are outside the hot path"
     plan = g.plan(bool(l.add_self_loops))
@@ -56,8 +64,13 @@ def gatv2_conv(l, g: GNNGraph, x, e=None):
     code, _ = _act_code(l.sigma)
     fuse = bool(l.concat)
     b = l.bias if (fuse and l.bias is not None) else None
+    p_drop = float(getattr(l, "dropout", 0.0))
+    if p_drop > 0.0:
+        if seed is None:
+            seed = l.next_seed()
+        l.last_seed = int(seed)
     out = attn_conv(plan, ATTN_GATV2, Wxj, Q=Wxi, a=l.a_hc, slope=l.negative_slope, bias=b,
-                    act=code if fuse else L.ACT_IDENTITY, H=H, C=C)
+                    act=code if fuse else L.ACT_IDENTITY, H=H, C=C, dropout=p_drop, seed=0 if seed is None else seed)
     return _heads_tail(out, l, g.num_nodes, H, C)
 
 
@@ -71,8 +84,11 @@ class GATv2Conv:
     def __init__(self, ch, sigma=None, heads=1, concat=True, negative_slope=0.2, bias=True, add_self_loops=True,
                  dropout=0.0, device="cuda", seed=None):
         cin, cout = ch
-        assert dropout == 0.0, "dropout is identity in the forward/test mode this engine covers"
+        assert 0.0 <= dropout < 1.0
         sd = (lambda k: None if seed is None else seed + k)
+        self.dropout = float(dropout)
+        self.last_seed = None
+        self._seed_rng = np.random.default_rng(None if seed is None else seed + 7)
         self.channel = (cin, cout)
         self.heads, self.concat, self.negative_slope = heads, concat, float(negative_slope)
         self.add_self_loops = add_self_loops
@@ -91,6 +107,10 @@ class GATv2Conv:
             self._a_hc = self.a.t().contiguous()          # [H][C]
             self._a_hc_key = key
         return self._a_hc
+
+    def next_seed(self):
+        """a fresh 64-bit mask seed per call (the reference draws a fresh mask from its default RNG on every call)"""
+        return int(self._seed_rng.integers(0, 2**63 - 1))
 
     def __call__(self, g, x, e=None):
         return gatv2_conv(self, g, x, e)

@@ -485,8 +485,18 @@ end
 # mode 1: gatv2_conv (conv.jl:171-214; Q = Wxi, K = Wxj, a = l.a (C, H) as stored)   mode 2: transformer_conv attention
 # (conv.jl:553-616; Q = W3x, K = W4x, V = W2x, scale = l.sqrt_out)   mode 3: agnn_conv (conv.jl:337-352; K = x, scale = l.β[1])
 function attention(g::GNNGraph{<:COO_T}, mode::Int, K::AnyROCMatrix{Float32}; Q = nothing, V = nothing, a = nothing,
-                   slope = 0.2f0, scale = 1f0, bias = nothing, relu = false, heads::Int = 1, self_loops::Bool)
+                   slope = 0.2f0, scale = 1f0, bias = nothing, relu = false, heads::Int = 1, self_loops::Bool,
+                   dropout = 0f0, seed::UInt64 = UInt64(0))
     out = similar(K)
+    if dropout > 0     # gatv2_conv's `α = dropout(α, l.dropout)` (conv.jl:191) inside the kernel; pass seed = attention_seed()
+        check(@ccall libgnnmp.gnnmp_attn_conv_drop_f32(plan(g; self_loops).handle::Ptr{Cvoid}, mode::Cint, devptr(Q)::Ptr{Cvoid},
+                                                       devptr(K)::Ptr{Cvoid}, devptr(V)::Ptr{Cvoid}, devptr(a)::Ptr{Cvoid},
+                                                       Float32(slope)::Cfloat, Float32(scale)::Cfloat, Float32(dropout)::Cfloat,
+                                                       seed::UInt64, devptr(bias)::Ptr{Cvoid}, Cint(relu)::Cint,
+                                                       devptr(out)::Ptr{Cvoid}, C_NULL::Ptr{Cvoid}, heads::Int64,
+                                                       (size(K, 1) ÷ heads)::Int64, stream_ptr()::Ptr{Cvoid})::Cint)
+        return out
+    end
     check(@ccall libgnnmp.gnnmp_attn_conv_f32(plan(g; self_loops).handle::Ptr{Cvoid}, mode::Cint, devptr(Q)::Ptr{Cvoid},
                                               devptr(K)::Ptr{Cvoid}, devptr(V)::Ptr{Cvoid}, devptr(a)::Ptr{Cvoid},
                                               Float32(slope)::Cfloat, Float32(scale)::Cfloat, devptr(bias)::Ptr{Cvoid},

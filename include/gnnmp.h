@@ -399,6 +399,17 @@ int gnnmp_gat_conv_grad_drop_f32(gnnmp_graph_t *plan, gnnmp_graph_t *plan_t, con
                                  const float *dout, float *line, float *dsd, float *dss, float *dWx_src, float *dWx_dst,
                                  float *da, int64_t H, int64_t C, gnnmp_stream_t stream);
 
+/* gnnmp_attn_conv_f32 with dropout on the attention coefficients — gatv2_conv's `α = dropout(α, l.dropout)` (conv.jl:191); same mask
+ * function, same rules as gnnmp_gat_conv_drop_f32 (mode GNNMP_ATTN_GAT or GNNMP_ATTN_GATV2; GNNMP_EUNSUPPORTED for the others, which
+ * have no dropout in the reference), and its pullback for the GATV2 logit (same p and seed; arguments as gnnmp_attn_conv_grad_f32). */
+int gnnmp_attn_conv_drop_f32(gnnmp_graph_t *plan, int mode, const float *Q, const float *K, const float *V, const float *a,
+                             float negative_slope, float scale, float p, uint64_t seed, const float *bias, int act, float *out,
+                             float *stats, int64_t H, int64_t C, gnnmp_stream_t stream);
+int gnnmp_attn_conv_grad_drop_f32(gnnmp_graph_t *plan, gnnmp_graph_t *plan_t, int mode, const float *Q, const float *K,
+                                  const float *V, const float *a, float negative_slope, float scale, float p, uint64_t seed,
+                                  const float *stats, const float *dout, float *line, float *dQ, float *dK, float *dV, float *dA,
+                                  float *da, int64_t H, int64_t C, gnnmp_stream_t stream);
+
 /* Pullback of gnnmp_attn_conv_f32 for the GATV2 and DOT logits (the GAT logit has the cheaper dedicated entry above; the
  * cosine logit has none yet: GNNMP_EUNSUPPORTED).  dout = Δ w.r.t. the aggregated (pre-bias, pre-σ) output; stats from the
  * forward; plan_t = plan of the reversed edge index.  Caller-supplied: line [n_dst][H][4] (16-byte aligned scratch),

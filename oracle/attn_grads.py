@@ -25,7 +25,7 @@ def _softmax_pullback(alpha, dalpha, ti, n, H):
 
 
 def grad_gatv2_conv(s, t, n, x, Wi, bi, Wj, a, bias, sigma, dy, heads=1, negative_slope=0.2, add_self_loops_=True,
-                    concat=True):
+                    concat=True, dropout=0.0, seed=0):
     """(Δx, ΔWi, Δbi, ΔWj, Δa, Δb); a: Julia shape (C, H)"""
     s, t = O._i64(s), O._i64(t)
     if add_self_loops_:
@@ -41,15 +41,17 @@ def grad_gatv2_conv(s, t, n, x, Wi, bi, Wj, a, bias, sigma, dy, heads=1, negativ
     lr = np.where(z > 0, z, negative_slope * z)
     l = (a_hc[None] * lr).sum(-1)
     alpha = _softmax_agg(l, ti, n, H)
+    # α' = k .* α with the constant k = keep / (1 - p) (conv.jl:191): its rule hands Δα = k .* Δα' to the softmax pullback
+    k = O.dropout_keep(seed, dropout, len(ti), H).astype(np.float64) / (1.0 - float(np.float32(dropout))) if dropout > 0.0 else 1.0
     o = np.zeros((n, H, C))
-    np.add.at(o, ti, alpha[..., None] * K[si])
+    np.add.at(o, ti, (alpha * k)[..., None] * K[si])
     y = (o.reshape(n, H * C) if concat else o.mean(axis=1)) + (0 if bias is None else np.asarray(bias, np.float64)[None, :])
     dz = np.asarray(dy, np.float64) * (y > 0) if sigma == "relu" else np.asarray(dy, np.float64)
     db = dz.sum(0)
     dzh = dz.reshape(n, H, C) if concat else np.repeat(dz[:, None, :] / H, H, axis=1)   # ∇mean(x, dims = 2)
     delta = dzh[ti]                                                 # Δβ = Δ[t]
-    dalpha = (delta * K[si]).sum(-1)
-    dKj = alpha[..., None] * delta
+    dalpha = (delta * K[si]).sum(-1) * k
+    dKj = (alpha * k)[..., None] * delta
     dl = _softmax_pullback(alpha, dalpha, ti, n, H)
     dlr = dl[..., None] * a_hc[None]                                # through sum(a .* lrelu)
     da = (dl[..., None] * lr).sum(0)                                # [H, C]

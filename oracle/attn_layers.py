@@ -48,8 +48,8 @@ def _heads_tail(y, n, H, C, concat, bias, sigma):
 
 
 def gatv2_conv(s, t, n, x, dense_i_weight, dense_i_bias, dense_j_weight, a, bias=None, sigma=None, heads=1, concat=True,
-               negative_slope=0.2, add_self_loops_=True):
-    """a: Julia shape (out, heads), numpy [C, H]"""
+               negative_slope=0.2, add_self_loops_=True, dropout=0.0, seed=0):
+    """a: Julia shape (out, heads), numpy [C, H]; dropout > 0: α = dropout(α, p) (conv.jl:191) with the mask of O.dropout_keep(seed)"""
     s, t = O._i64(s), O._i64(t)
     H = heads
     C = dense_i_weight.shape[0] // H
@@ -66,6 +66,9 @@ def gatv2_conv(s, t, n, x, dense_i_weight, dense_i_bias, dense_j_weight, a, bias
     a_hc = O._f32(np.asarray(a).T)                               # [H, C]
     logit = _sum_dim1((a_hc[None] * _lrelu(Wx, negative_slope)).astype(f32))     # :211  [E', H]
     alpha = O.softmax_edge_neighbors(t, n, logit)
+    if dropout > 0.0:
+        keep = O.dropout_keep(seed, dropout, len(s), H).astype(f32)
+        alpha = (alpha * keep * f32(1.0 / (1.0 - f32(dropout)))).astype(f32)
     beta = (alpha[..., None] * ej).astype(f32)
     y = O.scatter(O.SUM, beta.reshape(len(s), H * C), t, n).reshape(n, H, C)
     return _heads_tail(y, n, H, C, concat, bias, sigma)

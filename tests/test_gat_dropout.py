@@ -210,3 +210,85 @@ def test_backward_vs_oracle_given_the_mask(gm, oracle, H, C, Din, sigma, concat)
     xt2 = dev(x).requires_grad_(True)
     (gat_conv_ad(l, g, xt2, seed=seed) * dev(r)).sum().backward()
     assert bool((xt2.grad == xt.grad).all())
+
+
+# ---- GATv2Conv (conv.jl:191): the same mask function on the GATv2 logit ----------------------------------------------------------------
+def test_oracle_gatv2_dropout_adjoint_matches_finite_differences():
+    from oracle import attn_layers as AL, attn_grads as AG
+    rng = np.random.default_rng(21)
+    n, E, Din, H, C = 40, 260, 6, 2, 4
+    s = rng.integers(1, n + 1, E); t = rng.integers(1, n + 1, E)
+    keep = s != t
+    s, t = s[keep], t[keep]
+    x = rng.standard_normal((n, Din)).astype(np.float32)
+    Wi = (rng.standard_normal((H * C, Din)) / np.sqrt(Din)).astype(np.float32)
+    Wj = (rng.standard_normal((H * C, Din)) / np.sqrt(Din)).astype(np.float32)
+    bi = (rng.standard_normal(H * C) * 0.1).astype(np.float32)
+    a = (rng.standard_normal((C, H)) * 0.7).astype(np.float32)
+    b = (rng.standard_normal(H * C) * 0.1).astype(np.float32)
+    r = rng.standard_normal((n, H * C)).astype(np.float32)
+    p, seed = 0.3, 777
+
+    def loss(*v):
+        return float((AL.gatv2_conv(s, t, n, v[0], v[1], v[2], v[3], v[4], v[5], None, heads=H, dropout=p, seed=seed).astype(np.float64) * r).sum())
+
+    args = [x, Wi, bi, Wj, a, b]
+    grads = AG.grad_gatv2_conv(s, t, n, x, Wi, bi, Wj, a, b, None, r, heads=H, dropout=p, seed=seed)
+    eps, checked = 2e-3, 0
+    for which, grad in enumerate(grads):
+        for _ in range(8):
+            idx = tuple(int(rng.integers(0, d)) for d in args[which].shape)
+            ap = [v.copy() for v in args]; am = [v.copy() for v in args]
+            ap[which][idx] += eps; am[which][idx] -= eps
+            f0, fp, fm = loss(*args), loss(*ap), loss(*am)
+            if abs((fp - f0) - (f0 - fm)) > 0.05 * eps * max(1.0, abs(float(grad[idx]))):
+                continue                # a leakyrelu kink inside the stencil
+            assert (fp - fm) / (2 * eps) == pytest.approx(float(grad[idx]), rel=3e-2, abs=3e-2)
+            checked += 1
+    assert checked >= 36
+    # given the mask, the dropped layer is α .* keep ./ (1 - p); p = 0 is the undropped layer bit for bit
+    assert np.array_equal(AL.gatv2_conv(s, t, n, x, Wi, bi, Wj, a, b, "relu", heads=H, dropout=0.0, seed=3),
+                          AL.gatv2_conv(s, t, n, x, Wi, bi, Wj, a, b, "relu", heads=H))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,C,Din,sigma,concat", [(8, 16, 100, "relu", True), (2, 4, 6, None, True), (1, 64, 32, "relu", True),
+                                                  (4, 7, 12, None, True), (3, 2, 5, "relu", False)])
+def test_gatv2_dropout_forward_and_backward_vs_oracle(gm, H, C, Din, sigma, concat):
+    import torch
+    from oracle import attn_layers as AL, attn_grads as AG
+    from gnnmp.layers_attn import GATv2Conv, gatv2_conv
+    from gnnmp.backward_attn import gatv2_conv_ad
+    rng = np.random.default_rng(H * 77 + C)
+    n, E, p = 1500, 24000, 0.25
+    s, t = _graph(rng, n, E)
+    x = rng.standard_normal((n, Din)).astype(np.float32)
+    nb = H * C if concat else C
+    r = rng.standard_normal((n, nb)).astype(np.float32)
+    g = gm.GNNGraph(dev(s), dev(t), num_nodes=n)
+    l = GATv2Conv((Din, C), sigma, heads=H, concat=concat, dropout=p, seed=4)
+    l.dense_i_bias = dev((rng.standard_normal(H * C) * 0.1).astype(np.float32))
+    l.bias = dev((rng.standard_normal(nb) * 0.1).astype(np.float32))
+    prm = [l.dense_i_weight, l.dense_i_bias, l.dense_j_weight, l.a, l.bias]
+    ref_in = [q.cpu().numpy() for q in prm]
+    # forward (inference path)
+    y = l(g, dev(x))
+    seed = l.last_seed
+    ref = AL.gatv2_conv(s, t, n, x, *ref_in, sigma, heads=H, concat=concat, dropout=p, seed=seed)
+    assert np.linalg.norm(y.cpu().numpy() - ref) <= 1e-5 * np.linalg.norm(ref)
+    assert torch.equal(gatv2_conv(l, g, dev(x), seed=seed), y) and not torch.equal(l(g, dev(x)), y)
+    # forward + pullback through autograd with the same seed
+    for q in prm:
+        q.requires_grad_(True)
+    xt = dev(x).requires_grad_(True)
+    ya = gatv2_conv_ad(l, g, xt, seed=seed)
+    assert np.linalg.norm(ya.detach().cpu().numpy() - ref) <= 1e-5 * np.linalg.norm(ref)
+    (ya * dev(r)).sum().backward()
+    grads = AG.grad_gatv2_conv(s, t, n, x, *ref_in, sigma, r, heads=H, concat=concat, dropout=p, seed=seed)
+    for name, got, gref in zip(("dx", "dWi", "dbi", "dWj", "da", "db"), (xt.grad, *(q.grad for q in prm)), grads):
+        gotn = got.cpu().numpy()
+        assert gotn.shape == gref.shape, name
+        if np.linalg.norm(gref) < 1e-6:
+            assert np.linalg.norm(gotn) <= 1e-3, name
+        else:
+            assert np.linalg.norm(gotn - gref) <= 3e-5 * np.linalg.norm(gref), name

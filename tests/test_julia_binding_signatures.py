@@ -156,5 +156,5 @@ def test_extended_methods_exist_in_the_reference_with_that_arity():
 def test_round3_entry_points_are_bound():
     src = open(JL).read()
     for sym in ("gnnmp_graphconv_chain_f32", "gnnmp_chain_jobs_create", "gnnmp_shard_by_size", "gnnmp_allgather_f32", "gnnmp_segment_bounds",
-                "gnnmp_gat_conv_drop_f32", "gnnmp_gat_conv_grad_drop_f32"):
+                "gnnmp_gat_conv_drop_f32", "gnnmp_gat_conv_grad_drop_f32", "gnnmp_attn_conv_drop_f32"):
         assert sym in src, sym
