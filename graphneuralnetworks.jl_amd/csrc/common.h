@@ -49,7 +49,10 @@ enum Knob {
     KNOB_DENSE_SPLIT = 17,     // split-bf16 dense core (msplit.h, dense_split.hip): 0 = auto (on for its shapes), < 0 = the fp32-MFMA
                                // kernels of rounds 1-2 on every shape
     KNOB_CHAIN = 18,           // fused GraphConv chain kernel (graph_chain.hip): 0 = auto, < 0 = never (layer-by-layer path)
-    KNOB_COUNT = 19
+    KNOB_VARIANT = 19,         // A/B switches of round 3 (all variants are correct code): low 2 bits = 1: the wave-pair chain kernel with 8 waves
+                               // a block (default 12); 16: dense_split runs its column tiles one after the other; 32: dense_split stores
+                               // straight from the accumulator layout (default: through the per-wave LDS stage)
+    KNOB_COUNT = 20
 };
 int knob(int k);
 int device_cus();   // compute units of the current device, queried once (hipDeviceGetAttribute costs microseconds per call)

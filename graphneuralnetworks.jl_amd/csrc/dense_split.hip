@@ -263,10 +263,10 @@ static int launch_split_var(const SplitArgs &a0, hipStream_t stream) {
     // Several column tiles (Dout > DP: SAGEConv's 256 columns are two): a block fills a CU (LDS), so with `cus` blocks per column tile
     // the tiles ran one after the other and x came from HBM once per column tile.  cus / ny blocks per column tile instead: blocks
     // (b, 0), (b, 1), ... walk the same row tiles at the same time and — linear block ids b, b + gx, ... with gx a multiple of 8 — on
-    // the same XCD, so every read of x after the first is an L2 hit (knob 13 bit 4 = the old grid, for A/B runs).
+    // the same XCD, so every read of x after the first is an L2 hit (knob 19 bit 4 = the old grid, for A/B runs).
     const int ny = (a.Dout + DP - 1) / DP;
     int64_t bx = cus;
-    if (ny > 1 && !(knob(KNOB_T16_DEBUG) & 16)) bx = std::max<int64_t>(8, (int64_t)(cus / ny) & ~(int64_t)7);
+    if (ny > 1 && !(knob(KNOB_VARIANT) & 16)) bx = std::max<int64_t>(8, (int64_t)(cus / ny) & ~(int64_t)7);
     const int64_t gx = std::min<int64_t>(bx, (ntiles + waves - 1) / waves);
     dim3 grid((unsigned)gx, (unsigned)ny);
     dense_split_kernel<NCB, K0C, K1C, VAR><<<grid, 64 * waves, lds, stream>>>(a);
@@ -285,8 +285,8 @@ static int launch_split(const SplitArgs &a, hipStream_t stream) {
         }
     }
 #endif
-    // stores through the per-wave LDS stage (whole 128-byte lines) when 8 stages fit beside the image (knob 13 bit 5 = never, for A/B runs)
-    const bool staged = split_img_bytes(a.nkb * 16, NCB * 32) + (size_t)NCB * 32 * 4 + 8 * 4096 <= 160 * 1024 && !(knob(KNOB_T16_DEBUG) & 32);
+    // stores through the per-wave LDS stage (whole 128-byte lines) when 8 stages fit beside the image (knob 19 bit 5 = never, for A/B runs)
+    const bool staged = split_img_bytes(a.nkb * 16, NCB * 32) + (size_t)NCB * 32 * 4 + 8 * 4096 <= 160 * 1024 && !(knob(KNOB_VARIANT) & 32);
     if (a.Dout % (NCB * 32) == 0)
         return staged ? launch_split_var<NCB, K0C, K1C, 256 | 4096>(a, stream) : launch_split_var<NCB, K0C, K1C, 256>(a, stream);
     return staged ? launch_split_var<NCB, K0C, K1C, 4096>(a, stream) : launch_split_var<NCB, K0C, K1C, 0>(a, stream);

@@ -654,8 +654,8 @@ int graph_chain2_try(gnnmp_graph_t *p, const gnnmp_chain_jobs_t *J, const int64_
     a.trace = g_chain_trace;
 #endif
     a.G = (int)G;
-    // knob 13 (experiments): 1 = 8 waves a block (4 pairs, up to 256 registers a wave) instead of 12 (6 pairs, 168 registers)
-    const int waves = (knob(KNOB_T16_DEBUG) & 3) == 1 ? 8 : 12;
+    // knob 19 (A/B runs): 1 = 8 waves a block (4 pairs, up to 256 registers a wave) instead of 12 (6 pairs, 168 registers)
+    const int waves = (knob(KNOB_VARIANT) & 3) == 1 ? 8 : 12;
     const size_t lds = (size_t)3 * C2_UNITS1 * 16 + (size_t)3 * C2_UNITS2 * 16 + C2_D1 * 4 + C2_SLAB * 4 + 8 * C2_SLAB * 4 +
                        (size_t)(waves / 2) * C2_STAGE_BYTES + 4 * 2 * (size_t)waves;
     static bool attr_set = false;

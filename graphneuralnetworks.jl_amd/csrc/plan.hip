@@ -15,7 +15,7 @@
 namespace gnnmp {
 
 static thread_local char g_err[512] = "";
-static int g_knobs[KNOB_COUNT] = {0, -1, 0, 1, 0, 0, 0, 17, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+static int g_knobs[KNOB_COUNT] = {0, -1, 0, 1, 0, 0, 0, 17, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
 int fail(int status, const char *fmt, ...) {
     va_list ap;

@@ -5,7 +5,10 @@ paths: non-power-of-two heads, K > 128, D % 4 != 0, small graphs).  Here a core 
   0=1 | 0=2        one / two features per lane in every row kernel (default: four where alignment allows)
   6=2,10=-1,16=-1  the round-1 dense kernels, the round-1 ΔW kernel, the three-step softmax
   17=-1            every dense product on the fp32-MFMA kernels of rounds 1-2 (default: the split-bf16 core where its image fits)
-  18=1 | 18=-1     GraphConv chains on the general fused kernel / layer by layer (default: the wave-per-graph-group kernel)
+  18=1 | 18=-1     GraphConv chains on the general fused kernel / layer by layer (default: the wave-pair kernel)
+  19=1             the wave-pair chain kernel with 8 waves a block (4 pairs, the 512-thread instantiation; default 12 waves)
+  19=48            the split-bf16 dense kernel storing straight from the accumulator layout and running its column tiles one after
+                   the other (default: through the per-wave LDS stage, column tiles side by side)
 Each case IS the original test function, called with the knobs set."""
 import numpy as np
 import pytest
@@ -20,6 +23,8 @@ KNOB_SETS = {
     "fp32-mfma-dense(17=-1)": [(17, -1)],
     "chain-general(18=1)": [(18, 1)],
     "chain-off(18=-1)": [(18, -1)],
+    "chain-8-waves(19=1)": [(19, 1)],
+    "dense-split-direct-stores-serial-column-tiles(19=48)": [(19, 48)],
 }
 
 
@@ -88,3 +93,4 @@ def test_layers_and_chain(knobs, gm, oracle):
     T.test_arxiv_shape_gcn_and_gat_vs_oracle(gm, oracle)
     C.test_config5_shape_vs_oracle_and_layers(gm, oracle, 64)
     C.test_irregular_batches(gm, oracle, C.CASES[0], 0)
+    C.test_wave_job_kernel_on_irregular_batches(gm, oracle, "mean", "+", 1)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""graph_chain2_kernel launch variants (knob 13, read at gnnmp_chain_jobs_create and at launch): bit 3 = 32-row jobs (one MFMA tile a
+"""graph_chain2_kernel launch variants (knob 19, read at gnnmp_chain_jobs_create and at launch): bit 3 = 32-row jobs (one MFMA tile a
 wave; low bits 0: 16 waves a block, 1: 12, 2: 8), else 64-row jobs (low bits 0: 8 waves, 1: 4, 2: 6); bit 2 = scheduling barriers.
 usage: chain_variants.py [G] [nmin] [nmax]"""
 import os, sys
@@ -33,12 +33,12 @@ model = gnnmp.GNNChain(gnnmp.GraphConv((16, 128), "relu", seed=21), gnnmp.GraphC
 y0 = None
 variants = [int(v) for v in os.environ.get('VARIANTS', '3,0,1,2').split(',')]
 for kv in variants:
-    gnnmp.tune(13, kv)
+    gnnmp.tune(19, kv)
     g = gnnmp.batch_arrays(members, xs)          # (a fresh graph: the jobs are built under this knob value)
     f = lambda: model(g, g.x)
     y = f()
     if y0 is None:
         y0 = y
     cj = g._cache.get("chain_jobs"); info = (cj.njobs, cj.fill) if cj is not None else None
-    print(f"chain2 knob13={kv}: {t(f)*1e3:7.1f} us  max diff {float((y - y0).abs().max()):.1e}  jobs {info}", flush=True)
-gnnmp.tune(13, 0)
+    print(f"chain2 knob19={kv}: {t(f)*1e3:7.1f} us  max diff {float((y - y0).abs().max()):.1e}  jobs {info}", flush=True)
+gnnmp.tune(19, 0)

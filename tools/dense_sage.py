@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""dense_split_kernel A/B runs on one box (knob 13): bit 4 (16) = one column tile after the other instead of side by side (SAGEConv's
+"""dense_split_kernel A/B runs on one box (knob 19): bit 4 (16) = one column tile after the other instead of side by side (SAGEConv's
 256 columns), bit 5 (32) = stores straight from the accumulator layout instead of through the per-wave LDS stage."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -31,11 +31,11 @@ for (N, K, Dout, two) in [(2449029, 100, 128, False), (2449029, 100, 256, True),
     same = True
     for rep in range(4):                      # interleaved: clocks drift by 10 % over the first seconds of a run
         for kv in (0, 32, 16):
-            gnnmp.tune(13, kv)
+            gnnmp.tune(19, kv)
             same = same and bool(torch.equal(f(), y0))
             res[kv].append(t(f, 10))
     for kv in (0, 32, 16):
-        row.append(f"knob13={kv}: {sorted(res[kv])[1]*1e3:8.1f} us")
+        row.append(f"knob19={kv}: {sorted(res[kv])[1]*1e3:8.1f} us")
     row.append(f"equal={same}")
-    gnnmp.tune(13, 0)
+    gnnmp.tune(19, 0)
     print(f"N={N} K={K}{'+' + str(K) if two else ''} Dout={Dout}: " + "   ".join(row), flush=True)
