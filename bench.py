@@ -644,7 +644,8 @@ def main():
                                     f"(G_r, 2) logits per step (gnnmp.parallel.ShardPlan: no host work in the step)"}
 
     result = {
-        "metric": "edges/sec (fwd) GCNConv+GATConv, ogbn-products-shape; achieved HBM GB/s vs peak",
+        "metric": ("edges/sec (fwd) GCNConv+GATConv, ogbn-products-shape; achieved HBM GB/s vs peak" if args.workload == "products" else
+                   "edges/sec (fwd) GCNConv+GATConv, ogbn-arxiv-shape (BASELINE.json configs 2 + 3; not the headline metric)"),
         "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
