@@ -557,10 +557,13 @@ int gnnmp_allgather_f32(void *nccl_comm, const float *send, float *recv, int64_t
  * here agree to rounding (both are linear); the per-row aggregates have the bits of gnnmp_propagate_f32's.
  * ---------------------------------------------------------------------------------------------- */
 int64_t gnnmp_graphconv_chain_scratch_floats(int64_t N, int n_layers, const int64_t *dims, int64_t nout);
-/* Optional per-batch constant (like the plan): the member graphs packed into wave jobs of at most 64 rows (best fit decreasing), which
- * lets the chain 16 => 128 => 128 run with a WAVE per group of whole member graphs and no intermediate in memory at all
- * (csrc/graph_chain2.hip: layer 1's accumulators are layer 2's operands, neighbours are summed through a 4 KB LDS stage, the two
- * 64-column halves of layer 2 go to different workgroups and meet in one atomic add per logit — two addends, order-independent).
+/* Optional per-batch constant (like the plan): the member graphs packed into jobs of at most 64 rows (best fit decreasing), which lets
+ * the chain 16 => 128 => 128 run with a PAIR OF WAVES per group of whole member graphs and no layer output in memory at all
+ * (csrc/graph_chain2.hip: layer 1's accumulators are layer 2's operands, the neighbour sums of layer 2 run after its product through
+ * a 4 KB LDS stage the two waves share, the two 64-column halves of layer 2 go to different workgroups; each row's W_head * h2 — nout
+ * floats per half — is the only intermediate written, and a second small launch pools it per member graph in node order: no
+ * floating-point atomic, no memset, run-to-run identical).  The handle owns that intermediate and the list of jobs set aside for the
+ * exact fp32 path (non-finite operands), so — like a plan's workspace — it serves ONE stream at a time.
  * Built once per batched graph from the DEVICE seg_ptr; synchronises `stream` (graph prep).  A batch with a member graph of more than
  * 64 nodes, or without any, yields a handle without jobs: the chain then runs on the general kernel.  info[0] = jobs, [1] = member
  * graphs, [2] = rows, [3] = largest member graph, [4] = per-mille of the MFMA tiles' rows that are real rows. */
