@@ -167,7 +167,7 @@ def test_irregular_batches(gm, oracle, case, seed):
 @pytest.mark.parametrize("aggr,pool", [("+", "mean"), ("mean", "+")])
 @pytest.mark.parametrize("seed", [0, 1, 2])
 def test_wave_job_kernel_on_irregular_batches(gm, oracle, aggr, pool, seed):
-    """csrc/graph_chain2.hip (two layers 16 => 128 => 128, member graphs <= 64 nodes: a wave per job, nothing through memory) on
+    """csrc/graph_chain2.hip (two layers 16 => 128 => 128, member graphs <= 64 nodes: a pair of waves per job, no layer output in memory) on
     uneven batches: graphs of 1..64 nodes, isolated nodes, hubs with up to n in-neighbours (the tail loops of both gathers), jobs of
     one and two tiles, empty slots — against the oracle, the general kernel (knob 18 = 1) and the layer-by-layer path"""
     import torch
@@ -191,7 +191,7 @@ def test_wave_job_kernel_on_irregular_batches(gm, oracle, aggr, pool, seed):
     close(y_general.cpu().numpy(), ref, "general kernel vs oracle")
     close(y.cpu().numpy(), yl.cpu().numpy(), "wave-job kernel vs layers")
     for _ in range(3):
-        assert torch.equal(model(g, g.x), y), "not run-to-run identical (two atomic addends per logit: order must not matter)"
+        assert torch.equal(model(g, g.x), y), "not run-to-run identical (no atomic on the path: the pooling kernel adds the slabs' halves in a fixed order)"
 
 
 def ring_graph(n, rng, extra=0):
