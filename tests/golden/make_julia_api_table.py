@@ -47,13 +47,32 @@ def definitions(pkg, name):
     return sorted(out)
 
 
+def defined_names(pkg):
+    """every top-level name the package's sources define (functions, structs, abstract types, constants / type aliases) — names only"""
+    names = set()
+    pats = [re.compile(r"^\s*(?:@\w+\s+)*function\s+(?:[A-Za-z_][\w.]*\.)?([A-Za-z_]\w*!?)\s*[({]", re.M),
+            re.compile(r"^(?:[A-Za-z_][\w.]*\.)?([A-Za-z_]\w*!?)\([^\n=]*\)\s*(?:where\s*\{[^}]*\}\s*)?=(?!=)", re.M),
+            re.compile(r"^\s*(?:mutable\s+)?struct\s+([A-Za-z_]\w*)", re.M),
+            re.compile(r"^\s*abstract\s+type\s+([A-Za-z_]\w*)", re.M),
+            re.compile(r"^\s*const\s+([A-Za-z_]\w*)\s*=", re.M)]
+    for d in PKG_DIRS[pkg]:
+        for base, _, files in os.walk(os.path.join(REF, d)):
+            for f in files:
+                if f.endswith(".jl"):
+                    src = strip_comments_and_strings(open(os.path.join(base, f)).read())
+                    for pat in pats:
+                        names.update(pat.findall(src))
+    return sorted(names)
+
+
 def main():
     table = {}
     for pkg, name, _arity in extended_methods():
         table[f"{pkg}.{name}"] = definitions(pkg, name)
+    table["_names"] = {pkg: defined_names(pkg) for pkg in PKG_DIRS}
     path = os.path.join(ROOT, "tests", "golden", "julia_api_table.json")
     json.dump(table, open(path, "w"), indent=1, sort_keys=True)
-    print(path, {k: v for k, v in table.items()})
+    print(path, {k: v for k, v in table.items() if k != "_names"}, {k: len(v) for k, v in table["_names"].items()})
 
 
 if __name__ == "__main__":

@@ -153,6 +153,28 @@ def test_extended_methods_exist_in_the_reference_with_that_arity():
         assert json.dumps(json.load(open(os.path.join(ROOT, "tests", "golden", "julia_api_table.json"))), sort_keys=True) == before
 
 
+def test_every_reference_name_the_extension_uses_exists():
+    """`using GNNlib: ...` / `using GNNGraphs: ...` lists and every qualified `GNNlib.x` / `GNNGraphs.x` in the extension name something
+    the reference defines (tests/golden/julia_api_table.json "_names": names only, generated from /root/reference) — a misspelt import
+    is an UndefVarError at load time, i.e. the drop-in does not load.  GNNlib does `using GNNGraphs` (GNNlib/src/GNNlib.jl:10), so a
+    name qualified with GNNlib may be GNNGraphs'."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from julia_static import strip_comments_and_strings
+    names = json.load(open(os.path.join(ROOT, "tests", "golden", "julia_api_table.json")))["_names"]
+    src = strip_comments_and_strings(open(JL).read())
+    known = {"GNNlib": set(names["GNNlib"]) | set(names["GNNGraphs"]), "GNNGraphs": set(names["GNNGraphs"])}
+    used = set(re.findall(r"\b(GNNlib|GNNGraphs)\.([A-Za-z_]\w*!?)", src))
+    for m in re.finditer(r"^\s*(?:using|import)\s+(GNNlib|GNNGraphs)\s*:\s*(.*)$", src, flags=re.M):
+        used.update((m.group(1), n.strip()) for n in m.group(2).split(",") if n.strip())
+    assert len(used) >= 15
+    for pkg, name in sorted(used):
+        if name == pkg:
+            continue
+        assert name in known[pkg], f"{pkg}.{name} is not defined by the reference"
+
+
 def test_round3_entry_points_are_bound():
     src = open(JL).read()
     for sym in ("gnnmp_graphconv_chain_f32", "gnnmp_chain_jobs_create", "gnnmp_shard_by_size", "gnnmp_allgather_f32", "gnnmp_segment_bounds",
