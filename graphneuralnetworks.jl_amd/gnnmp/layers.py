@@ -511,7 +511,11 @@ def _chain_pattern(layers):
     aggr = convs[0].aggr
     if aggr not in ("+", "sum", "mean") or any(c.aggr != aggr for c in convs):
         return None
-    if any(c.sigma not in _ACT or c.weight1.shape[0] > 128 or c.weight1.shape[0] % 4 or c.weight1.shape[1] % 4 for c in convs):
+    # (the FIRST layer's input width may be anything: graphconv_chain zero-pads the features and that layer's weight columns — TUDataset
+    # node features are one-hot labels: MUTAG 7, PROTEINS 3)
+    if any(c.sigma not in _ACT or c.weight1.shape[0] > 128 or c.weight1.shape[0] % 4 for c in convs):
+        return None
+    if any(c.weight1.shape[1] % 4 for c in convs[1:]) or convs[0].weight1.shape[1] > 512:
         return None
     if any(convs[k + 1].weight1.shape[1] != convs[k].weight1.shape[0] for k in range(len(convs) - 1)):
         return None
@@ -538,11 +542,21 @@ def graphconv_chain(model, g: GNNGraph, x):
     nl = len(convs)
     # the ctypes argument block only changes when a weight tensor is replaced: cached on the model
     tensors = [t for c in convs for t in (c.weight1, c.weight2, c.bias)] + [head.weight, head.bias]
-    key = tuple((0 if t is None or t is False else t.data_ptr()) for t in tensors) + tuple(c.sigma for c in convs)
+    key = tuple((0 if t is None or t is False else (t.data_ptr(), t._version)) for t in tensors) + tuple(c.sigma for c in convs)
     if model._fused is None or model._fused[0] != key:
         keep = [t.contiguous() if isinstance(t, torch.Tensor) else None for t in tensors]
+        # Input width of the first layer: padded with zero columns (exact: the extra products are 0 * 0) to 16 when that makes the chain
+        # the wave-pair kernel's shape (16 => 128 => 128, csrc/graph_chain2.hip), else to the next multiple of 4 (the general kernel)
+        din = convs[0].weight1.shape[1]
+        widths = [c.weight1.shape[0] for c in convs]
+        din_p = 16 if (nl == 2 and widths == [128, 128] and din <= 16) else (din + 3) // 4 * 4
+        if din_p != din:
+            for k in (0, 1):
+                wp = torch.zeros((widths[0], din_p), dtype=torch.float32, device=keep[k].device)
+                wp[:, :din] = keep[k]
+                keep[k] = wp
         i64, vp = ctypes.c_int64, ctypes.c_void_p
-        dims = (i64 * (nl + 1))(convs[0].weight1.shape[1], *[c.weight1.shape[0] for c in convs])
+        dims = (i64 * (nl + 1))(din_p, *widths)
         wr = (vp * nl)(*[keep[3 * k].data_ptr() for k in range(nl)])
         wa = (vp * nl)(*[keep[3 * k + 1].data_ptr() for k in range(nl)])
         bs = (vp * nl)(*[(keep[3 * k + 2].data_ptr() if keep[3 * k + 2] is not None else None) for k in range(nl)])
@@ -568,6 +582,9 @@ def graphconv_chain(model, g: GNNGraph, x):
         g._cache["chain_scratch"] = scratch
     out = torch.empty((G, nout), dtype=torch.float32, device=x.device)
     xc = x.contiguous()
+    if dims[0] != x.shape[1]:                  # (zero-padded feature columns, see above: one strided copy)
+        xc = torch.zeros((N, dims[0]), dtype=torch.float32, device=x.device)
+        xc[:, : x.shape[1]] = x
     rc = lib.gnnmp_graphconv_chain_f32(g.plan(False).handle, jobs.handle, L.ptr(sp), G, L.ptr(xc), nl, dims, wr, wa, bs, act, 0,
                                        aggr_code(convs[0].aggr), aggr_code(pool.aggr), L.ptr(keep[-2]), L.ptr(keep[-1]), nout,
                                        L.ptr(scratch), L.ptr(out), L.stream_ptr())

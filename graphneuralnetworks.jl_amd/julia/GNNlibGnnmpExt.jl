@@ -555,19 +555,31 @@ function graphconv_chain(convs::Tuple, pool_aggr, head_weight::ROCMatrix{Float32
     aggr = convs[1].aggr
     (aggr === (+) || aggr === mean) && (pool_aggr === (+) || pool_aggr === mean) || return nothing
     all(c -> c.aggr === aggr && act_code(c.σ) !== nothing, convs) || return nothing
-    dims = Int64[size(x, 1); [size(c.weight1, 1) for c in convs]...]
+    # TUDataset node features are one-hot labels (MUTAG 7, PROTEINS 3): any input width is zero-padded — exact — to 16 when that makes the
+    # chain the wave-pair kernel's shape (16 => 128 => 128), else to the next multiple of 4; x (Din, N) grows by rows, the first layer's
+    # (out, in) weights by columns
+    din = size(x, 1)
+    widths = [size(c.weight1, 1) for c in convs]
+    din_p = (L == 2 && widths == [128, 128] && din <= 16) ? 16 : 4 * cld(din, 4)
+    w1r, w1a = convs[1].weight1, convs[1].weight2
+    if din_p != din
+        x = vcat(x, AMDGPU.zeros(Float32, din_p - din, size(x, 2)))
+        w1r = hcat(w1r, AMDGPU.zeros(Float32, widths[1], din_p - din))
+        w1a = hcat(w1a, AMDGPU.zeros(Float32, widths[1], din_p - din))
+    end
+    dims = Int64[din_p; widths...]
     nout = size(head_weight, 1)
     sp, jobs = chain_constants(g)
     nfloats = @ccall libgnnmp.gnnmp_graphconv_chain_scratch_floats(g.num_nodes::Int64, L::Cint, dims::Ptr{Int64}, nout::Int64)::Int64
     nfloats < 0 && return nothing
     scratch = ROCVector{Float32}(undef, nfloats)
     out = similar(x, nout, g.num_graphs)
-    wr = Ptr{Cvoid}[devptr(c.weight1) for c in convs]
-    wa = Ptr{Cvoid}[devptr(c.weight2) for c in convs]
+    wr = Ptr{Cvoid}[k == 1 ? devptr(w1r) : devptr(convs[k].weight1) for k in 1:L]
+    wa = Ptr{Cvoid}[k == 1 ? devptr(w1a) : devptr(convs[k].weight2) for k in 1:L]
     bs = Ptr{Cvoid}[c.bias isa AbstractArray ? devptr(c.bias) : C_NULL for c in convs]
     acts = Cint[act_code(c.σ) for c in convs]
     hb = head_bias isa AbstractArray ? head_bias : nothing
-    GC.@preserve convs head_weight hb scratch begin
+    GC.@preserve convs head_weight hb scratch w1r w1a x begin
         st = @ccall libgnnmp.gnnmp_graphconv_chain_f32(plan(g).handle::Ptr{Cvoid}, jobs.handle::Ptr{Cvoid}, devptr(sp)::Ptr{Cvoid},
                   g.num_graphs::Int64, devptr(x)::Ptr{Cvoid}, L::Cint, dims::Ptr{Int64}, wr::Ptr{Ptr{Cvoid}}, wa::Ptr{Ptr{Cvoid}},
                   bs::Ptr{Ptr{Cvoid}}, acts::Ptr{Cint}, 1::Cint, aggr_code(aggr)::Cint, aggr_code(pool_aggr)::Cint,

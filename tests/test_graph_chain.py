@@ -318,6 +318,52 @@ def test_julia_weight_layout(gm, dims):
     assert torch.equal(out, y)
 
 
+@pytest.mark.parametrize("din,dims", [(7, (128, 128)), (3, (128, 128)), (16, (128, 128)), (7, (64, 32)), (21, (128, 128)), (1, (128,))])
+def test_any_input_width_is_zero_padded_into_the_fused_kernels(gm, oracle, din, dims):
+    """TUDataset node features are one-hot labels (MUTAG 7, PROTEINS 3: examples/graph_classification_tudataset.jl:74-82 builds
+    GraphConv(nin => 128)): the host pads the features and the first layer's weight columns with zeros — exact — to 16 (the wave-pair
+    kernel's shape) or to the next multiple of 4 (the general kernel); the fused entry point is taken and the logits are the oracle's"""
+    import torch
+    from gnnmp import _lib as L
+    rng = np.random.default_rng(din * 31 + len(dims))
+    members = random_members(300, rng, nmin=10, nmax=28, hubs=False)
+    xs = []
+    for _, _, n in members:                                    # one-hot node labels
+        lab = rng.integers(0, din, n)
+        xs.append(np.eye(din, dtype=np.float32)[lab])
+    g = gm.batch_arrays(members, xs)
+    model = build(gm, (din,) + dims, 2, "+", "mean")
+    lib = L.load()
+    real, calls = lib.gnnmp_graphconv_chain_f32, []
+
+    class Spy:
+        def __call__(self, *a):
+            rc = real(*a)
+            calls.append(rc)
+            return rc
+    try:
+        lib.gnnmp_graphconv_chain_f32 = Spy()
+        y = model(g, g.x)
+    finally:
+        lib.gnnmp_graphconv_chain_f32 = real
+    assert calls == [0], "the chain did not run on the fused kernel"
+    if dims == (128, 128) and din <= 16:
+        assert g._cache["chain_jobs"].njobs > 0                # the wave-pair kernel's envelope
+    ref = oracle_chain(oracle, members, xs, model.layers[:-2], "mean", model.layers[-1])
+    close(y.cpu().numpy(), ref, f"din={din} dims={dims}")
+    before = gm.knob(18)
+    gm.tune(18, -1)
+    try:
+        close(model(g, g.x).cpu().numpy(), ref, f"layers din={din}")
+    finally:
+        gm.tune(18, before)
+    # replacing a weight in place (an optimiser step) invalidates the cached padded copy
+    with torch.no_grad():
+        model.layers[0].weight1.mul_(0.5)
+    ref2 = oracle_chain(oracle, members, xs, model.layers[:-2], "mean", model.layers[-1])
+    close(model(g, g.x).cpu().numpy(), ref2, "after an in-place weight update")
+
+
 def test_outside_the_envelope_falls_back(gm, oracle):
     """max aggregation, a wide layer, a non-batched graph: gnnmp_graphconv_chain_f32 says GNNMP_EUNSUPPORTED (or the host does not
     even ask) and the chain runs layer by layer with the same result contract"""
