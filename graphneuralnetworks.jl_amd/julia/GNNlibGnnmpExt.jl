@@ -536,14 +536,30 @@ function segment_bounds(g::GNNGraph)
     return sp
 end
 # per-batch constants, cached like the plans (identity of the indicator vector)
-const CHAIN_CACHE = Dict{UInt, Tuple{ROCVector{Int64}, ChainJobs}}()
+# Per-batch constants, keyed by the identity of the batch's graph_indicator like the plans are by (s, t): an entry dies with that array
+# (a finalizer clears its flag) and every miss sweeps the dead ones — a training loop makes a new batch every step, and a ChainJobs holds
+# ~16 MB of device memory at the config-5 size.
+mutable struct ChainEntry
+    seg_ptr::ROCVector{Int64}
+    jobs::ChainJobs
+    @atomic alive::Bool
+end
+const CHAIN_CACHE = Dict{UInt, ChainEntry}()
 function chain_constants(g::GNNGraph)
-    key = objectid(GNNGraphs.graph_indicator(g))
+    gi = GNNGraphs.graph_indicator(g)
+    key = objectid(gi)
     lock(PLANS_LOCK) do
-        get!(CHAIN_CACHE, key) do
+        ent = get(CHAIN_CACHE, key, nothing)
+        if ent === nothing || !(@atomic ent.alive)
+            filter!(kv -> (@atomic kv.second.alive), CHAIN_CACHE)
             sp = segment_bounds(g)
-            (sp, ChainJobs(sp, g.num_graphs))
+            ent = ChainEntry(sp, ChainJobs(sp, g.num_graphs), true)
+            let ent = ent
+                finalizer(_ -> (@atomic ent.alive = false), gi)
+            end
+            CHAIN_CACHE[key] = ent
         end
+        (ent.seg_ptr, ent.jobs)
     end
 end
 @non_differentiable chain_constants(::Any...)
