@@ -43,6 +43,8 @@ struct gnnmp_chain_jobs {
                                // finish kernel), [3..] (job * 2 + slab) of the tiles that met a non-finite operand in the running call
     float *zrows = nullptr;    // [2][N][8] the two slabs' z of every row (each word written once per call: no atomics, no memset)
     unsigned calls = 0;        // launches so far (host side; one stream at a time, like a plan)
+    void *block = nullptr;     // the ONE device allocation behind tab, bad and zrows
+    size_t block_bytes = 0;
 };
 
 namespace gnnmp {
@@ -518,6 +520,57 @@ __global__ void __launch_bounds__(THREADS) graph_chain2_kernel(const Chain2Args 
 
 using namespace gnnmp;
 
+// Parked device blocks of destroyed handles (at most four, process-wide).  A parked block may still be read or written by the last
+// launches of its former handle on whatever stream they run: it is handed out again only after a device-wide synchronisation (what
+// hipFree would have cost at the destroy).
+#include <mutex>
+namespace {
+struct ParkedBlock { void *p; size_t cap; };
+ParkedBlock g_parked[4] = {};
+std::mutex g_parked_lock;
+bool jobs_block_take(void **out, size_t *cap, size_t bytes) {
+    {
+        std::lock_guard<std::mutex> lk(g_parked_lock);
+        int best = -1;
+        for (int i = 0; i < 4; ++i)
+            if (g_parked[i].p && g_parked[i].cap >= bytes && (best < 0 || g_parked[i].cap < g_parked[best].cap)) best = i;
+        if (best >= 0 && g_parked[best].cap <= 2 * bytes + (1 << 20)) {
+            *out = g_parked[best].p;
+            *cap = g_parked[best].cap;
+            g_parked[best] = ParkedBlock{nullptr, 0};
+        } else {
+            *out = nullptr;
+        }
+    }
+    if (*out) return hipDeviceSynchronize() == hipSuccess;
+    *cap = bytes;
+    return hipMalloc(out, bytes) == hipSuccess;
+}
+void jobs_block_park(void *p, size_t cap) {
+    if (!p) return;
+    void *evict = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_parked_lock);
+        int slot = -1;
+        for (int i = 0; i < 4; ++i)
+            if (!g_parked[i].p) { slot = i; break; }
+        if (slot < 0) {       // full: the smallest block goes
+            slot = 0;
+            for (int i = 1; i < 4; ++i)
+                if (g_parked[i].cap < g_parked[slot].cap) slot = i;
+            if (g_parked[slot].cap >= cap) {
+                evict = p;
+                p = nullptr;
+            } else {
+                evict = g_parked[slot].p;
+            }
+        }
+        if (p) g_parked[slot] = ParkedBlock{p, cap};
+    }
+    if (evict) (void)hipFree(evict);
+}
+}  // namespace
+
 // Pack the member graphs of a batch (MLUtils.batch: contiguous row ranges seg_ptr[k] .. seg_ptr[k + 1]) into wave jobs of at most 64
 // rows, best-fit decreasing.  Graph prep like gnnmp_plan_create: once per batched graph, synchronises the stream.
 extern "C" int gnnmp_chain_jobs_create(gnnmp_chain_jobs_t **out, const int64_t *seg_ptr, int64_t G, gnnmp_stream_t stream_) {
@@ -577,12 +630,22 @@ extern "C" int gnnmp_chain_jobs_create(gnnmp_chain_jobs_t **out, const int64_t *
     J->njobs = njobs;
     J->fill = tiles > 0 ? (double)J->N / (32.0 * (double)tiles) : 0.0;
     if (njobs > 0) {
+        // one device block for the job table, the set-aside list and the z rows; a training loop builds a handle per batch, so freed
+        // blocks are parked and handed out again (jobs_block_take) instead of three hipMalloc + three hipFree (each a device-wide
+        // synchronisation) per batch.  (The create itself stays ~0.8 ms at G = 8192: the copy of seg_ptr to the host, the packing
+        // and the upload of the table — tools/batched_prep.py.)
         const size_t bytes = tab.size() * sizeof(int32_t);
-        if (hipMalloc(&J->tab, bytes) != hipSuccess || hipMalloc(&J->bad, sizeof(int32_t) * (size_t)(3 + 4 * njobs)) != hipSuccess ||
-            hipMalloc(&J->zrows, sizeof(float) * (size_t)2 * (size_t)J->N * 8) != hipSuccess) {
-            (void)gnnmp_chain_jobs_destroy(J);
+        const size_t off_bad = (bytes + 255) & ~(size_t)255;
+        const size_t off_z = (off_bad + sizeof(int32_t) * (size_t)(3 + 4 * njobs) + 255) & ~(size_t)255;
+        const size_t total = off_z + sizeof(float) * (size_t)2 * (size_t)J->N * 8;
+        if (!jobs_block_take(&J->block, &J->block_bytes, total)) {
+            delete J;
             return fail(GNNMP_EALLOC, "chain_jobs_create: hipMalloc failed");
         }
+        unsigned char *base = static_cast<unsigned char *>(J->block);
+        J->tab = reinterpret_cast<int32_t *>(base);
+        J->bad = reinterpret_cast<int32_t *>(base + off_bad);
+        J->zrows = reinterpret_cast<float *>(base + off_z);
         GNNMP_HIP(hipMemsetAsync(J->bad, 0, 3 * sizeof(int32_t), stream));
         GNNMP_HIP(hipMemcpyAsync(J->tab, tab.data(), bytes, hipMemcpyHostToDevice, stream));
         GNNMP_HIP(hipStreamSynchronize(stream));
@@ -593,9 +656,7 @@ extern "C" int gnnmp_chain_jobs_create(gnnmp_chain_jobs_t **out, const int64_t *
 
 extern "C" int gnnmp_chain_jobs_destroy(gnnmp_chain_jobs_t *J) {
     if (!J) return GNNMP_OK;
-    if (J->tab) (void)hipFree(J->tab);
-    if (J->bad) (void)hipFree(J->bad);
-    if (J->zrows) (void)hipFree(J->zrows);
+    jobs_block_park(J->block, J->block_bytes);
     delete J;
     return GNNMP_OK;
 }
