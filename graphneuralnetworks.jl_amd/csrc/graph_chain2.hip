@@ -590,13 +590,18 @@ extern "C" int gnnmp_chain_jobs_create(gnnmp_chain_jobs_t **out, const int64_t *
         *out = J;
         return GNNMP_OK;
     }
-    // best fit decreasing: graphs by decreasing size (ties by id), each into the fullest job that still takes it
-    std::vector<int32_t> order((size_t)G);
-    for (int64_t g = 0; g < G; ++g) order[(size_t)g] = (int32_t)g;
-    std::stable_sort(order.begin(), order.end(), [&](int32_t p, int32_t q) {
-        return sp[(size_t)p + 1] - sp[(size_t)p] > sp[(size_t)q + 1] - sp[(size_t)q];
-    });
-    std::vector<std::vector<int32_t>> members;             // graphs of each job
+    // best fit decreasing: graphs by decreasing size (ties by id: a counting sort, sizes are 1..64), each into the fullest job that
+    // still takes it.  Flat arrays only — this runs once per BATCH of a training loop.
+    std::vector<int32_t> order;
+    order.reserve((size_t)G);
+    {
+        std::vector<int32_t> start(66, 0);
+        for (int64_t g = 0; g < G; ++g) ++start[(size_t)(64 - (sp[(size_t)g + 1] - sp[(size_t)g])) + 1];    // bucket 0 = size 64
+        for (int b = 0; b < 65; ++b) start[(size_t)b + 1] += start[(size_t)b];
+        order.resize((size_t)G);
+        for (int64_t g = 0; g < G; ++g) order[(size_t)start[(size_t)(64 - (sp[(size_t)g + 1] - sp[(size_t)g]))]++] = (int32_t)g;
+    }
+    std::vector<int32_t> job_of((size_t)G, -1);
     std::vector<int> room;                                   // free slots of each job
     std::vector<std::vector<int32_t>> by_room(65);          // jobs with exactly r free slots (stack)
     for (int32_t g : order) {
@@ -609,31 +614,34 @@ extern "C" int gnnmp_chain_jobs_create(gnnmp_chain_jobs_t **out, const int64_t *
             j = by_room[(size_t)r].back();
             by_room[(size_t)r].pop_back();
         } else {
-            j = (int)members.size();
-            members.emplace_back();
+            j = (int)room.size();
             room.push_back(64);
         }
-        members[(size_t)j].push_back(g);
+        job_of[(size_t)g] = j;
         room[(size_t)j] -= sz;
         by_room[(size_t)room[(size_t)j]].push_back(j);
     }
-    const int njobs = (int)members.size();
+    const int njobs = (int)room.size();
     std::vector<int32_t> tab((size_t)njobs * 64, -1);
-    int64_t tiles = 0;
-    for (int j = 0; j < njobs; ++j) {
-        std::sort(members[(size_t)j].begin(), members[(size_t)j].end());   // rows of a job in node order
-        int s = 0;
-        for (int32_t g : members[(size_t)j])
-            for (int64_t r = sp[(size_t)g]; r < sp[(size_t)g + 1]; ++r, ++s) tab[(size_t)j * 64 + (size_t)s] = (int32_t)r;
-        tiles += s > 32 ? 2 : 1;
+    {
+        std::vector<int> cursor((size_t)njobs, 0);          // member graphs in ascending id: the rows of a job come out in node order
+        for (int64_t g = 0; g < G; ++g) {
+            const int j = job_of[(size_t)g];
+            if (j < 0) continue;
+            int c = cursor[(size_t)j];
+            for (int64_t r = sp[(size_t)g]; r < sp[(size_t)g + 1]; ++r, ++c) tab[(size_t)j * 64 + (size_t)c] = (int32_t)r;
+            cursor[(size_t)j] = c;
+        }
     }
+    int64_t tiles = 0;
+    for (int j = 0; j < njobs; ++j) tiles += (64 - room[(size_t)j]) > 32 ? 2 : 1;
     J->njobs = njobs;
     J->fill = tiles > 0 ? (double)J->N / (32.0 * (double)tiles) : 0.0;
     if (njobs > 0) {
         // one device block for the job table, the set-aside list and the z rows; a training loop builds a handle per batch, so freed
         // blocks are parked and handed out again (jobs_block_take) instead of three hipMalloc + three hipFree (each a device-wide
-        // synchronisation) per batch.  (The create itself stays ~0.8 ms at G = 8192: the copy of seg_ptr to the host, the packing
-        // and the upload of the table — tools/batched_prep.py.)
+        // synchronisation) per batch.  (tools/batched_prep.py: the create is ~0.37 ms at G = 8192 — the copy of seg_ptr to the host,
+        // the packing, the upload of the table; 0.8 ms while the packing sorted and kept a vector per job.)
         const size_t bytes = tab.size() * sizeof(int32_t);
         const size_t off_bad = (bytes + 255) & ~(size_t)255;
         const size_t off_z = (off_bad + sizeof(int32_t) * (size_t)(3 + 4 * njobs) + 255) & ~(size_t)255;
