@@ -306,6 +306,52 @@ def sage_conv_ad(l, g: GNNGraph, x):
 
 
 # ---------------------------------------------------------------------------------------------------------
+# GlobalPool (reduce_nodes over a batch's graph_indicator)
+# ---------------------------------------------------------------------------------------------------------
+class _GlobalPoolFn(torch.autograd.Function):
+    """reduce_nodes(+ | mean, g, x) = scatter(aggr, x, graph_indicator) (GNNlib/src/utils.jl:12-16, layers/pool.jl:3-5) and NNlib's
+    rule for it: Δx = gather(Δ, graph_indicator) (./ the member graph's node count for mean) — gnnmp_gather_f32 + gnnmp_mul_rows_f32"""
+
+    @staticmethod
+    def forward(ctx, x, g, aggr):
+        from .utils import reduce_nodes
+        ctx.g, ctx.aggr = g, aggr
+        return reduce_nodes(aggr, g, x.contiguous())
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .graph import graph_indicator
+        g = ctx.g
+        lib = L.load()
+        gi = graph_indicator(g)
+        N, G = g.num_nodes, g.num_graphs
+        dy = dy.contiguous()
+        D = dy.shape[1]
+        if ctx.aggr in ("mean",):
+            key = "pool_inv_count"
+            inv = g._cache.get(key)
+            if inv is None:
+                # node count of every member graph -> its reciprocal: a constant of the batch (graph prep, cached on the graph)
+                from .utils import reduce_nodes
+                cnt = reduce_nodes("+", g, torch.ones((N, 1), dtype=torch.float32, device=dy.device)).reshape(G)
+                inv = torch.reciprocal(cnt).reshape(G, 1).contiguous()
+                g._cache[key] = inv
+            scaled = torch.empty_like(dy)
+            L.check(lib.gnnmp_mul_rows_f32(L.ptr(inv), 1, L.ptr(dy), L.ptr(scaled), G, D, L.stream_ptr()))
+            dy = scaled
+        dx = torch.empty((N, D), dtype=torch.float32, device=dy.device)
+        L.check(lib.gnnmp_gather_f32(L.ptr(dy), L.ptr(gi), 8 if gi.dtype == torch.int64 else 4, g.index_base, N, L.ptr(dx), D,
+                                     L.stream_ptr()))
+        return dx, None, None
+
+
+def global_pool_ad(l, g: GNNGraph, x):
+    """differentiable GlobalPool(+ | mean) over a batched graph"""
+    assert l.aggr in ("+", "sum", "mean"), "the pullback covers + and mean pooling"
+    return _GlobalPoolFn.apply(x, g, "+" if l.aggr == "sum" else l.aggr)
+
+
+# ---------------------------------------------------------------------------------------------------------
 # GATConv
 # ---------------------------------------------------------------------------------------------------------
 class _GATConvFn(torch.autograd.Function):

@@ -331,3 +331,34 @@ def test_graph_and_sage_layer_backward_vs_oracle(gm, oracle, kind, aggr):
                            ("db", l.bias.grad.cpu().numpy(), db)):
         assert np.isfinite(got).all(), name
         assert np.linalg.norm(got - ref) <= 3e-5 * np.linalg.norm(ref), name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("aggr", ["+", "mean"])
+def test_global_pool_pullback(gm, aggr):
+    """∇reduce_nodes: NNlib's rule for scatter(+ | mean, x, graph_indicator) — Δx = gather(Δ, idx) (./ count[idx]) — through the
+    autograd wrapper, against the same two lines in numpy (float64); graphs of 1..40 nodes, D not a multiple of 4"""
+    import torch
+    from gnnmp import synth
+    from gnnmp.backward import global_pool_ad
+    rng = np.random.default_rng(5)
+    members = []
+    for _ in range(300):
+        n = int(rng.integers(1, 41))
+        members.append((np.zeros(0, np.int64), np.zeros(0, np.int64), n))
+    D = 7
+    xs = [rng.standard_normal((n, D)).astype(np.float32) for _, _, n in members]
+    g = gm.batch_arrays(members, xs)
+    x = g.x.clone().requires_grad_(True)
+    y = global_pool_ad(gm.GlobalPool(aggr), g, x)
+    r = rng.standard_normal((len(members), D)).astype(np.float32)
+    (y * dev(r)).sum().backward()
+    sizes = np.array([n for _, _, n in members])
+    gi = np.repeat(np.arange(len(members)), sizes)
+    ref_y = np.zeros((len(members), D))
+    np.add.at(ref_y, gi, np.concatenate(xs).astype(np.float64))
+    if aggr == "mean":
+        ref_y /= sizes[:, None]
+    ref_dx = r.astype(np.float64)[gi] / (sizes[gi][:, None] if aggr == "mean" else 1.0)
+    assert np.abs(y.detach().cpu().numpy() - ref_y).max() <= 1e-5 * np.abs(ref_y).max()
+    assert np.abs(x.grad.cpu().numpy() - ref_dx).max() <= 1e-6 * np.abs(ref_dx).max()

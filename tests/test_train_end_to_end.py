@@ -81,6 +81,58 @@ def test_full_batch_training_learns(kind):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("pool", ["mean", "+"])
+def test_graph_classification_training_learns(pool):
+    """BASELINE.json config 5's model — GNNChain(GraphConv(16 => 128, relu), GraphConv(128 => 128, relu), GlobalPool, Dense(128 => 2)),
+    examples/graph_classification_tudataset.jl:79-82 — trained on batched synthetic graphs whose class shows in the STRUCTURE (ring
+    vs ring + chords: the features carry no label): forward and pullback of every layer on the HIP kernels; after training, the
+    one-kernel inference chain (csrc/graph_chain2.hip) reproduces the training-path logits."""
+    import torch
+    import torch.nn.functional as F
+    import gnnmp
+    from gnnmp.backward import dense_ad, global_pool_ad, graph_conv_ad
+    gnnmp.load()
+    rng = np.random.default_rng(3)
+    G = 512
+    members, xs, ys = [], [], []
+    for k in range(G):
+        n = int(rng.integers(12, 33))
+        u = np.arange(n); v = (u + 1) % n
+        y = int(rng.integers(0, 2))
+        if y == 1:                                              # class 1: every node also links to the node two steps on
+            u = np.concatenate([u, np.arange(n)]); v = np.concatenate([v, (np.arange(n) + 2) % n])
+        s = np.concatenate([u, v]).astype(np.int64) + 1
+        t = np.concatenate([v, u]).astype(np.int64) + 1
+        members.append((s, t, n))
+        xs.append(np.concatenate([np.ones((n, 1), np.float32), 0.1 * rng.standard_normal((n, 15)).astype(np.float32)], 1))
+        ys.append(y)
+    g = gnnmp.batch_arrays(members, xs)
+    Y = torch.as_tensor(ys).cuda()
+    c1, c2 = gnnmp.GraphConv((16, 128), "relu", seed=1), gnnmp.GraphConv((128, 128), "relu", seed=2)
+    poolL, head = gnnmp.GlobalPool(pool), gnnmp.Dense((128, 2), seed=3)
+    params = [c1.weight1, c1.weight2, c1.bias, c2.weight1, c2.weight2, c2.bias, head.weight, head.bias]
+    for p in params:
+        p.requires_grad_(True)
+    fwd = lambda: dense_ad(head, global_pool_ad(poolL, g, graph_conv_ad(c2, g, graph_conv_ad(c1, g, g.x))))   # noqa: E731
+    opt = torch.optim.Adam(params, lr=3e-3 if pool == "mean" else 3e-4)
+    losses = []
+    for epoch in range(80):
+        opt.zero_grad()
+        logits = fwd()
+        loss = F.cross_entropy(logits, Y)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    with torch.no_grad():
+        logits = fwd()
+        acc = float((logits.argmax(1) == Y).float().mean())
+        fused = gnnmp.GNNChain(c1, c2, poolL, head)(g, g.x)
+    assert np.isfinite(losses).all()
+    assert losses[-1] < 0.5 * losses[0] and acc > 0.9, (losses[0], losses[-1], acc)
+    assert float((fused - logits).abs().max()) <= 1e-5 * float(logits.abs().max()) + 1e-6
+
+
+@pytest.mark.gpu
 def test_mini_batch_training_with_neighbor_loader_learns():
     """the same model trained on NeighborLoader mini-batches (device-side sampling -> induced subgraph -> HIP forward and
     backward on the mini-batch graph), evaluated full batch"""
