@@ -108,7 +108,8 @@ def cpu_baseline(products_graph=None):
     else:
         tg, ta, tgg, tfull = run()
     out = {
-        "value": 2 * Ep / (tg + ta), "unit": "edges/s", "cores": 1, "kind": "port",
+        "value": 2 * Ep / (tg + ta), "unit": "edges/s", "cores": 1, "kind": "port", "cpu_model": host_cpu_model(),
+        "host_cores": os.cpu_count(),
         "sample": f"1/{SCALE}-scale products-shaped graph N={N} E'={Ep} D={D}: GCNConv({D}=>{D},relu)+GATConv({D}=>{C},h={H},relu) "
                   f"forward once on the paths the reference takes with CPU arrays: GCN through the SpMM fast path (COO->CSC "
                   f"rebuild + CSC sweep per call) {tg:.2f}s, GAT through gather->message->scatter with materialised (D,E') "
@@ -136,6 +137,40 @@ def cpu_baseline(products_graph=None):
     except Exception as e:  # pragma: no cover — a missing OpenMP runtime must not sink the bench line
         out["best_cpu_allcore"] = {"error": repr(e)}
     return out
+
+
+def host_cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
+def julia_reference_baseline():
+    """SURVEY.md §8d's preferred CPU baseline: the reference itself (bench/reference_cpu.jl, BenchmarkTools, the pattern of
+    GraphNeuralNetworks/perf/perf.jl:25) — used iff a `julia` with the reference's packages is on this host; else None and the oracle port
+    above is the baseline (`kind: "port"`)."""
+    import shutil
+    import subprocess
+    jl = shutil.which("julia")
+    script = os.path.join(ROOT, "bench", "reference_cpu.jl")
+    if jl is None or not os.path.exists(script):
+        return None
+    try:
+        r = subprocess.run([jl, "--project=" + os.path.join(ROOT, "bench"), script, "--scale", "32"], capture_output=True, text=True, timeout=900)
+        for line in reversed(r.stdout.splitlines()):
+            if line.startswith("{"):
+                d = json.loads(line)
+                d["kind"] = "reference"
+                return d
+    except Exception as e:  # pragma: no cover
+        return {"error": repr(e)}
+    return None
 
 
 def batched_setup(rank, world, dist, G=8192, forward_factory=None, device=None):
@@ -170,8 +205,46 @@ def batched_setup(rank, world, dist, G=8192, forward_factory=None, device=None):
         torch.cuda.synchronize(); t2 = time.perf_counter()
         model(g2, g2.x)
         torch.cuda.synchronize(); t3 = time.perf_counter()
-        batched_setup.prep_ms = {"plan_ms": (t1 - t0) * 1e3, "chain_jobs_ms": ((t2 - t1) - (t3 - t2)) * 1e3}
+        batched_setup.prep_ms = {"plan_ms": (t1 - t0) * 1e3, "chain_jobs_ms": ((t2 - t1) - (t3 - t2)) * 1e3,
+                                 "what": "the reference's own way per new batch: MLUtils.batch on the host + upload (not timed here) + "
+                                         "gnnmp_plan_create (sort) + gnnmp_chain_jobs_create (host packing)"}
         del g2
+        # The loop the reference's example runs (graph_classification_tudataset.jl:70-71, 97-104): a NEW batch every step, here from the
+        # device-resident dataset (gnnmp.GraphDataset / DataLoader: plan by gnnmp_plan_select, features by one gather, wave jobs packed
+        # on the device by gnnmp_chain_jobs_pack — no sort, no host synchronisation).  Every step is a fresh shuffle of the G members.
+        ds = gnnmp.GraphDataset.from_members([members[i] for i in mine], [xs[i] for i in mine])
+        loader = gnnmp.DataLoader(ds, batchsize=len(mine), shuffle=True, seed=7)
+
+        def epochs(n, run_model):
+            torch.cuda.synchronize(); ta = time.perf_counter()
+            for _ in range(n):
+                for gb in loader:
+                    if run_model:
+                        yb = model(gb, gb.x)
+                    else:
+                        gnnmp.layers.ChainJobs(gb._cache["node_ptr"], gb.num_graphs, gb._cache["member_stats"])
+            torch.cuda.synchronize()
+            return (time.perf_counter() - ta) / n * 1e3
+
+        epochs(5, True)
+        t_new = epochs(50, True)
+        t_prep = epochs(50, False)
+
+        def prep_sync(n):          # one batch at a time, synchronised: the latency of one preparation (nothing to overlap with)
+            tot = 0.0
+            for _ in range(n):
+                torch.cuda.synchronize(); ta = time.perf_counter()
+                for gb in loader:
+                    jb = gnnmp.layers.ChainJobs(gb._cache["node_ptr"], gb.num_graphs, gb._cache["member_stats"])
+                torch.cuda.synchronize(); tot += time.perf_counter() - ta
+                del gb, jb
+            return tot / n * 1e3
+        batched_setup.new_batch = {
+            "batched_new_batch_every_step_ms": t_new, "prep_only_ms_pipelined": t_prep, "prep_only_ms_synchronised": prep_sync(20),
+            "what": "per step: shuffle on the host, ONE upload of the permutation (64 KB), gnnmp_plan_select (2 launches), gnnmp_gather_f32 "
+                    "of the features, gnnmp_chain_jobs_pack (1 launch), then the fused chain (2 launches); no host synchronisation in "
+                    "the loop (the host prepares step k + 1 while the device runs step k)"}
+        del loader, ds
         forward = lambda: model(g, g.x)                      # noqa: E731
         device = torch.device("cuda", torch.cuda.current_device())
     else:
@@ -444,18 +517,29 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    # HIP events around the step's kernels INSIDE the timed region, on the stream they are launched on (gnnmp._lib.EventProbe: two
+    # event records per launch, ~1 us each): roofline.avg_ms below is the in-step duration, the one a rocprofv3 kernel trace of this
+    # command shows — not the kernel timed alone back to back (the two differed by 8 %)
+    probe = L.EventProbe()
     barrier()
+    L.set_probe(probe)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     dt = time.perf_counter() - t0
+    L.set_probe(None)
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ms_per_step = dt / args.steps * 1e3
     value = world * 2 * Ep / (dt / args.steps)
+    instep = {}
+    for name in ("fused_conv", "gat_conv", "dense"):
+        ts = sorted(probe.times_ms(name))
+        if ts:
+            instep[name] = {"ms": sum(ts) / len(ts), "ms_median": ts[len(ts) // 2], "launches": len(ts)}
 
     # per-kernel durations: HIP events on the stream the kernels are launched on (torch's current stream)
     def event_time(fn, iters):
@@ -490,6 +574,14 @@ def main():
                           "alg_bytes": b_gat, "GBs": b_gat / tg_avg / 1e6,
                           "compulsory_bytes": compulsory_bytes(N, Ep, H * C, H * C) + 4 * N * H * C},
     }
+    # the step's two kernels: the duration INSIDE the timed steps is the figure of record; the back-to-back one stays next to it
+    for kname, pname in (("gcn_fused_layer", "fused_conv"), ("gat_aggregate", "gat_conv")):
+        if pname in instep:
+            k = kern[kname]
+            k["alone_back_to_back_ms"] = k["ms"]
+            k["ms"], k["ms_median"] = instep[pname]["ms"], instep[pname]["ms_median"]
+            k["timed"] = f"HIP events around the launch inside the {args.steps} timed steps"
+            k["GBs"] = k["alg_bytes"] / k["ms"] / 1e6
     for k in kern.values():   # the secondary line of SURVEY.md §8d: rate against the bytes an ideal cache could not avoid
         k["compulsory_GBs"] = k["compulsory_bytes"] / k["ms"] / 1e6
     kern["gcn_propagate"]["note"] = "the unfused propagate kernel, timed for reference: the step runs gcn_fused_layer instead"
@@ -525,6 +617,7 @@ def main():
     extras = {"plan_create_ms": plan_ms, "norm_cache_ms": norm_cache_ms, "kernels": kern,
               "gcn_layer_ms": layer_time(lambda: gcn(g, x), 5), "gat_layer_ms": layer_time(lambda: gat(g, x), 5),
               "max_in_degree": plan.max_degree, "long_rows": plan.n_long}
+    extras["in_step_kernels"] = instep
     extras["gcn_layer_edges_per_s"] = Ep / extras["gcn_layer_ms"] * 1e3
     extras["gat_layer_edges_per_s"] = Ep / extras["gat_layer_ms"] * 1e3
     if not args.no_extras:
@@ -562,12 +655,19 @@ def main():
             extras["gather_ceiling"] = ceil
         except OSError as e:
             extras["gather_ceiling"] = {"note": f"tools/ubench/libgather_probe.so not built: {e}"}
+    # the dense contractions: at this size they are bound by HBM requests, not by the matrix pipe (profiles/: the pipe is ~50 % busy) —
+    # rated on the bytes they must move (x in, y out) against the HBM peak; the fp32-equivalent TF/s next to it, against the bf16 pipe's
+    # 2.5 PF / 6 MFMAs per product (split-bf16) or the fp32 MFMA peak (dense_t16)
+    def dense_line(shape, ms, K, Dout, kernel):
+        b = 4.0 * N * (K + Dout)
+        tf = 2.0 * N * K * Dout / ms / 1e9
+        pipe_peak = 2500.0 / 6.0 if kernel.startswith("dense_split") else MFMA_F32_PEAK_TF
+        return {"shape": shape, "kernel": kernel, "ms": ms, "hbm_bytes": b, "GBs": b / ms / 1e6, "frac": b / ms / 1e6 / HBM_PEAK_GBS,
+                "bound": "hbm", "TFs_fp32_equivalent": tf, "matrix_pipe_peak_TFs": pipe_peak, "matrix_pipe_frac": tf / pipe_peak}
     extras["dense"] = {
-        "kernel": "dense_split_kernel (3-plane split-bf16, six bf16 MFMAs per product: 100=>128) / dense_t16_kernel (fp32 MFMA: 100=>100); TF/s of the fp32 product, rated against the fp32 matrix peak", "peak_TFs": MFMA_F32_PEAK_TF,
-        "gcn_W_x": {"shape": f"{N}x{D}=>{D}", "ms": t_dg, "TFs": 2.0 * N * D * D / t_dg / 1e9,
-                    "frac": 2.0 * N * D * D / t_dg / 1e9 / MFMA_F32_PEAK_TF},
-        "gat_dense_x": {"shape": f"{N}x{D}=>{H * C}", "ms": t_da, "TFs": 2.0 * N * D * H * C / t_da / 1e9,
-                        "frac": 2.0 * N * D * H * C / t_da / 1e9 / MFMA_F32_PEAK_TF}}
+        "gcn_W_x": dense_line(f"{N}x{D}=>{D}", t_dg, D, D, "dense_split_kernel (split-bf16)" if ((D + 31) // 32 * 32) * 10 <= D * 11 else "dense_t16_kernel (fp32 MFMA 16x16x4)"),
+        "gat_dense_x": dense_line(f"{N}x{D}=>{H * C}", t_da, D, H * C, "dense_split_kernel (3-plane split-bf16, six bf16 MFMAs per product, fp32 accumulate)"),
+        "in_step": instep.get("dense")}
     if rank == 0 and not args.no_extras and args.workload == "products":
         # BASELINE.json config 4: SAGEConv(100 => 256) on the same graph (no self loops), aggr = mean and aggr = +
         sage = gnnmp.SAGEConv((D, 256), "relu", aggr="mean", seed=13)
@@ -629,7 +729,8 @@ def main():
         tb = layer_time(bstep, 50)
         extras["batched"] = {"graphs": Gb, "nodes": nb, "edges": eb, "ms_per_step": tb,
                              "graphs_per_s": Gb / tb * 1e3, "edges_per_s": 2 * eb / tb * 1e3,
-                             "per_batch_prep_outside_the_timed_steps": getattr(batched_setup, "prep_ms", None)}
+                             "per_batch_prep_outside_the_timed_steps": getattr(batched_setup, "prep_ms", None),
+                             "new_batch_every_step": getattr(batched_setup, "new_batch", None)}
         del bstep
 
     # The one path of BASELINE.json that shards (config 5): when the driver runs the default workload on N > 1 ranks, the same N ranks
@@ -667,13 +768,24 @@ def main():
                                f"GCNConv({D}=>{D},relu) fwd + GATConv({D}=>{C},heads={H},relu) fwd per step; "
                                f"edges counted = 2*E' per GPU",
                    "parallelism": f"replicas x{world} (independent feature batches, no collective)",
-                   "index": "Int64 1-based COO as held by GNNGraph; plan = dst-sorted CSR (4-byte slots) built once"},
+                   "index": "Int64 1-based COO as held by GNNGraph; plan = dst-sorted CSR (4-byte slots) built once",
+                   "arithmetic": "fp32 operands, accumulation and results; aggregation in fp32 in the reference's edge order; the dense "
+                                 "contraction of the GAT layer (dense_x) runs on the bf16 matrix core as an exact 3-plane split of every fp32 "
+                                 "operand (six bf16 MFMAs per product, fp32 accumulate, dropped terms < 2^-21 of a product, truncation "
+                                 "split: a one-signed bias of that size), GCN's W through fp32 MFMA"},
         "roofline": roofline,
         "extras": extras,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             result["cpu_baseline"] = cpu_baseline((s, t, x_host) if keep_host else None)
+            ref = julia_reference_baseline()
+            if ref is not None and "value" in ref:      # the reference itself ran here: it is the baseline, the port stays next to it
+                ref["port"] = {k: result["cpu_baseline"][k] for k in ("value", "unit", "cores", "sample")}
+                ref.setdefault("cpu_model", host_cpu_model())
+                result["cpu_baseline"] = ref
+            elif ref is not None:
+                result["cpu_baseline"]["julia_reference"] = ref
         except Exception as e:  # the baseline must never take the bench line down
             result["cpu_baseline"] = {"value": None, "unit": "edges/s", "cores": 1, "kind": "port", "sample": f"failed: {e}"}
     if rank == 0:

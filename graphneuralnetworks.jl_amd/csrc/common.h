@@ -251,6 +251,11 @@ struct gnnmp_graph {
     // rows of a power-law graph are not, and a wave runs as long as its longest row (products shape: 1.43x the instruction
     // issue of perfectly packed rows with adjacent pairing, 1.13x with this order)
     int32_t *row_order = nullptr;
+    // plans made by gnnmp_plan_concat / gnnmp_plan_select (plan_batch.hip): rowptr, col, eid (and the member table) live in ONE block taken
+    // from the stream-ordered pool (pool.h); gnnmp_plan_release hands it back without a host synchronisation
+    void *block = nullptr;
+    size_t block_bytes = 0;
+    int32_t *status = nullptr;     // (pooled plans) device word: non-zero = the caller's totals did not match the member table
 };
 
 namespace gnnmp {
@@ -260,6 +265,10 @@ int ensure_workspace(gnnmp_graph *p, size_t floats);
 int ensure_ticket(gnnmp_graph *p, hipStream_t stream);
 // build plan->row_order on first use
 int ensure_row_order(gnnmp_graph *p, hipStream_t stream);
+// max_degree, n_long and the chunk tables of the rows longer than plan->long_thresh from plan->rowptr (synchronises the stream)
+int plan_build_long_rows(gnnmp_graph *p, hipStream_t stream);
+// the long-row threshold gnnmp_plan_create picks for a plan of Etot slots
+int plan_long_thresh(int64_t Etot);
 }
 
 namespace gnnmp {

@@ -504,8 +504,10 @@ extern "C" int gnnmp_graphconv_chain_f32(gnnmp_graph_t *p, const gnnmp_chain_job
     bool fullcols = true;
     for (int l = 0; l < n_layers; ++l) {
         const int64_t din = dims[l], dout = dims[l + 1];
+        // (a STORED layer — every layer but the last — narrower than 8 columns: split_store_all re-stores the lane's first piece at
+        // column 4 h for pieces past ncols, which lies outside a 4-column row)
         if (din < 4 || (din & 3) || dout < 4 || (dout & 3) || dout > CHAIN_DP || din > 512 || !W_root[l] || !W_agg[l] ||
-            (act[l] != GNNMP_ACT_IDENTITY && act[l] != GNNMP_ACT_RELU))
+            (l + 1 < n_layers && dout < 8) || (act[l] != GNNMP_ACT_IDENTITY && act[l] != GNNMP_ACT_RELU))
             return fail(GNNMP_EUNSUPPORTED, "graphconv_chain: layer %d (%lld => %lld) outside the fused kernel's envelope", l,
                         (long long)din, (long long)dout);
         ChainLayer &ly = a.L[l];

@@ -28,22 +28,29 @@
 // Envelope: exactly two layers 16 => 128 => 128, nout <= 8, aggr and pool in {+, mean}, member graphs of at most 64 nodes; everything
 // else is graph_chain.hip's.
 #include <algorithm>
+#include <atomic>
+#include <mutex>
 #include <vector>
 
+#include "chain_pack.h"
 #include "msplit.h"
+#include "pool.h"
 
 struct gnnmp_chain_jobs {
     int32_t *tab = nullptr;    // rows [njobs][64]: global row of each slot, -1 = empty
-    int njobs = 0;
+    int njobs = 0;             // host-packed handles: the number of jobs; device-packed ones: -1 (it lives in hdr[0])
+    int njobs_cap = 0;         // rows of `tab` that exist (device-packed: an upper bound of any best-fit packing, min(G, N / 32 + 2))
     int64_t G = 0, N = 0;
     int64_t max_graph = 0;     // largest member graph (> 64: no jobs, the general kernel runs)
     double fill = 0.0;         // rows / (32 x tiles): MFMA work spent on real rows
     int has_empty = 0;         // some member graph has no node (its logits are the head's bias: left to the general kernel)
     int32_t *bad = nullptr;    // [3 + 4 njobs]: [0], [1] the counters of set-aside jobs of even / odd calls (each re-armed by the other parity's
                                // finish kernel), [3..] (job * 2 + slab) of the tiles that met a non-finite operand in the running call
+    int32_t *hdr = nullptr;    // device-packed handles: [0] jobs, [1] 32-row tiles, [2] poison (the sizes contradict what the caller announced:
+                               // the finish kernel then writes NaN logits), [3] largest member graph seen, [4] member graphs without a node
     float *zrows = nullptr;    // [2][N][8] the two slabs' z of every row (each word written once per call: no atomics, no memset)
-    unsigned calls = 0;        // launches so far (host side; one stream at a time, like a plan)
-    void *block = nullptr;     // the ONE device allocation behind tab, bad and zrows
+    std::atomic<unsigned> calls{0};   // launches so far: picks the parity of the set-aside counters (a handle is used on ONE stream at a time)
+    void *block = nullptr;     // the ONE device allocation behind tab, bad, hdr and zrows
     size_t block_bytes = 0;
 };
 
@@ -59,6 +66,7 @@ struct Chain2Args {
     const int32_t *col;
     const int32_t *job_rows;
     int njobs;
+    const int32_t *hdr;   // device-packed jobs: hdr[0] = the number of jobs (njobs above is then only the bound the grid was sized for), hdr[2] = poison
     const int64_t *seg_ptr;
     const float *x;
     const float *W1r, *W1a, *b1, *W2r, *W2a, *b2, *Wh, *bh;
@@ -174,6 +182,13 @@ __device__ __forceinline__ void c2_pool_graph(const Chain2Args &a, int g, int sl
 // alone first redoes them with fp32 loops and then pools every graph; the other blocks leave.  The counter of set-aside jobs alternates
 // between two words from call to call: this launch reads one (nobody writes it now) and re-arms the other for the next call.
 __global__ void __launch_bounds__(256) graph_chain2_finish_kernel(const Chain2Args a) {
+    if (a.hdr && a.hdr[2] != 0) {
+        // the device packing found member graphs its caller had excluded (more than 64 nodes / none): no job ran.  Loud, not silent: NaN
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)a.G * a.nout; i += (int64_t)gridDim.x * 256)
+            a.out[i] = __builtin_nanf("");
+        if (blockIdx.x == 0 && threadIdx.x == 0) *a.bad_reset = 0;
+        return;
+    }
     const int nbad = *a.bad_count;
     if (nbad == 0) {
         const int i = blockIdx.x * 256 + threadIdx.x;                // (the grid covers 2 G lanes)
@@ -273,7 +288,8 @@ __global__ void __launch_bounds__(THREADS) graph_chain2_kernel(const Chain2Args 
 
     // Jobs: a contiguous share per block, dealt to its pairs round-robin (the jobs are packed to the same size: a ticket balances nothing,
     // and a known next job is what lets its table entries be fetched ahead)
-    const int jb0 = (int)(((int64_t)a.njobs * blockIdx.x) / gridDim.x), jb1 = (int)(((int64_t)a.njobs * (blockIdx.x + 1)) / gridDim.x);
+    const int njobs = a.hdr ? __builtin_amdgcn_readfirstlane(a.hdr[0]) : a.njobs;
+    const int jb0 = (int)(((int64_t)njobs * blockIdx.x) / gridDim.x), jb1 = (int)(((int64_t)njobs * (blockIdx.x + 1)) / gridDim.x);
     auto pre_a = [&](int job, JobPre &p) {
         const int32_t *q = a.job_rows + (int64_t)job * 64;
         p.rid = q[32 * T + n];
@@ -414,7 +430,9 @@ __global__ void __launch_bounds__(THREADS) graph_chain2_kernel(const Chain2Args 
                         make_float4(tacc[k >> 2][4 * (k & 3)], tacc[k >> 2][4 * (k & 3) + 1], tacc[k >> 2][4 * (k & 3) + 2], tacc[k >> 2][4 * (k & 3) + 3]);
                 if (two) pair_arrive(pc);
             };
-            if (two && ev_stage) pair_wait(pc, ev_stage);      // (an event of a whole K loop ago: falls through)
+            // (an event of a whole K loop ago: falls through.  Also on a ONE-tile job that follows a two-tile job: the partner may still be reading
+            // chunk 6 / 7 of the previous job from the half put(0) writes; its counter is monotonic, so the wait cannot deadlock)
+            if (ev_stage) pair_wait(pc, ev_stage);
             put(0);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -520,56 +538,128 @@ __global__ void __launch_bounds__(THREADS) graph_chain2_kernel(const Chain2Args 
 
 using namespace gnnmp;
 
-// Parked device blocks of destroyed handles (at most four, process-wide).  A parked block may still be read or written by the last
-// launches of its former handle on whatever stream they run: it is handed out again only after a device-wide synchronisation (what
-// hipFree would have cost at the destroy).
-#include <mutex>
-namespace {
-struct ParkedBlock { void *p; size_t cap; };
-ParkedBlock g_parked[4] = {};
-std::mutex g_parked_lock;
-bool jobs_block_take(void **out, size_t *cap, size_t bytes) {
-    {
-        std::lock_guard<std::mutex> lk(g_parked_lock);
-        int best = -1;
-        for (int i = 0; i < 4; ++i)
-            if (g_parked[i].p && g_parked[i].cap >= bytes && (best < 0 || g_parked[i].cap < g_parked[best].cap)) best = i;
-        if (best >= 0 && g_parked[best].cap <= 2 * bytes + (1 << 20)) {
-            *out = g_parked[best].p;
-            *cap = g_parked[best].cap;
-            g_parked[best] = ParkedBlock{nullptr, 0};
-        } else {
-            *out = nullptr;
-        }
+// ---- the job packing on the device (chain_pack.h): ONE block; no copy of the sizes to the host, no synchronisation ------------------------
+namespace gnnmp {
+constexpr int PK_THREADS = 1024, PK_WAVES = PK_THREADS / 64;
+
+struct PackArgs {
+    const int64_t *seg_ptr;
+    int G;
+    int njobs_cap;        // rows of tab that exist
+    int32_t *tab;         // [njobs_cap][64]
+    int32_t *sorted;      // [G] scratch: member graphs by decreasing size (ties by id)
+    int32_t *hdr;         // [8] out: jobs, tiles, poison, largest graph, empty graphs
+    int32_t *bad;         // [3] the set-aside counters of the chain kernel (zeroed here)
+};
+
+__global__ void __launch_bounds__(PK_THREADS) chain_pack_kernel(const PackArgs a) {
+    __shared__ PackState st;
+    __shared__ int32_t cnt[PACK_ROWS + 2], start[PACK_ROWS + 2], work[3 * (PACK_ROWS + 1)];
+    __shared__ int32_t wcnt[PK_WAVES][PACK_ROWS + 1];       // per wave: graphs of each size in its range, then the running output position
+    __shared__ int32_t flags[2];                             // largest size seen, graphs without a node
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < PK_WAVES * (PACK_ROWS + 1); i += PK_THREADS) (&wcnt[0][0])[i] = 0;
+    if (tid < 2) flags[tid] = 0;
+    __syncthreads();
+    // every wave owns a contiguous range of member graphs (whole steps of 64)
+    const int per = ((a.G + PK_WAVES - 1) / PK_WAVES + 63) & ~63;
+    const int g0 = wave * per, g1 = min(a.G, g0 + per);
+    auto size_of = [&](int g) -> int {
+        if (g >= g1) return 0;
+        const int64_t d = a.seg_ptr[g + 1] - a.seg_ptr[g];
+        return d > 0x7fffffff ? 0x7fffffff : (int)d;
+    };
+    int mx = 0, empties = 0;
+    for (int g = g0 + lane; g - lane < g1; g += 64) {
+        const int sz = size_of(g);
+        if (g < g1) { mx = max(mx, sz); empties += sz == 0; }
+        if (sz >= 1 && sz <= PACK_ROWS) atomicAdd(&wcnt[wave][sz], 1);
     }
-    if (*out) return hipDeviceSynchronize() == hipSuccess;
-    *cap = bytes;
-    return hipMalloc(out, bytes) == hipSuccess;
-}
-void jobs_block_park(void *p, size_t cap) {
-    if (!p) return;
-    void *evict = nullptr;
+    if (mx > 0) atomicMax(&flags[0], mx);
+    if (empties) atomicAdd(&flags[1], empties);
+    __syncthreads();
+    if (tid >= 1 && tid <= PACK_ROWS) {
+        int c = 0;
+        for (int w = 0; w < PK_WAVES; ++w) c += wcnt[w][tid];
+        cnt[tid] = c;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int pos = 0;
+        for (int s = PACK_ROWS; s >= 1; --s) { start[s] = pos; pos += cnt[s]; }
+        start[0] = pos;                                       // = the number of graphs that are packed
+    }
+    __syncthreads();
+    if (tid >= 1 && tid <= PACK_ROWS) {                        // counts -> first output position of (wave, size)
+        int pos = start[tid];
+        for (int w = 0; w < PK_WAVES; ++w) { const int c = wcnt[w][tid]; wcnt[w][tid] = pos; pos += c; }
+    }
+    __syncthreads();
+    // stable counting sort: position = first position of (wave, size) + rank among the equal sizes of this step's lower lanes
     {
-        std::lock_guard<std::mutex> lk(g_parked_lock);
-        int slot = -1;
-        for (int i = 0; i < 4; ++i)
-            if (!g_parked[i].p) { slot = i; break; }
-        if (slot < 0) {       // full: the smallest block goes
-            slot = 0;
-            for (int i = 1; i < 4; ++i)
-                if (g_parked[i].cap < g_parked[slot].cap) slot = i;
-            if (g_parked[slot].cap >= cap) {
-                evict = p;
-                p = nullptr;
-            } else {
-                evict = g_parked[slot].p;
+        volatile int32_t *wpos = wcnt[wave];
+        for (int g = g0 + lane; g - lane < g1; g += 64) {
+            const int sz = size_of(g);
+            const bool ok = sz >= 1 && sz <= PACK_ROWS;
+            unsigned long long eq = __builtin_amdgcn_ballot_w64(ok);
+#pragma unroll
+            for (int b = 0; b < 7; ++b) {
+                const unsigned long long m = __builtin_amdgcn_ballot_w64((sz >> b) & 1);
+                eq &= ((sz >> b) & 1) ? m : ~m;
             }
+            if (ok) {
+                const int rank = __popcll(eq & ((1ull << lane) - 1ull));
+                const int base = wpos[sz];
+                a.sorted[base + rank] = g;
+                if ((eq >> lane) == 1ull) wpos[sz] = base + __popcll(eq);      // the highest lane of the group moves the cursor
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        if (p) g_parked[slot] = ParkedBlock{p, cap};
     }
-    if (evict) (void)hipFree(evict);
+    // the records (one thread) while the others clear the job table
+    if (tid == 0) {
+        pack_records(cnt, start, &st, work);
+    } else {
+        const int4 fill = make_int4(-1, -1, -1, -1);
+        int4 *t4 = reinterpret_cast<int4 *>(a.tab);
+        for (int64_t i = tid - 1; i < (int64_t)a.njobs_cap * 16; i += PK_THREADS - 1) t4[i] = fill;
+        if (tid <= 3) a.bad[tid - 1] = 0;
+    }
+    __threadfence();
+    __syncthreads();
+    if (tid <= PACK_ROWS) pack_class_count(&st, tid, &work[tid]);
+    __syncthreads();
+    if (tid == 0) {
+        st.cls_start[0] = 0;
+        for (int d = 0; d <= PACK_ROWS; ++d) st.cls_start[d + 1] = st.cls_start[d] + work[d];
+    }
+    __syncthreads();
+    if (tid <= PACK_ROWS) pack_class_fill(&st, tid);
+    __syncthreads();
+    const int nitems = start[0];
+    const bool poison = flags[0] > PACK_ROWS || flags[1] > 0 || st.njobs > a.njobs_cap;
+    if (!poison) {
+        for (int p = tid; p < nitems; p += PK_THREADS) {
+            const int g = a.sorted[p];
+            int32_t job, slot;
+            pack_place(&st, p, &job, &slot);
+            const int64_t r0 = a.seg_ptr[g];
+            const int sz = (int)(a.seg_ptr[g + 1] - r0);
+            int32_t *row = a.tab + (int64_t)job * PACK_ROWS + slot;
+            for (int i = 0; i < sz; ++i) row[i] = (int32_t)(r0 + i);
+        }
+    }
+    if (tid == 0) {
+        a.hdr[0] = poison ? 0 : st.njobs;
+        a.hdr[1] = st.tiles;
+        a.hdr[2] = poison ? 1 : 0;
+        a.hdr[3] = flags[0];
+        a.hdr[4] = flags[1];
+    }
 }
-}  // namespace
+}  // namespace gnnmp
 
 // Pack the member graphs of a batch (MLUtils.batch: contiguous row ranges seg_ptr[k] .. seg_ptr[k + 1]) into wave jobs of at most 64
 // rows, best-fit decreasing.  Graph prep like gnnmp_plan_create: once per batched graph, synchronises the stream.
@@ -646,7 +736,7 @@ extern "C" int gnnmp_chain_jobs_create(gnnmp_chain_jobs_t **out, const int64_t *
         const size_t off_bad = (bytes + 255) & ~(size_t)255;
         const size_t off_z = (off_bad + sizeof(int32_t) * (size_t)(3 + 4 * njobs) + 255) & ~(size_t)255;
         const size_t total = off_z + sizeof(float) * (size_t)2 * (size_t)J->N * 8;
-        if (!jobs_block_take(&J->block, &J->block_bytes, total)) {
+        if (!pool_take(&J->block, &J->block_bytes, total, stream)) {
             delete J;
             return fail(GNNMP_EALLOC, "chain_jobs_create: hipMalloc failed");
         }
@@ -654,9 +744,15 @@ extern "C" int gnnmp_chain_jobs_create(gnnmp_chain_jobs_t **out, const int64_t *
         J->tab = reinterpret_cast<int32_t *>(base);
         J->bad = reinterpret_cast<int32_t *>(base + off_bad);
         J->zrows = reinterpret_cast<float *>(base + off_z);
-        GNNMP_HIP(hipMemsetAsync(J->bad, 0, 3 * sizeof(int32_t), stream));
-        GNNMP_HIP(hipMemcpyAsync(J->tab, tab.data(), bytes, hipMemcpyHostToDevice, stream));
-        GNNMP_HIP(hipStreamSynchronize(stream));
+        J->njobs_cap = njobs;
+        hipError_t e = hipMemsetAsync(J->bad, 0, 3 * sizeof(int32_t), stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(J->tab, tab.data(), bytes, hipMemcpyHostToDevice, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) {                 // (the block goes back, the handle does not leak)
+            pool_park(J->block, J->block_bytes, stream, false);
+            delete J;
+            return hip_fail(e, "chain_jobs_create: upload of the job table");
+        }
     }
     *out = J;
     return GNNMP_OK;
@@ -664,8 +760,94 @@ extern "C" int gnnmp_chain_jobs_create(gnnmp_chain_jobs_t **out, const int64_t *
 
 extern "C" int gnnmp_chain_jobs_destroy(gnnmp_chain_jobs_t *J) {
     if (!J) return GNNMP_OK;
-    jobs_block_park(J->block, J->block_bytes);
+    pool_park(J->block, J->block_bytes, nullptr, false);
     delete J;
+    return GNNMP_OK;
+}
+
+/* stream-ordered destroy: the handle's device block goes back to the pool behind the work enqueued on `stream` so far (gnnmp.h) */
+extern "C" int gnnmp_chain_jobs_release(gnnmp_chain_jobs_t *J, gnnmp_stream_t stream) {
+    if (!J) return GNNMP_OK;
+    pool_park(J->block, J->block_bytes, (hipStream_t)stream, true);
+    delete J;
+    return GNNMP_OK;
+}
+
+/* The same packing ON THE DEVICE (chain_pack.h, chain_pack_kernel): one launch of one block, no copy to the host, no synchronisation.
+ * The caller says what it knows on the host — every GNNGraph carries num_nodes as a host integer (GNNGraphs/src/gnngraph.jl:108-117): n_rows
+ * (the batch's nodes), max_graph (its largest member), has_empty (a member without nodes).  max_graph > 64 or has_empty: no jobs (the
+ * general kernel runs), exactly like gnnmp_chain_jobs_create.  Sizes that contradict the announcement poison the handle: the chain then
+ * writes NaN logits (and gnnmp_chain_jobs_info, which synchronises, reports it). */
+extern "C" int gnnmp_chain_jobs_pack(gnnmp_chain_jobs_t **out, const int64_t *seg_ptr, int64_t G, int64_t n_rows, int64_t max_graph,
+                                     int has_empty, gnnmp_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!out || G < 0 || n_rows < 0 || max_graph < 0 || (G > 0 && !seg_ptr)) return fail(GNNMP_EINVAL, "chain_jobs_pack: bad argument");
+    *out = nullptr;
+    gnnmp_chain_jobs *J = new gnnmp_chain_jobs();
+    J->G = G;
+    J->N = n_rows;
+    J->max_graph = max_graph;
+    J->has_empty = has_empty ? 1 : 0;
+    if (max_graph > 64 || has_empty || n_rows >= ((int64_t)1 << 31) || G >= ((int64_t)1 << 31) || G == 0 || n_rows == 0) {
+        *out = J;                                    // no jobs: the caller's chain runs on the general kernel
+        return GNNMP_OK;
+    }
+    // any best fit leaves at most one job half empty: jobs <= 2 N / 64 + 1; and every job holds a graph
+    const int64_t cap = std::min<int64_t>(G, n_rows / 32 + 2);
+    const size_t b_tab = (size_t)cap * PACK_ROWS * sizeof(int32_t);
+    const size_t off_bad = (b_tab + 255) & ~(size_t)255;
+    const size_t off_hdr = (off_bad + sizeof(int32_t) * (size_t)(3 + 4 * cap) + 255) & ~(size_t)255;
+    const size_t off_sorted = off_hdr + 256;
+    const size_t off_z = (off_sorted + sizeof(int32_t) * (size_t)G + 255) & ~(size_t)255;
+    const size_t total = off_z + sizeof(float) * (size_t)2 * (size_t)n_rows * 8;
+    if (!pool_take(&J->block, &J->block_bytes, total, stream)) {
+        delete J;
+        return fail(GNNMP_EALLOC, "chain_jobs_pack: hipMalloc of %zu bytes failed", total);
+    }
+    unsigned char *base = static_cast<unsigned char *>(J->block);
+    J->tab = reinterpret_cast<int32_t *>(base);
+    J->bad = reinterpret_cast<int32_t *>(base + off_bad);
+    J->hdr = reinterpret_cast<int32_t *>(base + off_hdr);
+    J->zrows = reinterpret_cast<float *>(base + off_z);
+    J->njobs = -1;
+    J->njobs_cap = (int)cap;
+    PackArgs a = {};
+    a.seg_ptr = seg_ptr;
+    a.G = (int)G;
+    a.njobs_cap = (int)cap;
+    a.tab = J->tab;
+    a.sorted = reinterpret_cast<int32_t *>(base + off_sorted);
+    a.hdr = J->hdr;
+    a.bad = J->bad;
+    chain_pack_kernel<<<1, PK_THREADS, 0, stream>>>(a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        pool_park(J->block, J->block_bytes, stream, true);
+        delete J;
+        return hip_fail(e, "chain_pack_kernel");
+    }
+    *out = J;
+    return GNNMP_OK;
+}
+
+/* the job table as the chain kernel sees it: tab_out[cap_rows][64] int32 (device), hdr_out[8] int32 (device; host-packed handles: [0] = jobs,
+ * rest 0).  Tests and debugging: asynchronous copies on `stream`. */
+extern "C" int gnnmp_chain_jobs_export(const gnnmp_chain_jobs_t *J, int32_t *tab_out, int64_t cap_rows, int32_t *hdr_out,
+                                       gnnmp_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!J || cap_rows < 0) return fail(GNNMP_EINVAL, "chain_jobs_export: bad argument");
+    const int64_t rows = std::min<int64_t>(cap_rows, J->njobs_cap);
+    if (tab_out && rows > 0)
+        GNNMP_HIP(hipMemcpyAsync(tab_out, J->tab, sizeof(int32_t) * PACK_ROWS * (size_t)rows, hipMemcpyDeviceToDevice, stream));
+    if (hdr_out) {
+        if (J->hdr) {
+            GNNMP_HIP(hipMemcpyAsync(hdr_out, J->hdr, sizeof(int32_t) * 8, hipMemcpyDeviceToDevice, stream));
+        } else {
+            const int32_t h[8] = {J->njobs, 0, 0, (int32_t)J->max_graph, J->has_empty, 0, 0, 0};
+            GNNMP_HIP(hipMemcpyAsync(hdr_out, h, sizeof(h), hipMemcpyHostToDevice, stream));
+            GNNMP_HIP(hipStreamSynchronize(stream));
+        }
+    }
     return GNNMP_OK;
 }
 
@@ -673,7 +855,19 @@ extern "C" int gnnmp_chain_jobs_destroy(gnnmp_chain_jobs_t *J) {
  * that are real rows */
 extern "C" int gnnmp_chain_jobs_info(const gnnmp_chain_jobs_t *J, int64_t *info) {
     if (!J || !info) return fail(GNNMP_EINVAL, "chain_jobs_info: null pointer");
-    info[0] = J->njobs; info[1] = J->G; info[2] = J->N; info[3] = J->max_graph; info[4] = (int64_t)(J->fill * 1000.0 + 0.5);
+    int64_t njobs = J->njobs;
+    double fill = J->fill;
+    if (J->hdr) {          // packed on the device: read the header back (synchronises the device: a query, not part of a step)
+        int32_t h[8] = {0};
+        GNNMP_HIP(hipDeviceSynchronize());
+        GNNMP_HIP(hipMemcpy(h, J->hdr, sizeof(h), hipMemcpyDeviceToHost));
+        if (h[2] != 0)
+            return fail(GNNMP_EINVAL, "chain_jobs_pack: the batch holds a member graph of %d nodes / %d empty member graphs, its caller "
+                                      "announced max_graph = %lld, has_empty = %d", h[3], h[4], (long long)J->max_graph, J->has_empty);
+        njobs = h[0];
+        fill = h[1] > 0 ? (double)J->N / (32.0 * (double)h[1]) : 0.0;
+    }
+    info[0] = njobs; info[1] = J->G; info[2] = J->N; info[3] = J->max_graph; info[4] = (int64_t)(fill * 1000.0 + 0.5);
     return GNNMP_OK;
 }
 
@@ -692,7 +886,7 @@ int graph_chain2_try(gnnmp_graph_t *p, const gnnmp_chain_jobs_t *J, const int64_
                      const int64_t *dims, const float *const *W_root, const float *const *W_agg, const float *const *bias,
                      const int *act, int w_layout, int aggr, int pool_aggr, const float *W_head, const float *b_head, int64_t nout,
                      float *out, hipStream_t stream) {
-    if (!J || J->njobs <= 0 || J->has_empty || J->G != G || J->N != p->n_dst) return 1;
+    if (!J || J->njobs_cap <= 0 || J->has_empty || J->G != G || J->N != p->n_dst) return 1;
     if (n_layers != 2 || dims[0] != C2_D0 || dims[1] != C2_D1 || dims[2] != C2_D2 || nout > 8) return 1;
     if (knob(KNOB_CHAIN) == 1) return 1;    // 1 = the general kernel only (A/B runs)
     if ((reinterpret_cast<uintptr_t>(x) & 15)) return 1;
@@ -700,7 +894,8 @@ int graph_chain2_try(gnnmp_graph_t *p, const gnnmp_chain_jobs_t *J, const int64_
     a.rowptr = p->rowptr;
     a.col = p->col;
     a.job_rows = J->tab;
-    a.njobs = J->njobs;
+    a.njobs = J->hdr ? J->njobs_cap : J->njobs;      // (device-packed: the bound the grid is sized for; the kernel reads hdr[0])
+    a.hdr = J->hdr;
     a.seg_ptr = seg_ptr;
     a.x = x;
     a.W1r = W_root[0]; a.W1a = W_agg[0]; a.b1 = bias ? bias[0] : nullptr;
@@ -712,7 +907,7 @@ int graph_chain2_try(gnnmp_graph_t *p, const gnnmp_chain_jobs_t *J, const int64_
     a.mean_aggr = aggr == GNNMP_MEAN;
     a.pool_mean = pool_aggr == GNNMP_MEAN;
     a.out = out;
-    const unsigned parity = const_cast<gnnmp_chain_jobs_t *>(J)->calls++ & 1u;
+    const unsigned parity = const_cast<gnnmp_chain_jobs_t *>(J)->calls.fetch_add(1u, std::memory_order_relaxed) & 1u;
     a.bad_count = J->bad + parity;
     a.bad_reset = J->bad + (parity ^ 1u);
     a.bad_list = J->bad + 3;
@@ -727,14 +922,14 @@ int graph_chain2_try(gnnmp_graph_t *p, const gnnmp_chain_jobs_t *J, const int64_
     const int waves = (knob(KNOB_VARIANT) & 3) == 1 ? 8 : 12;
     const size_t lds = (size_t)3 * C2_UNITS1 * 16 + (size_t)3 * C2_UNITS2 * 16 + C2_D1 * 4 + C2_SLAB * 4 + 8 * C2_SLAB * 4 +
                        (size_t)(waves / 2) * C2_STAGE_BYTES + 4 * 2 * (size_t)waves;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&graph_chain2_kernel<768>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&graph_chain2_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(graph_chain2_kernel)");
-        attr_set = true;
-    }
+    static std::once_flag attr_once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(attr_once, [] {
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(&graph_chain2_kernel<768>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (attr_err == hipSuccess)
+            attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(&graph_chain2_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    if (attr_err != hipSuccess) return hip_fail(attr_err, "hipFuncSetAttribute(graph_chain2_kernel)");
     const int cus = device_cus();
     const int gx = std::max(1, std::min(cus / 2, (a.njobs + waves / 2 - 1) / (waves / 2)));     // one block a CU: half of them per slab
     const dim3 grid((unsigned)gx, 2);

@@ -10,6 +10,7 @@
 
 
 #include "common.h"
+#include "pool.h"
 #include "sort_scan.h"
 
 namespace gnnmp {
@@ -40,6 +41,8 @@ int device_cus() {
     }
     return cached[dev];
 }
+
+int plan_dispose(gnnmp_graph_t *p, hipStream_t stream, bool stream_known);
 
 int ensure_workspace(gnnmp_graph *p, size_t floats) {
     if (floats <= p->ws_floats) return GNNMP_OK;
@@ -228,6 +231,102 @@ __global__ void batch_indicator_kernel(const int64_t *node_ptr, int64_t G, int64
 
 static inline unsigned nblocks(int64_t n, int bs) { return (unsigned)((n + bs - 1) / bs); }
 
+// Long-row threshold: a row is reduced sequentially by one lane group, ~0.25 us per edge once HBM latency is the
+// limit, while the whole kernel moves an edge every ~0.1 ns; rows above ~4e-5 * E' edges would become the tail.
+// Clamped to [GNNMP_MIN_LONG_ROW, GNNMP_LONG_ROW]; rows up to this length keep the exact reference edge order.
+int plan_long_thresh(int64_t Etot) {
+    if (knob(KNOB_LONG_ROW) > 0) return knob(KNOB_LONG_ROW);
+    int th = GNNMP_MIN_LONG_ROW;
+    while (th < GNNMP_LONG_ROW && (double)th < 4e-5 * (double)Etot) th <<= 1;
+    return th;
+}
+
+int plan_build_long_rows(gnnmp_graph *p, hipStream_t stream) {
+    const int64_t n_dst = p->n_dst, Etot = p->n_total;
+    const int BS = 256;
+    int *flags = nullptr;       // [0] long count; [2..3] = one unsigned long long: max degree
+    int64_t *long_tmp = nullptr;
+    int rc = GNNMP_OK;
+#define PLAN_HIP(expr)                                  \
+    do {                                                \
+        hipError_t e__ = (expr);                        \
+        if (e__ != hipSuccess) {                        \
+            rc = hip_fail(e__, #expr);                  \
+            goto done;                                  \
+        }                                               \
+    } while (0)
+    {
+        // long rows: at most Etot / thresh of them
+        int cap = (int)std::min<int64_t>(Etot / std::max(1, p->long_thresh) + 1, n_dst + 1);
+        PLAN_HIP(hipMalloc((void **)&flags, sizeof(int) * 4));
+        PLAN_HIP(hipMemsetAsync(flags, 0, sizeof(int) * 4, stream));
+        PLAN_HIP(hipMalloc((void **)&long_tmp, sizeof(int64_t) * 3 * (size_t)std::max(cap, 1)));
+        if (n_dst > 0) {
+            plan_long_rows<<<nblocks(n_dst, BS), BS, 0, stream>>>(p->rowptr, n_dst, p->long_thresh, long_tmp, cap, flags,
+                                                                  reinterpret_cast<unsigned long long *>(flags + 2));
+            PLAN_HIP(hipGetLastError());
+        }
+        int meta[4] = {0, 0, 0, 0};
+        PLAN_HIP(hipMemcpyAsync(meta, flags, sizeof(int) * 4, hipMemcpyDeviceToHost, stream));
+        PLAN_HIP(hipStreamSynchronize(stream));
+        {
+            unsigned long long md;
+            memcpy(&md, meta + 2, sizeof(md));
+            p->max_degree = (int64_t)md;
+        }
+        p->n_long = std::min(meta[0], cap);
+        if (p->n_long > 0) {
+            struct Tri { int64_t row, beg, end; };
+            std::vector<Tri> h((size_t)p->n_long);
+            PLAN_HIP(hipMemcpy(h.data(), long_tmp, sizeof(Tri) * h.size(), hipMemcpyDeviceToHost));
+            // atomics filled the list in arbitrary order: make it canonical (ascending row)
+            std::sort(h.begin(), h.end(), [](const Tri &a, const Tri &b) { return a.row < b.row; });
+            std::vector<int32_t> rows, cptr, crow;
+            std::vector<uint32_t> cbeg, cend;
+            cptr.push_back(0);
+            for (const Tri &t : h) {
+                const int64_t len = t.end - t.beg;
+                const int64_t nch = (len + p->long_thresh - 1) / p->long_thresh;
+                const int64_t csz = (len + nch - 1) / nch;  // balanced chunks, each <= long_thresh slots
+                for (int64_t c = 0; c < nch; ++c) {
+                    crow.push_back((int32_t)t.row);
+                    cbeg.push_back((uint32_t)(t.beg + c * csz));
+                    cend.push_back((uint32_t)std::min(t.beg + (c + 1) * csz, t.end));
+                }
+                rows.push_back((int32_t)t.row);
+                cptr.push_back((int32_t)crow.size());
+            }
+            if (crow.size() >= (size_t)INT32_MAX) {
+                rc = fail(GNNMP_EUNSUPPORTED, "plan_create: %zu chunks of split rows exceed the int32 chunk index", crow.size());
+                goto done;
+            }
+            p->n_chunks = (int)crow.size();
+            auto upload = [&](int32_t **dst, const std::vector<int32_t> &v) -> hipError_t {
+                hipError_t e = hipMalloc((void **)dst, sizeof(int32_t) * v.size());
+                if (e != hipSuccess) return e;
+                p->bytes += (int64_t)(sizeof(int32_t) * v.size());
+                return hipMemcpy(*dst, v.data(), sizeof(int32_t) * v.size(), hipMemcpyHostToDevice);
+            };
+            PLAN_HIP(upload(&p->long_rows, rows));
+            PLAN_HIP(upload(&p->long_cptr, cptr));
+            PLAN_HIP(upload(&p->chunk_row, crow));
+            auto upload_u = [&](uint32_t **dst, const std::vector<uint32_t> &v) -> hipError_t {
+                hipError_t e = hipMalloc((void **)dst, sizeof(uint32_t) * v.size());
+                if (e != hipSuccess) return e;
+                p->bytes += (int64_t)(sizeof(uint32_t) * v.size());
+                return hipMemcpy(*dst, v.data(), sizeof(uint32_t) * v.size(), hipMemcpyHostToDevice);
+            };
+            PLAN_HIP(upload_u(&p->chunk_beg, cbeg));
+            PLAN_HIP(upload_u(&p->chunk_end, cend));
+        }
+    }
+done:
+    if (flags) (void)hipFree(flags);
+    if (long_tmp) (void)hipFree(long_tmp);
+#undef PLAN_HIP
+    return rc;
+}
+
 }  // namespace gnnmp
 
 using namespace gnnmp;
@@ -244,8 +343,23 @@ int gnnmp_tune(int k, int value) {
     return GNNMP_OK;
 }
 
-int gnnmp_plan_destroy(gnnmp_graph_t *p) {
+int gnnmp_plan_destroy(gnnmp_graph_t *p) { return plan_dispose(p, nullptr, false); }
+
+/* stream-ordered destroy of a pooled plan (gnnmp_plan_concat / gnnmp_plan_select): see gnnmp.h */
+int gnnmp_plan_release(gnnmp_graph_t *p, gnnmp_stream_t stream) { return plan_dispose(p, (hipStream_t)stream, true); }
+
+}  // extern "C"
+
+namespace gnnmp {
+int plan_dispose(gnnmp_graph_t *p, hipStream_t stream, bool stream_known) {
     if (!p) return GNNMP_OK;
+    if (p->block) {
+        // rowptr / col / eid are pieces of the pooled block: back to the pool (with an event on `stream` when the caller names it)
+        pool_park(p->block, p->block_bytes, stream, stream_known);
+        p->rowptr = nullptr;
+        p->col = nullptr;
+        p->eid = nullptr;
+    }
     if (p->rowptr) (void)hipFree(p->rowptr);
     if (p->col) (void)hipFree(p->col);
     if (p->eid) (void)hipFree(p->eid);
@@ -260,6 +374,9 @@ int gnnmp_plan_destroy(gnnmp_graph_t *p) {
     delete p;
     return GNNMP_OK;
 }
+}  // namespace gnnmp
+
+extern "C" {
 
 int gnnmp_plan_create(gnnmp_graph_t **out, const void *src, const void *dst, int idx_bytes,
                       int index_base, int64_t n_src, int64_t n_dst, int64_t n_edges,
@@ -290,20 +407,10 @@ int gnnmp_plan_create(gnnmp_graph_t **out, const void *src, const void *dst, int
     p->n_edges = n_edges;
     p->n_total = Etot;
     p->self_loops = add_self_loops ? 1 : 0;
-    // Long-row threshold: a row is reduced sequentially by one lane group, ~0.25 us per edge once HBM latency is the
-    // limit, while the whole kernel moves an edge every ~0.1 ns; rows above ~4e-5 * E' edges would become the tail.
-    // Clamped to [GNNMP_MIN_LONG_ROW, GNNMP_LONG_ROW]; rows up to this length keep the exact reference edge order.
-    if (knob(KNOB_LONG_ROW) > 0) {
-        p->long_thresh = knob(KNOB_LONG_ROW);
-    } else {
-        int th = GNNMP_MIN_LONG_ROW;
-        while (th < GNNMP_LONG_ROW && (double)th < 4e-5 * (double)Etot) th <<= 1;
-        p->long_thresh = th;
-    }
+    p->long_thresh = plan_long_thresh(Etot);
 
     uint32_t *keys_in = nullptr, *keys_out = nullptr, *vals_in = nullptr;
-    int *flags = nullptr;  // [0] bad index, [1] long count; [2..3] = one unsigned long long: max degree
-    int64_t *long_tmp = nullptr;
+    int *flags = nullptr;  // [0] bad index
     int rc = GNNMP_OK;
     const int BS = 256;
     const size_t epad = (size_t)std::max<int64_t>(Etot, 1);
@@ -357,74 +464,11 @@ int gnnmp_plan_create(gnnmp_graph_t **out, const void *src, const void *dst, int
     plan_rowptr<<<nblocks(n_dst + 1, BS), BS, 0, stream>>>(keys_out, Etot, n_dst, p->rowptr);
     PLAN_HIP(hipGetLastError());
 
-    {
-        // long rows: at most Etot / thresh of them
-        int cap = (int)std::min<int64_t>(Etot / std::max(1, p->long_thresh) + 1, n_dst + 1);
-        PLAN_HIP(hipMalloc((void **)&long_tmp, sizeof(int64_t) * 3 * (size_t)std::max(cap, 1)));
-        if (n_dst > 0) {
-            plan_long_rows<<<nblocks(n_dst, BS), BS, 0, stream>>>(p->rowptr, n_dst, p->long_thresh, long_tmp, cap, flags + 1,
-                                                                  reinterpret_cast<unsigned long long *>(flags + 2));
-            PLAN_HIP(hipGetLastError());
-        }
-        int meta[3] = {0, 0, 0};
-        PLAN_HIP(hipMemcpyAsync(meta, flags + 1, sizeof(int) * 3, hipMemcpyDeviceToHost, stream));
-        PLAN_HIP(hipStreamSynchronize(stream));
-        {
-            unsigned long long md;
-            memcpy(&md, meta + 1, sizeof(md));
-            p->max_degree = (int64_t)md;
-        }
-        p->n_long = std::min(meta[0], cap);
-        if (p->n_long > 0) {
-            struct Tri { int64_t row, beg, end; };
-            std::vector<Tri> h((size_t)p->n_long);
-            PLAN_HIP(hipMemcpy(h.data(), long_tmp, sizeof(Tri) * h.size(), hipMemcpyDeviceToHost));
-            // atomics filled the list in arbitrary order: make it canonical (ascending row)
-            std::sort(h.begin(), h.end(), [](const Tri &a, const Tri &b) { return a.row < b.row; });
-            std::vector<int32_t> rows, cptr, crow;
-            std::vector<uint32_t> cbeg, cend;
-            cptr.push_back(0);
-            for (const Tri &t : h) {
-                const int64_t len = t.end - t.beg;
-                const int64_t nch = (len + p->long_thresh - 1) / p->long_thresh;
-                const int64_t csz = (len + nch - 1) / nch;  // balanced chunks, each <= long_thresh slots
-                for (int64_t c = 0; c < nch; ++c) {
-                    crow.push_back((int32_t)t.row);
-                    cbeg.push_back((uint32_t)(t.beg + c * csz));
-                    cend.push_back((uint32_t)std::min(t.beg + (c + 1) * csz, t.end));
-                }
-                rows.push_back((int32_t)t.row);
-                cptr.push_back((int32_t)crow.size());
-            }
-            if (crow.size() >= (size_t)INT32_MAX) {
-                rc = fail(GNNMP_EUNSUPPORTED, "plan_create: %zu chunks of split rows exceed the int32 chunk index", crow.size());
-                goto done;
-            }
-            p->n_chunks = (int)crow.size();
-            auto upload = [&](int32_t **dst, const std::vector<int32_t> &v) -> hipError_t {
-                hipError_t e = hipMalloc((void **)dst, sizeof(int32_t) * v.size());
-                if (e != hipSuccess) return e;
-                p->bytes += (int64_t)(sizeof(int32_t) * v.size());
-                return hipMemcpy(*dst, v.data(), sizeof(int32_t) * v.size(), hipMemcpyHostToDevice);
-            };
-            PLAN_HIP(upload(&p->long_rows, rows));
-            PLAN_HIP(upload(&p->long_cptr, cptr));
-            PLAN_HIP(upload(&p->chunk_row, crow));
-            auto upload_u = [&](uint32_t **dst, const std::vector<uint32_t> &v) -> hipError_t {
-                hipError_t e = hipMalloc((void **)dst, sizeof(uint32_t) * v.size());
-                if (e != hipSuccess) return e;
-                p->bytes += (int64_t)(sizeof(uint32_t) * v.size());
-                return hipMemcpy(*dst, v.data(), sizeof(uint32_t) * v.size(), hipMemcpyHostToDevice);
-            };
-            PLAN_HIP(upload_u(&p->chunk_beg, cbeg));
-            PLAN_HIP(upload_u(&p->chunk_end, cend));
-        }
-    }
+    rc = plan_build_long_rows(p, stream);
 
 done:
     if (keys_in) (void)hipFree(keys_in);   // keys_out and vals_in live in the same allocation
     if (flags) (void)hipFree(flags);
-    if (long_tmp) (void)hipFree(long_tmp);
 #undef PLAN_HIP
     if (rc != GNNMP_OK) {
         gnnmp_plan_destroy(p);

@@ -7,6 +7,8 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <cstdio>
+#include <mutex>
 #include <numeric>
 #include <vector>
 
@@ -51,15 +53,27 @@ extern "C" int gnnmp_shard_by_size(const int64_t *sizes, int64_t G, int world, i
 extern "C" int gnnmp_allgather_f32(void *nccl_comm, const float *send, float *recv, int64_t count, gnnmp_stream_t stream) {
     if (!nccl_comm || !send || !recv || count < 0) return fail(GNNMP_EINVAL, "allgather: bad argument");
     typedef int (*allgather_fn)(const void *, void *, size_t, int, void *, hipStream_t);
+    // The communicator was made by an RCCL that is ALREADY in the process (e.g. torch's bundled librccl.so, SONAME librccl.so.1): its
+    // ncclAllGather is the only one the handle may be given to.  So: the process's global symbols first, then the loaded copies by SONAME
+    // (RTLD_NOLOAD: never map a second build next to the caller's), and only when no RCCL is loaded at all a fresh dlopen.
     static allgather_fn fn = nullptr;
-    if (!fn) {
-        void *h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-        if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
-        if (!h) return fail(GNNMP_EUNSUPPORTED, "allgather: librccl.so not found (%s)", dlerror());
-        fn = reinterpret_cast<allgather_fn>(dlsym(h, "ncclAllGather"));
-        if (!fn) return fail(GNNMP_EUNSUPPORTED, "allgather: ncclAllGather not found in librccl.so");
-    }
+    static std::once_flag once;
+    static char why[256] = "";
+    std::call_once(once, [] {
+        void *sym = dlsym(RTLD_DEFAULT, "ncclAllGather");
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"};
+        for (int pass = 0; pass < 2 && !sym; ++pass)
+            for (const char *nm : names) {
+                void *h = dlopen(nm, pass == 0 ? (RTLD_NOW | RTLD_NOLOAD) : (RTLD_NOW | RTLD_GLOBAL));
+                if (h && (sym = dlsym(h, "ncclAllGather"))) break;
+            }
+        if (!sym) {
+            const char *e = dlerror();
+            snprintf(why, sizeof(why), "%s", e ? e : "ncclAllGather not found");
+        }
+        fn = reinterpret_cast<allgather_fn>(sym);
+    });
+    if (!fn) return fail(GNNMP_EUNSUPPORTED, "allgather: no RCCL with ncclAllGather in this process or on the library path (%s)", why);
     const int rc = fn(send, recv, (size_t)count, 7 /* ncclFloat32 */, nccl_comm, (hipStream_t)stream);
     if (rc != 0) return fail(GNNMP_ELAUNCH, "allgather: ncclAllGather returned %d", rc);
     return GNNMP_OK;

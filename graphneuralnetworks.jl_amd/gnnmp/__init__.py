@@ -17,6 +17,7 @@ from .layers_khop import (GlobalAttentionPool, ResGatedGraphConv, SGConv, TAGCon
 from .layers_more import (CGConv, ChebConv, DConv, EdgeConv, EGNNConv, GatedGraphConv, GMMConv, MEGNetConv,  # noqa: F401
                           NNConv, Set2Set, cg_conv, cheb_conv, d_conv, edge_conv, egnn_conv, gated_graph_conv, gmm_conv,
                           megnet_conv, nn_conv, set2set_pool)
+from .dataset import DataLoader, GraphDataset, concat_plans  # noqa: F401
 from .sampling import (NeighborLoader, NodeSet, has_self_loops, induced_subgraph, is_bidirected, sample_neighbors,  # noqa: F401
                        sort_edge_index)
 from .utils import (broadcast_edges, broadcast_nodes, expand_srcdst, reduce_edges, reduce_nodes,  # noqa: F401

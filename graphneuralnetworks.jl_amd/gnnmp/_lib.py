@@ -21,6 +21,8 @@ LONG_ROW = 512
 SYMBOLS = (
     "gnnmp_version", "gnnmp_last_error",
     "gnnmp_plan_create", "gnnmp_plan_destroy", "gnnmp_plan_info", "gnnmp_plan_export", "gnnmp_plan_export64",
+    "gnnmp_plan_concat", "gnnmp_plan_select", "gnnmp_plan_release", "gnnmp_plan_status", "gnnmp_plan_edge_index",
+    "gnnmp_chain_jobs_pack", "gnnmp_chain_jobs_release", "gnnmp_chain_jobs_export",
     "gnnmp_add_self_loops", "gnnmp_batch_coo",
     "gnnmp_sort_edge_index", "gnnmp_is_bidirected", "gnnmp_has_self_loops", "gnnmp_sample_neighbors",
     "gnnmp_unique_append", "gnnmp_induced_subgraph",
@@ -71,6 +73,14 @@ def load():
         "gnnmp_plan_info": [vp, ctypes.POINTER(i64)],
         "gnnmp_plan_export": [vp, vp, vp, vp, vp],
         "gnnmp_plan_export64": [vp, vp, vp, vp, vp],
+        "gnnmp_plan_concat": [ctypes.POINTER(vp), ctypes.POINTER(vp), i64, vp, vp, i, i, vp],
+        "gnnmp_plan_select": [ctypes.POINTER(vp), vp, vp, i64, vp, i, i, i64, i64, i64, vp, vp, vp, vp],
+        "gnnmp_plan_release": [vp, vp],
+        "gnnmp_plan_status": [vp, vp],
+        "gnnmp_plan_edge_index": [vp, i, i, vp, vp, vp],
+        "gnnmp_chain_jobs_pack": [ctypes.POINTER(vp), vp, i64, i64, i64, i, vp],
+        "gnnmp_chain_jobs_release": [vp, vp],
+        "gnnmp_chain_jobs_export": [vp, vp, i64, vp, vp],
         "gnnmp_add_self_loops": [vp, vp, i, i, i64, i64, vp, vp, vp, vp, vp],
         "gnnmp_batch_coo": [vp, vp, i, i, vp, vp, i64, vp, vp, vp, vp],
         "gnnmp_sort_edge_index": [vp, vp, i, i, i64, vp, vp, vp],
@@ -190,6 +200,40 @@ def ptr(t):
     if t is None:
         return None
     return ctypes.c_void_p(t.data_ptr())
+
+
+# ---- kernel probe: HIP events around named launches, on the stream they are launched on -------------------------------------------------
+# bench.py times the dominant kernels INSIDE its timed steps with this (the roofline figure of the bench line is the in-step duration, the
+# one a rocprofv3 kernel trace of the same command shows); off (None) it costs one global read per call.
+_probe = None
+
+
+class EventProbe:
+    """spans[name] = list of (start, end) torch.cuda.Event pairs recorded around every launch of `name` while the probe is set"""
+
+    def __init__(self):
+        self.spans = {}
+
+    def begin(self):
+        import torch
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def end(self, name, e0):
+        import torch
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.spans.setdefault(name, []).append((e0, e1))
+
+    def times_ms(self, name):
+        """call after a synchronisation"""
+        return [a.elapsed_time(b) for a, b in self.spans.get(name, [])]
+
+
+def set_probe(p):
+    global _probe
+    _probe = p
 
 
 KNOB_DEFAULTS = {1: -1, 3: 1, 7: 17}      # every other knob starts at 0 (csrc/plan.cpp g_knobs)

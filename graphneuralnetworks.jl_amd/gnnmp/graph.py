@@ -62,9 +62,34 @@ class Plan:
         self.max_degree, self.n_long, self.bytes, self.long_thresh = info[4], info[5], info[6], info[7]
         self.device = s.device
 
+    @classmethod
+    def _adopt(cls, handle, device):
+        """wrap a handle made by gnnmp_plan_concat / gnnmp_plan_select (a POOLED plan: released stream-ordered, no host sync)"""
+        self = object.__new__(cls)
+        self._lib = L.load()
+        self._h = handle
+        self._pooled = True
+        info = (ctypes.c_int64 * 8)()
+        L.check(self._lib.gnnmp_plan_info(self._h, info))
+        self.n_src, self.n_dst, self.n_edges, self.n_total = info[0], info[1], info[2], info[3]
+        self.max_degree, self.n_long, self.bytes, self.long_thresh = info[4], info[5], info[6], info[7]
+        self.device = device
+        return self
+
     @property
     def handle(self):
         return self._h
+
+    def status(self):
+        """pooled plans: raises if the member table did not match the announced totals (synchronises the stream)"""
+        L.check(self._lib.gnnmp_plan_status(self._h, L.stream_ptr()))
+
+    def edge_index(self, dtype=torch.int64, index_base=1):
+        """(s, t) of the plan's graph in original edge order (gnnmp_plan_edge_index)"""
+        s = torch.empty(self.n_edges, dtype=dtype, device=self.device)
+        t = torch.empty(self.n_edges, dtype=dtype, device=self.device)
+        L.check(self._lib.gnnmp_plan_edge_index(self._h, 8 if dtype == torch.int64 else 4, index_base, L.ptr(s), L.ptr(t), L.stream_ptr()))
+        return s, t
 
     def export(self):
         """(rowptr, col, eid) int32 device tensors — the plan's bit-exact index outputs (plans of fewer than 2^31 slots)"""
@@ -86,7 +111,11 @@ class Plan:
     def __del__(self):
         try:
             if self._h:
-                self._lib.gnnmp_plan_destroy(self._h)
+                if getattr(self, "_pooled", False):
+                    # stream-ordered: the block goes back to the library's pool behind the work enqueued so far (no host synchronisation)
+                    self._lib.gnnmp_plan_release(self._h, L.stream_ptr())
+                else:
+                    self._lib.gnnmp_plan_destroy(self._h)
                 self._h = ctypes.c_void_p()
         except Exception:
             pass
@@ -121,7 +150,7 @@ class GNNGraph:
         assert self.w is None or self.w.numel() == s.numel(), "length(val) == length(s)"
         if num_nodes is None:
             num_nodes = 0 if s.numel() == 0 else int(max(int(s.max()), int(t.max()))) + (1 - self.index_base)
-        self.s, self.t = s, t
+        self._s, self._t = s, t
         self.num_nodes = int(num_nodes)
         self.num_edges = int(s.numel())
         self.num_graphs = int(num_graphs)
@@ -137,6 +166,50 @@ class GNNGraph:
         self._indices_validated = bool(_validated)
         if not _validated:
             self.plan(False)  # builds the CSR plan and validates 1 <= s,t <= n (convert.jl:47-54)
+
+    @classmethod
+    def _from_plan(cls, plan: "Plan", num_graphs, graph_indicator, x, index_base, idx_dtype, self_loops=False):
+        """A graph that exists as its PLAN (gnnmp_plan_select / gnnmp_plan_concat: the batch of a training step): s and t are
+        materialised from the plan only if somebody asks for them (gnnmp_plan_edge_index)."""
+        g = object.__new__(cls)
+        g.index_base = int(index_base)
+        g._s = g._t = None
+        g._idx_dtype = idx_dtype
+        g.w = None
+        g.num_nodes = int(plan.n_dst)
+        g.num_edges = int(plan.n_edges)
+        g.num_graphs = int(num_graphs)
+        g.graph_indicator = graph_indicator
+        g.x = x
+        g.device = plan.device
+        g._plans = {bool(self_loops): plan}
+        g._cache = {}
+        g._indices_validated = True
+        return g
+
+    def _materialise(self):
+        p = self._plans.get(False) or self._plans.get(True)
+        self._s, self._t = p.edge_index(self._idx_dtype, self.index_base)
+
+    @property
+    def s(self):
+        if self._s is None:
+            self._materialise()
+        return self._s
+
+    @s.setter
+    def s(self, v):
+        self._s = v
+
+    @property
+    def t(self):
+        if self._t is None:
+            self._materialise()
+        return self._t
+
+    @t.setter
+    def t(self, v):
+        self._t = v
 
     # -- plans (cached; the reference rebuilds sparse(s,t,...) on every call, convert.jl:221-237) --
     def plan(self, add_self_loops: bool = False) -> Plan:
@@ -163,7 +236,8 @@ class GNNGraph:
 
     @property
     def idx_bytes(self):
-        return 8 if self.s.dtype == torch.int64 else 4
+        dt = self._s.dtype if self._s is not None else self._idx_dtype
+        return 8 if dt == torch.int64 else 4
 
     def __repr__(self):
         return f"GNNGraph(num_nodes={self.num_nodes}, num_edges={self.num_edges}, num_graphs={self.num_graphs})"

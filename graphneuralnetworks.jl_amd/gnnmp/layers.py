@@ -55,13 +55,17 @@ def dense(x, W, bias=None, sigma=None, x2=None, W2=None):
     code, post = _act_code(sigma)
     out = torch.empty((N, Dout), dtype=torch.float32, device=x.device)
     b = None if bias is None or bias is False else bias.contiguous()
+    pr = L._probe
+    e0 = pr.begin() if pr is not None else None
     L.check(L.load().gnnmp_dense_f32(L.ptr(x), L.ptr(W), D1, W.stride(0), L.ptr(x2), L.ptr(W2), D2, ld2, 0,
                                      L.ptr(b), code, L.ptr(out), N, Dout, L.stream_ptr()))
+    if pr is not None:
+        pr.end("dense", e0)
     return post(out) if post is not None else out
 
 
 def fused_conv(plan, aggr, xj, W_agg, bias=None, sigma=None, xi=None, W_root=None, w=None, scale_src=None, w_slot=None,
-               ss_slot=None, scale_dst=None, return_aggregate=False, w_layout=0):
+               ss_slot=None, scale_dst=None, return_aggregate=False, w_layout=0, out=None):
     """act(W_root * xi + W_agg * A + bias) with A = the plan's aggregation of xj (same arguments as gnnmp_propagate_f32 /
     gnnmp_propagate_slots_f32), in ONE kernel: A stays in LDS (csrc/fused_conv.hip).  Returns None when the shape is outside
     the kernel's envelope (the caller then runs propagate + dense); with return_aggregate the pre-GEMM aggregate comes back
@@ -90,11 +94,18 @@ def fused_conv(plan, aggr, xj, W_agg, bias=None, sigma=None, xi=None, W_root=Non
     k14 = _knob14()
     if k14 < 0 or (k14 == 0 and (D1 > 0 or plan.n_dst * D * 4 < (128 << 20))):
         return None
-    out = torch.empty((plan.n_dst, Dout), dtype=torch.float32, device=xf.device)
+    if out is None:
+        out = torch.empty((plan.n_dst, Dout), dtype=torch.float32, device=xf.device)
+    else:
+        assert out.shape == (plan.n_dst, Dout) and out.dtype == torch.float32 and out.is_contiguous()
     agg = torch.empty((plan.n_dst, D), dtype=torch.float32, device=xf.device) if return_aggregate else None
+    pr = L._probe
+    e0 = pr.begin() if pr is not None else None
     rc = lib.gnnmp_fused_conv_f32(plan.handle, aggr, L.ptr(xf), L.ptr(w), L.ptr(scale_src), L.ptr(w_slot), L.ptr(ss_slot),
                                   L.ptr(scale_dst), D, L.ptr(xi), D1, L.ptr(W_root), 0 if W_root is None else W_root.stride(0),
                                   L.ptr(W_agg), W_agg.stride(0), int(w_layout), L.ptr(b), code, L.ptr(out), Dout, L.ptr(agg), L.stream_ptr())
+    if pr is not None:
+        pr.end("fused_conv", e0)
     if rc == L.EUNSUPPORTED:
         return None
     L.check(rc)
@@ -334,6 +345,7 @@ def gat_conv(l, g: GNNGraph, x, e=None, return_alpha=False, exact_order=False, s
     if p_drop > 0.0:
         # like the reference, the layer function drops whenever l.dropout > 0 (NNlib.dropout has no test mode of its own)
         assert e is None and not (return_alpha or exact_order), "attention dropout: one-pass kernel only (no edge features / alpha output)"
+        _check_drop_width(H, C, "GATConv")
         if seed is None:
             seed = l.next_seed()
         l.last_seed = int(seed)
@@ -361,8 +373,12 @@ def gat_conv(l, g: GNNGraph, x, e=None, return_alpha=False, exact_order=False, s
                                             H, C, L.stream_ptr()))
     else:
         # one pass over the edges: in-register logits + online softmax (csrc/gat_fused.hip)
+        pr = L._probe
+        e0 = pr.begin() if pr is not None else None
         L.check(lib.gnnmp_gat_conv_f32(plan.handle, L.ptr(Wx), None, L.ptr(a_hc), float(l.negative_slope), L.ptr(b),
                                        code if fuse_tail else L.ACT_IDENTITY, L.ptr(out), H, C, L.stream_ptr()))
+        if pr is not None:
+            pr.end("gat_conv", e0)
     if fuse_tail:
         y = post(out) if post is not None else out
     else:
@@ -372,6 +388,16 @@ def gat_conv(l, g: GNNGraph, x, e=None, return_alpha=False, exact_order=False, s
         L.check(lib.gnnmp_head_mean_f32(L.ptr(out), L.ptr(bb), code, L.ptr(y), N, H, C, L.stream_ptr()))
         y = post(y) if post is not None else y
     return (y, alpha) if return_alpha else y
+
+
+def _check_drop_width(H, C, name):
+    """attention dropout lives inside the one-pass kernel, which needs a feature row that fits one wave (gnnmp.h:
+    gnnmp_gat_conv_drop_f32).  The Julia extension falls back to the reference's generic path on wider rows; this host mirror has no
+    generic path, so the combination is refused here with a message instead of a GNNMP_EUNSUPPORTED from the C call."""
+    vec = 4 if C % 4 == 0 else (2 if C % 2 == 0 else 1)
+    if (H * C) // vec > 64:
+        raise ValueError(f"{name}(dropout > 0) with heads * out = {H * C} channels: the feature row does not fit one wave "
+                         f"({(H * C) // vec} lanes of {vec} floats > 64); attention dropout is only available on the one-pass kernel")
 
 
 class GATConv:
@@ -479,20 +505,60 @@ class GNNChain:
 
 
 class ChainJobs:
-    """gnnmp_chain_jobs_t of a batched graph (csrc/graph_chain2.hip): its member graphs packed into wave jobs of <= 64 rows"""
+    """gnnmp_chain_jobs_t of a batched graph (csrc/graph_chain2.hip): its member graphs packed into wave jobs of <= 64 rows.
+    member_stats = (n_rows, largest member, some member empty) when the caller knows them on the host (gnnmp.dataset): the packing then
+    runs ON THE DEVICE (gnnmp_chain_jobs_pack: no copy of the sizes to the host, no synchronisation) and the handle is released
+    stream-ordered; otherwise the host packing of gnnmp_chain_jobs_create."""
 
-    def __init__(self, seg_ptr, G):
+    def __init__(self, seg_ptr, G, member_stats=None):
         import ctypes
         self.handle = ctypes.c_void_p()
-        L.check(L.load().gnnmp_chain_jobs_create(ctypes.byref(self.handle), L.ptr(seg_ptr), G, L.stream_ptr()))
+        self._packed = member_stats is not None
+        self._keep = seg_ptr
+        if self._packed:
+            n_rows, max_graph, has_empty = member_stats
+            L.check(L.load().gnnmp_chain_jobs_pack(ctypes.byref(self.handle), L.ptr(seg_ptr), G, int(n_rows), int(max_graph),
+                                                   1 if has_empty else 0, L.stream_ptr()))
+            self.G, self.N, self.max_graph = G, int(n_rows), int(max_graph)
+            self._info = None
+        else:
+            L.check(L.load().gnnmp_chain_jobs_create(ctypes.byref(self.handle), L.ptr(seg_ptr), G, L.stream_ptr()))
+            self._info = self._read_info()
+
+    def _read_info(self):
+        import ctypes
         info = (ctypes.c_int64 * 5)()
         L.check(L.load().gnnmp_chain_jobs_info(self.handle, info))
-        self.njobs, self.G, self.N, self.max_graph, self.fill = info[0], info[1], info[2], info[3], info[4] / 1000.0
+        self.G, self.N, self.max_graph = info[1], info[2], info[3]
+        return info[0], info[4] / 1000.0
+
+    @property
+    def njobs(self):
+        if self._info is None:
+            self._info = self._read_info()      # (device-packed: synchronises the device)
+        return self._info[0]
+
+    @property
+    def fill(self):
+        if self._info is None:
+            self._info = self._read_info()
+        return self._info[1]
+
+    def export(self):
+        """(tab [njobs][64] int32, hdr [8] int32) as the kernel reads them (tests)"""
+        cap = max(int(self.G), 1)
+        tab = torch.full((cap, 64), -2, dtype=torch.int32, device="cuda")
+        hdr = torch.zeros(8, dtype=torch.int32, device="cuda")
+        L.check(L.load().gnnmp_chain_jobs_export(self.handle, L.ptr(tab), cap, L.ptr(hdr), L.stream_ptr()))
+        return tab, hdr
 
     def __del__(self):
         try:
             if self.handle:
-                L.load().gnnmp_chain_jobs_destroy(self.handle)
+                if self._packed:
+                    L.load().gnnmp_chain_jobs_release(self.handle, L.stream_ptr())
+                else:
+                    L.load().gnnmp_chain_jobs_destroy(self.handle)
                 self.handle = None
         except Exception:
             pass
@@ -518,6 +584,8 @@ def _chain_pattern(layers):
     if any(c.weight1.shape[1] % 4 for c in convs[1:]) or convs[0].weight1.shape[1] > 512:
         return None
     if any(convs[k + 1].weight1.shape[1] != convs[k].weight1.shape[0] for k in range(len(convs) - 1)):
+        return None
+    if any(c.weight1.shape[0] < 8 for c in convs[:-1]):      # a stored hidden layer of 4 columns is outside the kernel's envelope
         return None
     if head.weight.shape[1] != convs[-1].weight1.shape[0]:
         return None
@@ -573,13 +641,13 @@ def graphconv_chain(model, g: GNNGraph, x):
     nout = head.weight.shape[0]
     jobs = g._cache.get("chain_jobs")
     if jobs is None:
-        jobs = ChainJobs(sp, G)      # member graphs packed into wave jobs: a constant of the batch, like its plan
+        jobs = ChainJobs(sp, G, g._cache.get("member_stats"))      # member graphs packed into wave jobs: a constant of the batch, like its plan
         g._cache["chain_jobs"] = jobs
     need = lib.gnnmp_graphconv_chain_scratch_floats(N, nl, dims, nout)
-    scratch = g._cache.get("chain_scratch")
-    if scratch is None or scratch.numel() < need:
+    scratch = getattr(model, "_scratch", None)      # (on the model, grow-only: a training loop meets a new batch object every step)
+    if scratch is None or scratch.numel() < need or scratch.device != x.device:
         scratch = torch.empty(need, dtype=torch.float32, device=x.device)
-        g._cache["chain_scratch"] = scratch
+        model._scratch = scratch
     out = torch.empty((G, nout), dtype=torch.float32, device=x.device)
     xc = x.contiguous()
     if dims[0] != x.shape[1]:                  # (zero-padded feature columns, see above: one strided copy)

@@ -66,6 +66,8 @@ def gatv2_conv(l, g: GNNGraph, x, e=None, seed=None):
     b = l.bias if (fuse and l.bias is not None) else None
     p_drop = float(getattr(l, "dropout", 0.0))
     if p_drop > 0.0:
+        from .layers import _check_drop_width
+        _check_drop_width(H, C, "GATv2Conv")
         if seed is None:
             seed = l.next_seed()
         l.last_seed = int(seed)

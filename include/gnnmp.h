@@ -128,6 +128,50 @@ int gnnmp_plan_export64(const gnnmp_graph_t *plan, int64_t *rowptr, int32_t *col
                         gnnmp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * The plan of a BATCH without a sort (csrc/plan_batch.hip).  MLUtils.batch(gs) (GNNGraphs/src/transform.jl:682-709) offsets the
+ * members' node ids by the nodes before them and concatenates their edge lists member after member, so the batch's dst-sorted stable
+ * CSR is the concatenation of the members' CSRs (rowptr pieces shifted by the slots before them, col by the nodes, edge positions by the
+ * edges; plan-added self loops stay at E_batch + node).  The reference's graph-classification loop makes a new batch EVERY step
+ * (GraphNeuralNetworks/examples/graph_classification_tudataset.jl:70-71 DataLoader(...; shuffle = true, collate = true), :97-104): these
+ * entry points are per-step work — two launches, NO host synchronisation, index arrays from a stream-ordered pool of device blocks — and
+ * the result is bit-identical to gnnmp_plan_create on the batched COO (tests/test_plan_batch.py).
+ *
+ *   gnnmp_plan_concat  members as plan handles, in batch order (what a `batch(gs)` override holds: one cached plan per member graph;
+ *                      all square, all with or all without added self loops).  The member table (48 bytes per member) is built on the
+ *                      host and uploaded with the call.
+ *   gnnmp_plan_select  members as graph ids (ids[k], idx_bytes / index_base like every index array) into ONE resident plan of the whole
+ *                      dataset batched once — `dataset` = the plan of MLUtils.batch(all graphs), node_ptr[n_graphs + 1] (device, int64)
+ *                      its node offsets — in the order of `ids`: the plan of batch(gs[ids]), which is also what getobs / getgraph of a
+ *                      batched graph returns for ascending ids (GNNGraphs/src/gnngraph.jl:311, transform.jl:827-876).  Nothing crosses
+ *                      PCIe per step.  The dataset's edge list must be member-major (what batch produces).  n_rows / n_slots: the
+ *                      batch's node count and its E' (edges + added self loops if the dataset plan has them), which the caller knows
+ *                      on the host (every GNNGraph carries num_nodes / num_edges as host integers); they size the allocation.  If they
+ *                      disagree with the selected members the plan comes out EMPTY (rowptr = 0) and gnnmp_plan_status reports it.
+ *   Optional outputs (device, NULL to skip): seg_ptr_out int64[k + 1] the batch's node offsets (the seg_ptr of gnnmp_graphconv_chain_f32
+ *   / gnnmp_segment_pool_ptr_f32), node_map_out int32[n_rows] the dataset row of every batch row (0-based: the `nmap` of getgraph; feed
+ *   it to gnnmp_gather_f32 to collate node features), graph_indicator_out [n_rows] in the index type of `ids` (concat: idx_bytes /
+ *   index_base arguments).
+ * Rows longer than the new plan's long-row threshold (hubs) need the chunk tables: only then the call synchronises the stream.
+ * gnnmp_plan_info's max in-degree of a selected plan is the dataset's (an upper bound).
+ *
+ *   gnnmp_plan_release  stream-ordered destroy: the plan's block returns to the pool behind the work enqueued on `stream` so far; the next
+ *                      pooled object created on ANY stream waits for that work on the device (no host synchronisation).  The caller
+ *                      promises that no later work uses the plan.  gnnmp_plan_destroy works on these plans too (the block is then handed
+ *                      out again only after a device-wide synchronisation).
+ *   gnnmp_plan_edge_index  s, t of the plan's graph in original edge order (plan-added self loops skipped): the batch's COO for callers
+ *                      that want it (out_src / out_dst: n_edges entries of idx_bytes each).
+ * ---------------------------------------------------------------------------------------------- */
+int gnnmp_plan_concat(gnnmp_graph_t **out, const gnnmp_graph_t *const *members, int64_t k, int64_t *seg_ptr_out,
+                      void *graph_indicator_out, int idx_bytes, int index_base, gnnmp_stream_t stream);
+int gnnmp_plan_select(gnnmp_graph_t **out, const gnnmp_graph_t *dataset, const int64_t *node_ptr, int64_t n_graphs, const void *ids,
+                      int idx_bytes, int index_base, int64_t k, int64_t n_rows, int64_t n_slots, int64_t *seg_ptr_out,
+                      int32_t *node_map_out, void *graph_indicator_out, gnnmp_stream_t stream);
+int gnnmp_plan_release(gnnmp_graph_t *plan, gnnmp_stream_t stream);
+int gnnmp_plan_status(const gnnmp_graph_t *plan, gnnmp_stream_t stream);   /* synchronises `stream`; 0 = the member table matched */
+int gnnmp_plan_edge_index(const gnnmp_graph_t *plan, int idx_bytes, int index_base, void *out_src, void *out_dst,
+                          gnnmp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Index ops (bit-exact)
  * ---------------------------------------------------------------------------------------------- */
 /* add_self_loops(g::GNNGraph{COO}) — GNNGraphs/src/transform.jl:12-28.
@@ -563,7 +607,8 @@ int64_t gnnmp_graphconv_chain_scratch_floats(int64_t N, int n_layers, const int6
  * a 4 KB LDS stage the two waves share, the two 64-column halves of layer 2 go to different workgroups; each row's W_head * h2 — nout
  * floats per half — is the only intermediate written, and a second small launch pools it per member graph in node order: no
  * floating-point atomic, no memset, run-to-run identical).  The handle owns that intermediate and the list of jobs set aside for the
- * exact fp32 path (non-finite operands), so — like a plan's workspace — it serves ONE stream at a time.
+ * exact fp32 path (non-finite operands), so — like a plan's workspace — it serves ONE stream at a time (and one host thread at a time:
+ * the chain call picks the parity of its set-aside counters from a per-handle call count).
  * Built once per batched graph from the DEVICE seg_ptr; synchronises `stream` (graph prep).  A batch with a member graph of more than
  * 64 nodes, or without any, yields a handle without jobs: the chain then runs on the general kernel.  info[0] = jobs, [1] = member
  * graphs, [2] = rows, [3] = largest member graph, [4] = per-mille of the MFMA tiles' rows that are real rows. */
@@ -571,6 +616,21 @@ typedef struct gnnmp_chain_jobs gnnmp_chain_jobs_t;
 int gnnmp_chain_jobs_create(gnnmp_chain_jobs_t **out, const int64_t *seg_ptr, int64_t G, gnnmp_stream_t stream);
 int gnnmp_chain_jobs_destroy(gnnmp_chain_jobs_t *jobs);
 int gnnmp_chain_jobs_info(const gnnmp_chain_jobs_t *jobs, int64_t *info);
+/* The same packing ON THE DEVICE (csrc/chain_pack.h: best fit decreasing on the histogram of the jobs' free room, one thread block): one
+ * launch, no copy of the sizes to the host, no synchronisation — the per-step form for a loop that makes a new batch every step
+ * (examples/graph_classification_tudataset.jl:97-104).  The caller passes what it holds on the host (num_nodes of every member graph is a
+ * host integer, GNNGraphs/src/gnngraph.jl:108-117): n_rows = the batch's nodes, max_graph = its largest member, has_empty = some member has
+ * no node.  max_graph > 64 or has_empty gives a handle without jobs, as above.  If the device finds sizes that contradict the announcement
+ * the handle is poisoned: the chain writes NaN logits and gnnmp_chain_jobs_info fails.  gnnmp_chain_jobs_info on such a handle
+ * synchronises the device.  A jobs handle serves ONE stream at a time and one host thread at a time (its z rows and set-aside list are
+ * scratch of the running call).
+ *   gnnmp_chain_jobs_release  stream-ordered destroy (see gnnmp_plan_release)
+ *   gnnmp_chain_jobs_export   the job table as the kernel reads it: tab_out[cap_rows][64] int32 (global row of each slot, -1 = empty),
+ *                             hdr_out[8] int32 ([0] jobs [1] 32-row tiles [2] poisoned [3] largest member seen [4] empty members): tests */
+int gnnmp_chain_jobs_pack(gnnmp_chain_jobs_t **out, const int64_t *seg_ptr, int64_t G, int64_t n_rows, int64_t max_graph, int has_empty,
+                          gnnmp_stream_t stream);
+int gnnmp_chain_jobs_release(gnnmp_chain_jobs_t *jobs, gnnmp_stream_t stream);
+int gnnmp_chain_jobs_export(const gnnmp_chain_jobs_t *jobs, int32_t *tab_out, int64_t cap_rows, int32_t *hdr_out, gnnmp_stream_t stream);
 /* jobs: NULL or the handle of THIS batch (gnnmp_chain_jobs_create on the same seg_ptr) */
 int gnnmp_graphconv_chain_f32(gnnmp_graph_t *plan, const gnnmp_chain_jobs_t *jobs, const int64_t *seg_ptr, int64_t G, const float *x, int n_layers,
                               const int64_t *dims, const float *const *W_root, const float *const *W_agg,

@@ -164,6 +164,47 @@ def test_irregular_batches(gm, oracle, case, seed):
     close(y.cpu().numpy(), yl.cpu().numpy(), f"fused vs layers {case}", k=2.0)
 
 
+def test_narrow_hidden_layer_is_refused_and_still_right(gm, oracle):
+    """a STORED hidden layer of 4 columns is outside the chain kernel's envelope (its unconditional stores re-store a piece at
+    column 4 h, i.e. into the next row when the row is 4 wide): the C entry refuses it (GNNMP_EUNSUPPORTED), the host mirror does not
+    offer it, and GNNChain still gives the oracle's logits through the layer path"""
+    import ctypes
+    import torch
+    from gnnmp import _lib as L, layers
+    rng = np.random.default_rng(77)
+    members = random_members(150, rng)
+    xs = [rng.standard_normal((n, 16), dtype=np.float32) for _, _, n in members]
+    g = gm.batch_arrays(members, xs)
+    model = build(gm, (16, 4, 8), 2, "+", "mean", seed=41)
+    assert layers._chain_pattern(model.layers) is None
+    y = model(g, g.x)
+    ref = oracle_chain(oracle, members, xs, model.layers[:-2], "mean", model.layers[-1])
+    close(y.cpu().numpy(), ref, "(16, 4, 8) through the layer path")
+    # the C entry itself
+    lib = L.load()
+    convs, head = model.layers[:2], model.layers[-1]
+    i64, vp = ctypes.c_int64, ctypes.c_void_p
+    dims = (i64 * 3)(16, 4, 8)
+    wr = (vp * 2)(*[c.weight1.data_ptr() for c in convs])
+    wa = (vp * 2)(*[c.weight2.data_ptr() for c in convs])
+    bs = (vp * 2)(*[c.bias.data_ptr() for c in convs])
+    act = (ctypes.c_int * 2)(L.ACT_RELU, L.ACT_RELU)
+    N, G = g.num_nodes, g.num_graphs
+    sp = torch.empty(G + 1, dtype=torch.int64, device="cuda")
+    L.check(lib.gnnmp_segment_bounds(L.ptr(g.graph_indicator), 8, 1, N, G, L.ptr(sp), L.stream_ptr()))
+    need = lib.gnnmp_graphconv_chain_scratch_floats(N, 2, dims, 2)
+    scratch = torch.empty(max(need, 16), dtype=torch.float32, device="cuda")
+    out = torch.empty((G, 2), dtype=torch.float32, device="cuda")
+    rc = lib.gnnmp_graphconv_chain_f32(g.plan(False).handle, None, L.ptr(sp), G, L.ptr(g.x), 2, dims, wr, wa, bs, act, 0, L.SUM, L.MEAN,
+                                       L.ptr(head.weight), L.ptr(head.bias), 2, L.ptr(scratch), L.ptr(out), L.stream_ptr())
+    assert rc == L.EUNSUPPORTED
+    # a LAST layer of 4 columns is fine (it is never stored): (16, 8, 4)
+    model2 = build(gm, (16, 8, 4), 2, "+", "mean", seed=43)
+    y2, yl2 = run_both(gm, model2, g)
+    ref2 = oracle_chain(oracle, members, xs, model2.layers[:-2], "mean", model2.layers[-1])
+    close(y2.cpu().numpy(), ref2, "(16, 8, 4) fused")
+
+
 @pytest.mark.parametrize("aggr,pool", [("+", "mean"), ("mean", "+")])
 @pytest.mark.parametrize("seed", [0, 1, 2])
 def test_wave_job_kernel_on_irregular_batches(gm, oracle, aggr, pool, seed):
