@@ -548,36 +548,75 @@ struct PackArgs {
     int njobs_cap;        // rows of tab that exist
     int32_t *tab;         // [njobs_cap][64]
     int32_t *sorted;      // [G] scratch: member graphs by decreasing size (ties by id)
-    int32_t *hdr;         // [8] out: jobs, tiles, poison, largest graph, empty graphs
+    int32_t *hdr;         // out: [0] jobs, [1] tiles, [2] poison, [3] largest graph, [4] empty graphs, [5] graphs packed; [16..] phase stamps
     int32_t *bad;         // [3] the set-aside counters of the chain kernel (zeroed here)
+    PackState *gst;       // the records and class lists for chain_expand_kernel (global copy of the packing block's LDS state)
 };
+
+// chain_pack.h's table accessor on the device: entry i (0..63) lives in lane i of one VGPR, entry 64 in a second (uniform) one; the wave
+// runs pack_records_t in lockstep, every lane holding the same scalars
+struct PackLaneArr {
+    int32_t lo, hi;
+    int lane;
+    __device__ __forceinline__ int32_t get(int i) const {
+        const int u = __builtin_amdgcn_readfirstlane(i);
+        return u == PACK_ROWS ? hi : __builtin_amdgcn_readlane(lo, u);
+    }
+    __device__ __forceinline__ void set(int i, int32_t x) {
+        const int u = __builtin_amdgcn_readfirstlane(i);
+        if (u == PACK_ROWS) hi = x; else lo = lane == u ? x : lo;
+    }
+    __device__ __forceinline__ bool writer() const { return lane == 0; }
+};
+
+constexpr int PK_PER = 16;     // graphs per lane whose sizes stay in registers between the two passes of the counting sort: 16 waves x 64
+                               // lanes x 16 = 16 384 member graphs; a larger batch reads its sizes twice
 
 __global__ void __launch_bounds__(PK_THREADS) chain_pack_kernel(const PackArgs a) {
     __shared__ PackState st;
-    __shared__ int32_t cnt[PACK_ROWS + 2], start[PACK_ROWS + 2], work[3 * (PACK_ROWS + 1)];
+    __shared__ int32_t cnt[PACK_ROWS + 2], start[PACK_ROWS + 2], work[PACK_ROWS + 2];
     __shared__ int32_t wcnt[PK_WAVES][PACK_ROWS + 1];       // per wave: graphs of each size in its range, then the running output position
     __shared__ int32_t flags[2];                             // largest size seen, graphs without a node
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // phase stamps (100 MHz wall clock) in hdr[16..]: tools/pack_phases.py
+    long long *stamp = reinterpret_cast<long long *>(a.hdr + 16);
+#define PK_STAMP(i) do { if (tid == 0) stamp[i] = (long long)wall_clock64(); } while (0)
+    PK_STAMP(0);
     for (int i = tid; i < PK_WAVES * (PACK_ROWS + 1); i += PK_THREADS) (&wcnt[0][0])[i] = 0;
     if (tid < 2) flags[tid] = 0;
+    if (tid < 3) a.bad[tid] = 0;
     __syncthreads();
-    // every wave owns a contiguous range of member graphs (whole steps of 64)
+    // every wave owns a contiguous range of member graphs (whole steps of 64), PK_PER steps at a time: all loads of a chunk are issued
+    // before the first is used (a lone block is bound by memory round trips, not by bytes)
     const int per = ((a.G + PK_WAVES - 1) / PK_WAVES + 63) & ~63;
     const int g0 = wave * per, g1 = min(a.G, g0 + per);
-    auto size_of = [&](int g) -> int {
-        if (g >= g1) return 0;
-        const int64_t d = a.seg_ptr[g + 1] - a.seg_ptr[g];
-        return d > 0x7fffffff ? 0x7fffffff : (int)d;
+    const int nchunks = (per / 64 + PK_PER - 1) / PK_PER;
+    int32_t R0[PK_PER], SZ[PK_PER];      // first row and size of this lane's graphs of the chunk (SZ = -1: no graph)
+    auto load_chunk = [&](int chunk) {
+#pragma unroll
+        for (int it = 0; it < PK_PER; ++it) {
+            const int g = g0 + (chunk * PK_PER + it) * 64 + lane;
+            const bool v = g < g1;
+            const int64_t b0 = v ? a.seg_ptr[g] : 0, b1 = v ? a.seg_ptr[g + 1] : 0;
+            const int64_t d = b1 - b0;
+            R0[it] = (int32_t)b0;
+            SZ[it] = !v ? -1 : (d < 0 || d > 0x7ffffff0 ? 0x7ffffff0 : (int32_t)d);
+        }
     };
     int mx = 0, empties = 0;
-    for (int g = g0 + lane; g - lane < g1; g += 64) {
-        const int sz = size_of(g);
-        if (g < g1) { mx = max(mx, sz); empties += sz == 0; }
-        if (sz >= 1 && sz <= PACK_ROWS) atomicAdd(&wcnt[wave][sz], 1);
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        load_chunk(chunk);
+#pragma unroll
+        for (int it = 0; it < PK_PER; ++it) {
+            const int sz = SZ[it];
+            if (sz >= 0) { mx = max(mx, sz); empties += sz == 0; }
+            if (sz >= 1 && sz <= PACK_ROWS) atomicAdd(&wcnt[wave][sz], 1);
+        }
     }
     if (mx > 0) atomicMax(&flags[0], mx);
     if (empties) atomicAdd(&flags[1], empties);
     __syncthreads();
+    PK_STAMP(1);
     if (tid >= 1 && tid <= PACK_ROWS) {
         int c = 0;
         for (int w = 0; w < PK_WAVES; ++w) c += wcnt[w][tid];
@@ -595,40 +634,46 @@ __global__ void __launch_bounds__(PK_THREADS) chain_pack_kernel(const PackArgs a
         for (int w = 0; w < PK_WAVES; ++w) { const int c = wcnt[w][tid]; wcnt[w][tid] = pos; pos += c; }
     }
     __syncthreads();
-    // stable counting sort: position = first position of (wave, size) + rank among the equal sizes of this step's lower lanes
+    PK_STAMP(2);
+    // stable counting sort: position = first position of (wave, size) + rank among the equal sizes of this step's lower lanes.  What is
+    // sorted is the graph's FIRST ROW (its size is the record's): nothing else of a graph is needed to place it.
     {
         volatile int32_t *wpos = wcnt[wave];
-        for (int g = g0 + lane; g - lane < g1; g += 64) {
-            const int sz = size_of(g);
-            const bool ok = sz >= 1 && sz <= PACK_ROWS;
-            unsigned long long eq = __builtin_amdgcn_ballot_w64(ok);
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            if (nchunks > 1) load_chunk(chunk);
 #pragma unroll
-            for (int b = 0; b < 7; ++b) {
-                const unsigned long long m = __builtin_amdgcn_ballot_w64((sz >> b) & 1);
-                eq &= ((sz >> b) & 1) ? m : ~m;
+            for (int it = 0; it < PK_PER; ++it) {
+                if ((chunk * PK_PER + it) * 64 >= per) break;          // (uniform)
+                const int sz = SZ[it];
+                const bool ok = sz >= 1 && sz <= PACK_ROWS;
+                unsigned long long eq = __builtin_amdgcn_ballot_w64(ok);
+#pragma unroll
+                for (int b = 0; b < 7; ++b) {
+                    const unsigned long long m = __builtin_amdgcn_ballot_w64((sz >> b) & 1);
+                    eq &= ((sz >> b) & 1) ? m : ~m;
+                }
+                if (ok) {
+                    const int rank = __popcll(eq & ((1ull << lane) - 1ull));
+                    const int base = wpos[sz];
+                    a.sorted[base + rank] = R0[it];
+                    if ((eq >> lane) == 1ull) wpos[sz] = base + __popcll(eq);      // the highest lane of the group moves the cursor
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
-            if (ok) {
-                const int rank = __popcll(eq & ((1ull << lane) - 1ull));
-                const int base = wpos[sz];
-                a.sorted[base + rank] = g;
-                if ((eq >> lane) == 1ull) wpos[sz] = base + __popcll(eq);      // the highest lane of the group moves the cursor
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
     }
-    // the records (one thread) while the others clear the job table
-    if (tid == 0) {
-        pack_records(cnt, start, &st, work);
-    } else {
-        const int4 fill = make_int4(-1, -1, -1, -1);
-        int4 *t4 = reinterpret_cast<int4 *>(a.tab);
-        for (int64_t i = tid - 1; i < (int64_t)a.njobs_cap * 16; i += PK_THREADS - 1) t4[i] = fill;
-        if (tid <= 3) a.bad[tid - 1] = 0;
+    __syncthreads();
+    PK_STAMP(3);
+    if (wave == 0) {          // (the job table was set to -1 by a memset node before this launch)
+        PackLaneArr c = {cnt[lane], cnt[PACK_ROWS], lane}, s0 = {start[lane], start[PACK_ROWS], lane};
+        PackLaneArr room = {0, 0, lane}, exits = {0, 0, lane}, entries = {0, 0, lane};
+        pack_records_t(c, s0, room, exits, entries, &st);
     }
     __threadfence();
     __syncthreads();
+    PK_STAMP(4);
     if (tid <= PACK_ROWS) pack_class_count(&st, tid, &work[tid]);
     __syncthreads();
     if (tid == 0) {
@@ -638,25 +683,62 @@ __global__ void __launch_bounds__(PK_THREADS) chain_pack_kernel(const PackArgs a
     __syncthreads();
     if (tid <= PACK_ROWS) pack_class_fill(&st, tid);
     __syncthreads();
+    PK_STAMP(5);
     const int nitems = start[0];
     const bool poison = flags[0] > PACK_ROWS || flags[1] > 0 || st.njobs > a.njobs_cap;
-    if (!poison) {
-        for (int p = tid; p < nitems; p += PK_THREADS) {
-            const int g = a.sorted[p];
-            int32_t job, slot;
-            pack_place(&st, p, &job, &slot);
-            const int64_t r0 = a.seg_ptr[g];
-            const int sz = (int)(a.seg_ptr[g + 1] - r0);
-            int32_t *row = a.tab + (int64_t)job * PACK_ROWS + slot;
-            for (int i = 0; i < sz; ++i) row[i] = (int32_t)(r0 + i);
-        }
+    {
+        // the records and the class lists go to memory for chain_expand_kernel (many blocks write the job table: one block's store
+        // instructions alone took 58 us)
+        const int nrec = st.nrec;
+        int32_t *src = reinterpret_cast<int32_t *>(&st.rec[0]), *dst = reinterpret_cast<int32_t *>(&a.gst->rec[0]);
+        for (int i = tid; i < nrec * (int)(sizeof(PackRec) / 4); i += PK_THREADS) dst[i] = src[i];
+        for (int i = tid; i < nrec; i += PK_THREADS) a.gst->cls_list[i] = st.cls_list[i];
+        if (tid < PACK_ROWS + 2) a.gst->cls_start[tid] = st.cls_start[tid];
+        if (tid == 0) { a.gst->nrec = nrec; a.gst->njobs = st.njobs; a.gst->tiles = st.tiles; }
     }
+    __syncthreads();
+    PK_STAMP(6);
+#undef PK_STAMP
     if (tid == 0) {
         a.hdr[0] = poison ? 0 : st.njobs;
         a.hdr[1] = st.tiles;
         a.hdr[2] = poison ? 1 : 0;
         a.hdr[3] = flags[0];
         a.hdr[4] = flags[1];
+        a.hdr[5] = nitems;
+    }
+}
+
+// The job table itself: a lane per packed graph finds (job, first slot) from the records (chain_pack.h: pack_place), then the WAVE writes
+// each graph's rows with one store (lane i = row i of the graph).  Many blocks: the table is ~250 000 rows.
+constexpr int PX_THREADS = 256;
+__global__ void __launch_bounds__(PX_THREADS) chain_expand_kernel(const PackArgs a) {
+    __shared__ PackState st;
+    if (a.hdr[2] != 0) return;             // poisoned: nothing to place
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nrec = a.gst->nrec;
+    {
+        const int32_t *src = reinterpret_cast<const int32_t *>(&a.gst->rec[0]);
+        int32_t *dst = reinterpret_cast<int32_t *>(&st.rec[0]);
+        for (int i = tid; i < nrec * (int)(sizeof(PackRec) / 4); i += PX_THREADS) dst[i] = src[i];
+        for (int i = tid; i < nrec; i += PX_THREADS) st.cls_list[i] = a.gst->cls_list[i];
+        if (tid < PACK_ROWS + 2) st.cls_start[tid] = a.gst->cls_start[tid];
+        if (tid == 0) st.nrec = nrec;
+    }
+    __syncthreads();
+    const int nitems = a.hdr[5];
+    const int ngroups = (nitems + 63) / 64;
+    for (int gq = blockIdx.x * (PX_THREADS / 64) + wave; gq < ngroups; gq += gridDim.x * (PX_THREADS / 64)) {
+        const int p = gq * 64 + lane;
+        int32_t job = 0, slot = 0, sz = 0;
+        const int32_t r0 = p < nitems ? a.sorted[p] : 0;
+        if (p < nitems) pack_place(&st, p, &job, &slot, &sz);
+        const int dst = job * PACK_ROWS + slot;
+        const int n_here = min(64, nitems - gq * 64);
+        for (int i = 0; i < n_here; ++i) {
+            const int d = __builtin_amdgcn_readlane(dst, i), r = __builtin_amdgcn_readlane(r0, i), n = __builtin_amdgcn_readlane(sz, i);
+            if (lane < n) a.tab[(int64_t)d + lane] = r + lane;
+        }
     }
 }
 }  // namespace gnnmp
@@ -798,7 +880,8 @@ extern "C" int gnnmp_chain_jobs_pack(gnnmp_chain_jobs_t **out, const int64_t *se
     const size_t off_bad = (b_tab + 255) & ~(size_t)255;
     const size_t off_hdr = (off_bad + sizeof(int32_t) * (size_t)(3 + 4 * cap) + 255) & ~(size_t)255;
     const size_t off_sorted = off_hdr + 256;
-    const size_t off_z = (off_sorted + sizeof(int32_t) * (size_t)G + 255) & ~(size_t)255;
+    const size_t off_pst = (off_sorted + sizeof(int32_t) * (size_t)G + 255) & ~(size_t)255;
+    const size_t off_z = (off_pst + sizeof(PackState) + 255) & ~(size_t)255;
     const size_t total = off_z + sizeof(float) * (size_t)2 * (size_t)n_rows * 8;
     if (!pool_take(&J->block, &J->block_bytes, total, stream)) {
         delete J;
@@ -819,8 +902,17 @@ extern "C" int gnnmp_chain_jobs_pack(gnnmp_chain_jobs_t **out, const int64_t *se
     a.sorted = reinterpret_cast<int32_t *>(base + off_sorted);
     a.hdr = J->hdr;
     a.bad = J->bad;
-    chain_pack_kernel<<<1, PK_THREADS, 0, stream>>>(a);
-    hipError_t e = hipGetLastError();
+    a.gst = reinterpret_cast<PackState *>(base + off_pst);
+    hipError_t e = hipMemsetAsync(J->tab, 0xff, b_tab, stream);        // every slot empty (-1): a full-chip fill, not one block's stores
+    if (e == hipSuccess) {
+        chain_pack_kernel<<<1, PK_THREADS, 0, stream>>>(a);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) {
+        const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(128, (G + 255) / 256));
+        chain_expand_kernel<<<blocks, PX_THREADS, 0, stream>>>(a);
+        e = hipGetLastError();
+    }
     if (e != hipSuccess) {
         pool_park(J->block, J->block_bytes, stream, true);
         delete J;
@@ -841,9 +933,9 @@ extern "C" int gnnmp_chain_jobs_export(const gnnmp_chain_jobs_t *J, int32_t *tab
         GNNMP_HIP(hipMemcpyAsync(tab_out, J->tab, sizeof(int32_t) * PACK_ROWS * (size_t)rows, hipMemcpyDeviceToDevice, stream));
     if (hdr_out) {
         if (J->hdr) {
-            GNNMP_HIP(hipMemcpyAsync(hdr_out, J->hdr, sizeof(int32_t) * 8, hipMemcpyDeviceToDevice, stream));
+            GNNMP_HIP(hipMemcpyAsync(hdr_out, J->hdr, sizeof(int32_t) * 32, hipMemcpyDeviceToDevice, stream));
         } else {
-            const int32_t h[8] = {J->njobs, 0, 0, (int32_t)J->max_graph, J->has_empty, 0, 0, 0};
+            const int32_t h[32] = {J->njobs, 0, 0, (int32_t)J->max_graph, J->has_empty};
             GNNMP_HIP(hipMemcpyAsync(hdr_out, h, sizeof(h), hipMemcpyHostToDevice, stream));
             GNNMP_HIP(hipStreamSynchronize(stream));
         }

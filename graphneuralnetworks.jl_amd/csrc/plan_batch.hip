@@ -40,9 +40,12 @@ struct BatchTab {             // device arrays inside the plan's block
                               //     bit 1: totals differ) — every index array is then left empty (rowptr = 0)
 };
 
-constexpr int SEL_THREADS = 1024, SEL_PER = 4;     // members per thread and round of the table kernel
+constexpr int SEL_THREADS = 256;
 
-// ---- the member table of gnnmp_plan_select: ONE block, a member per thread, SEL_PER members per thread in flight -------------------
+// ---- the member table of gnnmp_plan_select.  A member per thread over MANY blocks: the three dependent loads of a member (id -> node
+// offsets -> slot offsets) touch a different cache line each — one block alone spends 79 us on the 25 000 line requests of 8 192 members
+// (measured), the whole chip a few.  Sizes go to row_off / slot_off in place; the block that finishes LAST (a ticket in status[1]) turns
+// them into offsets with one in-place exclusive scan (integer sums: the same bits whichever block it is) -----------------------------------
 __global__ void __launch_bounds__(SEL_THREADS) select_table_kernel(const uint32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
                                                                    const int32_t *__restrict__ eid, int self_loops, int64_t src_edges,
                                                                    const int64_t *__restrict__ node_ptr, int64_t n_graphs,
@@ -50,80 +53,89 @@ __global__ void __launch_bounds__(SEL_THREADS) select_table_kernel(const uint32_
                                                                    int64_t n_rows, int64_t n_slots, BatchTab tab, int64_t *seg_ptr_out) {
     __shared__ int64_t wave_rows[SEL_THREADS / 64];
     __shared__ int64_t wave_slots[SEL_THREADS / 64];
+    __shared__ int is_last;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int64_t run_rows = 0, run_slots = 0;      // totals of the members before this round (uniform)
-    int bad = 0;
-    for (int64_t m0 = 0; m0 < k; m0 += (int64_t)SEL_THREADS * SEL_PER) {
-        // member (round r, thread t) = m0 + r * SEL_THREADS + t: three dependent loads per member, SEL_PER members in flight
-        int64_t nb[SEL_PER], ne[SEL_PER];
-        uint32_t sb[SEL_PER], se[SEL_PER];
-#pragma unroll
-        for (int r = 0; r < SEL_PER; ++r) {
-            const int64_t m = m0 + (int64_t)r * SEL_THREADS + tid;
-            int64_t g = m < k ? load_index(ids, m, idx_bytes, base) : 0;
-            if (g < 0 || g >= n_graphs) { bad |= (m < k); g = 0; }
-            nb[r] = node_ptr[g];
-            ne[r] = m < k ? node_ptr[g + 1] : nb[r];
-        }
-#pragma unroll
-        for (int r = 0; r < SEL_PER; ++r) {
-            sb[r] = rowptr[nb[r]];
-            se[r] = rowptr[ne[r]];
-        }
-#pragma unroll
-        for (int r = 0; r < SEL_PER; ++r) {
-            const int64_t m = m0 + (int64_t)r * SEL_THREADS + tid;
-            const int64_t rows = ne[r] - nb[r], slots = (int64_t)se[r] - (int64_t)sb[r];
-            // block-wide exclusive scan of (rows, slots) in member order
-            int64_t ir = rows, is = slots;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int64_t ur = __shfl_up(ir, o, 64), us = __shfl_up(is, o, 64);
-                if (lane >= o) { ir += ur; is += us; }
-            }
-            __syncthreads();                   // (the previous round's readers of wave_* are done)
-            if (lane == 63) { wave_rows[wave] = ir; wave_slots[wave] = is; }
-            __syncthreads();
-            int64_t pre_r = 0, pre_s = 0, tot_r = 0, tot_s = 0;
-#pragma unroll
-            for (int w = 0; w < SEL_THREADS / 64; ++w) {
-                const int64_t wr = wave_rows[w], ws = wave_slots[w];
-                if (w < wave) { pre_r += wr; pre_s += ws; }
-                tot_r += wr; tot_s += ws;
-            }
-            if (m < k) {
-                const int64_t ro = run_rows + pre_r + ir - rows, so = run_slots + pre_s + is - slots;
-                tab.row_off[m] = ro;
-                tab.slot_off[m] = (uint32_t)so;
-                if (seg_ptr_out) seg_ptr_out[m] = ro;
-                MemberDesc d;
-                d.rowptr = rowptr + nb[r];
-                d.col = col + sb[r];
-                d.eid = eid + sb[r];
-                d.slot_base = sb[r];
-                d.node_base = (int32_t)nb[r];
-                d.edge_base = sb[r] - (self_loops ? (uint32_t)nb[r] : 0u);   // the dataset's edges are member-major like its rows
-                d.src_edges = (uint32_t)src_edges;
-                tab.desc[m] = d;
-            }
-            run_rows += tot_r;
-            run_slots += tot_s;
+    {
+        const int64_t m = (int64_t)blockIdx.x * SEL_THREADS + tid;
+        if (m < k) {
+            int64_t g = load_index(ids, m, idx_bytes, base);
+            if (g < 0 || g >= n_graphs) { atomicOr(tab.status, 1); g = 0; }
+            const int64_t nb = node_ptr[g], ne = node_ptr[g + 1];
+            const uint32_t sb = rowptr[nb], se = rowptr[ne];
+            tab.row_off[m] = ne - nb;                  // sizes for now
+            tab.slot_off[m] = se - sb;
+            MemberDesc d;
+            d.rowptr = rowptr + nb;
+            d.col = col + sb;
+            d.eid = eid + sb;
+            d.slot_base = sb;
+            d.node_base = (int32_t)nb;
+            d.edge_base = sb - (self_loops ? (uint32_t)nb : 0u);   // the dataset's edges are member-major like its rows
+            d.src_edges = (uint32_t)src_edges;
+            tab.desc[m] = d;
         }
     }
-    // (every thread holds the same totals)
-    const int any_bad = __syncthreads_or(bad);
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) is_last = atomicAdd(tab.status + 1, 1) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    // the last block: rounds of SEL_THREADS x 8 members, thread t owns 8 CONSECUTIVE ones (their loads in flight together: the round trips
+    // of a sequential walk were 20 us of this kernel), one block-wide scan of the threads' sums per round
+    constexpr int PER = 8;
+    int64_t tot_r = 0, tot_s = 0;          // members before this round (uniform)
+    for (int64_t q0 = 0; q0 < k; q0 += (int64_t)SEL_THREADS * PER) {
+        const int64_t mt = q0 + (int64_t)tid * PER;
+        int64_t rr[PER];
+        uint32_t ss[PER];
+#pragma unroll
+        for (int r = 0; r < PER; ++r) {
+            const bool v = mt + r < k;
+            rr[r] = v ? tab.row_off[mt + r] : 0;
+            ss[r] = v ? tab.slot_off[mt + r] : 0u;
+        }
+        int64_t trow = 0, tslot = 0;
+#pragma unroll
+        for (int r = 0; r < PER; ++r) { trow += rr[r]; tslot += ss[r]; }
+        int64_t ir = trow, is = tslot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int64_t ur = __shfl_up(ir, o, 64), us = __shfl_up(is, o, 64);
+            if (lane >= o) { ir += ur; is += us; }
+        }
+        __syncthreads();
+        if (lane == 63) { wave_rows[wave] = ir; wave_slots[wave] = is; }
+        __syncthreads();
+        int64_t run_r = tot_r + ir - trow, run_s = tot_s + is - tslot;
+#pragma unroll
+        for (int w = 0; w < SEL_THREADS / 64; ++w) {
+            const int64_t wr = wave_rows[w], ws = wave_slots[w];
+            if (w < wave) { run_r += wr; run_s += ws; }
+            tot_r += wr; tot_s += ws;
+        }
+#pragma unroll
+        for (int r = 0; r < PER; ++r) {
+            if (mt + r < k) {
+                tab.row_off[mt + r] = run_r;
+                tab.slot_off[mt + r] = (uint32_t)run_s;
+                if (seg_ptr_out) seg_ptr_out[mt + r] = run_r;
+            }
+            run_r += rr[r];
+            run_s += ss[r];
+        }
+    }
     if (tid == 0) {
-        tab.row_off[k] = run_rows;
-        tab.slot_off[k] = (uint32_t)run_slots;
-        if (seg_ptr_out) seg_ptr_out[k] = run_rows;
-        tab.status[0] = (any_bad ? 1 : 0) | ((run_rows != n_rows || run_slots != n_slots) ? 2 : 0);
+        tab.row_off[k] = tot_r;
+        tab.slot_off[k] = (uint32_t)tot_s;
+        if (seg_ptr_out) seg_ptr_out[k] = tot_r;
+        if (tot_r != n_rows || tot_s != n_slots) atomicOr(tab.status, 2);
     }
 }
 
-// largest m in [0, k) with off[m] <= x  (off[k] > x)
+// largest m in [lo, hi) with off[m] <= x  (off[hi] > x)
 template <class T>
-__device__ __forceinline__ int member_of(const T *__restrict__ off, int k, T x) {
-    int lo = 0, hi = k;
+__device__ __forceinline__ int member_of(const T *__restrict__ off, int lo, int hi, T x) {
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
         if (off[mid] <= x) lo = mid; else hi = mid;
@@ -137,12 +149,27 @@ __global__ void __launch_bounds__(256) batch_fill_kernel(BatchTab tab, int k, in
                                                          int32_t *__restrict__ eid, int32_t *__restrict__ node_map,
                                                          void *__restrict__ indicator, int ind_bytes, int ind_base) {
     const bool ok = tab.status[0] == 0;
-    if (blockIdx.x < row_blocks) {
+    // the members this block's 256 consecutive rows / slots can belong to: two 13-step searches per BLOCK (first and last item), then
+    // every thread searches only that handful of members (a 20..40-node member graph holds ~30 rows / ~120 slots)
+    __shared__ int span[2];
+    const bool rows = blockIdx.x < row_blocks;
+    if (ok && threadIdx.x < 2 && k > 0) {
+        if (rows) {
+            const int64_t i = min((int64_t)blockIdx.x * 256 + (threadIdx.x ? 255 : 0), n_rows > 0 ? n_rows - 1 : 0);
+            span[threadIdx.x] = member_of<int64_t>(tab.row_off, 0, k, i);
+        } else {
+            const int64_t p = min((int64_t)(blockIdx.x - row_blocks) * 256 + (threadIdx.x ? 255 : 0), n_slots > 0 ? n_slots - 1 : 0);
+            span[threadIdx.x] = member_of<uint32_t>(tab.slot_off, 0, k, (uint32_t)p);
+        }
+    }
+    __syncthreads();
+    const int mlo = span[0], mhi = span[1] + 1;
+    if (rows) {
         const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
         if (i > n_rows) return;
         if (!ok) { rowptr[i] = 0; return; }
         if (i == n_rows) { rowptr[i] = (uint32_t)n_slots; return; }
-        const int m = member_of<int64_t>(tab.row_off, k, i);
+        const int m = member_of<int64_t>(tab.row_off, mlo, mhi, i);
         const MemberDesc d = tab.desc[m];
         const int64_t local = i - tab.row_off[m];
         rowptr[i] = tab.slot_off[m] + (d.rowptr[local] - d.slot_base);
@@ -151,7 +178,7 @@ __global__ void __launch_bounds__(256) batch_fill_kernel(BatchTab tab, int k, in
     } else {
         const int64_t p = (int64_t)(blockIdx.x - row_blocks) * 256 + threadIdx.x;
         if (p >= n_slots || !ok) return;
-        const int m = member_of<uint32_t>(tab.slot_off, k, (uint32_t)p);
+        const int m = member_of<uint32_t>(tab.slot_off, mlo, mhi, (uint32_t)p);
         const MemberDesc d = tab.desc[m];
         const uint32_t so = tab.slot_off[m];
         const int64_t ro = tab.row_off[m];
@@ -254,9 +281,13 @@ int gnnmp_plan_select(gnnmp_graph_t **out, const gnnmp_graph_t *ds, const int64_
     BatchTab tab = {};
     int rc = batch_plan_alloc(&p, &tab, k, n_rows, n_slots, ds->self_loops, stream);
     if (rc != GNNMP_OK) return rc;
-    select_table_kernel<<<1, SEL_THREADS, 0, stream>>>(ds->rowptr, ds->col, ds->eid, ds->self_loops, ds->n_edges, node_ptr, n_graphs, ids,
-                                                      idx_bytes, index_base, k, n_rows, n_slots, tab, seg_ptr_out);
-    hipError_t e = hipGetLastError();
+    hipError_t e = hipMemsetAsync(tab.status, 0, 4 * sizeof(int32_t), stream);        // [0] status, [1] the last-block ticket
+    if (e == hipSuccess) {
+        select_table_kernel<<<(unsigned)std::max<int64_t>(1, (k + SEL_THREADS - 1) / SEL_THREADS), SEL_THREADS, 0, stream>>>(
+            ds->rowptr, ds->col, ds->eid, ds->self_loops, ds->n_edges, node_ptr, n_graphs, ids, idx_bytes, index_base, k, n_rows, n_slots, tab,
+            seg_ptr_out);
+        e = hipGetLastError();
+    }
     if (e == hipSuccess)
         rc = batch_plan_fill(p, tab, k, node_map_out, graph_indicator_out, idx_bytes, index_base, ds->max_degree, stream);
     else
@@ -310,7 +341,7 @@ int gnnmp_plan_concat(gnnmp_graph_t **out, const gnnmp_graph_t *const *members, 
     hipError_t e = hipMemcpyAsync(tab.row_off, row_off.data(), sizeof(int64_t) * row_off.size(), hipMemcpyHostToDevice, stream);
     if (e == hipSuccess) e = hipMemcpyAsync(tab.slot_off, slot_off.data(), sizeof(uint32_t) * slot_off.size(), hipMemcpyHostToDevice, stream);
     if (e == hipSuccess && k > 0) e = hipMemcpyAsync(tab.desc, desc.data(), sizeof(MemberDesc) * desc.size(), hipMemcpyHostToDevice, stream);
-    if (e == hipSuccess) e = hipMemsetAsync(tab.status, 0, sizeof(int32_t), stream);
+    if (e == hipSuccess) e = hipMemsetAsync(tab.status, 0, 4 * sizeof(int32_t), stream);
     if (e == hipSuccess && seg_ptr_out)
         e = hipMemcpyAsync(seg_ptr_out, row_off.data(), sizeof(int64_t) * row_off.size(), hipMemcpyHostToDevice, stream);
     // (the host vectors die with this call: the copies above are from pageable memory, which hipMemcpyAsync stages before it returns)

@@ -545,10 +545,10 @@ class ChainJobs:
         return self._info[1]
 
     def export(self):
-        """(tab [njobs][64] int32, hdr [8] int32) as the kernel reads them (tests)"""
+        """(tab [njobs][64] int32, hdr [32] int32) as the kernel reads them (tests)"""
         cap = max(int(self.G), 1)
         tab = torch.full((cap, 64), -2, dtype=torch.int32, device="cuda")
-        hdr = torch.zeros(8, dtype=torch.int32, device="cuda")
+        hdr = torch.zeros(32, dtype=torch.int32, device="cuda")
         L.check(L.load().gnnmp_chain_jobs_export(self.handle, L.ptr(tab), cap, L.ptr(hdr), L.stream_ptr()))
         return tab, hdr
 

@@ -626,7 +626,8 @@ int gnnmp_chain_jobs_info(const gnnmp_chain_jobs_t *jobs, int64_t *info);
  * scratch of the running call).
  *   gnnmp_chain_jobs_release  stream-ordered destroy (see gnnmp_plan_release)
  *   gnnmp_chain_jobs_export   the job table as the kernel reads it: tab_out[cap_rows][64] int32 (global row of each slot, -1 = empty),
- *                             hdr_out[8] int32 ([0] jobs [1] 32-row tiles [2] poisoned [3] largest member seen [4] empty members): tests */
+ *                             hdr_out[32] int32 ([0] jobs [1] 32-row tiles [2] poisoned [3] largest member seen [4] empty members,
+ *                             [16..29] seven 64-bit phase stamps of the packing kernel, 100 MHz): tests and tools */
 int gnnmp_chain_jobs_pack(gnnmp_chain_jobs_t **out, const int64_t *seg_ptr, int64_t G, int64_t n_rows, int64_t max_graph, int has_empty,
                           gnnmp_stream_t stream);
 int gnnmp_chain_jobs_release(gnnmp_chain_jobs_t *jobs, gnnmp_stream_t stream);

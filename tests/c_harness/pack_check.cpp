@@ -43,8 +43,7 @@ static int check(const std::vector<int> &sizes, const char *tag) {
     std::vector<int32_t> sorted(G), fill(start.begin(), start.end());
     for (int g = 0; g < G; ++g) sorted[fill[sizes[g]]++] = g;
     static PackState st;
-    int32_t work[3 * 65];
-    pack_records(cnt.data(), start.data(), &st, work);
+    pack_records(cnt.data(), start.data(), &st);
     if (st.nrec > PACK_MAX_REC) { printf("%s: %d records\n", tag, st.nrec); return 1; }
     int32_t counts[65];
     for (int d = 0; d <= 64; ++d) pack_class_count(&st, d, &counts[d]);
