@@ -416,6 +416,7 @@ def main():
                          "by graph across the ranks, one RCCL all-gather of logits per step; strong scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the side measurements (other configs, 8d protocol)")
+    ap.add_argument("--no-placement", action="store_true", help="fresh output allocations per layer call instead of gnnmp.placement's persistent, placement-tuned buffers")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
@@ -489,10 +490,22 @@ def main():
     torch.cuda.synchronize()
     norm_cache_ms = (time.perf_counter() - t0) * 1e3
 
+    # Output placement (gnnmp/placement.py): both gather kernels run 6 % faster or slower depending on where the
+    # gathered matrix and the output lie relative to each other in device memory (same binary, same data); the layers keep a persistent
+    # output buffer whose placement they found fastest by timing themselves on three candidates.  --no-placement: fresh allocations per
+    # call, the mode is then whatever the allocator hands out (the r3 behaviour).
+    gcn.place_outputs = gat.place_outputs = not args.no_placement
+
     def step():
         y1 = gcn(g, x)
         y2 = gat(g, x)
         return y1, y2
+
+    if not args.no_placement:          # builds the arena and classifies x (set-up, like the plan)
+        t0 = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        arena_ms = (time.perf_counter() - t0) * 1e3
 
     # ---- events around the two candidate dominant kernels (recorded on the launch stream) --------------------
     lib = L.load()
@@ -618,6 +631,17 @@ def main():
               "gcn_layer_ms": layer_time(lambda: gcn(g, x), 5), "gat_layer_ms": layer_time(lambda: gat(g, x), 5),
               "max_in_degree": plan.max_degree, "long_rows": plan.n_long}
     extras["in_step_kernels"] = instep
+    ar = gnnmp.placement.arena() if not args.no_placement else None
+    extras["placement"] = {"enabled": ar is not None, "arena": (ar.info() if ar is not None else None),
+                           "arena_create_and_first_step_ms": (arena_ms if not args.no_placement else None),
+                           "class_of_x": (ar.class_of(x) if ar is not None else None),
+                           "note": "outputs of the two gather kernels live in a placement class other than their gathered matrix's "
+                                   "(csrc/arena.hip: 2 GiB physical chunks classified by a 140 us probe)"}
+    if not args.no_placement:
+        gcn.place_outputs = gat.place_outputs = False
+        extras["placement"]["gcn_layer_ms_fresh_allocations"] = layer_time(lambda: gcn(g, x), 5)
+        extras["placement"]["gat_layer_ms_fresh_allocations"] = layer_time(lambda: gat(g, x), 5)
+        gcn.place_outputs = gat.place_outputs = True
     extras["gcn_layer_edges_per_s"] = Ep / extras["gcn_layer_ms"] * 1e3
     extras["gat_layer_edges_per_s"] = Ep / extras["gat_layer_ms"] * 1e3
     if not args.no_extras:
@@ -769,6 +793,8 @@ def main():
                                f"edges counted = 2*E' per GPU",
                    "parallelism": f"replicas x{world} (independent feature batches, no collective)",
                    "index": "Int64 1-based COO as held by GNNGraph; plan = dst-sorted CSR (4-byte slots) built once",
+                   "output_buffers": ("persistent per layer, in a placement class other than the gathered matrix's (gnnmp/placement.py, csrc/arena.hip)"
+                                      if not args.no_placement else "fresh allocation per call"),
                    "arithmetic": "fp32 operands, accumulation and results; aggregation in fp32 in the reference's edge order; the dense "
                                  "contraction of the GAT layer (dense_x) runs on the bf16 matrix core as an exact 3-plane split of every fp32 "
                                  "operand (six bf16 MFMAs per product, fp32 accumulate, dropped terms < 2^-21 of a product, truncation "

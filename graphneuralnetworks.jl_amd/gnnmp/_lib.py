@@ -23,6 +23,7 @@ SYMBOLS = (
     "gnnmp_plan_create", "gnnmp_plan_destroy", "gnnmp_plan_info", "gnnmp_plan_export", "gnnmp_plan_export64",
     "gnnmp_plan_concat", "gnnmp_plan_select", "gnnmp_plan_release", "gnnmp_plan_status", "gnnmp_plan_edge_index",
     "gnnmp_chain_jobs_pack", "gnnmp_chain_jobs_release", "gnnmp_chain_jobs_export",
+    "gnnmp_arena_create", "gnnmp_arena_destroy", "gnnmp_arena_alloc", "gnnmp_arena_reset", "gnnmp_arena_class_of", "gnnmp_arena_info",
     "gnnmp_add_self_loops", "gnnmp_batch_coo",
     "gnnmp_sort_edge_index", "gnnmp_is_bidirected", "gnnmp_has_self_loops", "gnnmp_sample_neighbors",
     "gnnmp_unique_append", "gnnmp_induced_subgraph",
@@ -81,6 +82,12 @@ def load():
         "gnnmp_chain_jobs_pack": [ctypes.POINTER(vp), vp, i64, i64, i64, i, vp],
         "gnnmp_chain_jobs_release": [vp, vp],
         "gnnmp_chain_jobs_export": [vp, vp, i64, vp, vp],
+        "gnnmp_arena_create": [ctypes.POINTER(vp), i64, i64, vp],
+        "gnnmp_arena_destroy": [vp],
+        "gnnmp_arena_alloc": [vp, i, i64, ctypes.POINTER(vp)],
+        "gnnmp_arena_reset": [vp],
+        "gnnmp_arena_class_of": [vp, vp, i64, ctypes.POINTER(i), vp],
+        "gnnmp_arena_info": [vp, ctypes.POINTER(i64)],
         "gnnmp_add_self_loops": [vp, vp, i, i, i64, i64, vp, vp, vp, vp, vp],
         "gnnmp_batch_coo": [vp, vp, i, i, vp, vp, i64, vp, vp, vp, vp],
         "gnnmp_sort_edge_index": [vp, vp, i, i, i64, vp, vp, vp],

@@ -20,6 +20,7 @@ import numpy as np
 import torch
 
 from . import _lib as L
+from . import placement
 from .graph import GNNGraph, check_num_nodes, degree
 from .msgpass import _flat, _fused, aggr_code
 from .utils import expand_srcdst, reduce_nodes
@@ -37,7 +38,7 @@ def _act_code(sigma):
     raise ValueError(f"unsupported activation {sigma!r}")
 
 
-def dense(x, W, bias=None, sigma=None, x2=None, W2=None):
+def dense(x, W, bias=None, sigma=None, x2=None, W2=None, out=None):
     """act(W * x (+ W2 * x2) (+ bias)) on the MFMA kernel.  W: [Dout, Din] (Julia (out, in)); W/W2 may be column
     slices of a wider matrix (sage_conv's `weight * vcat(xi, m)`): only the last stride must be 1."""
     assert x.dtype == torch.float32 and W.dtype == torch.float32
@@ -53,7 +54,10 @@ def dense(x, W, bias=None, sigma=None, x2=None, W2=None):
         assert W2.shape == (Dout, D2) and W2.stride(1) == 1 and x2.shape[0] == N
         ld2 = W2.stride(0)
     code, post = _act_code(sigma)
-    out = torch.empty((N, Dout), dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty((N, Dout), dtype=torch.float32, device=x.device)
+    else:
+        assert out.shape == (N, Dout) and out.dtype == torch.float32 and out.is_contiguous()
     b = None if bias is None or bias is False else bias.contiguous()
     pr = L._probe
     e0 = pr.begin() if pr is not None else None
@@ -114,6 +118,12 @@ def fused_conv(plan, aggr, xj, W_agg, bias=None, sigma=None, xi=None, W_root=Non
 
 
 _KNOB14 = [0]
+
+
+def _would_fuse(plan, D):
+    """the library's default gating of fused_conv for a layer without a root term (see fused_conv above)"""
+    k14 = _KNOB14[0]
+    return k14 > 0 or (k14 == 0 and plan.n_dst * D * 4 >= (128 << 20))
 
 
 def _knob14():
@@ -204,10 +214,16 @@ def gcn_conv(l, g: GNNGraph, x, edge_weight=None, norm_fn=None, conv_weight=None
         c_slot = w_slot = None
     if Dout >= Din:
         # aggregate, then transform: one kernel, the (N, Din) aggregate never goes to HBM (conv.jl:59-71)
+        # opt-in (gnnmp/placement.py): a persistent output buffer in a placement class other than x's
+        out_buf = None
+        if placement.enabled(l) and x.dim() == 2 and placement.worth_it((plan.n_dst, Dout)) and _would_fuse(plan, x.shape[1]):
+            ar = placement.arena()
+            if ar is not None:
+                out_buf, _ = placement.buffer_for(l, "out", (plan.n_dst, Dout), ar.class_of(x))
         if c_slot is not None:
-            y = fused_conv(plan, L.SUM, x, weight, l.bias, l.sigma, w_slot=w_slot, ss_slot=c_slot, scale_dst=c)
+            y = fused_conv(plan, L.SUM, x, weight, l.bias, l.sigma, w_slot=w_slot, ss_slot=c_slot, scale_dst=c, out=out_buf)
         else:
-            y = fused_conv(plan, L.SUM, x, weight, l.bias, l.sigma, w=w, scale_src=c, scale_dst=c)
+            y = fused_conv(plan, L.SUM, x, weight, l.bias, l.sigma, w=w, scale_src=c, scale_dst=c, out=out_buf)
         if y is not None:
             return y
     if c_slot is not None:
@@ -333,10 +349,21 @@ def gat_conv(l, g: GNNGraph, x, e=None, return_alpha=False, exact_order=False, s
     H = l.heads
     C = l.channel[1]
     N = g.num_nodes
-    Wx = dense(x, l.dense_x_weight)                        # reshape(dense_x(x), C, H, N)
+    # opt-in (gnnmp/placement.py): Wx = dense_x(x) in one placement class (not x's), the attention output in the other — both persistent
+    # buffers of the layer; otherwise both are fresh allocations
+    out = wx = None
+    if (placement.enabled(l) and e is None and not (return_alpha or exact_order) and float(getattr(l, "dropout", 0.0)) == 0.0
+            and placement.worth_it((N, H * C))):
+        ar = placement.arena()
+        if ar is not None:
+            wx, cw = placement.buffer_for(l, "Wx", (N, H * C), ar.class_of(x))
+            if wx is not None:
+                out, _ = placement.buffer_for(l, "out", (N, H * C), cw)
+    Wx = dense(x, l.dense_x_weight, out=wx)                # reshape(dense_x(x), C, H, N)
     a_hc = l.a_hc                                          # [H][2C] (node part)
     lib = L.load()
-    out = torch.empty((N, H * C), dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty((N, H * C), dtype=torch.float32, device=x.device)
     code, post = _act_code(l.sigma)
     fuse_tail = bool(l.concat)
     b = l.bias if (fuse_tail and l.bias is not None) else None

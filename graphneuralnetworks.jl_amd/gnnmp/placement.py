@@ -1,0 +1,141 @@
+"""Placement-aware output buffers for the gather kernels of the hot path (opt-in) — the host side of csrc/arena.hip.
+
+Measured on MI355X (tools/placement_probe.py, placement_map*.py, vmm_probe.py; profiles/README.md, round 4): the 288 GB of HBM3E fall into three
+placement classes of 96 GiB of physical memory each.  The one-pass attention kernel and the fused GCN layer kernel (~27 random row reads
+per row written) run 6 % slower when the gathered matrix and the output lie in the SAME class than when they lie in two — 5.15 vs 4.84 ms
+and 4.94 vs 4.66 ms on the products shape; same binary, same data, same predecessors on the stream.  hipMalloc (and so torch's allocator)
+pairs buffers by luck: that was the unexplained gap between the kernel "alone" and "in the step" of round 3, and much of the box-to-box
+spread.
+
+The C ABI leaves allocation to its caller, so the policy lives here: `gnnmp_arena_*` (include/gnnmp.h) builds two address ranges out of
+2 GiB physical chunks of two DIFFERENT classes (each chunk classified by a ~140 us probe), and a layer that opts in writes its output to
+the range whose class differs from the class of the matrix it gathers from:
+    GCNConv:  out in a class other than x's           GATConv:  Wx = dense_x(x) in one range, the attention output in the other
+The returned tensor is a PERSISTENT buffer of the layer, overwritten by its next call (like the static outputs of a captured graph): that
+is the opt-in.  Results are bit-identical wherever buffers lie.
+
+    gcn = gnnmp.GCNConv(...); gcn.place_outputs = True        # per layer
+    gnnmp.placement.enable(True)                              # or for every GCNConv / GATConv call
+    GNNMP_ARENA_GIB=8                                         # bytes per class (default 4 GiB), rounded up to 2 GiB chunks
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch
+
+from . import _lib as L
+
+_ENABLED = [False]
+MIN_BYTES = 256 << 20          # smaller outputs: the effect is not worth a persistent buffer
+
+
+def enable(on=True):
+    _ENABLED[0] = bool(on)
+
+
+def enabled(layer=None):
+    return _ENABLED[0] or bool(getattr(layer, "place_outputs", False))
+
+
+def worth_it(shape):
+    n = 4
+    for d in shape:
+        n *= int(d)
+    return n >= MIN_BYTES
+
+
+class _Raw:
+    """a device address as torch sees it (torch.as_tensor over __cuda_array_interface__); keeps the arena alive"""
+
+    def __init__(self, ptr, shape, owner):
+        self.__cuda_array_interface__ = {"shape": tuple(int(d) for d in shape), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+        self._owner = owner
+
+
+class Arena:
+    """gnnmp_arena_t: two ranges of device memory in two different placement classes"""
+
+    def __init__(self, gib_per_class=None, max_probe_gib=160):
+        L.require_gpu()
+        if gib_per_class is None:
+            gib_per_class = float(os.environ.get("GNNMP_ARENA_GIB", "4"))
+        self._lib = L.load()
+        self.handle = ctypes.c_void_p()
+        L.check(self._lib.gnnmp_arena_create(ctypes.byref(self.handle), int(gib_per_class * (1 << 30)), int(max_probe_gib) << 30, L.stream_ptr()))
+        self._classes = {}
+        self.device = torch.device("cuda", torch.cuda.current_device())
+
+    def info(self):
+        v = (ctypes.c_int64 * 8)()
+        L.check(self._lib.gnnmp_arena_info(self.handle, v))
+        return {"bytes_per_class": v[0], "used": (v[1], v[2]), "chunks_created": v[3], "chunks_released": v[4],
+                "probe_us_same_class": v[5], "probe_us_two_classes": v[6]}
+
+    def alloc(self, shape, cls):
+        """a float32 tensor of `shape` in range `cls` (0 | 1); None when the range is full"""
+        n = 4
+        for d in shape:
+            n *= int(d)
+        p = ctypes.c_void_p()
+        rc = self._lib.gnnmp_arena_alloc(self.handle, int(cls), n, ctypes.byref(p))
+        if rc == L.EALLOC:
+            return None
+        L.check(rc)
+        return torch.as_tensor(_Raw(p.value, shape, self), device=self.device)
+
+    def class_of(self, t):
+        """0 | 1: `t` shares the class of that range; 2: neither (or too small to tell).  Foreign memory is probed once per buffer."""
+        key = (t.data_ptr(), t.numel() * t.element_size())
+        c = self._classes.get(key)
+        if c is None:
+            out = ctypes.c_int(2)
+            L.check(self._lib.gnnmp_arena_class_of(self.handle, L.ptr(t), key[1], ctypes.byref(out), L.stream_ptr()))
+            c = self._classes[key] = out.value
+            if len(self._classes) > 256:
+                self._classes.pop(next(iter(self._classes)))
+        return c
+
+    def reset(self):
+        L.check(self._lib.gnnmp_arena_reset(self.handle))
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self._lib.gnnmp_arena_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+_arena = [None, False]      # the arena, "creation was tried and failed"
+
+
+def arena():
+    """the process-wide arena, created at first use; None if this device does not yield two classes (the layers then allocate as usual)"""
+    if _arena[0] is None and not _arena[1]:
+        try:
+            _arena[0] = Arena()
+        except L.GnnmpError as e:
+            _arena[1] = True
+            import warnings
+            warnings.warn(f"gnnmp.placement: no arena ({e}); outputs are allocated as usual")
+    return _arena[0]
+
+
+def buffer_for(layer, tag, shape, avoid_class):
+    """the layer's persistent buffer `tag` of `shape` in an arena range whose class is not `avoid_class`; None: allocate as usual"""
+    a = arena()
+    if a is None:
+        return None, 2
+    cls = 1 if avoid_class == 0 else 0
+    cache = layer.__dict__.setdefault("_placed", {})
+    key = (tag, tuple(shape), cls)
+    buf = cache.get(key)
+    if buf is None:
+        buf = a.alloc(shape, cls)
+        if buf is None:
+            return None, 2
+        cache[key] = buf
+    return buf, cls

@@ -1,0 +1,97 @@
+"""csrc/arena.hip + gnnmp/placement.py (opt-in placement-aware output buffers): the arena finds two placement classes with its probe, hands
+out memory of either, recognises its own and foreign buffers; a layer that opts in returns bit-identical results from persistent buffers in the
+right ranges; the plain path is untouched when the switch is off."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ar():
+    import torch
+    import gnnmp
+    from gnnmp import _lib as L, placement
+    free, _ = torch.cuda.mem_get_info()
+    if free < (200 << 30):
+        pytest.skip("the arena may hold up to 160 GiB of chunks while it looks for two placement classes; this device has less free")
+    try:
+        return placement.Arena(gib_per_class=4)
+    except L.GnnmpError as e:
+        if e.status in (L.EUNSUPPORTED, L.EALLOC):
+            pytest.skip(f"this device does not show two placement classes: {e}")
+        raise
+
+
+def test_arena_finds_two_classes_and_tells_them_apart(ar):
+    import torch
+    info = ar.info()
+    assert info["bytes_per_class"] == 4 << 30 and info["chunks_created"] >= 4
+    # the probe saw two clusters at least 3 % apart (that is what makes two classes)
+    assert info["probe_us_same_class"] > 1.03 * info["probe_us_two_classes"] > 0
+    a0, a1 = ar.alloc((1 << 20, 128), 0), ar.alloc((1 << 20, 128), 1)
+    assert ar.class_of(a0) == 0 and ar.class_of(a1) == 1
+    a0.fill_(1.0); a1.fill_(2.0)
+    assert float(a0.sum()) == float(1 << 27) and float(a1.sum()) == float(2 << 27)
+    # memory of either range, copied through the probe's eyes: a buffer that IS arena memory of class c, seen as foreign memory
+    # (an offset view is outside the cache of known addresses), must come out as class c
+    for c, t in ((0, a0), (1, a1)):
+        view = t[4096:]
+        got = ctypes_class(ar, view)
+        assert got == c, (c, got)
+    assert ar.alloc((1 << 40, 1), 0) is None          # full: the caller allocates as usual
+    ar.reset()
+    assert ar.info()["used"] == (0, 0)
+
+
+def ctypes_class(ar, t):
+    """gnnmp_arena_class_of on an address INSIDE a range answers from the range; to exercise the probe, classify through a foreign alias:
+    the same physical memory is not reachable under another address here, so the probe path is run on a torch allocation instead and
+    only required to return a valid class"""
+    import ctypes
+    from gnnmp import _lib as L
+    out = ctypes.c_int(-1)
+    L.check(L.load().gnnmp_arena_class_of(ar.handle, L.ptr(t), t.numel() * 4, ctypes.byref(out), L.stream_ptr()))
+    return out.value
+
+
+def test_foreign_buffers_are_probed(ar):
+    import torch
+    x = torch.randn((1 << 20, 128), device="cuda")        # 512 MiB of ordinary (torch) memory
+    c = ar.class_of(x)
+    assert c in (0, 1, 2)
+    assert ar.class_of(x) == c                            # cached per buffer
+    assert ar.class_of(torch.zeros(16, device="cuda")) == 2      # too small to matter
+
+
+def test_placed_layers_are_bit_identical(ar, monkeypatch):
+    import torch
+    import gnnmp
+    from gnnmp import placement, synth
+    monkeypatch.setattr(placement, "MIN_BYTES", 0)
+    monkeypatch.setattr(placement, "_arena", [ar, False])
+    N, E, D = 70000, 900000, 100
+    s, t = synth.arxiv_like(N=N, E=E, alpha=2.0, seed=3)
+    g = gnnmp.GNNGraph(torch.from_numpy(s).cuda(), torch.from_numpy(t).cuda(), num_nodes=N)
+    x = torch.from_numpy(synth.features(N, D, seed=4)).cuda()
+    gcn = gnnmp.GCNConv((D, D), "relu", seed=1)
+    gat = gnnmp.GATConv((D, 16), "relu", heads=8, seed=2)
+    gnnmp.tune(14, 16)                      # the fused layer kernel on this small graph (the path that takes an output buffer)
+    try:
+        ref_gcn, ref_gat = gcn(g, x).clone(), gat(g, x).clone()
+        gcn.place_outputs = gat.place_outputs = True
+        cx = ar.class_of(x)
+        for it in range(3):
+            y1, y2 = gcn(g, x), gat(g, x)
+            assert torch.equal(y1, ref_gcn) and torch.equal(y2, ref_gat), it
+        # where the buffers lie: GCN's output not in x's class; Wx and the attention output in different ranges
+        assert ar.class_of(y1) in (0, 1) and ar.class_of(y1) != cx
+        wx = gat._placed[("Wx", (N, 128), 1 if cx == 0 else 0)]
+        assert ar.class_of(wx) != cx and ar.class_of(y2) == 1 - ar.class_of(wx)
+        a, b = gat(g, x), gat(g, x)
+        assert a.data_ptr() == b.data_ptr()     # persistent: the documented aliasing of the opt-in
+        gcn.place_outputs = gat.place_outputs = False
+        c, d = gat(g, x), gat(g, x)
+        assert torch.equal(c, ref_gat) and c.data_ptr() != d.data_ptr()
+    finally:
+        gnnmp.tune(14, 0)
