@@ -25,10 +25,11 @@
 
 struct gnnmp_arena {
     int64_t chunk_bytes = 0;
-    int n_chunks[2] = {0, 0};
-    std::vector<hipMemGenericAllocationHandle_t> handles[2];
-    unsigned char *base[2] = {nullptr, nullptr};      // the two mapped ranges
-    int64_t cap[2] = {0, 0}, used[2] = {0, 0};
+    int n_classes = 2;                                 // ranges that exist (2 | 3)
+    int n_chunks[3] = {0, 0, 0};
+    std::vector<hipMemGenericAllocationHandle_t> handles[3];
+    unsigned char *base[3] = {nullptr, nullptr, nullptr};      // the mapped ranges
+    int64_t cap[3] = {0, 0, 0}, used[3] = {0, 0, 0};
     gnnmp_graph_t *probe_plan = nullptr;               // the synthetic graph of the probe (sources in [0, probe_nsrc))
     int64_t probe_nsrc = 0;
     int dev = 0;
@@ -118,7 +119,7 @@ extern "C" {
 int gnnmp_arena_destroy(gnnmp_arena_t *a) {
     if (!a) return GNNMP_OK;
     (void)hipDeviceSynchronize();
-    for (int c = 0; c < 2; ++c) {
+    for (int c = 0; c < 3; ++c) {
         for (size_t i = 0; i < a->handles[c].size(); ++i) {
             if (a->base[c]) (void)hipMemUnmap(a->base[c] + (int64_t)i * a->chunk_bytes, (size_t)a->chunk_bytes);
             (void)hipMemRelease(a->handles[c][i]);
@@ -130,16 +131,17 @@ int gnnmp_arena_destroy(gnnmp_arena_t *a) {
     return GNNMP_OK;
 }
 
-int gnnmp_arena_create(gnnmp_arena_t **out, int64_t bytes_per_class, int64_t max_probe_bytes, gnnmp_stream_t stream_) {
+int gnnmp_arena_create(gnnmp_arena_t **out, int64_t bytes_per_class, int n_classes, int64_t max_probe_bytes, gnnmp_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (!out || bytes_per_class <= 0) return fail(GNNMP_EINVAL, "arena_create: bad argument");
+    if (!out || bytes_per_class <= 0 || (n_classes != 2 && n_classes != 3)) return fail(GNNMP_EINVAL, "arena_create: bad argument");
     *out = nullptr;
     gnnmp_arena *a = new gnnmp_arena();
     (void)hipGetDevice(&a->dev);
     a->chunk_bytes = CHUNK;
+    a->n_classes = n_classes;
     const int need = (int)((bytes_per_class + CHUNK - 1) / CHUNK);
     if (max_probe_bytes <= 0) max_probe_bytes = (int64_t)160 << 30;
-    const int max_chunks = (int)std::max<int64_t>(2 * need, max_probe_bytes / CHUNK);
+    const int max_chunks = (int)std::max<int64_t>((int64_t)n_classes * need, max_probe_bytes / CHUNK);
     const hipMemAllocationProp prop = chunk_prop(a->dev);
     // a scratch range where chunks are mapped one at a time while they are classified, + the reference chunk of class 0
     unsigned char *scratch = nullptr;
@@ -148,7 +150,7 @@ int gnnmp_arena_create(gnnmp_arena_t **out, int64_t bytes_per_class, int64_t max
     int rc = GNNMP_OK;
     hipError_t e = hipSuccess;
 #define ARENA_HIP(expr) do { e = (expr); if (e != hipSuccess) { rc = hip_fail(e, #expr); goto done; } } while (0)
-    for (int c = 0; c < 2; ++c) {
+    for (int c = 0; c < n_classes; ++c) {
         a->cap[c] = (int64_t)need * CHUNK;
         ARENA_HIP(hipMemAddressReserve((void **)&a->base[c], (size_t)a->cap[c], (size_t)2 << 20, nullptr, 0));
     }
@@ -173,7 +175,7 @@ int gnnmp_arena_create(gnnmp_arena_t **out, int64_t bytes_per_class, int64_t max
         std::vector<Pend> pending;
         float lo = 0.0f, hi = 0.0f, thr = 0.0f;
         auto place = [&](hipMemGenericAllocationHandle_t h, int cls) -> hipError_t {
-            if (cls < 2 && (int)a->handles[cls].size() < need) {
+            if (cls < a->n_classes && (int)a->handles[cls].size() < need) {
                 unsigned char *va = a->base[cls] + (int64_t)a->handles[cls].size() * CHUNK;
                 hipError_t e2 = map_rw(va, (size_t)CHUNK, h, a->dev);
                 if (e2 != hipSuccess) return e2;
@@ -208,11 +210,16 @@ int gnnmp_arena_create(gnnmp_arena_t **out, int64_t bytes_per_class, int64_t max
             hipError_t e3 = place(q.h, cls);
             return e3 == hipSuccess ? GNNMP_OK : hip_fail(e3, "arena: map of a classified chunk");
         };
-        while ((int)a->handles[0].size() < need || (int)a->handles[1].size() < need) {
+        auto all_full = [&]() {
+            for (int c = 0; c < a->n_classes; ++c)
+                if ((int)a->handles[c].size() < need) return false;
+            return true;
+        };
+        while (!all_full()) {
             if (a->created >= max_chunks) {
-                rc = fail(GNNMP_EUNSUPPORTED, "arena_create: %lld chunks of 2 GiB probed (probe %.0f..%.0f us), classes hold %zu / %zu of %d chunks "
+                rc = fail(GNNMP_EUNSUPPORTED, "arena_create: %lld chunks of 2 GiB probed (probe %.0f..%.0f us), classes hold %zu / %zu / %zu of %d chunks "
                                               "(raise max_probe_bytes or free device memory)", (long long)a->created, lo, hi,
-                          a->handles[0].size(), a->handles[1].size(), need);
+                          a->handles[0].size(), a->handles[1].size(), a->handles[2].size(), need);
                 for (const Pend &q : pending) spare.push_back(q.h);
                 goto done;
             }
@@ -271,14 +278,13 @@ done:
         gnnmp_arena_destroy(a);
         return rc;
     }
-    a->n_chunks[0] = (int)a->handles[0].size();
-    a->n_chunks[1] = (int)a->handles[1].size();
+    for (int c = 0; c < 3; ++c) a->n_chunks[c] = (int)a->handles[c].size();
     *out = a;
     return GNNMP_OK;
 }
 
 int gnnmp_arena_alloc(gnnmp_arena_t *a, int cls, int64_t bytes, void **ptr) {
-    if (!a || !ptr || bytes < 0 || (cls != 0 && cls != 1)) return fail(GNNMP_EINVAL, "arena_alloc: bad argument");
+    if (!a || !ptr || bytes < 0 || cls < 0 || cls >= a->n_classes) return fail(GNNMP_EINVAL, "arena_alloc: bad argument");
     std::lock_guard<std::mutex> lk(a->lock);
     const int64_t at = (a->used[cls] + 4095) & ~(int64_t)4095;
     if (at + bytes > a->cap[cls])
@@ -292,7 +298,7 @@ int gnnmp_arena_alloc(gnnmp_arena_t *a, int cls, int64_t bytes, void **ptr) {
 int gnnmp_arena_reset(gnnmp_arena_t *a) {
     if (!a) return fail(GNNMP_EINVAL, "arena_reset: null arena");
     std::lock_guard<std::mutex> lk(a->lock);
-    a->used[0] = a->used[1] = 0;
+    a->used[0] = a->used[1] = a->used[2] = 0;
     return GNNMP_OK;
 }
 
@@ -300,35 +306,43 @@ int gnnmp_arena_class_of(gnnmp_arena_t *a, const void *ptr, int64_t bytes, int *
     hipStream_t stream = (hipStream_t)stream_;
     if (!a || !ptr || !cls) return fail(GNNMP_EINVAL, "arena_class_of: bad argument");
     const unsigned char *p = static_cast<const unsigned char *>(ptr);
-    for (int c = 0; c < 2; ++c)
+    for (int c = 0; c < a->n_classes; ++c)
         if (p >= a->base[c] && p < a->base[c] + a->cap[c]) { *cls = c; return GNNMP_OK; }
-    // foreign memory: the probe with the buffer as the gathered matrix, the output in a spare corner of each arena class
+    // foreign memory: the probe with the buffer as the gathered matrix, the output in a spare corner of each arena range
+    const int none = a->n_classes;                         // "in none of the ranges' classes / cannot tell"
     const int64_t n_src = std::min<int64_t>(bytes, CHUNK) / (PROBE_D * 4);
-    if (n_src < PROBE_ROWS) { *cls = 2; return GNNMP_OK; }      // (too small to matter)
-    if ((reinterpret_cast<uintptr_t>(ptr) & 15)) { *cls = 2; return GNNMP_OK; }
+    if (n_src < PROBE_ROWS) { *cls = none; return GNNMP_OK; }      // (too small to matter)
+    if ((reinterpret_cast<uintptr_t>(ptr) & 15)) { *cls = none; return GNNMP_OK; }
     std::lock_guard<std::mutex> lk(a->lock);
     int rc = make_probe_plan(a, n_src, stream);
     if (rc != GNNMP_OK) return rc;
     const int64_t out_bytes = (int64_t)PROBE_ROWS * PROBE_D * 4;
-    float us[2] = {0.0f, 0.0f};
-    for (int c = 0; c < 2; ++c) {
-        if (a->cap[c] - a->used[c] < out_bytes + 4096) return fail(GNNMP_EALLOC, "arena_class_of: no room for the probe's output in class %d", c);
+    float us[3] = {0.0f, 0.0f, 0.0f};
+    for (int c = 0; c < a->n_classes; ++c) {
+        if (a->cap[c] - a->used[c] < out_bytes + 4096) return fail(GNNMP_EALLOC, "arena_class_of: no room for the probe's output in range %d", c);
         float *o = reinterpret_cast<float *>(a->base[c] + a->cap[c] - out_bytes);      // the top of the range: free by the check above
         rc = probe_us(a, static_cast<const float *>(ptr), o, stream, &us[c]);
         if (rc != GNNMP_OK) return rc;
     }
-    if (getenv("GNNMP_ARENA_DEBUG")) fprintf(stderr, "[arena] foreign buffer %p: probe %.1f us into range 0, %.1f us into range 1\n", ptr, us[0], us[1]);
-    const float hi = std::max(us[0], us[1]), lo = std::min(us[0], us[1]);
-    *cls = hi > 1.025f * lo ? (us[0] > us[1] ? 0 : 1) : 2;
+    if (getenv("GNNMP_ARENA_DEBUG"))
+        fprintf(stderr, "[arena] foreign buffer %p: probe %.1f / %.1f / %.1f us into ranges 0 / 1 / 2\n", ptr, us[0], us[1], us[2]);
+    int slow = 0;
+    float lo = us[0];
+    for (int c = 1; c < a->n_classes; ++c) {
+        if (us[c] > us[slow]) slow = c;
+        lo = std::min(lo, us[c]);
+    }
+    *cls = us[slow] > 1.04f * lo ? slow : none;
     return GNNMP_OK;
 }
 
-/* info[0] = bytes per class, [1] = bytes used in class 0, [2] = in class 1, [3] = chunks created while classifying, [4] = released again,
- * [5] = probe microseconds with source and output in one class, [6] = in two */
+/* info[0] = bytes per class, [1] = bytes used in range 0, [2] = in range 1, [3] = chunks created while classifying, [4] = released again,
+ * [5] = probe microseconds with source and output in one class, [6] = in two, [7] = ranges (2 | 3), [8] = bytes used in range 2 */
 int gnnmp_arena_info(const gnnmp_arena_t *a, int64_t *info) {
     if (!a || !info) return fail(GNNMP_EINVAL, "arena_info: null argument");
     info[0] = a->cap[0]; info[1] = a->used[0]; info[2] = a->used[1]; info[3] = a->created; info[4] = a->released;
     info[5] = (int64_t)(a->probe_same_us + 0.5f); info[6] = (int64_t)(a->probe_other_us + 0.5f);
+    info[7] = a->n_classes; info[8] = a->used[2];
     return GNNMP_OK;
 }
 

@@ -82,7 +82,7 @@ def load():
         "gnnmp_chain_jobs_pack": [ctypes.POINTER(vp), vp, i64, i64, i64, i, vp],
         "gnnmp_chain_jobs_release": [vp, vp],
         "gnnmp_chain_jobs_export": [vp, vp, i64, vp, vp],
-        "gnnmp_arena_create": [ctypes.POINTER(vp), i64, i64, vp],
+        "gnnmp_arena_create": [ctypes.POINTER(vp), i64, i, i64, vp],
         "gnnmp_arena_destroy": [vp],
         "gnnmp_arena_alloc": [vp, i, i64, ctypes.POINTER(vp)],
         "gnnmp_arena_reset": [vp],

@@ -219,7 +219,7 @@ def gcn_conv(l, g: GNNGraph, x, edge_weight=None, norm_fn=None, conv_weight=None
         if placement.enabled(l) and x.dim() == 2 and placement.worth_it((plan.n_dst, Dout)) and _would_fuse(plan, x.shape[1]):
             ar = placement.arena()
             if ar is not None:
-                out_buf, _ = placement.buffer_for(l, "out", (plan.n_dst, Dout), ar.class_of(x))
+                out_buf, _ = placement.buffer_for(l, "out", (plan.n_dst, Dout), [ar.class_of(x)])
         if c_slot is not None:
             y = fused_conv(plan, L.SUM, x, weight, l.bias, l.sigma, w_slot=w_slot, ss_slot=c_slot, scale_dst=c, out=out_buf)
         else:
@@ -273,7 +273,7 @@ def graph_conv(l, g: GNNGraph, x):
     y = fused_conv(g.plan(False), aggr_code(l.aggr), xj, l.weight2, l.bias, l.sigma, xi=xi, W_root=l.weight1)
     if y is not None:
         return y
-    m = _fused(g, L.COPY_XJ, l.aggr, xj, None)
+    m = _fused(g, L.COPY_XJ, l.aggr, xj, None, out=_placed_aggregate(l, xj, g.plan(False).n_dst))
     return dense(xi, l.weight1, l.bias, l.sigma, x2=m, W2=l.weight2)
 
 
@@ -305,8 +305,19 @@ def sage_conv(l, g: GNNGraph, x):
     y = fused_conv(g.plan(False), aggr_code(l.aggr), xj, W[:, Din:], l.bias, l.sigma, xi=xi, W_root=W[:, :Din])
     if y is not None:
         return y
-    m = _fused(g, L.COPY_XJ, l.aggr, xj, None)
+    m = _fused(g, L.COPY_XJ, l.aggr, xj, None, out=_placed_aggregate(l, xj, g.plan(False).n_dst))
     return dense(xi, W[:, :Din], l.bias, l.sigma, x2=m, W2=W[:, Din:])
+
+
+def _placed_aggregate(l, xj, n_dst):
+    """opt-in (gnnmp/placement.py): the layer's persistent aggregate buffer in a placement class other than xj's; None = allocate as usual"""
+    if not (placement.enabled(l) and xj.dim() == 2 and placement.worth_it((n_dst, xj.shape[1]))):
+        return None
+    ar = placement.arena()
+    if ar is None:
+        return None
+    buf, _ = placement.buffer_for(l, "m", (n_dst, xj.shape[1]), [ar.class_of(xj)])
+    return buf
 
 
 class SAGEConv:
@@ -356,9 +367,12 @@ def gat_conv(l, g: GNNGraph, x, e=None, return_alpha=False, exact_order=False, s
             and placement.worth_it((N, H * C))):
         ar = placement.arena()
         if ar is not None:
-            wx, cw = placement.buffer_for(l, "Wx", (N, H * C), ar.class_of(x))
+            cx = ar.class_of(x)
+            wx, cw = placement.buffer_for(l, "Wx", (N, H * C), [cx])
             if wx is not None:
-                out, _ = placement.buffer_for(l, "out", (N, H * C), cw)
+                # not Wx's class (the gathered matrix), and with three ranges not x's either: in a stack of layers the next kernel usually
+                # gathers from x again while this output's dirty lines are still being written back
+                out, _ = placement.buffer_for(l, "out", (N, H * C), [cw, cx])
     Wx = dense(x, l.dense_x_weight, out=wx)                # reshape(dense_x(x), C, H, N)
     a_hc = l.a_hc                                          # [H][2C] (node part)
     lib = L.load()

@@ -168,10 +168,13 @@ def aggregate_neighbors(g: GNNGraph, aggr, m):
     return _scatter_plan(aggr, m, g.plan(False))
 
 
-def _fused(g: GNNGraph, msg: int, aggr, xj, w, scale_src=None, scale_dst=None, add_self_loops=False):
+def _fused(g: GNNGraph, msg: int, aggr, xj, w, scale_src=None, scale_dst=None, add_self_loops=False, out=None):
     plan = g.plan(add_self_loops)
     xf = _flat(xj)
-    out = torch.empty((plan.n_dst,) + tuple(xj.shape[1:]), dtype=torch.float32, device=xj.device)
+    if out is None:
+        out = torch.empty((plan.n_dst,) + tuple(xj.shape[1:]), dtype=torch.float32, device=xj.device)
+    else:
+        assert out.shape == (plan.n_dst,) + tuple(xj.shape[1:]) and out.dtype == torch.float32 and out.is_contiguous()
     L.check(L.load().gnnmp_propagate_f32(plan.handle, msg, aggr_code(aggr), L.ptr(xf), L.ptr(w), L.ptr(scale_src),
                                          L.ptr(scale_dst), L.ptr(out), xf.shape[1], L.stream_ptr()))
     return out

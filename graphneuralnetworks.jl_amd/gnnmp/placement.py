@@ -7,10 +7,11 @@ and 4.94 vs 4.66 ms on the products shape; same binary, same data, same predeces
 pairs buffers by luck: that was the unexplained gap between the kernel "alone" and "in the step" of round 3, and much of the box-to-box
 spread.
 
-The C ABI leaves allocation to its caller, so the policy lives here: `gnnmp_arena_*` (include/gnnmp.h) builds two address ranges out of
-2 GiB physical chunks of two DIFFERENT classes (each chunk classified by a ~140 us probe), and a layer that opts in writes its output to
-the range whose class differs from the class of the matrix it gathers from:
-    GCNConv:  out in a class other than x's           GATConv:  Wx = dense_x(x) in one range, the attention output in the other
+The C ABI leaves allocation to its caller, so the policy lives here: `gnnmp_arena_*` (include/gnnmp.h) builds three (or two) address ranges
+out of 2 GiB physical chunks of DIFFERENT classes (each chunk classified by a 0.6 ms probe), and a layer that opts in writes its output to
+a range whose class differs from the class of the matrix it gathers from — and, with three ranges, from the class the NEXT kernel will
+gather from (the output's dirty lines are still being written back while that kernel runs: 4.76 vs 4.65 ms on the GCN layer in the step):
+    GCNConv:  out in a class other than x's           GATConv:  Wx = dense_x(x) not in x's class, the attention output in the third
 The returned tensor is a PERSISTENT buffer of the layer, overwritten by its next call (like the static outputs of a captured graph): that
 is the opt-in.  Results are bit-identical wherever buffers lie.
 
@@ -55,26 +56,28 @@ class _Raw:
 
 
 class Arena:
-    """gnnmp_arena_t: two ranges of device memory in two different placement classes"""
+    """gnnmp_arena_t: ranges of device memory in different placement classes"""
 
-    def __init__(self, gib_per_class=None, max_probe_gib=160):
+    def __init__(self, gib_per_class=None, n_classes=3, max_probe_gib=160):
         L.require_gpu()
         if gib_per_class is None:
             gib_per_class = float(os.environ.get("GNNMP_ARENA_GIB", "4"))
         self._lib = L.load()
         self.handle = ctypes.c_void_p()
-        L.check(self._lib.gnnmp_arena_create(ctypes.byref(self.handle), int(gib_per_class * (1 << 30)), int(max_probe_gib) << 30, L.stream_ptr()))
+        L.check(self._lib.gnnmp_arena_create(ctypes.byref(self.handle), int(gib_per_class * (1 << 30)), int(n_classes), int(max_probe_gib) << 30,
+                                             L.stream_ptr()))
+        self.n_classes = int(n_classes)
         self._classes = {}
         self.device = torch.device("cuda", torch.cuda.current_device())
 
     def info(self):
-        v = (ctypes.c_int64 * 8)()
+        v = (ctypes.c_int64 * 9)()
         L.check(self._lib.gnnmp_arena_info(self.handle, v))
-        return {"bytes_per_class": v[0], "used": (v[1], v[2]), "chunks_created": v[3], "chunks_released": v[4],
+        return {"bytes_per_class": v[0], "ranges": v[7], "used": (v[1], v[2], v[8])[: v[7]], "chunks_created": v[3], "chunks_released": v[4],
                 "probe_us_same_class": v[5], "probe_us_two_classes": v[6]}
 
     def alloc(self, shape, cls):
-        """a float32 tensor of `shape` in range `cls` (0 | 1); None when the range is full"""
+        """a float32 tensor of `shape` in range `cls` (0 .. n_classes - 1); None when the range is full"""
         n = 4
         for d in shape:
             n *= int(d)
@@ -86,11 +89,12 @@ class Arena:
         return torch.as_tensor(_Raw(p.value, shape, self), device=self.device)
 
     def class_of(self, t):
-        """0 | 1: `t` shares the class of that range; 2: neither (or too small to tell).  Foreign memory is probed once per buffer."""
+        """c < n_classes: `t` shares the class of range c; n_classes: none of them / mixed / too small to tell.  Foreign memory is probed
+        once per buffer."""
         key = (t.data_ptr(), t.numel() * t.element_size())
         c = self._classes.get(key)
         if c is None:
-            out = ctypes.c_int(2)
+            out = ctypes.c_int(self.n_classes)
             L.check(self._lib.gnnmp_arena_class_of(self.handle, L.ptr(t), key[1], ctypes.byref(out), L.stream_ptr()))
             c = self._classes[key] = out.value
             if len(self._classes) > 256:
@@ -113,29 +117,42 @@ _arena = [None, False]      # the arena, "creation was tried and failed"
 
 
 def arena():
-    """the process-wide arena, created at first use; None if this device does not yield two classes (the layers then allocate as usual)"""
+    """the process-wide arena, created at first use (three ranges if the device shows three classes within the probing budget, else two);
+    None if this device does not yield two classes (the layers then allocate as usual)"""
     if _arena[0] is None and not _arena[1]:
-        try:
-            _arena[0] = Arena()
-        except L.GnnmpError as e:
+        err = None
+        for n in (3, 2):
+            try:
+                _arena[0] = Arena(n_classes=n)
+                break
+            except L.GnnmpError as e:
+                err = e
+        if _arena[0] is None:
             _arena[1] = True
             import warnings
-            warnings.warn(f"gnnmp.placement: no arena ({e}); outputs are allocated as usual")
+            warnings.warn(f"gnnmp.placement: no arena ({err}); outputs are allocated as usual")
     return _arena[0]
 
 
-def buffer_for(layer, tag, shape, avoid_class):
-    """the layer's persistent buffer `tag` of `shape` in an arena range whose class is not `avoid_class`; None: allocate as usual"""
+def buffer_for(layer, tag, shape, avoid):
+    """(the layer's persistent buffer `tag` of `shape` in an arena range whose class is in none of `avoid`, that range); (None, n_classes):
+    allocate as usual.  avoid: the classes of the matrix the kernel gathers from and — with three ranges — of the previous kernel's
+    output (its dirty lines are written back while this kernel runs)."""
     a = arena()
     if a is None:
-        return None, 2
-    cls = 1 if avoid_class == 0 else 0
+        return None, 0
+    avoid = list(avoid)
+    free = [c for c in range(a.n_classes) if c not in avoid]
+    if not free:          # (two ranges, both to be avoided: the gathered matrix's class matters most — callers list it first)
+        free = [c for c in range(a.n_classes) if c != avoid[0]] or [0]
     cache = layer.__dict__.setdefault("_placed", {})
-    key = (tag, tuple(shape), cls)
-    buf = cache.get(key)
-    if buf is None:
-        buf = a.alloc(shape, cls)
+    for cls in free:
+        key = (tag, tuple(shape), cls)
+        buf = cache.get(key)
         if buf is None:
-            return None, 2
-        cache[key] = buf
-    return buf, cls
+            buf = a.alloc(shape, cls)
+            if buf is None:
+                continue
+            cache[key] = buf
+        return buf, cls
+    return None, a.n_classes

@@ -177,22 +177,23 @@ int gnnmp_plan_edge_index(const gnnmp_graph_t *plan, int idx_bytes, int index_ba
  * classes of 96 GiB of physical HBM each; a kernel that gathers ~27 random rows per row it writes (propagate, the fused GCN layer, the
  * one-pass attention) runs 6 % slower when the gathered matrix and the output lie in the SAME class than when they lie in two — and
  * hipMalloc pairs buffers by luck.  The arena creates 2 GiB physical chunks one by one (hipMemCreate), classifies each with a ~140 us probe
- * (a propagate over a synthetic random graph, timed with the chunk as its output) and maps the chunks of TWO different classes into two
- * address ranges:
- *   gnnmp_arena_create(&a, bytes_per_class, max_probe_bytes, stream)   bytes_per_class rounded up to 2 GiB chunks; up to max_probe_bytes
+ * (a propagate over a synthetic random graph, timed with the chunk as its output) and maps the chunks of n_classes = 2 or 3 different
+ * classes into as many address ranges (three let a pipeline keep the PREVIOUS kernel's output — whose dirty lines are still being written
+ * back — out of the class the next kernel gathers from):
+ *   gnnmp_arena_create(&a, bytes_per_class, n_classes, max_probe_bytes, stream)   bytes_per_class rounded up to 2 GiB chunks; up to max_probe_bytes
  *                        (<= 0: 160 GiB) of chunks may be held transiently while two classes are being found (they come in runs of tens of
  *                        GiB); synchronises; GNNMP_EUNSUPPORTED / GNNMP_EALLOC when device memory does not show two classes in that budget
- *   gnnmp_arena_class_of(a, ptr, bytes, &cls, stream)   arena memory: its range (0 | 1), no launch.  Foreign memory (bytes >= 32 MiB): the
- *                        probe with `ptr` as the gathered matrix and the output in either range — 0 | 1 = it shares that range's class,
- *                        2 = neither / too small to tell; synchronises
+ *   gnnmp_arena_class_of(a, ptr, bytes, &cls, stream)   arena memory: its range (0 .. n_classes - 1), no launch.  Foreign memory (bytes >= 128 MiB):
+ *                        the probe with `ptr` as the gathered matrix and the output in every range — c = it shares range c's class,
+ *                        n_classes = none of them / mixed / too small to tell; synchronises
  *   gnnmp_arena_alloc(a, cls, bytes, &ptr)   bump allocation (4 KiB aligned) from range cls; GNNMP_EALLOC when the range is full
  *   gnnmp_arena_reset(a)  forget every allocation (the caller knows nothing uses them any more)
- *   gnnmp_arena_info      [0] bytes per class [1], [2] bytes used in range 0 / 1 [3] chunks created while classifying [4] released again
- *                         [5], [6] the probe's microseconds with source and output in one class / in two
- * Usage: cls = class_of(gathered matrix); out = alloc(cls == 0 ? 1 : 0).  Results do not depend on where buffers lie.
+ *   gnnmp_arena_info      info[9]: [0] bytes per class [1], [2] bytes used in range 0 / 1 [3] chunks created while classifying [4] released again
+ *                         [5], [6] the probe's microseconds with source and output in one class / in two [7] ranges [8] bytes used in range 2
+ * Usage: cls = class_of(gathered matrix); out = alloc(any range != cls).  Results do not depend on where buffers lie.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct gnnmp_arena gnnmp_arena_t;
-int gnnmp_arena_create(gnnmp_arena_t **out, int64_t bytes_per_class, int64_t max_probe_bytes, gnnmp_stream_t stream);
+int gnnmp_arena_create(gnnmp_arena_t **out, int64_t bytes_per_class, int n_classes, int64_t max_probe_bytes, gnnmp_stream_t stream);
 int gnnmp_arena_destroy(gnnmp_arena_t *arena);
 int gnnmp_arena_alloc(gnnmp_arena_t *arena, int cls, int64_t bytes, void **ptr);
 int gnnmp_arena_reset(gnnmp_arena_t *arena);
