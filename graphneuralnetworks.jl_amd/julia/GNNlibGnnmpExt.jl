@@ -66,6 +66,14 @@ mutable struct Plan
         finalizer(p -> (@ccall libgnnmp.gnnmp_plan_destroy(p.handle::Ptr{Cvoid})::Cint), p)
         return p
     end
+    # a handle the library made (gnnmp_plan_select / gnnmp_plan_concat: a pooled plan).  gnnmp_plan_destroy in the finalizer — the pooled
+    # block is then handed out again only after a device synchronisation; `release!` is the stream-ordered path for a loop that knows
+    # when its batch is done (gnnmp_plan_destroy(NULL) is a no-op)
+    function Plan(h::Ptr{Cvoid})
+        p = new(h)
+        finalizer(p -> (@ccall libgnnmp.gnnmp_plan_destroy(p.handle::Ptr{Cvoid})::Cint), p)
+        return p
+    end
 end
 
 # The cache is keyed on the IDENTITY of the two index vectors plus everything else a plan depends on.  (Round 1 keyed a
@@ -521,6 +529,16 @@ mutable struct ChainJobs
         finalizer(j -> (@ccall libgnnmp.gnnmp_chain_jobs_destroy(j.handle::Ptr{Cvoid})::Cint), j)
         return j
     end
+    # packed ON THE DEVICE (no copy of the sizes to the host, no synchronisation): the caller states what it knows on the host — the batch's
+    # nodes, its largest member, whether a member is empty (num_nodes of every member graph is a host integer, gnngraph.jl:108-117)
+    function ChainJobs(seg_ptr::ROCVector{Int64}, G::Int, n_rows::Int, max_graph::Int, has_empty::Bool)
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        check(@ccall libgnnmp.gnnmp_chain_jobs_pack(h::Ptr{Ptr{Cvoid}}, devptr(seg_ptr)::Ptr{Cvoid}, G::Int64, n_rows::Int64,
+                                                    max_graph::Int64, has_empty::Cint, stream_ptr()::Ptr{Cvoid})::Cint)
+        j = new(h[])
+        finalizer(j -> (@ccall libgnnmp.gnnmp_chain_jobs_destroy(j.handle::Ptr{Cvoid})::Cint), j)
+        return j
+    end
 end
 function chain_jobs_info(j::ChainJobs)
     info = zeros(Int64, 5)
@@ -606,6 +624,149 @@ function graphconv_chain(convs::Tuple, pool_aggr, head_weight::ROCMatrix{Float32
     check(st)
     return out
 end
+
+# ---- a NEW batch every step without a sort and without a host synchronisation ----------------------------------------------------------
+# examples/graph_classification_tudataset.jl:70-71, 97-104: DataLoader(...; shuffle = true, collate = true) calls MLUtils.batch(gs[idx])
+# (GNNGraphs/src/transform.jl:682-709) on the CPU and uploads the result, every step.  With the dataset resident on the device —
+# `DeviceDataset(gs)` = batch(gs) |> gpu once, its plan, the node offsets, and the members' sizes as the host integers they already are
+# (gnngraph.jl:108-117) — a step's batch is `batch_from(ds, ids)`: the batch's plan from gnnmp_plan_select (the dst-sorted CSR of a batch is
+# the concatenation of its members' CSRs: two launches), its COO from gnnmp_plan_edge_index, its features from one gnnmp_gather_f32, the
+# fused chain's wave jobs from gnnmp_chain_jobs_pack; the plan and the jobs are registered in the caches above under the new arrays'
+# identities, so every layer call on the returned GNNGraph finds them.  Members appear in the order of `ids`, like batch(gs[ids]).
+struct DeviceDataset{G <: GNNGraph}
+    gall::G                       # MLUtils.batch(all member graphs), COO on the device
+    num_nodes::Vector{Int64}      # of every member graph (host)
+    num_edges::Vector{Int64}
+    node_ptr::ROCVector{Int64}    # 0-based first node of every member graph, G + 1 entries
+end
+function DeviceDataset(gall::GNNGraph{<:COO_T}, num_nodes::Vector{Int64}, num_edges::Vector{Int64})
+    @assert length(num_nodes) == gall.num_graphs == length(num_edges)
+    @assert sum(num_nodes) == gall.num_nodes && sum(num_edges) == gall.num_edges
+    return DeviceDataset(gall, num_nodes, num_edges, ROCVector{Int64}(vcat(0, cumsum(num_nodes))))
+end
+
+adopt_plan(h::Ptr{Cvoid}) = Plan(h)
+function release!(p::Plan)
+    check(@ccall libgnnmp.gnnmp_plan_release(p.handle::Ptr{Cvoid}, stream_ptr()::Ptr{Cvoid})::Cint)
+    p.handle = C_NULL
+    return nothing
+end
+
+function batch_from(ds::DeviceDataset, ids::Vector{Int}; ids_dev::ROCVector{Int64} = ROCVector{Int64}(ids))
+    isempty(ids) && throw(ArgumentError("Cannot batch an empty vector of graphs"))
+    gall = ds.gall
+    k = length(ids)
+    n_rows = sum(@view ds.num_nodes[ids])
+    n_edges = sum(@view ds.num_edges[ids])
+    seg = ROCVector{Int64}(undef, k + 1)
+    nmap = ROCVector{Int32}(undef, n_rows)
+    gi = ROCVector{Int64}(undef, n_rows)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(@ccall libgnnmp.gnnmp_plan_select(h::Ptr{Ptr{Cvoid}}, plan(gall).handle::Ptr{Cvoid}, devptr(ds.node_ptr)::Ptr{Cvoid},
+                                            gall.num_graphs::Int64, devptr(ids_dev)::Ptr{Cvoid}, 8::Cint, 1::Cint, k::Int64,
+                                            n_rows::Int64, n_edges::Int64, devptr(seg)::Ptr{Cvoid}, devptr(nmap)::Ptr{Cvoid},
+                                            devptr(gi)::Ptr{Cvoid}, stream_ptr()::Ptr{Cvoid})::Cint)
+    p = adopt_plan(h[])
+    s, t = ROCVector{Int64}(undef, n_edges), ROCVector{Int64}(undef, n_edges)
+    check(@ccall libgnnmp.gnnmp_plan_edge_index(p.handle::Ptr{Cvoid}, 8::Cint, 1::Cint, devptr(s)::Ptr{Cvoid}, devptr(t)::Ptr{Cvoid},
+                                                stream_ptr()::Ptr{Cvoid})::Cint)
+    x = gall.ndata.x
+    D = size(x, 1)
+    xb = similar(x, D, n_rows)
+    check(@ccall libgnnmp.gnnmp_gather_f32(devptr(x)::Ptr{Cvoid}, devptr(nmap)::Ptr{Cvoid}, 4::Cint, 0::Cint, n_rows::Int64,
+                                           devptr(xb)::Ptr{Cvoid}, D::Int64, stream_ptr()::Ptr{Cvoid})::Cint)
+    g = GNNGraph((s, t, nothing), n_rows, n_edges, k, gi, GNNGraphs.DataStore(n_rows, (; x = xb)), GNNGraphs.DataStore(n_edges),
+                 GNNGraphs.DataStore(k))
+    jobs = ChainJobs(seg, k, n_rows, maximum(@view ds.num_nodes[ids]), any(==(0), @view ds.num_nodes[ids]))
+    lock(PLANS_LOCK) do
+        ent = PlanEntry(p, true)
+        cent = ChainEntry(seg, jobs, true)
+        let ent = ent, cent = cent
+            finalizer(_ -> (@atomic ent.alive = false), s)
+            finalizer(_ -> (@atomic ent.alive = false), t)
+            finalizer(_ -> (@atomic cent.alive = false), gi)
+        end
+        PLANS[PlanKey(objectid(s), objectid(t), n_rows, false, false)] = ent
+        CHAIN_CACHE[objectid(gi)] = cent
+    end
+    return g
+end
+
+# the plan of MLUtils.batch(gs) from the members' cached plans (gnnmp_plan_concat): for a `batch` method on device graphs that keeps the
+# members' plans alive — `gs` are the member graphs (COO on the device), `gb` the batched graph MLUtils.batch built from them
+function register_concat_plan!(gb::GNNGraph{<:COO_T}, gs::Vector{<:GNNGraph}; self_loops::Bool = false)
+    handles = Ptr{Cvoid}[plan(m; self_loops).handle for m in gs]
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve gs begin
+        check(@ccall libgnnmp.gnnmp_plan_concat(h::Ptr{Ptr{Cvoid}}, handles::Ptr{Ptr{Cvoid}}, length(gs)::Int64, C_NULL::Ptr{Cvoid},
+                                                C_NULL::Ptr{Cvoid}, 8::Cint, 1::Cint, stream_ptr()::Ptr{Cvoid})::Cint)
+    end
+    p = adopt_plan(h[])
+    s, t = edge_index(gb)
+    lock(PLANS_LOCK) do
+        ent = PlanEntry(p, true)
+        let ent = ent
+            finalizer(_ -> (@atomic ent.alive = false), s)
+            finalizer(_ -> (@atomic ent.alive = false), t)
+        end
+        PLANS[PlanKey(objectid(s), objectid(t), gb.num_nodes, self_loops, false)] = ent
+    end
+    return p
+end
+
+# ---- the placement arena (csrc/arena.hip): outputs of the gather kernels in a placement class other than their gathered matrix's ---------
+# MI355X: device memory falls into three placement classes; propagate / the fused layers / the one-pass attention run 6 % slower when the
+# matrix they gather from and their output share a class.  `arena_similar(x, dims...)` = similar(x, dims...) from an arena range whose
+# class differs from x's; node features allocated with `arena_array` have a known class from the start.  Arena arrays are bump-allocated
+# and live until `arena_reset!()`: use them for buffers that persist across steps (layer outputs of a fixed shape), not for temporaries.
+mutable struct Arena
+    handle::Ptr{Cvoid}
+    n_classes::Int
+end
+const ARENA = Ref{Union{Nothing, Arena}}(nothing)
+function arena(; gib_per_class::Real = parse(Float64, get(ENV, "GNNMP_ARENA_GIB", "4")))
+    ARENA[] === nothing || return ARENA[]
+    for n in (3, 2)
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        st = @ccall libgnnmp.gnnmp_arena_create(h::Ptr{Ptr{Cvoid}}, round(Int64, gib_per_class * 2.0^30)::Int64, n::Cint,
+                                                0::Int64, stream_ptr()::Ptr{Cvoid})::Cint
+        if st == 0
+            a = Arena(h[], n)
+            finalizer(q -> (@ccall libgnnmp.gnnmp_arena_destroy(q.handle::Ptr{Cvoid})::Cint), a)
+            ARENA[] = a
+            return a
+        end
+    end
+    return nothing                                                 # this device does not show two classes: allocate as usual
+end
+function arena_class_of(x::ROCArray{Float32})
+    a = arena()
+    a === nothing && return 0
+    cls = Ref{Cint}(0)
+    check(@ccall libgnnmp.gnnmp_arena_class_of(a.handle::Ptr{Cvoid}, devptr(x)::Ptr{Cvoid}, sizeof(x)::Int64, cls::Ptr{Cint},
+                                               stream_ptr()::Ptr{Cvoid})::Cint)
+    return Int(cls[])
+end
+function arena_array(dims::Dims, cls::Int)
+    a = arena()
+    a === nothing && return nothing
+    ptr = Ref{Ptr{Cvoid}}(C_NULL)
+    st = @ccall libgnnmp.gnnmp_arena_alloc(a.handle::Ptr{Cvoid}, cls::Cint, (4 * prod(dims))::Int64, ptr::Ptr{Ptr{Cvoid}})::Cint
+    st == 0 || return nothing                                      # range full: the caller allocates as usual
+    return unsafe_wrap(ROCArray, Ptr{Float32}(ptr[]), dims; lock = false)
+end
+function arena_similar(x::ROCArray{Float32}, dims::Int...; avoid = ())
+    a = arena()
+    a === nothing && return similar(x, dims...)
+    bad = (arena_class_of(x), avoid...)
+    for c in 0:(a.n_classes - 1)
+        c in bad && continue
+        y = arena_array(dims, c)
+        y === nothing || return y
+    end
+    return similar(x, dims...)
+end
+arena_reset!() = (a = arena(); a === nothing || check(@ccall libgnnmp.gnnmp_arena_reset(a.handle::Ptr{Cvoid})::Cint); nothing)
 
 # ---- graph-parallel step for batched graphs (SURVEY.md §8e): shard by graph, ONE all-gather of the per-shard logits -----------------
 # Host side of the recipe in INTEGRATION.md §2b.  `sizes` = num_nodes of every member graph BEFORE batching (a host Vector{Int}).
