@@ -43,6 +43,11 @@ struct GatBwdArgs {
     float slope;
     const int32_t *eid;   // DROP: plan slot -> original edge position (of the plan the running pass walks)
     DropArgs drop;
+    // gnnmp_gat_conv_grad2_f32: what the training forward saved (gnnmp_gat_conv_train_f32) — the destination side then needs no edge pass
+    const float *outk;    // [n_dst][D] the forward's output act(o + bias) with act in {identity, relu}
+    const float *bias;    // [D] or null
+    const float *oplus;   // [n_dst][D]
+    const float *pplus;   // [n_dst][H]
 };
 
 __device__ __forceinline__ float lrelu_b(float x, float slope) { return x > 0.0f ? x : x * slope; }
@@ -169,6 +174,58 @@ __global__ void __launch_bounds__(256) gat_bwd_dst_kernel(const GatBwdArgs a) {
     ln[2] = end > beg ? rden : 0.0f;
     ln[3] = S1;
     a.dsd[(int64_t)row * a.H + h] = S2 - S1 * S3;
+}
+
+// The destination side WITHOUT an edge pass (round 4).  With o_i = Σ_j α_ij Wx_j (the forward's output before bias and σ):
+//   D_i = Σ_j α_ij g_ij = Δ_i . o_i                                   (g_ij = Δ_i . Wx_j is linear in Wx_j)
+//   dsd_i = Σ_j α_ij (g_ij - D_i) lrelu'(z_ij),  lrelu' = slope + (1 - slope) [z_ij > 0]
+//         = slope D_i + (1 - slope) Δ_i . o+_i - D_i (slope + (1 - slope) P_i) = (1 - slope) (Δ_i . o+_i - D_i P_i)
+// o+_i / P_i = the same sums over the edges with z_ij > 0 only: the training forward accumulates them next to o_i (gat_fused.hip,
+// ATTN_GAT_PLUS).  o_i is read back from the forward's output act(o_i + b): on entries that relu switched off Δ is zero (the caller
+// passes dL/d(o + b)), elsewhere o = out - b.  One lane group per row, three row loads, three butterflies: 3.8 GB instead of the
+// 5.7 ms gather of every Wx_j.
+template <int VEC, int LPH>
+__global__ void __launch_bounds__(256) gat_bwd_node_kernel(const GatBwdArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int G = 1 << a.log2g;
+    const int lig = lane & (G - 1);
+    const int grp = lane >> a.log2g;
+    const int rpw = 64 >> a.log2g;
+    const int64_t r64 = ((int64_t)blockIdx.x * (blockDim.x >> 6) + wave) * rpw + grp;
+    if (r64 >= a.n_rows) return;
+    const int row = (int)r64;
+    const int f0 = lig * VEC;
+    const bool active = f0 < a.D;
+    const int fc = active ? f0 : 0;
+    const int h = fc / a.C;
+    float vi[VEC], di[VEC], ok[VEC], op[VEC];
+    Vec<VEC>::load(a.Wx_dst + (int64_t)row * a.D + fc, vi);
+    Vec<VEC>::load(a.dout + (int64_t)row * a.D + fc, di);
+    Vec<VEC>::load(a.outk + (int64_t)row * a.D + fc, ok);
+    Vec<VEC>::load(a.oplus + (int64_t)row * a.D + fc, op);
+    const float *ah = a.a + (int64_t)h * 2 * a.C + (fc - h * a.C);
+    float sd = 0.0f, Dv = 0.0f, Tv = 0.0f;
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) {
+        const float d = active ? di[q] : 0.0f;
+        const float o = ok[q] - (a.bias ? a.bias[fc + q] : 0.0f);
+        sd = fmaf(active ? ah[q] : 0.0f, vi[q], sd);
+        Dv = fmaf(d, o, Dv);
+        Tv = fmaf(d, op[q], Tv);
+    }
+    sd = group_sum<LPH>(sd, a.lph);
+    Dv = group_sum<LPH>(Dv, a.lph);
+    Tv = group_sum<LPH>(Tv, a.lph);
+    if (!active || (f0 % a.C) != 0) return;
+    const float m = a.stats[((int64_t)row * a.H + h) * 2];
+    const float den = a.stats[((int64_t)row * a.H + h) * 2 + 1];
+    const bool any = a.rowptr[row + 1] > a.rowptr[row];
+    float *ln = a.line + ((int64_t)row * a.H + h) * 4;
+    ln[0] = sd;
+    ln[1] = m;
+    ln[2] = any ? 1.0f / den : 0.0f;
+    ln[3] = any ? Dv : 0.0f;
+    a.dsd[(int64_t)row * a.H + h] = any ? (1.0f - a.slope) * (Tv - Dv * a.pplus[(int64_t)row * a.H + h]) : 0.0f;
 }
 
 __global__ void __launch_bounds__(256) gat_bwd_dst_combine_kernel(const GatBwdArgs a) {
@@ -416,7 +473,13 @@ static int launch_gat_bwd(GatBwdArgs g, gnnmp_graph *plan, gnnmp_graph *plan_t, 
     // ---- pass 1: destinations (forward plan)
     fill_plan(g, plan);
     g.eid = plan->eid;
-    {
+    if (g.oplus) {        // the training forward saved o+ / P: a node kernel, no edge pass
+        const int64_t blocks = ((int64_t)g.n_rows + (int64_t)rpw * 4 - 1) / ((int64_t)rpw * 4);
+        if (blocks > 0) {
+            gat_bwd_node_kernel<VEC, LPH><<<(unsigned)blocks, 256, 0, stream>>>(g);
+            GNNMP_LAUNCH_CHECK("gat_bwd_node_kernel");
+        }
+    } else {
         const int64_t nvirt = (int64_t)g.n_rows + g.n_chunks;
         const int64_t blocks = (nvirt + (int64_t)rpw * waves - 1) / ((int64_t)rpw * waves);
         if (blocks > 0) {
@@ -485,8 +548,10 @@ using namespace gnnmp;
 static int gat_conv_grad_impl(gnnmp_graph_t *plan, gnnmp_graph_t *plan_t, const float *Wx_src,
                               const float *Wx_dst, const float *a, float negative_slope, float drop_p, uint64_t drop_seed,
                               const float *stats, const float *dout, float *line, float *dsd, float *dss, float *dWx_src,
-                              float *dWx_dst, float *da, int64_t H, int64_t C, gnnmp_stream_t stream_) {
+                              float *dWx_dst, float *da, int64_t H, int64_t C, gnnmp_stream_t stream_, const float *outk = nullptr,
+                              const float *bias = nullptr, const float *oplus = nullptr, const float *pplus = nullptr) {
     hipStream_t stream = (hipStream_t)stream_;
+    if (oplus && (!outk || !pplus || drop_p > 0.0f)) return fail(GNNMP_EINVAL, "gat_conv_grad2: needs out, oplus and pplus of gnnmp_gat_conv_train_f32");
     if (!(drop_p >= 0.0f && drop_p < 1.0f)) return fail(GNNMP_EINVAL, "gat_conv_grad: dropout probability %g outside [0, 1)", (double)drop_p);
     if (!plan || !plan_t) return fail(GNNMP_EINVAL, "gat_conv_grad: null plan");
     if (H <= 0 || C <= 0 || H * C > (1 << 20)) return fail(GNNMP_EINVAL, "gat_conv_grad: bad H/C");
@@ -542,6 +607,12 @@ static int gat_conv_grad_impl(gnnmp_graph_t *plan, gnnmp_graph_t *plan_t, const 
     g.slope = negative_slope;
     g.eid = nullptr;
     g.drop = make_drop(drop_p, drop_seed);
+    g.outk = outk;
+    g.bias = bias;
+    g.oplus = oplus;
+    g.pplus = pplus;
+    if (oplus && ((reinterpret_cast<uintptr_t>(outk) | reinterpret_cast<uintptr_t>(oplus)) & (4 * vec - 1)) != 0)
+        return fail(GNNMP_EINVAL, "gat_conv_grad2: out / oplus not aligned like Wx");
     if (drop_p > 0.0f) {   // the dropout variants walk the head butterfly with the run-time lane count (one instantiation per width)
         if (vec == 4) return launch_gat_bwd<4, 0, true>(g, plan, plan_t, dWx_dst, da, stream);
         if (vec == 2) return launch_gat_bwd<2, 0, true>(g, plan, plan_t, dWx_dst, da, stream);
@@ -575,4 +646,15 @@ extern "C" int gnnmp_gat_conv_grad_drop_f32(gnnmp_graph_t *plan, gnnmp_graph_t *
                                             gnnmp_stream_t stream) {
     return gat_conv_grad_impl(plan, plan_t, Wx_src, Wx_dst, a, negative_slope, p, seed, stats, dout, line, dsd, dss, dWx_src, dWx_dst,
                               da, H, C, stream);
+}
+
+/* The pullback after gnnmp_gat_conv_train_f32 (see gnnmp.h): the destination side is a node kernel on (Δ, out, o+, P), one edge pass
+ * (the source side) instead of two */
+extern "C" int gnnmp_gat_conv_grad2_f32(gnnmp_graph_t *plan, gnnmp_graph_t *plan_t, const float *Wx_src, const float *Wx_dst,
+                                        const float *a, float negative_slope, const float *stats, const float *out, const float *bias,
+                                        const float *oplus, const float *pplus, const float *dout, float *line, float *dsd, float *dss,
+                                        float *dWx_src, float *dWx_dst, float *da, int64_t H, int64_t C, gnnmp_stream_t stream) {
+    if (!out || !oplus || !pplus) return fail(GNNMP_EINVAL, "gat_conv_grad2: null out / oplus / pplus");
+    return gat_conv_grad_impl(plan, plan_t, Wx_src, Wx_dst, a, negative_slope, 0.0f, 0, stats, dout, line, dsd, dss, dWx_src, dWx_dst,
+                              da, H, C, stream, out, bias, oplus, pplus);
 }

@@ -42,6 +42,8 @@ struct GatFusedArgs {
     float *out;           // [n_dst][D]
     float *partial;       // [n_chunks][D + 2*D/VEC]
     float *stats;         // [n_dst][H][2] = (running max m, denominator) of every destination, or null (saved for the adjoint)
+    float *oplus;         // ATTN_GAT_PLUS: [n_dst][D]  o+_i = sum over the neighbours with a POSITIVE pre-activation logit of α_ij Wx_j
+    float *pplus;         // ATTN_GAT_PLUS: [n_dst][H]  P_i = sum of those α_ij            (gat_backward.hip: the pullback's dsd_i from them)
     const int32_t *chunk_row;
     const uint32_t *chunk_beg, *chunk_end;
     const int32_t *long_rows, *long_cptr;
@@ -69,7 +71,14 @@ constexpr int ATTN_GAT_EDGE = 4;
 // keep_ij / (1 - p) * exp(l_ij - m), the denominator and the saved statistics are those of the undropped softmax
 constexpr int ATTN_GAT_DROP = 5;
 constexpr int ATTN_GATV2_DROP = 6;      // the same for gatv2_conv (conv.jl:191)
-__host__ __device__ constexpr bool is_gat(int mode) { return mode == GNNMP_ATTN_GAT || mode == ATTN_GAT_EDGE || mode == ATTN_GAT_DROP; }
+// internal eighth mode: the TRAINING forward of GATConv (gnnmp_gat_conv_train_f32): next to the output and (m, den) it accumulates the
+// same weighted sum restricted to the edges whose logit z_ij = a_d.Wx_i + a_s.Wx_j is positive (leakyrelu' = 1 there, slope elsewhere):
+//   dsd_i = Σ_j α_ij (g_ij - D_i) lrelu'(z_ij) = (1 - slope) (Δ_i . o+_i - D_i P_i)   with  D_i = Δ_i . o_i
+// so the pullback needs NO pass over the destination-sorted edges (gat_backward.hip: gat_bwd_node_kernel)
+constexpr int ATTN_GAT_PLUS = 7;
+__host__ __device__ constexpr bool is_gat(int mode) {
+    return mode == GNNMP_ATTN_GAT || mode == ATTN_GAT_EDGE || mode == ATTN_GAT_DROP || mode == ATTN_GAT_PLUS;
+}
 __host__ __device__ constexpr bool is_gatv2(int mode) { return mode == GNNMP_ATTN_GATV2 || mode == ATTN_GATV2_DROP; }
 __host__ __device__ constexpr bool is_drop(int mode) { return mode == ATTN_GAT_DROP || mode == ATTN_GATV2_DROP; }
 __host__ __device__ constexpr bool needs_eid(int mode) { return mode == ATTN_GAT_EDGE || is_drop(mode); }
@@ -97,8 +106,10 @@ struct LaneRow {
 //   batch within the stretch, n: slots in the stretch.
 template <int VEC, int U, int LPH, int MODE, bool OFF24>
 __device__ __forceinline__ void gat_batch(const GatFusedArgs &a, int c, int ev, int gbase, int j, int n, int fc,
-                                          const LaneRow<VEC> &r, float &m, float &den, float acc[VEC]) {
+                                          const LaneRow<VEC> &r, float &m, float &den, float acc[VEC], float &den2, float acc2[VEC]) {
     constexpr bool edge_term = MODE == ATTN_GAT_EDGE;
+    constexpr bool plus = MODE == ATTN_GAT_PLUS;      // (den2 / acc2 are dead code in every other mode)
+    bool pos[plus ? U : 1];
     float v[U][VEC];                                  // K_j
     float w[MODE == GNNMP_ATTN_DOT ? U : 1][VEC];     // V_j when it is a different array
     float es[U];
@@ -157,6 +168,7 @@ __device__ __forceinline__ void gat_batch(const GatFusedArgs &a, int c, int ev, 
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         float lu = l[u];
+        if (plus) pos[plus ? u : 0] = r.s0 + lu > 0.0f;
         if (is_gat(MODE)) lu = lrelu(edge_term ? (r.s0 + lu) + es[u] : r.s0 + lu, a.slope);
         if (MODE == GNNMP_ATTN_DOT) lu = lu / a.scale;
         if (MODE == GNNMP_ATTN_COS) lu = a.scale * (lu / (r.s0 * sqrtf(nn[u])));
@@ -167,6 +179,11 @@ __device__ __forceinline__ void gat_batch(const GatFusedArgs &a, int c, int ev, 
     den *= sc;
 #pragma unroll
     for (int q = 0; q < VEC; ++q) acc[q] *= sc;
+    if (plus) {
+        den2 *= sc;
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) acc2[q] *= sc;
+    }
     m = mn;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -176,6 +193,12 @@ __device__ __forceinline__ void gat_batch(const GatFusedArgs &a, int c, int ev, 
 #pragma unroll
         for (int q = 0; q < VEC; ++q)
             acc[q] = fmaf(pw, MODE == GNNMP_ATTN_DOT ? w[MODE == GNNMP_ATTN_DOT ? u : 0][q] : v[u][q], acc[q]);
+        if (plus) {
+            const float pp = pos[plus ? u : 0] ? pe : 0.0f;      // (slots past the end: pe = exp(-inf) = 0)
+            den2 += pp;
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) acc2[q] = fmaf(pp, v[u][q], acc2[q]);
+        }
     }
 }
 
@@ -185,7 +208,7 @@ __device__ __forceinline__ void gat_batch(const GatFusedArgs &a, int c, int ev, 
 template <int VEC, int U, int LPH, int MODE, bool OFF24>
 __device__ __forceinline__ void gat_online_range(const GatFusedArgs &a, uint32_t beg, uint32_t end, int lig,
                                                  int gbase, int G, int fc, const LaneRow<VEC> &r,
-                                                 float &m, float &den, float acc[VEC]) {
+                                                 float &m, float &den, float acc[VEC], float &den2, float acc2[VEC]) {
     for (uint32_t base = beg; base < end; base += G) {   // slots are unsigned 32-bit (see csr_reduce.h: reduce_range)
         const uint32_t p = base + lig;
         const int c = p < end ? a.col[p] : 0;
@@ -194,15 +217,15 @@ __device__ __forceinline__ void gat_online_range(const GatFusedArgs &a, uint32_t
         const int ev = (needs_eid(MODE) && p < end) ? a.eid[p] : 0;
         const int n = (int)min((uint32_t)G, end - base);
         int j = 0;
-        for (; j + U <= n; j += U) gat_batch<VEC, U, LPH, MODE, OFF24>(a, c, ev, gbase, j, n, fc, r, m, den, acc);
+        for (; j + U <= n; j += U) gat_batch<VEC, U, LPH, MODE, OFF24>(a, c, ev, gbase, j, n, fc, r, m, den, acc, den2, acc2);
         const int rem = n - j;
         if (rem > 0) {
             if (U >= 8 && rem <= U / 4)
-                gat_batch<VEC, (U >= 8 ? U / 4 : U), LPH, MODE, OFF24>(a, c, ev, gbase, j, n, fc, r, m, den, acc);
+                gat_batch<VEC, (U >= 8 ? U / 4 : U), LPH, MODE, OFF24>(a, c, ev, gbase, j, n, fc, r, m, den, acc, den2, acc2);
             else if (U >= 4 && rem <= U / 2)
-                gat_batch<VEC, (U >= 4 ? U / 2 : U), LPH, MODE, OFF24>(a, c, ev, gbase, j, n, fc, r, m, den, acc);
+                gat_batch<VEC, (U >= 4 ? U / 2 : U), LPH, MODE, OFF24>(a, c, ev, gbase, j, n, fc, r, m, den, acc, den2, acc2);
             else
-                gat_batch<VEC, U, LPH, MODE, OFF24>(a, c, ev, gbase, j, n, fc, r, m, den, acc);
+                gat_batch<VEC, U, LPH, MODE, OFF24>(a, c, ev, gbase, j, n, fc, r, m, den, acc, den2, acc2);
         }
     }
 }
@@ -291,41 +314,54 @@ __global__ void __launch_bounds__(256) gat_fused_rows_kernel(const GatFusedArgs 
         }
     }
 
-    float m = -__builtin_inff(), den = 0.0f;
-    float acc[VEC];
+    constexpr bool plus = MODE == ATTN_GAT_PLUS;
+    float m = -__builtin_inff(), den = 0.0f, den2 = 0.0f;
+    float acc[VEC], acc2[VEC];
 #pragma unroll
-    for (int q = 0; q < VEC; ++q) acc[q] = 0.0f;
+    for (int q = 0; q < VEC; ++q) acc[q] = acc2[q] = 0.0f;
     if (a.off24)
-        gat_online_range<VEC, U, LPH, MODE, true>(a, beg, end, lig, gbase, G, fc, r, m, den, acc);
+        gat_online_range<VEC, U, LPH, MODE, true>(a, beg, end, lig, gbase, G, fc, r, m, den, acc, den2, acc2);
     else
-        gat_online_range<VEC, U, LPH, MODE, false>(a, beg, end, lig, gbase, G, fc, r, m, den, acc);
+        gat_online_range<VEC, U, LPH, MODE, false>(a, beg, end, lig, gbase, G, fc, r, m, den, acc, den2, acc2);
     if (is_chunk) {
         if (active) {
             const int LN = a.D / VEC;
-            float *pc = a.partial + (int64_t)v * (a.D + 2 * LN);
+            float *pc = a.partial + (int64_t)v * (plus ? 2 * a.D + 3 * LN : a.D + 2 * LN);
             Vec<VEC>::store(pc + f0, acc);
             pc[a.D + f0 / VEC] = m;
             pc[a.D + LN + f0 / VEC] = den;
+            if (plus) {
+                Vec<VEC>::store(pc + a.D + 2 * LN + f0, acc2);
+                pc[2 * a.D + 2 * LN + f0 / VEC] = den2;
+            }
         }
         return;
     }
     if (end > beg) {
 #pragma unroll
         for (int q = 0; q < VEC; ++q) acc[q] = acc[q] / den;
+        if (plus) {
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) acc2[q] = acc2[q] / den;
+            den2 = den2 / den;
+        }
     }
     if (a.stats && active && (f0 % a.C) == 0) {
         float *st = a.stats + ((int64_t)row * a.H + f0 / a.C) * 2;
         st[0] = m;
         st[1] = den;
+        if (plus) a.pplus[(int64_t)row * a.H + f0 / a.C] = den2;
     }
+    if (plus && active) Vec<VEC>::store(a.oplus + (int64_t)row * a.D + f0, acc2);
     gat_fused_store<VEC>(a, row, f0, active, acc);
 }
 
 // one BLOCK per long row (see csr_combine_kernel): every lane group merges a contiguous slice of the row's chunk partials
 // (acc, m, den) with the log-sum-exp rescale, the slice results meet in LDS, group 0 merges them in slice order.
-template <int VEC>
+template <int VEC, bool PLUS>
 __global__ void __launch_bounds__(256) gat_fused_combine_kernel(const GatFusedArgs a) {
-    __shared__ float red[256 * (VEC + 2)];
+    constexpr int RS = PLUS ? 2 * VEC + 3 : VEC + 2;        // floats a thread parks in LDS: acc, M, den (, acc2, den2)
+    __shared__ float red[256 * RS];
     const int G = 1 << a.log2g;
     const int lig = threadIdx.x & (G - 1);
     const int grp = threadIdx.x >> a.log2g;
@@ -339,8 +375,8 @@ __global__ void __launch_bounds__(256) gat_fused_combine_kernel(const GatFusedAr
     const int per = (c1 - c0 + NG - 1) / NG;
     const int s0 = min(c1, c0 + grp * per), s1 = min(c1, s0 + per);
     const int LN = a.D / VEC;
-    const int64_t S = a.D + 2 * LN;
-    constexpr int CB = 8;
+    const int64_t S = PLUS ? 2 * a.D + 3 * LN : a.D + 2 * LN;
+    constexpr int CB = PLUS ? 4 : 8;
     const int li = fc / VEC;
     float M = -__builtin_inff();
     for (int c = s0; c < s1; c += CB) {
@@ -350,17 +386,21 @@ __global__ void __launch_bounds__(256) gat_fused_combine_kernel(const GatFusedAr
 #pragma unroll
         for (int u = 0; u < CB; ++u) M = fmaxf(M, mv[u]);
     }
-    float den = 0.0f, acc[VEC];
+    float den = 0.0f, den2 = 0.0f, acc[VEC], acc2[VEC];
 #pragma unroll
-    for (int q = 0; q < VEC; ++q) acc[q] = 0.0f;
+    for (int q = 0; q < VEC; ++q) acc[q] = acc2[q] = 0.0f;
     for (int c = s0; c < s1; c += CB) {
-        float mv[CB], dv[CB], v[CB][VEC];
+        float mv[CB], dv[CB], v[CB][VEC], dv2[PLUS ? CB : 1], v2[PLUS ? CB : 1][VEC];
 #pragma unroll
         for (int u = 0; u < CB; ++u) {
             const float *pc = a.partial + (int64_t)min(c + u, s1 - 1) * S;
             mv[u] = pc[a.D + li];
             dv[u] = pc[a.D + LN + li];
             Vec<VEC>::load(pc + fc, v[u]);
+            if (PLUS) {
+                Vec<VEC>::load(pc + a.D + 2 * LN + fc, v2[PLUS ? u : 0]);
+                dv2[PLUS ? u : 0] = pc[2 * a.D + 2 * LN + li];
+            }
         }
 #pragma unroll
         for (int u = 0; u < CB; ++u) {
@@ -369,34 +409,50 @@ __global__ void __launch_bounds__(256) gat_fused_combine_kernel(const GatFusedAr
                 den = fmaf(dv[u], sc, den);
 #pragma unroll
                 for (int q = 0; q < VEC; ++q) acc[q] = fmaf(v[u][q], sc, acc[q]);
+                if (PLUS) {
+                    den2 = fmaf(dv2[PLUS ? u : 0], sc, den2);
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) acc2[q] = fmaf(v2[PLUS ? u : 0][q], sc, acc2[q]);
+                }
             }
         }
     }
-    float *mine = red + threadIdx.x * (VEC + 2);
+    float *mine = red + threadIdx.x * RS;
 #pragma unroll
     for (int q = 0; q < VEC; ++q) mine[q] = acc[q];
     mine[VEC] = M;
     mine[VEC + 1] = den;
+    if (PLUS) {
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) mine[VEC + 2 + q] = acc2[q];
+        mine[2 * VEC + 2] = den2;
+    }
     __syncthreads();
     if (grp != 0 || !active) return;
     float Mt = M;
     for (int k = 1; k < NG; ++k) {
         if (c0 + k * per >= c1) break;
-        Mt = fmaxf(Mt, red[((k << a.log2g) + lig) * (VEC + 2) + VEC]);
+        Mt = fmaxf(Mt, red[((k << a.log2g) + lig) * RS + VEC]);
     }
     {
         const float sc = expf(M - Mt);
         den *= sc;
+        den2 *= sc;
 #pragma unroll
-        for (int q = 0; q < VEC; ++q) acc[q] *= sc;
+        for (int q = 0; q < VEC; ++q) { acc[q] *= sc; acc2[q] *= sc; }
     }
     for (int k = 1; k < NG; ++k) {
         if (c0 + k * per >= c1) break;
-        const float *o = red + ((k << a.log2g) + lig) * (VEC + 2);
+        const float *o = red + ((k << a.log2g) + lig) * RS;
         const float sc = expf(o[VEC] - Mt);
         den = fmaf(o[VEC + 1], sc, den);
 #pragma unroll
         for (int q = 0; q < VEC; ++q) acc[q] = fmaf(o[q], sc, acc[q]);
+        if (PLUS) {
+            den2 = fmaf(o[2 * VEC + 2], sc, den2);
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) acc2[q] = fmaf(o[VEC + 2 + q], sc, acc2[q]);
+        }
     }
 #pragma unroll
     for (int q = 0; q < VEC; ++q) acc[q] = acc[q] / den;
@@ -404,6 +460,12 @@ __global__ void __launch_bounds__(256) gat_fused_combine_kernel(const GatFusedAr
         float *st = a.stats + ((int64_t)row * a.H + f0 / a.C) * 2;
         st[0] = Mt;
         st[1] = den;
+        if (PLUS) a.pplus[(int64_t)row * a.H + f0 / a.C] = den2 / den;
+    }
+    if (PLUS) {
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) acc2[q] = acc2[q] / den;
+        Vec<VEC>::store(a.oplus + (int64_t)row * a.D + f0, acc2);
     }
     gat_fused_store<VEC>(a, row, f0, true, acc);
 }
@@ -464,7 +526,10 @@ static int launch_gat_fused(GatFusedArgs a, hipStream_t stream) {
         GNNMP_LAUNCH_CHECK("gat_fused_rows_kernel");
     }
     if (a.n_long > 0) {
-        gat_fused_combine_kernel<VEC><<<(unsigned)a.n_long, 256, 0, stream>>>(a);
+        if (MODE == ATTN_GAT_PLUS)
+            gat_fused_combine_kernel<VEC, true><<<(unsigned)a.n_long, 256, 0, stream>>>(a);
+        else
+            gat_fused_combine_kernel<VEC, false><<<(unsigned)a.n_long, 256, 0, stream>>>(a);
         GNNMP_LAUNCH_CHECK("gat_fused_combine_kernel");
     }
     return GNNMP_OK;
@@ -486,8 +551,11 @@ using namespace gnnmp;
 static int attn_conv_impl(gnnmp_graph_t *plan, int mode, const float *Q, const float *K, const float *V, const float *a,
                           float negative_slope, float scale, const float *bias, int act, float *out, float *stats,
                           int64_t H, int64_t C, gnnmp_stream_t stream_, const float *escore = nullptr, float drop_p = 0.0f,
-                          uint64_t drop_seed = 0) {
+                          uint64_t drop_seed = 0, float *oplus = nullptr, float *pplus = nullptr) {
     hipStream_t stream = (hipStream_t)stream_;
+    const bool plus = oplus != nullptr;
+    if (plus && (mode != GNNMP_ATTN_GAT || !stats || !pplus || escore || drop_p > 0.0f))
+        return fail(GNNMP_EINVAL, "gat_conv_train: needs stats, oplus and pplus; plain GAT logits only");
     if (!plan) return fail(GNNMP_EINVAL, "attn_conv: null plan");
     if (!(drop_p >= 0.0f && drop_p < 1.0f)) return fail(GNNMP_EINVAL, "gat_conv: dropout probability %g outside [0, 1)", (double)drop_p);
     if (drop_p > 0.0f && ((mode != GNNMP_ATTN_GAT && mode != GNNMP_ATTN_GATV2) || escore))
@@ -515,7 +583,7 @@ static int attn_conv_impl(gnnmp_graph_t *plan, int mode, const float *Q, const f
     while ((1 << log2g) < lanes) ++log2g;   // one feature tile: the head butterfly needs the whole row in one group
     if (H == 1 && lanes <= 64) lph = 1 << log2g;   // a single head may spill over idle lanes: they carry zeros
     if (lanes > 64) {
-        if (mode != GNNMP_ATTN_GAT || stats || escore || drop_p > 0.0f)
+        if (mode != GNNMP_ATTN_GAT || stats || escore || drop_p > 0.0f || plus)
             return fail(GNNMP_EUNSUPPORTED,
                         "attn_conv: the one-pass kernel needs a feature row that fits one wave (H*C = %lld lanes %d > 64)",
                         (long long)(H * C), lanes);
@@ -528,9 +596,11 @@ static int attn_conv_impl(gnnmp_graph_t *plan, int mode, const float *Q, const f
         return gnnmp_gat_aggregate_f32(plan, K, sdst, ssrc, negative_slope, bias, act, out, nullptr, H, C, stream_);
     }
     if (plan->n_chunks > 0) {
-        if (int rc = ensure_workspace(plan, (size_t)plan->n_chunks * (size_t)(D + 2 * lanes))) return rc;
+        if (int rc = ensure_workspace(plan, (size_t)plan->n_chunks * (size_t)(plus ? 2 * D + 3 * lanes : D + 2 * lanes))) return rc;
     }
     GatFusedArgs g;
+    g.oplus = oplus;
+    g.pplus = pplus;
     g.rowptr = plan->rowptr;
     g.row_order = nullptr;
     if (use_row_order(plan->n_src, D) && lanes <= 32) {   // two or more rows per wave: pair rows of equal length
@@ -573,6 +643,7 @@ static int attn_conv_impl(gnnmp_graph_t *plan, int mode, const float *Q, const f
     g.drop = make_drop(drop_p, drop_seed);
     if (drop_p > 0.0f)
         return mode == GNNMP_ATTN_GATV2 ? launch_mode<ATTN_GATV2_DROP>(g, vec, stream) : launch_mode<ATTN_GAT_DROP>(g, vec, stream);
+    if (plus) return launch_mode<ATTN_GAT_PLUS>(g, vec, stream);
     switch (mode) {
         case GNNMP_ATTN_GATV2: return launch_mode<GNNMP_ATTN_GATV2>(g, vec, stream);
         case GNNMP_ATTN_DOT: return launch_mode<GNNMP_ATTN_DOT>(g, vec, stream);
@@ -593,6 +664,14 @@ extern "C" int gnnmp_gat_conv_stats_f32(gnnmp_graph_t *plan, const float *Wx_src
     if (!stats) return fail(GNNMP_EINVAL, "gat_conv_stats: null stats");
     return attn_conv_impl(plan, GNNMP_ATTN_GAT, Wx_dst, Wx_src, nullptr, a, negative_slope, 1.0f, bias, act, out, stats, H,
                           C, stream);
+}
+/* the training forward: out, (m, den), and what lets the pullback skip its destination-side edge pass (see ATTN_GAT_PLUS above) */
+extern "C" int gnnmp_gat_conv_train_f32(gnnmp_graph_t *plan, const float *Wx_src, const float *Wx_dst, const float *a,
+                                        float negative_slope, const float *bias, int act, float *out, float *stats, float *oplus,
+                                        float *pplus, int64_t H, int64_t C, gnnmp_stream_t stream) {
+    if (!stats || !oplus || !pplus) return fail(GNNMP_EINVAL, "gat_conv_train: null stats / oplus / pplus");
+    return attn_conv_impl(plan, GNNMP_ATTN_GAT, Wx_dst, Wx_src, nullptr, a, negative_slope, 1.0f, bias, act, out, stats, H, C, stream,
+                          nullptr, 0.0f, 0, oplus, pplus);
 }
 extern "C" int gnnmp_gat_conv_edge_f32(gnnmp_graph_t *plan, const float *Wx_src, const float *Wx_dst, const float *a,
                                        const float *edge_score, float negative_slope, const float *bias, int act,

@@ -32,6 +32,7 @@ SYMBOLS = (
     "gnnmp_degree_f32", "gnnmp_inv_sqrt_f32",
     "gnnmp_edge_softmax_f32", "gnnmp_segment_softmax_f32", "gnnmp_gat_node_scores_f32", "gnnmp_gat_aggregate_f32", "gnnmp_gat_conv_f32",
     "gnnmp_gat_conv_edge_f32", "gnnmp_gat_conv_stats_f32", "gnnmp_gat_conv_grad_f32", "gnnmp_attn_conv_f32",
+    "gnnmp_gat_conv_train_f32", "gnnmp_gat_conv_grad2_f32",
     "gnnmp_gat_conv_drop_f32", "gnnmp_dropout_keep_u8", "gnnmp_gat_conv_grad_drop_f32", "gnnmp_attn_conv_drop_f32", "gnnmp_attn_conv_grad_drop_f32",
     "gnnmp_attn_conv_grad_f32",
     "gnnmp_bias_act_f32",
@@ -109,6 +110,8 @@ def load():
         "gnnmp_gat_conv_f32": [vp, vp, vp, vp, f, vp, i, vp, i64, i64, vp],
         "gnnmp_gat_conv_edge_f32": [vp, vp, vp, vp, vp, f, vp, i, vp, i64, i64, vp],
         "gnnmp_gat_conv_stats_f32": [vp, vp, vp, vp, f, vp, i, vp, vp, i64, i64, vp],
+        "gnnmp_gat_conv_train_f32": [vp, vp, vp, vp, f, vp, i, vp, vp, vp, vp, i64, i64, vp],
+        "gnnmp_gat_conv_grad2_f32": [vp, vp, vp, vp, vp, f, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, vp],
         "gnnmp_attn_conv_f32": [vp, i, vp, vp, vp, vp, f, f, vp, i, vp, vp, i64, i64, vp],
         "gnnmp_attn_conv_grad_f32": [vp, vp, i, vp, vp, vp, vp, f, f, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, vp],
         "gnnmp_gat_conv_grad_f32": [vp, vp, vp, vp, vp, f, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, vp],

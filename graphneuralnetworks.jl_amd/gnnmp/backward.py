@@ -378,9 +378,14 @@ class _GATConvFn(torch.autograd.Function):
                                                 L.ptr(bias) if concat else None, _act_code(sigma) if concat else L.ACT_IDENTITY,
                                                 L.ptr(out), L.ptr(stats), H, C, L.stream_ptr()))
         else:
-            L.check(lib.gnnmp_gat_conv_stats_f32(plan.handle, L.ptr(Wx), None, L.ptr(a_hc), float(slope),
+            # the training forward also saves o+ / P (csrc/gat_fused.hip ATTN_GAT_PLUS): the pullback's destination side is then a node
+            # kernel, not an edge pass (csrc/gat_backward.hip: gat_bwd_node_kernel)
+            oplus = torch.empty((N, H * C), dtype=torch.float32, device=x.device)
+            pplus = torch.empty((N, H), dtype=torch.float32, device=x.device)
+            L.check(lib.gnnmp_gat_conv_train_f32(plan.handle, L.ptr(Wx), None, L.ptr(a_hc), float(slope),
                                                  L.ptr(bias) if concat else None, _act_code(sigma) if concat else L.ACT_IDENTITY,
-                                                 L.ptr(out), L.ptr(stats), H, C, L.stream_ptr()))
+                                                 L.ptr(out), L.ptr(stats), L.ptr(oplus), L.ptr(pplus), H, C, L.stream_ptr()))
+            ctx.plus = (oplus, pplus, out, bias if concat else None)
         if not concat:
             y = torch.empty((N, C), dtype=torch.float32, device=x.device)
             L.check(lib.gnnmp_head_mean_f32(L.ptr(out), L.ptr(bias), _act_code(sigma), L.ptr(y), N, H, C, L.stream_ptr()))
@@ -389,6 +394,8 @@ class _GATConvFn(torch.autograd.Function):
         ctx.g, ctx.sigma, ctx.H, ctx.C, ctx.slope, ctx.loops, ctx.has_bias = g, sigma, H, C, slope, add_self_loops, bias is not None
         ctx.concat = concat
         ctx.p_drop, ctx.seed = float(p_drop), int(seed)
+        if p_drop > 0.0:
+            ctx.plus = None
         return out
 
     @staticmethod
@@ -417,9 +424,10 @@ class _GATConvFn(torch.autograd.Function):
                                                      ctx.p_drop, ctx.seed, L.ptr(stats), L.ptr(dz), L.ptr(line), L.ptr(dsd),
                                                      L.ptr(dss), L.ptr(dWx), None, L.ptr(da_hc), H, C, L.stream_ptr()))
         else:
-            L.check(lib.gnnmp_gat_conv_grad_f32(plan.handle, plan_t.handle, L.ptr(Wx), None, L.ptr(a_hc), float(ctx.slope),
-                                                L.ptr(stats), L.ptr(dz), L.ptr(line), L.ptr(dsd), L.ptr(dss), L.ptr(dWx), None,
-                                                L.ptr(da_hc), H, C, L.stream_ptr()))
+            oplus, pplus, outk, bk = ctx.plus
+            L.check(lib.gnnmp_gat_conv_grad2_f32(plan.handle, plan_t.handle, L.ptr(Wx), None, L.ptr(a_hc), float(ctx.slope),
+                                                 L.ptr(stats), L.ptr(outk), L.ptr(bk), L.ptr(oplus), L.ptr(pplus), L.ptr(dz), L.ptr(line),
+                                                 L.ptr(dsd), L.ptr(dss), L.ptr(dWx), None, L.ptr(da_hc), H, C, L.stream_ptr()))
         dW = dense_grad_w(dWx, x, need_b=False)[0] if ctx.needs_input_grad[1] else None
         dx = dense_grad_x(dWx, weight) if ctx.needs_input_grad[0] else None
         return dx, dW, da_hc.t(), db, None, None, None, None, None, None, None, None

@@ -434,6 +434,21 @@ int gnnmp_gat_conv_stats_f32(gnnmp_graph_t *plan, const float *Wx_src, const flo
  * fit one wave and there are no edge features (GNNMP_EUNSUPPORTED otherwise).  A fresh seed per call gives the reference's behaviour;
  * the same seed must be handed to gnnmp_gat_conv_grad_drop_f32.
  * gnnmp_dropout_keep_u8 writes that mask, keep[e][h] in {0, 1}, for n_edges edge positions (tests, or a caller that wants α .* mask). */
+/* The TRAINING forward of GATConv and its pullback with ONE edge pass (round 4).  With o_i = Σ_j α_ij Wx_j the softmax rrule's
+ * D_i = Σ_j α_ij (Δ_i . Wx_j) is Δ_i . o_i, and dsd_i = Σ_j α_ij (g_ij - D_i) lrelu'(z_ij) = (1 - slope) (Δ_i . o+_i - D_i P_i) with
+ * o+_i / P_i the same sums restricted to the edges whose logit z_ij is positive — so the forward also writes oplus [n_dst][H*C] and pplus
+ * [n_dst][H] (4 bytes per feature and node more), and the destination side of the pullback becomes a node kernel on (dout, out, oplus,
+ * pplus): the gather of every Wx_j by destination (5.7 ms on the products shape) is gone; the source-side pass, dWx, dss, da are those of
+ * gnnmp_gat_conv_grad_f32.  `out` / `bias` of grad2 are the forward's output act(o + bias) and its bias (act = identity | relu): o is read
+ * back as out - bias, which is exact wherever dout is not zero when dout = dL/d(o + bias) (relu's switched-off entries carry dout = 0).
+ * No dropout, no edge features (those keep gnnmp_gat_conv_stats_f32 / gnnmp_gat_conv_grad_f32). */
+int gnnmp_gat_conv_train_f32(gnnmp_graph_t *plan, const float *Wx_src, const float *Wx_dst, const float *a, float negative_slope,
+                             const float *bias, int act, float *out, float *stats, float *oplus, float *pplus, int64_t H, int64_t C,
+                             gnnmp_stream_t stream);
+int gnnmp_gat_conv_grad2_f32(gnnmp_graph_t *plan, gnnmp_graph_t *plan_t, const float *Wx_src, const float *Wx_dst, const float *a,
+                             float negative_slope, const float *stats, const float *out, const float *bias, const float *oplus,
+                             const float *pplus, const float *dout, float *line, float *dsd, float *dss, float *dWx_src, float *dWx_dst,
+                             float *da, int64_t H, int64_t C, gnnmp_stream_t stream);
 int gnnmp_gat_conv_drop_f32(gnnmp_graph_t *plan, const float *Wx_src, const float *Wx_dst, const float *a,
                             float negative_slope, float p, uint64_t seed, const float *bias, int act, float *out,
                             float *stats, int64_t H, int64_t C, gnnmp_stream_t stream);

@@ -71,3 +71,9 @@ tb = t(lambda: L.check(lib.gnnmp_gat_conv_grad_f32(plan.handle, plan_t.handle, L
 Ep = E + N
 alg = Ep * (512 + 4) + N * (3 * 512 + 64 + 32) + Ep * (512 + 128 + 4) + N * (2 * 512 + 64)
 print(f"GAT attention: forward+stats {tf:.3f} ms | adjoint (2 edge passes + da) {tb:.3f} ms = {alg/tb/1e6:.0f} GB/s algorithmic")
+# round 4: the training forward (out, stats, o+, P) and the one-edge-pass pullback (node kernel + source pass + da)
+op = torch.empty((N, 128), device="cuda"); pp = torch.empty((N, H), device="cuda")
+tf2 = t(lambda: L.check(lib.gnnmp_gat_conv_train_f32(plan.handle, L.ptr(Wx), None, L.ptr(a_hc), 0.2, None, 0, L.ptr(out), L.ptr(stats), L.ptr(op), L.ptr(pp), H, C, L.stream_ptr())))
+tb2 = t(lambda: L.check(lib.gnnmp_gat_conv_grad2_f32(plan.handle, plan_t.handle, L.ptr(Wx), None, L.ptr(a_hc), 0.2, L.ptr(stats), L.ptr(out), None, L.ptr(op), L.ptr(pp), L.ptr(dyg), L.ptr(line), L.ptr(dsd), L.ptr(dss), L.ptr(dWx), None, L.ptr(da), H, C, L.stream_ptr())))
+print(f"GAT attention, round 4: training forward (+ o+, P) {tf2:.3f} ms | adjoint (node kernel + 1 edge pass + da) {tb2:.3f} ms")
+
