@@ -122,7 +122,7 @@ def hub_graph(rng, n, E):
     return s[p], t[p]
 
 
-def close(got, ref, tol=3e-5):
+def close(got, ref, tol=1e-5):
     got = got.detach().cpu().numpy() if hasattr(got, "detach") else got
     assert got.shape == ref.shape
     if np.linalg.norm(ref) < 1e-6:

@@ -2,7 +2,7 @@
 (csrc/gat_fused.hip, mode ATTN_GAT_DROP) and its pullback (csrc/gat_backward.hip).  The reference's mask comes from Julia's RNG, so the
 draws cannot be matched; what is checked: (1) the mask is the documented function of (seed, edge, head) — known answers computed from
 the header's definition with plain Python integers (tests/golden/dropout_keep.json), the oracle's numpy restatement and the HIP code
-all agree — and Bernoulli(1 - p); (2) GIVEN that mask, forward and gradients are the reference's formulas (oracle) to 1e-5 / 3e-5."""
+all agree — and Bernoulli(1 - p); (2) GIVEN that mask, forward and gradients are the reference's formulas (oracle) to 1e-5 (forward) / 1e-5 (gradients: tightened from 3e-5 in round 4)."""
 import json
 import os
 
@@ -205,7 +205,7 @@ def test_backward_vs_oracle_given_the_mask(gm, oracle, H, C, Din, sigma, concat)
     for name, got, ref in (("dx", xt.grad, dx), ("dW", l.dense_x_weight.grad, dW), ("da", l.a.grad, da), ("db", l.bias.grad, db)):
         gotn = got.cpu().numpy()
         assert gotn.shape == ref.shape, name
-        assert np.linalg.norm(gotn - ref) <= 3e-5 * np.linalg.norm(ref), name
+        assert np.linalg.norm(gotn - ref) <= 1e-5 * np.linalg.norm(ref), name
     # run-to-run identical with the same seed
     xt2 = dev(x).requires_grad_(True)
     (gat_conv_ad(l, g, xt2, seed=seed) * dev(r)).sum().backward()
@@ -291,4 +291,4 @@ def test_gatv2_dropout_forward_and_backward_vs_oracle(gm, H, C, Din, sigma, conc
         if np.linalg.norm(gref) < 1e-6:
             assert np.linalg.norm(gotn) <= 1e-3, name
         else:
-            assert np.linalg.norm(gotn - gref) <= 3e-5 * np.linalg.norm(gref), name
+            assert np.linalg.norm(gotn - gref) <= 1e-5 * np.linalg.norm(gref), name

@@ -102,7 +102,7 @@ def test_the_binding_covers_the_reference_seam():
         assert f"ChainRulesCore.rrule(::typeof({wrapped})" in src, f"no rrule for {wrapped}"
     assert "objectid(s), objectid(t), g.num_nodes, self_loops" in src      # the cache key (round 1 keyed on s alone)
     assert "WeakKeyDict" not in "\n".join(l for l in src.splitlines() if not l.lstrip().startswith("#"))
-    assert "gnnmp_fused_conv_f32" in src and "gnnmp_gat_conv_grad_f32" in src
+    assert "gnnmp_fused_conv_f32" in src and "gnnmp_gat_conv_grad2_f32" in src and "gnnmp_gat_conv_train_f32" in src
 
 
 # ---- what a Julia parser / method table would have told us: checked statically ------------------------------------
