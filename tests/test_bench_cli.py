@@ -47,4 +47,4 @@ def test_byte_models():
     for k in ("gat_fused_rows_kernel", "fused_conv_kernel"):
         assert doc["products"][k]["hbm_read_bytes"] > 0 and doc["products"][k]["round"] == "r04"
         t, src = bench.traffic_from_profiles("products", k)
-        assert t == doc["products"][k]["hbm_read_bytes"] + doc["products"][k]["hbm_write_bytes"] and src["round"] == "r03"
+        assert t == doc["products"][k]["hbm_read_bytes"] + doc["products"][k]["hbm_write_bytes"] and src["round"] == "r04"
