@@ -515,6 +515,9 @@ def main():
         step()
         torch.cuda.synchronize()
         arena_ms = (time.perf_counter() - t0) * 1e3
+        for _ in range(12):        # the layers time themselves on their candidate buffers (three calls each) and keep the fastest
+            step()
+            torch.cuda.synchronize()
 
     # ---- events around the two candidate dominant kernels (recorded on the launch stream) --------------------
     lib = L.load()
@@ -644,6 +647,8 @@ def main():
     extras["placement"] = {"enabled": ar is not None, "arena": (ar.info() if ar is not None else None),
                            "arena_create_and_first_step_ms": (arena_ms if not args.no_placement else None),
                            "class_of_x": (ar.class_of(x) if ar is not None else None),
+                           "trials_ms": {name: {k[0]: ch.times_ms for k, ch in getattr(layer, "_placed", {}).items() if hasattr(ch, "times_ms")}
+                                         for name, layer in (("gcn", gcn), ("gat", gat))},
                            "note": "outputs of the two gather kernels live in a placement class other than their gathered matrix's "
                                    "(csrc/arena.hip: 2 GiB physical chunks classified by a 140 us probe)"}
     if not args.no_placement:

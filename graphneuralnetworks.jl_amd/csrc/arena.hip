@@ -7,10 +7,11 @@
 // predecessors on the stream): the writes land on the dies the read stream is saturating.  hipMalloc does not say where memory lies, and a
 // single allocation is a patchwork of power-of-two blocks of any class, so two ordinary allocations pair up by luck (box-to-box "noise").
 //
-// The arena takes the luck out: physical chunks of 2 GiB are created one by one (hipMemCreate), classified by timing a small probe — a
-// propagate(copy_xj, +) over a synthetic random graph, 262 144 rows x 26 sources of 512 bytes, ~550 us, 7 % apart between the two cases —
-// and the chunks of two different classes are mapped back to back into two address ranges (hipMemMap).  A caller (the host mirror's layers,
-// the Julia extension) allocates a layer's output from the range whose class differs from the gathered matrix's class:
+// The arena takes the luck out: blocks of 4 GiB are allocated one by one (plain hipMalloc), classified where they lie by timing a small probe
+// — a propagate(copy_xj, +) over a synthetic random graph, 262 144 rows x 26 sources of 512 bytes out of a reference block, ~550 us, 10 %
+// apart between "output in the reference's class" and "not" — at both halves of the block; blocks of the three (or two) classes are kept,
+// the others freed at the end.  A caller (the host mirror's layers, the Julia extension) allocates a layer's output from a block whose
+// class differs from the gathered matrix's class:
 //     gnnmp_arena_class_of(arena, x)            -> 0 / 1 (x is in that arena class), 2 (in neither: any range is fine)
 //     gnnmp_arena_alloc(arena, 1 - cls, bytes)  -> the output buffer
 // The C ABI's rule — the caller allocates — stands: this is an allocator the caller MAY use.  Creation synchronises (graph prep); alloc
@@ -24,23 +25,22 @@
 #include "common.h"
 
 struct gnnmp_arena {
-    int64_t chunk_bytes = 0;
-    int n_classes = 2;                                 // ranges that exist (2 | 3)
-    int n_chunks[3] = {0, 0, 0};
-    std::vector<hipMemGenericAllocationHandle_t> handles[3];
-    unsigned char *base[3] = {nullptr, nullptr, nullptr};      // the mapped ranges
-    int64_t cap[3] = {0, 0, 0}, used[3] = {0, 0, 0};
+    int64_t block_bytes = 0;
+    int n_classes = 2;                                 // classes that exist (2 | 3)
+    struct Block { unsigned char *p; int64_t used; };
+    std::vector<Block> blocks[3];                      // per class: plain hipMalloc'd blocks whose two halves probed alike
+    int64_t cap = 0;                                   // bytes per class
     gnnmp_graph_t *probe_plan = nullptr;               // the synthetic graph of the probe (sources in [0, probe_nsrc))
     int64_t probe_nsrc = 0;
     int dev = 0;
-    int64_t created = 0, released = 0;                 // chunks made / given back during classification
-    float probe_same_us = 0.0f, probe_other_us = 0.0f; // what the probe measured on the reference pair (info)
+    int64_t created = 0, released = 0;                 // blocks made / given back during classification
+    float probe_same_us = 0.0f, probe_other_us = 0.0f; // what the probe measured (info)
     std::mutex lock;
 };
 
 namespace gnnmp {
 namespace {
-constexpr int64_t CHUNK = (int64_t)2 << 30;
+constexpr int64_t CHUNK = (int64_t)4 << 30;      // a block: one hipMalloc; classified by its two halves
 constexpr int PROBE_ROWS = 262144, PROBE_DEG = 26, PROBE_D = 128;    // 512-byte rows like the attention kernel's; the two cases are 5 % apart at 65 536 rows, 7 % here
 
 __global__ void probe_edges_kernel(int64_t n_src, int64_t *src, int64_t *dst) {
@@ -49,23 +49,6 @@ __global__ void probe_edges_kernel(int64_t n_src, int64_t *src, int64_t *dst) {
     const uint32_t r = drop_mix32(drop_mix32((uint32_t)e ^ 0x9e3779b9u) + 0x7f4a7c15u);
     src[e] = (int64_t)(((uint64_t)r * (uint64_t)n_src) >> 32) + 1;
     dst[e] = e / PROBE_DEG + 1;
-}
-
-hipMemAllocationProp chunk_prop(int dev) {
-    hipMemAllocationProp p = {};
-    p.type = hipMemAllocationTypePinned;
-    p.location.type = hipMemLocationTypeDevice;
-    p.location.id = dev;
-    return p;
-}
-hipError_t map_rw(void *va, size_t size, hipMemGenericAllocationHandle_t h, int dev) {
-    hipError_t e = hipMemMap(va, size, 0, h, 0);
-    if (e != hipSuccess) return e;
-    hipMemAccessDesc d = {};
-    d.location.type = hipMemLocationTypeDevice;
-    d.location.id = dev;
-    d.flags = hipMemAccessFlagsProtReadWrite;
-    return hipMemSetAccess(va, size, &d, 1);
 }
 
 // median of `reps` timed launches of the probe: source rows at `src`, output at `out` (PROBE_ROWS x PROBE_D floats); microseconds
@@ -96,6 +79,17 @@ int probe_us(gnnmp_arena *a, const float *src, float *out, hipStream_t stream, f
     return GNNMP_OK;
 }
 
+// a block under test, probed at its start and at its middle (an allocation is a patchwork of whatever physical blocks were free: only
+// blocks whose two halves agree are used); *lo / *hi = the smaller / larger of the two times
+int probe_chunk(gnnmp_arena *a, const float *src, unsigned char *chunk, hipStream_t stream, float *lo, float *hi) {
+    float t0 = 0.0f, t1 = 0.0f;
+    int rc = probe_us(a, src, reinterpret_cast<float *>(chunk), stream, &t0);
+    if (rc == GNNMP_OK) rc = probe_us(a, src, reinterpret_cast<float *>(chunk + CHUNK / 2), stream, &t1);
+    *lo = std::min(t0, t1);
+    *hi = std::max(t0, t1);
+    return rc;
+}
+
 int make_probe_plan(gnnmp_arena *a, int64_t n_src, hipStream_t stream) {
     if (a->probe_plan && a->probe_nsrc == n_src) return GNNMP_OK;
     if (a->probe_plan) { gnnmp_plan_destroy(a->probe_plan); a->probe_plan = nullptr; }
@@ -118,14 +112,8 @@ extern "C" {
 
 int gnnmp_arena_destroy(gnnmp_arena_t *a) {
     if (!a) return GNNMP_OK;
-    (void)hipDeviceSynchronize();
-    for (int c = 0; c < 3; ++c) {
-        for (size_t i = 0; i < a->handles[c].size(); ++i) {
-            if (a->base[c]) (void)hipMemUnmap(a->base[c] + (int64_t)i * a->chunk_bytes, (size_t)a->chunk_bytes);
-            (void)hipMemRelease(a->handles[c][i]);
-        }
-        if (a->base[c]) (void)hipMemAddressFree(a->base[c], (size_t)a->cap[c]);
-    }
+    for (int c = 0; c < 3; ++c)
+        for (auto &b : a->blocks[c]) (void)hipFree(b.p);      // (hipFree waits for the device)
     if (a->probe_plan) gnnmp_plan_destroy(a->probe_plan);
     delete a;
     return GNNMP_OK;
@@ -137,148 +125,121 @@ int gnnmp_arena_create(gnnmp_arena_t **out, int64_t bytes_per_class, int n_class
     *out = nullptr;
     gnnmp_arena *a = new gnnmp_arena();
     (void)hipGetDevice(&a->dev);
-    a->chunk_bytes = CHUNK;
+    a->block_bytes = CHUNK;
     a->n_classes = n_classes;
     const int need = (int)((bytes_per_class + CHUNK - 1) / CHUNK);
+    a->cap = (int64_t)need * CHUNK;
     if (max_probe_bytes <= 0) max_probe_bytes = (int64_t)160 << 30;
-    const int max_chunks = (int)std::max<int64_t>((int64_t)n_classes * need, max_probe_bytes / CHUNK);
-    const hipMemAllocationProp prop = chunk_prop(a->dev);
-    // a scratch range where chunks are mapped one at a time while they are classified, + the reference chunk of class 0
-    unsigned char *scratch = nullptr;
-    std::vector<hipMemGenericAllocationHandle_t> spare;      // chunks of a class that is already full (or of the third class): released at the end
-    std::vector<unsigned char *> test_mapped;                // test addresses that still hold a chunk
+    const int max_blocks = (int)std::max<int64_t>((int64_t)n_classes * need, max_probe_bytes / CHUNK);
+    // Blocks are plain hipMalloc allocations, each classified where it lies and then kept or freed — no remapping.  (A first version built
+    // the ranges out of hipMemCreate chunks moved between addresses with hipMemMap / hipMemUnmap: translations of an unmapped range
+    // outlived the unmap — 80 different chunks probed through one address measured alike — and two runs in six ended in a GPU memory
+    // fault.)  A block is used only if its two halves probe alike (a 4 GiB allocation is usually one physical block, but need not be).
+    struct Pend { unsigned char *p; float lo, hi; };
+    std::vector<Pend> pending;
+    std::vector<unsigned char *> spare;                      // blocks of a class that is full / mixed blocks: freed at the end (freeing
+                                                             // one earlier would hand the same physical memory out again)
     int rc = GNNMP_OK;
-    hipError_t e = hipSuccess;
-#define ARENA_HIP(expr) do { e = (expr); if (e != hipSuccess) { rc = hip_fail(e, #expr); goto done; } } while (0)
-    for (int c = 0; c < n_classes; ++c) {
-        a->cap[c] = (int64_t)need * CHUNK;
-        ARENA_HIP(hipMemAddressReserve((void **)&a->base[c], (size_t)a->cap[c], (size_t)2 << 20, nullptr, 0));
-    }
-    // every chunk under test gets an address of its OWN (slot = its creation number): probing different chunks one after the other through ONE
-    // address measured the first chunk every time — 80 chunks, one time (the translation of an unmapped range outlives the unmap)
-    ARENA_HIP(hipMemAddressReserve((void **)&scratch, (size_t)max_chunks * (size_t)CHUNK, (size_t)2 << 20, nullptr, 0));
-    rc = make_probe_plan(a, CHUNK / (PROBE_D * 4), stream);
-    if (rc != GNNMP_OK) goto done;
-    {
-        // chunk 0 is class 0 by definition and the probe's source from now on
-        hipMemGenericAllocationHandle_t h0 = nullptr;
-        ARENA_HIP(hipMemCreate(&h0, (size_t)CHUNK, &prop, 0));
-        ++a->created;
-        a->handles[0].push_back(h0);
-        ARENA_HIP(map_rw(a->base[0], (size_t)CHUNK, h0, a->dev));
-        ARENA_HIP(hipMemsetAsync(a->base[0], 0, (size_t)CHUNK, stream));
-        const float *ref0 = reinterpret_cast<const float *>(a->base[0]);
-        const float *ref1 = nullptr;            // the first chunk of class 1, once found
-        // Every further chunk is timed as the probe's OUTPUT against chunk 0.  The times fall into two clusters ~5 % apart (run-to-run
-        // spread ~1 %): the slow one = chunk 0's class.  Until both clusters have shown up nothing is decided (`pending`).
-        struct Pend { hipMemGenericAllocationHandle_t h; float us0; unsigned char *va; };      // va: where the chunk is mapped while under test
-        std::vector<Pend> pending;
-        float lo = 0.0f, hi = 0.0f, thr = 0.0f;
-        auto place = [&](hipMemGenericAllocationHandle_t h, int cls) -> hipError_t {
-            if (cls < a->n_classes && (int)a->handles[cls].size() < need) {
-                unsigned char *va = a->base[cls] + (int64_t)a->handles[cls].size() * CHUNK;
-                hipError_t e2 = map_rw(va, (size_t)CHUNK, h, a->dev);
-                if (e2 != hipSuccess) return e2;
-                a->handles[cls].push_back(h);
-                if (cls == 1 && !ref1) {
-                    e2 = hipMemsetAsync(va, 0, (size_t)CHUNK, stream);
-                    ref1 = reinterpret_cast<const float *>(va);
-                }
-                return e2;
-            }
-            spare.push_back(h);      // held until the end: releasing it now would hand the same physical chunk out again
-            return hipSuccess;
-        };
-        auto classify = [&](const Pend &q) -> int {      // rc; places the chunk
-            int cls;
-            if (q.us0 > thr) {
-                cls = 0;
-            } else if (!ref1) {
-                cls = 1;
-            } else {
-                float us1 = 0.0f;
-                int r2 = probe_us(a, ref1, reinterpret_cast<float *>(q.va), stream, &us1);
-                if (r2 != GNNMP_OK) return r2;
-                cls = us1 > thr ? 1 : 2;
-                if (getenv("GNNMP_ARENA_DEBUG")) fprintf(stderr, "[arena]   against the class-1 reference %.1f us -> class %d\n", us1, cls);
-            }
-            {
-                hipError_t e2 = hipMemUnmap(q.va, (size_t)CHUNK);       // leaves its test address for good
-                if (e2 != hipSuccess) return hip_fail(e2, "arena: unmap of a classified chunk");
-                test_mapped.erase(std::find(test_mapped.begin(), test_mapped.end(), q.va));
-            }
-            hipError_t e3 = place(q.h, cls);
-            return e3 == hipSuccess ? GNNMP_OK : hip_fail(e3, "arena: map of a classified chunk");
-        };
-        auto all_full = [&]() {
-            for (int c = 0; c < a->n_classes; ++c)
-                if ((int)a->handles[c].size() < need) return false;
-            return true;
-        };
-        while (!all_full()) {
-            if (a->created >= max_chunks) {
-                rc = fail(GNNMP_EUNSUPPORTED, "arena_create: %lld chunks of 2 GiB probed (probe %.0f..%.0f us), classes hold %zu / %zu / %zu of %d chunks "
-                                              "(raise max_probe_bytes or free device memory)", (long long)a->created, lo, hi,
-                          a->handles[0].size(), a->handles[1].size(), a->handles[2].size(), need);
-                for (const Pend &q : pending) spare.push_back(q.h);
-                goto done;
-            }
-            hipMemGenericAllocationHandle_t h = nullptr;
-            e = hipMemCreate(&h, (size_t)CHUNK, &prop, 0);
-            if (e != hipSuccess) {
-                rc = hip_fail(e, "hipMemCreate(arena chunk): device memory exhausted while looking for two placement classes");
-                for (const Pend &q : pending) spare.push_back(q.h);
-                goto done;
-            }
-            ++a->created;
-            Pend q = {h, 0.0f, scratch + (a->created - 1) * CHUNK};
-            e = map_rw(q.va, (size_t)CHUNK, h, a->dev);
-            if (e == hipSuccess) test_mapped.push_back(q.va);
-            if (e == hipSuccess) rc = probe_us(a, ref0, reinterpret_cast<float *>(q.va), stream, &q.us0);
-            if (e != hipSuccess && rc == GNNMP_OK) rc = hip_fail(e, "arena: map of a chunk under test");
-            if (rc != GNNMP_OK) {
-                spare.push_back(h);
-                for (const Pend &w : pending) spare.push_back(w.h);
-                goto done;
-            }
-            if (getenv("GNNMP_ARENA_DEBUG")) fprintf(stderr, "[arena] chunk %lld: probe against chunk 0 %.1f us\n", (long long)a->created - 1, q.us0);
-            lo = lo == 0.0f ? q.us0 : std::min(lo, q.us0);
-            hi = std::max(hi, q.us0);
-            if (thr == 0.0f) {
-                pending.push_back(q);
-                if (hi > 1.04f * lo) {                    // both clusters seen: decide everything held back
-                    thr = 0.5f * (lo + hi);
-                    a->probe_same_us = hi;
-                    a->probe_other_us = lo;
-                    for (size_t i = 0; i < pending.size() && rc == GNNMP_OK; ++i) {
-                        rc = classify(pending[i]);
-                        if (rc != GNNMP_OK)
-                            for (size_t k2 = i; k2 < pending.size(); ++k2) spare.push_back(pending[k2].h);
-                    }
-                    pending.clear();
-                    if (rc != GNNMP_OK) goto done;
-                }
-            } else {
-                rc = classify(q);
-                if (rc != GNNMP_OK) { spare.push_back(h); goto done; }
-            }
+    float lo = 0.0f, hi = 0.0f, thr = 0.0f;
+    const float *ref0 = nullptr, *ref1 = nullptr;
+    auto keep = [&](unsigned char *p, int cls) {
+        if (cls < a->n_classes && (int)a->blocks[cls].size() < need) a->blocks[cls].push_back({p, 0});
+        else spare.push_back(p);
+    };
+    auto classify = [&](const Pend &q) -> int {
+        int cls;
+        if (q.lo > thr) {
+            cls = 0;                                         // both halves as slow as block 0's own class
+        } else if (q.hi > thr) {
+            cls = 3;                                         // the halves disagree: a mixed block, not used
+        } else if (!ref1) {
+            cls = 1;
+            ref1 = reinterpret_cast<const float *>(q.p);
+            if (hipMemsetAsync(q.p, 0, (size_t)CHUNK / 4, stream) != hipSuccess) return fail(GNNMP_ELAUNCH, "arena: memset of the second reference");
+        } else {
+            float lo1 = 0.0f, hi1 = 0.0f;
+            int r2 = probe_chunk(a, ref1, q.p, stream, &lo1, &hi1);
+            if (r2 != GNNMP_OK) return r2;
+            cls = lo1 > thr ? 1 : (hi1 > thr ? 3 : 2);
+            if (getenv("GNNMP_ARENA_DEBUG")) fprintf(stderr, "[arena]   against the class-1 reference %.1f / %.1f us -> class %d\n", lo1, hi1, cls);
         }
-        for (const Pend &q : pending) spare.push_back(q.h);
+        keep(q.p, cls);
+        return GNNMP_OK;
+    };
+    auto all_full = [&]() {
+        for (int c = 0; c < a->n_classes; ++c)
+            if ((int)a->blocks[c].size() < need) return false;
+        return true;
+    };
+    rc = make_probe_plan(a, (CHUNK / 4) / (PROBE_D * 4), stream);      // the probe gathers from the first GiB of a reference block
+    if (rc == GNNMP_OK) {
+        unsigned char *p0 = nullptr;
+        hipError_t e = hipMalloc((void **)&p0, (size_t)CHUNK);
+        if (e != hipSuccess) rc = hip_fail(e, "hipMalloc(arena block 0)");
+        else {
+            ++a->created;
+            a->blocks[0].push_back({p0, 0});                 // block 0 is class 0 by definition and the probe's source from now on
+            ref0 = reinterpret_cast<const float *>(p0);
+            e = hipMemsetAsync(p0, 0, (size_t)CHUNK / 4, stream);      // (the GiB the probe gathers from)
+            if (e != hipSuccess) rc = hip_fail(e, "hipMemsetAsync(arena block 0)");
+        }
     }
-    ARENA_HIP(hipStreamSynchronize(stream));
-done:
-#undef ARENA_HIP
-    for (hipMemGenericAllocationHandle_t h : spare) { (void)hipMemRelease(h); ++a->released; }
+    while (rc == GNNMP_OK && !all_full()) {
+        if (a->created >= max_blocks) {
+            rc = fail(GNNMP_EUNSUPPORTED, "arena_create: %lld blocks of 4 GiB probed (probe %.0f..%.0f us), classes hold %zu / %zu / %zu of %d blocks "
+                                          "(raise max_probe_bytes or free device memory)", (long long)a->created, lo, hi,
+                      a->blocks[0].size(), a->blocks[1].size(), a->blocks[2].size(), need);
+            break;
+        }
+        unsigned char *p = nullptr;
+        hipError_t e = hipMalloc((void **)&p, (size_t)CHUNK);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            rc = fail(GNNMP_EALLOC, "arena_create: device memory exhausted after %lld blocks while looking for %d placement classes",
+                      (long long)a->created, a->n_classes);
+            break;
+        }
+        ++a->created;
+        Pend q = {p, 0.0f, 0.0f};
+        rc = probe_chunk(a, ref0, p, stream, &q.lo, &q.hi);
+        if (rc != GNNMP_OK) { spare.push_back(p); break; }
+        if (getenv("GNNMP_ARENA_DEBUG"))
+            fprintf(stderr, "[arena] block %lld @ %p: probe against block 0 %.1f / %.1f us\n", (long long)a->created - 1, (void *)p, q.lo, q.hi);
+        lo = lo == 0.0f ? q.lo : std::min(lo, q.lo);
+        hi = std::max(hi, q.hi);
+        if (thr == 0.0f) {
+            pending.push_back(q);
+            if (hi > 1.06f * lo) {                        // both clusters seen (pure pairs are 10 % apart): decide everything held back
+                thr = 0.5f * (lo + hi);
+                a->probe_same_us = hi;
+                a->probe_other_us = lo;
+                size_t i = 0;
+                for (; i < pending.size() && rc == GNNMP_OK; ++i) rc = classify(pending[i]);
+                for (; i < pending.size(); ++i) spare.push_back(pending[i].p);
+                pending.clear();
+            }
+        } else {
+            rc = classify(q);
+        }
+    }
+    for (const Pend &q : pending) spare.push_back(q.p);
+    pending.clear();
+    // the finished classes against the reference once more: every block of class 0 slow, every other block fast
+    for (int c = 0; c < a->n_classes && rc == GNNMP_OK; ++c)
+        for (size_t i = (c == 0 ? 1 : 0); i < a->blocks[c].size() && rc == GNNMP_OK; ++i) {
+            float l2 = 0.0f, h2 = 0.0f;
+            rc = probe_chunk(a, ref0, a->blocks[c][i].p, stream, &l2, &h2);
+            if (rc == GNNMP_OK && (c == 0 ? l2 <= thr : h2 > thr))
+                rc = fail(GNNMP_EUNSUPPORTED, "arena_create: class %d block %zu probes %.0f / %.0f us against a threshold of %.0f: the "
+                                              "placement classes of this device are not stable enough to use", c, i, l2, h2, thr);
+        }
+    if (rc == GNNMP_OK && hipStreamSynchronize(stream) != hipSuccess) rc = fail(GNNMP_ELAUNCH, "arena_create: stream synchronisation failed");
     (void)hipDeviceSynchronize();
-    if (scratch) {
-        for (unsigned char *va : test_mapped) (void)hipMemUnmap(va, (size_t)CHUNK);
-        (void)hipMemAddressFree(scratch, (size_t)max_chunks * (size_t)CHUNK);
-    }
+    for (unsigned char *p : spare) { (void)hipFree(p); ++a->released; }
     if (rc != GNNMP_OK) {
         gnnmp_arena_destroy(a);
         return rc;
     }
-    for (int c = 0; c < 3; ++c) a->n_chunks[c] = (int)a->handles[c].size();
     *out = a;
     return GNNMP_OK;
 }
@@ -286,19 +247,23 @@ done:
 int gnnmp_arena_alloc(gnnmp_arena_t *a, int cls, int64_t bytes, void **ptr) {
     if (!a || !ptr || bytes < 0 || cls < 0 || cls >= a->n_classes) return fail(GNNMP_EINVAL, "arena_alloc: bad argument");
     std::lock_guard<std::mutex> lk(a->lock);
-    const int64_t at = (a->used[cls] + 4095) & ~(int64_t)4095;
-    if (at + bytes > a->cap[cls])
-        return fail(GNNMP_EALLOC, "arena_alloc: class %d holds %lld of %lld bytes, %lld more do not fit", cls, (long long)a->used[cls],
-                    (long long)a->cap[cls], (long long)bytes);
-    *ptr = a->base[cls] + at;
-    a->used[cls] = at + bytes;
-    return GNNMP_OK;
+    for (auto &b : a->blocks[cls]) {                          // a buffer lies inside ONE block
+        const int64_t at = (b.used + 4095) & ~(int64_t)4095;
+        if (at + bytes <= a->block_bytes) {
+            *ptr = b.p + at;
+            b.used = at + bytes;
+            return GNNMP_OK;
+        }
+    }
+    return fail(GNNMP_EALLOC, "arena_alloc: no block of class %d has %lld bytes left (blocks of %lld bytes)", cls, (long long)bytes,
+                (long long)a->block_bytes);
 }
 
 int gnnmp_arena_reset(gnnmp_arena_t *a) {
     if (!a) return fail(GNNMP_EINVAL, "arena_reset: null arena");
     std::lock_guard<std::mutex> lk(a->lock);
-    a->used[0] = a->used[1] = a->used[2] = 0;
+    for (int c = 0; c < 3; ++c)
+        for (auto &b : a->blocks[c]) b.used = 0;
     return GNNMP_OK;
 }
 
@@ -307,11 +272,12 @@ int gnnmp_arena_class_of(gnnmp_arena_t *a, const void *ptr, int64_t bytes, int *
     if (!a || !ptr || !cls) return fail(GNNMP_EINVAL, "arena_class_of: bad argument");
     const unsigned char *p = static_cast<const unsigned char *>(ptr);
     for (int c = 0; c < a->n_classes; ++c)
-        if (p >= a->base[c] && p < a->base[c] + a->cap[c]) { *cls = c; return GNNMP_OK; }
+        for (const auto &b : a->blocks[c])
+            if (p >= b.p && p < b.p + a->block_bytes) { *cls = c; return GNNMP_OK; }
     // foreign memory: the probe with the buffer as the gathered matrix, the output in a spare corner of each arena range
     const int none = a->n_classes;                         // "in none of the ranges' classes / cannot tell"
-    const int64_t n_src = std::min<int64_t>(bytes, CHUNK) / (PROBE_D * 4);
-    if (n_src < PROBE_ROWS) { *cls = none; return GNNMP_OK; }      // (too small to matter)
+    const int64_t n_src = std::min<int64_t>(bytes, CHUNK / 4) / (PROBE_D * 4);
+    if (n_src < 4 * PROBE_ROWS) { *cls = none; return GNNMP_OK; }      // (under 512 MiB: served by the Infinity Cache, no contrast)
     if ((reinterpret_cast<uintptr_t>(ptr) & 15)) { *cls = none; return GNNMP_OK; }
     std::lock_guard<std::mutex> lk(a->lock);
     int rc = make_probe_plan(a, n_src, stream);
@@ -319,8 +285,9 @@ int gnnmp_arena_class_of(gnnmp_arena_t *a, const void *ptr, int64_t bytes, int *
     const int64_t out_bytes = (int64_t)PROBE_ROWS * PROBE_D * 4;
     float us[3] = {0.0f, 0.0f, 0.0f};
     for (int c = 0; c < a->n_classes; ++c) {
-        if (a->cap[c] - a->used[c] < out_bytes + 4096) return fail(GNNMP_EALLOC, "arena_class_of: no room for the probe's output in range %d", c);
-        float *o = reinterpret_cast<float *>(a->base[c] + a->cap[c] - out_bytes);      // the top of the range: free by the check above
+        const auto &b = a->blocks[c].back();
+        if (a->block_bytes - b.used < out_bytes + 4096) return fail(GNNMP_EALLOC, "arena_class_of: no room for the probe's output in class %d", c);
+        float *o = reinterpret_cast<float *>(b.p + a->block_bytes - out_bytes);      // the top of the block: free by the check above
         rc = probe_us(a, static_cast<const float *>(ptr), o, stream, &us[c]);
         if (rc != GNNMP_OK) return rc;
     }
@@ -332,7 +299,7 @@ int gnnmp_arena_class_of(gnnmp_arena_t *a, const void *ptr, int64_t bytes, int *
         if (us[c] > us[slow]) slow = c;
         lo = std::min(lo, us[c]);
     }
-    *cls = us[slow] > 1.04f * lo ? slow : none;
+    *cls = us[slow] > 1.06f * lo ? slow : none;
     return GNNMP_OK;
 }
 
@@ -340,9 +307,12 @@ int gnnmp_arena_class_of(gnnmp_arena_t *a, const void *ptr, int64_t bytes, int *
  * [5] = probe microseconds with source and output in one class, [6] = in two, [7] = ranges (2 | 3), [8] = bytes used in range 2 */
 int gnnmp_arena_info(const gnnmp_arena_t *a, int64_t *info) {
     if (!a || !info) return fail(GNNMP_EINVAL, "arena_info: null argument");
-    info[0] = a->cap[0]; info[1] = a->used[0]; info[2] = a->used[1]; info[3] = a->created; info[4] = a->released;
+    int64_t used[3] = {0, 0, 0};
+    for (int c = 0; c < 3; ++c)
+        for (const auto &b : a->blocks[c]) used[c] += b.used;
+    info[0] = a->cap; info[1] = used[0]; info[2] = used[1]; info[3] = a->created; info[4] = a->released;
     info[5] = (int64_t)(a->probe_same_us + 0.5f); info[6] = (int64_t)(a->probe_other_us + 0.5f);
-    info[7] = a->n_classes; info[8] = a->used[2];
+    info[7] = a->n_classes; info[8] = used[2];
     return GNNMP_OK;
 }
 

@@ -214,16 +214,20 @@ def gcn_conv(l, g: GNNGraph, x, edge_weight=None, norm_fn=None, conv_weight=None
         c_slot = w_slot = None
     if Dout >= Din:
         # aggregate, then transform: one kernel, the (N, Din) aggregate never goes to HBM (conv.jl:59-71)
-        # opt-in (gnnmp/placement.py): a persistent output buffer in a placement class other than x's
-        out_buf = None
+        # opt-in (gnnmp/placement.py): a persistent output buffer in a placement class other than x's, the best of the candidates by trial
+        out_buf = ch = tok = None
         if placement.enabled(l) and x.dim() == 2 and placement.worth_it((plan.n_dst, Dout)) and _would_fuse(plan, x.shape[1]):
             ar = placement.arena()
             if ar is not None:
-                out_buf, _ = placement.buffer_for(l, "out", (plan.n_dst, Dout), [ar.class_of(x)])
+                ch = placement.choice_for(l, "out", (plan.n_dst, Dout), [ar.class_of(x)])
+                if ch is not None:
+                    out_buf, tok = ch.begin()
         if c_slot is not None:
             y = fused_conv(plan, L.SUM, x, weight, l.bias, l.sigma, w_slot=w_slot, ss_slot=c_slot, scale_dst=c, out=out_buf)
         else:
             y = fused_conv(plan, L.SUM, x, weight, l.bias, l.sigma, w=w, scale_src=c, scale_dst=c, out=out_buf)
+        if ch is not None:
+            ch.end(tok)
         if y is not None:
             return y
     if c_slot is not None:
@@ -273,7 +277,10 @@ def graph_conv(l, g: GNNGraph, x):
     y = fused_conv(g.plan(False), aggr_code(l.aggr), xj, l.weight2, l.bias, l.sigma, xi=xi, W_root=l.weight1)
     if y is not None:
         return y
-    m = _fused(g, L.COPY_XJ, l.aggr, xj, None, out=_placed_aggregate(l, xj, g.plan(False).n_dst))
+    mb, ch, tok = _placed_aggregate(l, xj, g.plan(False).n_dst)
+    m = _fused(g, L.COPY_XJ, l.aggr, xj, None, out=mb)
+    if ch is not None:
+        ch.end(tok)
     return dense(xi, l.weight1, l.bias, l.sigma, x2=m, W2=l.weight2)
 
 
@@ -305,19 +312,26 @@ def sage_conv(l, g: GNNGraph, x):
     y = fused_conv(g.plan(False), aggr_code(l.aggr), xj, W[:, Din:], l.bias, l.sigma, xi=xi, W_root=W[:, :Din])
     if y is not None:
         return y
-    m = _fused(g, L.COPY_XJ, l.aggr, xj, None, out=_placed_aggregate(l, xj, g.plan(False).n_dst))
+    mb, ch, tok = _placed_aggregate(l, xj, g.plan(False).n_dst)
+    m = _fused(g, L.COPY_XJ, l.aggr, xj, None, out=mb)
+    if ch is not None:
+        ch.end(tok)
     return dense(xi, W[:, :Din], l.bias, l.sigma, x2=m, W2=W[:, Din:])
 
 
 def _placed_aggregate(l, xj, n_dst):
-    """opt-in (gnnmp/placement.py): the layer's persistent aggregate buffer in a placement class other than xj's; None = allocate as usual"""
+    """opt-in (gnnmp/placement.py): (the layer's persistent aggregate buffer in a placement class other than xj's, its Choice, token);
+    (None, None, None) = allocate as usual"""
     if not (placement.enabled(l) and xj.dim() == 2 and placement.worth_it((n_dst, xj.shape[1]))):
-        return None
+        return None, None, None
     ar = placement.arena()
     if ar is None:
-        return None
-    buf, _ = placement.buffer_for(l, "m", (n_dst, xj.shape[1]), [ar.class_of(xj)])
-    return buf
+        return None, None, None
+    ch = placement.choice_for(l, "m", (n_dst, xj.shape[1]), [ar.class_of(xj)])
+    if ch is None:
+        return None, None, None
+    buf, tok = ch.begin()
+    return buf, ch, tok
 
 
 class SAGEConv:
@@ -360,9 +374,9 @@ def gat_conv(l, g: GNNGraph, x, e=None, return_alpha=False, exact_order=False, s
     H = l.heads
     C = l.channel[1]
     N = g.num_nodes
-    # opt-in (gnnmp/placement.py): Wx = dense_x(x) in one placement class (not x's), the attention output in the other — both persistent
-    # buffers of the layer; otherwise both are fresh allocations
-    out = wx = None
+    # opt-in (gnnmp/placement.py): Wx = dense_x(x) in a placement class other than x's, the attention output in a class other than both
+    # (the best of the candidates by trial) — persistent buffers of the layer; otherwise both are fresh allocations
+    out = wx = ch = tok = None
     if (placement.enabled(l) and e is None and not (return_alpha or exact_order) and float(getattr(l, "dropout", 0.0)) == 0.0
             and placement.worth_it((N, H * C))):
         ar = placement.arena()
@@ -370,12 +384,14 @@ def gat_conv(l, g: GNNGraph, x, e=None, return_alpha=False, exact_order=False, s
             cx = ar.class_of(x)
             wx, cw = placement.buffer_for(l, "Wx", (N, H * C), [cx])
             if wx is not None:
-                # not Wx's class (the gathered matrix), and with three ranges not x's either: in a stack of layers the next kernel usually
+                # not Wx's class (the gathered matrix), and with three classes not x's either: in a stack of layers the next kernel usually
                 # gathers from x again while this output's dirty lines are still being written back
-                out, _ = placement.buffer_for(l, "out", (N, H * C), [cw, cx])
+                ch = placement.choice_for(l, "out", (N, H * C), [cw], prefer_not=[cx])
     Wx = dense(x, l.dense_x_weight, out=wx)                # reshape(dense_x(x), C, H, N)
     a_hc = l.a_hc                                          # [H][2C] (node part)
     lib = L.load()
+    if ch is not None:
+        out, tok = ch.begin()
     if out is None:
         out = torch.empty((N, H * C), dtype=torch.float32, device=x.device)
     code, post = _act_code(l.sigma)
@@ -420,6 +436,8 @@ def gat_conv(l, g: GNNGraph, x, e=None, return_alpha=False, exact_order=False, s
                                        code if fuse_tail else L.ACT_IDENTITY, L.ptr(out), H, C, L.stream_ptr()))
         if pr is not None:
             pr.end("gat_conv", e0)
+        if ch is not None:
+            ch.end(tok)
     if fuse_tail:
         y = post(out) if post is not None else out
     else:

@@ -134,18 +134,87 @@ def arena():
     return _arena[0]
 
 
+class Choice:
+    """A layer's persistent output buffer, chosen among candidates in different arena classes by TIMING the layer's own kernel on each
+    (HIP events around the launch, polled on later calls: no synchronisation).  The arena's probe classifies a block at two places;
+    a buffer of a gigabyte can still straddle physical blocks of different classes, and what counts in the end is the time of the
+    real kernel on the real buffers: every candidate is used three times (the first is a warm-up), then the fastest stays."""
+    TRIALS = 2
+
+    def __init__(self, bufs):
+        self.bufs = bufs
+        self.spans = [[] for _ in bufs]
+        self.rr = 0
+        self.times_ms = None
+        if len(bufs) == 1:
+            self.spans = None
+
+    def _resolve(self):
+        if any(len(s) < self.TRIALS + 1 for s in self.spans):
+            return
+        if not all(e1.query() for s in self.spans for _, e1 in s):
+            return
+        self.times_ms = [sorted(a.elapsed_time(b) for a, b in s[1:])[len(s[1:]) // 2] for s in self.spans]
+        tmin = min(self.times_ms)
+        best = next(i for i, t in enumerate(self.times_ms) if t <= 1.01 * tmin)      # the first (most preferred) within 1 % of the best
+        self.bufs = [self.bufs[best]]          # (the others stay allocated in the arena: it is a bump allocator)
+        self.spans = None
+
+    def begin(self):
+        """-> (buffer, token); call end(token) right after the kernel launch"""
+        if self.spans is not None:
+            self._resolve()
+        if self.spans is None:
+            return self.bufs[0], None
+        i = self.rr % len(self.bufs)
+        self.rr += 1
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        return self.bufs[i], (i, e0)
+
+    def end(self, tok):
+        if tok is None or self.spans is None:
+            return
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.spans[tok[0]].append((tok[1], e1))
+
+    @property
+    def settled(self):
+        return self.spans is None
+
+
+def choice_for(layer, tag, shape, avoid, prefer_not=()):
+    """the layer's Choice for buffer `tag` of `shape`: one candidate per arena class that is in none of `avoid` (the class of the matrix
+    the kernel gathers from); classes in `prefer_not` (the class of the matrix the NEXT kernel gathers from: this output's dirty lines
+    are written back while that kernel runs) come last and are taken only if they are more than 1 % faster.  None: allocate as usual."""
+    a = arena()
+    if a is None:
+        return None
+    cache = layer.__dict__.setdefault("_placed", {})
+    avoid = list(avoid)
+    key = (tag, tuple(shape), tuple(avoid))
+    ch = cache.get(key)
+    if ch is None:
+        free = [c for c in range(a.n_classes) if c not in avoid and c not in prefer_not]
+        free += [c for c in range(a.n_classes) if c not in avoid and c in prefer_not]
+        if not free:
+            free = [c for c in range(a.n_classes) if c != avoid[0]] or [0]
+        bufs = [b for b in (a.alloc(shape, c) for c in free) if b is not None]
+        if not bufs:
+            return None
+        ch = cache[key] = Choice(bufs)
+    return ch
+
+
 def buffer_for(layer, tag, shape, avoid):
-    """(the layer's persistent buffer `tag` of `shape` in an arena range whose class is in none of `avoid`, that range); (None, n_classes):
-    allocate as usual.  avoid: the classes of the matrix the kernel gathers from and — with three ranges — of the previous kernel's
-    output (its dirty lines are written back while this kernel runs)."""
+    """a single persistent buffer (no trial): (buffer | None, its class)"""
     a = arena()
     if a is None:
         return None, 0
-    avoid = list(avoid)
-    free = [c for c in range(a.n_classes) if c not in avoid]
-    if not free:          # (two ranges, both to be avoided: the gathered matrix's class matters most — callers list it first)
-        free = [c for c in range(a.n_classes) if c != avoid[0]] or [0]
     cache = layer.__dict__.setdefault("_placed", {})
+    avoid = list(avoid)
+    free = [c for c in range(a.n_classes) if c not in avoid] or [c for c in range(a.n_classes) if c != avoid[0]] or [0]
     for cls in free:
         key = (tag, tuple(shape), cls)
         buf = cache.get(key)

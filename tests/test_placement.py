@@ -26,9 +26,9 @@ def ar():
 def test_arena_finds_two_classes_and_tells_them_apart(ar):
     import torch
     info = ar.info()
-    assert info["bytes_per_class"] == 4 << 30 and info["chunks_created"] >= 6 and info["ranges"] == 3
+    assert info["bytes_per_class"] == 4 << 30 and info["chunks_created"] >= 3 and info["ranges"] == 3
     # the probe saw two clusters at least 3 % apart (that is what makes two classes)
-    assert info["probe_us_same_class"] > 1.03 * info["probe_us_two_classes"] > 0
+    assert info["probe_us_same_class"] > 1.06 * info["probe_us_two_classes"] > 0
     a0, a1, a2 = ar.alloc((1 << 20, 128), 0), ar.alloc((1 << 20, 128), 1), ar.alloc((1 << 20, 128), 2)
     assert ar.class_of(a0) == 0 and ar.class_of(a1) == 1 and ar.class_of(a2) == 2
     a0.fill_(1.0); a1.fill_(2.0)
@@ -39,7 +39,7 @@ def test_arena_finds_two_classes_and_tells_them_apart(ar):
         view = t[4096:]
         got = ctypes_class(ar, view)
         assert got == c, (c, got)
-    assert ar.alloc((1 << 40, 1), 0) is None          # full: the caller allocates as usual
+    assert ar.alloc((1 << 31, 1), 0) is None          # 8 GiB do not fit a 4 GiB block: the caller allocates as usual
     ar.reset()
     assert ar.info()["used"] == (0, 0, 0)
 
@@ -57,7 +57,7 @@ def ctypes_class(ar, t):
 
 def test_foreign_buffers_are_probed(ar):
     import torch
-    x = torch.randn((1 << 20, 128), device="cuda")        # 512 MiB of ordinary (torch) memory
+    x = torch.randn((1 << 21, 128), device="cuda")        # 1 GiB of ordinary (torch) memory
     c = ar.class_of(x)
     assert c in (0, 1, 2, 3)
     assert ar.class_of(x) == c                            # cached per buffer
@@ -81,13 +81,17 @@ def test_placed_layers_are_bit_identical(ar, monkeypatch):
         ref_gcn, ref_gat = gcn(g, x).clone(), gat(g, x).clone()
         gcn.place_outputs = gat.place_outputs = True
         cx = ar.class_of(x)
-        for it in range(3):
+        for it in range(12):
             y1, y2 = gcn(g, x), gat(g, x)
             assert torch.equal(y1, ref_gcn) and torch.equal(y2, ref_gat), it
-        # where the buffers lie: GCN's output not in x's class; Wx and the attention output in different ranges
+            torch.cuda.synchronize()        # (lets the polled events complete; the layers themselves never wait)
+        # where the buffers lie: GCN's output not in x's class; Wx and the attention output in different classes; the trials are over
         assert ar.class_of(y1) in (0, 1, 2) and ar.class_of(y1) != cx
         (wx,) = [b for k, b in gat._placed.items() if k[0] == "Wx"]
-        assert ar.class_of(wx) != cx and ar.class_of(y2) not in (ar.class_of(wx), cx)
+        assert ar.class_of(wx) != cx and ar.class_of(y2) != ar.class_of(wx)
+        for layer in (gcn, gat):
+            (ch,) = [c for k, c in layer._placed.items() if k[0] == "out"]
+            assert ch.settled and len(ch.times_ms) in (2, 3)      # (x is ordinary torch memory here: its class may be none of the arena's)
         a, b = gat(g, x), gat(g, x)
         assert a.data_ptr() == b.data_ptr()     # persistent: the documented aliasing of the opt-in
         gcn.place_outputs = gat.place_outputs = False
