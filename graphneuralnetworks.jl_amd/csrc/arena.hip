@@ -7,9 +7,9 @@
 // predecessors on the stream): the writes land on the dies the read stream is saturating.  hipMalloc does not say where memory lies, and a
 // single allocation is a patchwork of power-of-two blocks of any class, so two ordinary allocations pair up by luck (box-to-box "noise").
 //
-// The arena takes the luck out: blocks of 4 GiB are allocated one by one (plain hipMalloc), classified where they lie by timing a small probe
+// The arena takes the luck out: blocks of 2 GiB are allocated one by one (plain hipMalloc), classified where they lie by timing a small probe
 // — a propagate(copy_xj, +) over a synthetic random graph, 262 144 rows x 26 sources of 512 bytes out of a reference block, ~550 us, 10 %
-// apart between "output in the reference's class" and "not" — at both halves of the block; blocks of the three (or two) classes are kept,
+// apart between "output in the reference's class" and "not" — at four places of the block; blocks of the three (or two) classes are kept,
 // the others freed at the end.  A caller (the host mirror's layers, the Julia extension) allocates a layer's output from a block whose
 // class differs from the gathered matrix's class:
 //     gnnmp_arena_class_of(arena, x)            -> 0 / 1 (x is in that arena class), 2 (in neither: any range is fine)
@@ -40,7 +40,7 @@ struct gnnmp_arena {
 
 namespace gnnmp {
 namespace {
-constexpr int64_t CHUNK = (int64_t)4 << 30;      // a block: one hipMalloc; classified by its two halves
+constexpr int64_t CHUNK = (int64_t)2 << 30;      // a block: one hipMalloc; classified at four places (every 512 MiB)
 constexpr int PROBE_ROWS = 262144, PROBE_DEG = 26, PROBE_D = 128;    // 512-byte rows like the attention kernel's; the two cases are 5 % apart at 65 536 rows, 7 % here
 
 __global__ void probe_edges_kernel(int64_t n_src, int64_t *src, int64_t *dst) {
@@ -82,12 +82,16 @@ int probe_us(gnnmp_arena *a, const float *src, float *out, hipStream_t stream, f
 // a block under test, probed at its start and at its middle (an allocation is a patchwork of whatever physical blocks were free: only
 // blocks whose two halves agree are used); *lo / *hi = the smaller / larger of the two times
 int probe_chunk(gnnmp_arena *a, const float *src, unsigned char *chunk, hipStream_t stream, float *lo, float *hi) {
-    float t0 = 0.0f, t1 = 0.0f;
-    int rc = probe_us(a, src, reinterpret_cast<float *>(chunk), stream, &t0);
-    if (rc == GNNMP_OK) rc = probe_us(a, src, reinterpret_cast<float *>(chunk + CHUNK / 2), stream, &t1);
-    *lo = std::min(t0, t1);
-    *hi = std::max(t0, t1);
-    return rc;
+    *lo = 1e30f;
+    *hi = 0.0f;
+    for (int k = 0; k < 4; ++k) {
+        float t = 0.0f;
+        int rc = probe_us(a, src, reinterpret_cast<float *>(chunk + (int64_t)k * (CHUNK / 4)), stream, &t);
+        if (rc != GNNMP_OK) return rc;
+        *lo = std::min(*lo, t);
+        *hi = std::max(*hi, t);
+    }
+    return GNNMP_OK;
 }
 
 int make_probe_plan(gnnmp_arena *a, int64_t n_src, hipStream_t stream) {
@@ -134,7 +138,7 @@ int gnnmp_arena_create(gnnmp_arena_t **out, int64_t bytes_per_class, int n_class
     // Blocks are plain hipMalloc allocations, each classified where it lies and then kept or freed — no remapping.  (A first version built
     // the ranges out of hipMemCreate chunks moved between addresses with hipMemMap / hipMemUnmap: translations of an unmapped range
     // outlived the unmap — 80 different chunks probed through one address measured alike — and two runs in six ended in a GPU memory
-    // fault.)  A block is used only if its two halves probe alike (a 4 GiB allocation is usually one physical block, but need not be).
+    // fault.)  A block is used only if its four windows probe alike (an allocation of 2 GiB is usually one physical block, but need not be).
     struct Pend { unsigned char *p; float lo, hi; };
     std::vector<Pend> pending;
     std::vector<unsigned char *> spare;                      // blocks of a class that is full / mixed blocks: freed at the end (freeing
@@ -155,7 +159,7 @@ int gnnmp_arena_create(gnnmp_arena_t **out, int64_t bytes_per_class, int n_class
         } else if (!ref1) {
             cls = 1;
             ref1 = reinterpret_cast<const float *>(q.p);
-            if (hipMemsetAsync(q.p, 0, (size_t)CHUNK / 4, stream) != hipSuccess) return fail(GNNMP_ELAUNCH, "arena: memset of the second reference");
+            if (hipMemsetAsync(q.p, 0, (size_t)CHUNK / 2, stream) != hipSuccess) return fail(GNNMP_ELAUNCH, "arena: memset of the second reference");
         } else {
             float lo1 = 0.0f, hi1 = 0.0f;
             int r2 = probe_chunk(a, ref1, q.p, stream, &lo1, &hi1);
@@ -171,7 +175,7 @@ int gnnmp_arena_create(gnnmp_arena_t **out, int64_t bytes_per_class, int n_class
             if ((int)a->blocks[c].size() < need) return false;
         return true;
     };
-    rc = make_probe_plan(a, (CHUNK / 4) / (PROBE_D * 4), stream);      // the probe gathers from the first GiB of a reference block
+    rc = make_probe_plan(a, (CHUNK / 2) / (PROBE_D * 4), stream);      // the probe gathers from the first GiB of a reference block
     if (rc == GNNMP_OK) {
         unsigned char *p0 = nullptr;
         hipError_t e = hipMalloc((void **)&p0, (size_t)CHUNK);
@@ -180,13 +184,13 @@ int gnnmp_arena_create(gnnmp_arena_t **out, int64_t bytes_per_class, int n_class
             ++a->created;
             a->blocks[0].push_back({p0, 0});                 // block 0 is class 0 by definition and the probe's source from now on
             ref0 = reinterpret_cast<const float *>(p0);
-            e = hipMemsetAsync(p0, 0, (size_t)CHUNK / 4, stream);      // (the GiB the probe gathers from)
+            e = hipMemsetAsync(p0, 0, (size_t)CHUNK / 2, stream);      // (the GiB the probe gathers from)
             if (e != hipSuccess) rc = hip_fail(e, "hipMemsetAsync(arena block 0)");
         }
     }
     while (rc == GNNMP_OK && !all_full()) {
         if (a->created >= max_blocks) {
-            rc = fail(GNNMP_EUNSUPPORTED, "arena_create: %lld blocks of 4 GiB probed (probe %.0f..%.0f us), classes hold %zu / %zu / %zu of %d blocks "
+            rc = fail(GNNMP_EUNSUPPORTED, "arena_create: %lld blocks of 2 GiB probed (probe %.0f..%.0f us), classes hold %zu / %zu / %zu of %d blocks "
                                           "(raise max_probe_bytes or free device memory)", (long long)a->created, lo, hi,
                       a->blocks[0].size(), a->blocks[1].size(), a->blocks[2].size(), need);
             break;
@@ -276,7 +280,7 @@ int gnnmp_arena_class_of(gnnmp_arena_t *a, const void *ptr, int64_t bytes, int *
             if (p >= b.p && p < b.p + a->block_bytes) { *cls = c; return GNNMP_OK; }
     // foreign memory: the probe with the buffer as the gathered matrix, the output in a spare corner of each arena range
     const int none = a->n_classes;                         // "in none of the ranges' classes / cannot tell"
-    const int64_t n_src = std::min<int64_t>(bytes, CHUNK / 4) / (PROBE_D * 4);
+    const int64_t n_src = std::min<int64_t>(bytes, CHUNK / 2) / (PROBE_D * 4);
     if (n_src < 4 * PROBE_ROWS) { *cls = none; return GNNMP_OK; }      // (under 512 MiB: served by the Infinity Cache, no contrast)
     if ((reinterpret_cast<uintptr_t>(ptr) & 15)) { *cls = none; return GNNMP_OK; }
     std::lock_guard<std::mutex> lk(a->lock);

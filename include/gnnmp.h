@@ -176,17 +176,17 @@ int gnnmp_plan_edge_index(const gnnmp_graph_t *plan, int idx_bytes, int index_ba
  * this is an allocator the caller may use.  Measured on MI355X (profiles/README.md, round 4): device memory falls into three placement
  * classes of 96 GiB of physical HBM each; a kernel that gathers ~27 random rows per row it writes (propagate, the fused GCN layer, the
  * one-pass attention) runs 6 % slower when the gathered matrix and the output lie in the SAME class than when they lie in two — and
- * hipMalloc pairs buffers by luck.  The arena allocates 4 GiB blocks one by one (plain hipMalloc), classifies each where it lies with a
- * 0.6 ms probe (a propagate over a synthetic random graph, timed with either half of the block as its output: 10 % apart between the two
+ * hipMalloc pairs buffers by luck.  The arena allocates 2 GiB blocks one by one (plain hipMalloc), classifies each where it lies with a
+ * 0.6 ms probe (a propagate over a synthetic random graph, timed with the block as its output at four places: 10 % apart between the two
  * cases) and keeps blocks of n_classes = 2 or 3 different classes (three let a pipeline keep the PREVIOUS kernel's output — whose dirty
  * lines are still being written back — out of the class the next kernel gathers from); the other blocks are freed:
- *   gnnmp_arena_create(&a, bytes_per_class, n_classes, max_probe_bytes, stream)   bytes_per_class rounded up to 4 GiB blocks; up to max_probe_bytes
+ *   gnnmp_arena_create(&a, bytes_per_class, n_classes, max_probe_bytes, stream)   bytes_per_class rounded up to 2 GiB blocks; up to max_probe_bytes
  *                        (<= 0: 160 GiB) of blocks may be held transiently while the classes are being found (they come in runs of tens of
  *                        GiB); synchronises; GNNMP_EUNSUPPORTED / GNNMP_EALLOC when device memory does not show two classes in that budget
  *   gnnmp_arena_class_of(a, ptr, bytes, &cls, stream)   arena memory: its range (0 .. n_classes - 1), no launch.  Foreign memory (bytes >= 128 MiB):
  *                        the probe with `ptr` as the gathered matrix and the output in every range — c = it shares range c's class,
  *                        n_classes = none of them / mixed / too small to tell; synchronises
- *   gnnmp_arena_alloc(a, cls, bytes, &ptr)   bump allocation (4 KiB aligned) inside ONE block of class cls (bytes <= 4 GiB); GNNMP_EALLOC when
+ *   gnnmp_arena_alloc(a, cls, bytes, &ptr)   bump allocation (4 KiB aligned) inside ONE block of class cls (bytes <= 2 GiB); GNNMP_EALLOC when
  *                        no block of the class has room
  *   gnnmp_arena_reset(a)  forget every allocation (the caller knows nothing uses them any more)
  *   gnnmp_arena_info      info[9]: [0] bytes per class [1], [2] bytes used in range 0 / 1 [3] chunks created while classifying [4] released again

@@ -39,7 +39,7 @@ def test_arena_finds_two_classes_and_tells_them_apart(ar):
         view = t[4096:]
         got = ctypes_class(ar, view)
         assert got == c, (c, got)
-    assert ar.alloc((1 << 31, 1), 0) is None          # 8 GiB do not fit a 4 GiB block: the caller allocates as usual
+    assert ar.alloc((1 << 30, 1), 0) is None          # 4 GiB do not fit a 2 GiB block: the caller allocates as usual
     ar.reset()
     assert ar.info()["used"] == (0, 0, 0)
 
