@@ -3,7 +3,8 @@
  * argument conventions of a Julia host: 1-based Int64 COO vectors, column-major (D, N) features = row-major [N][D], a
  * (Dout, Din) column-major weight = w_layout 1 with ldw = Dout, `a` (2C, H) column-major = [H][2C].
  *   plan_create(validate) -> plan_info / plan_export -> degree -> propagate(copy_xj | w_mul_xj; +, mean, max) ->
- *   dense -> fused_conv -> gat_conv -> plan_destroy, and the EBOUNDS error path.
+ *   dense -> fused_conv -> gat_conv -> plan_destroy, the EBOUNDS error path, and (round 4) a batch taken from a resident dataset:
+ *   plan_select == plan_create on the concatenated COO, plan_edge_index, the node map, chain_jobs_pack / export, plan_release.
  * Expected values come from plain host loops in this file (edge order, separately rounded products: bit-exact where the
  * library promises bits).  Prints C_HARNESS_OK and exits 0 on success.   Built by __graft_entry__.build() / tests. */
 #include <hip/hip_runtime_api.h>
@@ -228,6 +229,109 @@ int main(void) {
             }
         }
     REQUIRE(rel_err(go, gref, n * HC) <= 1e-5, "gat_conv rel err %g", rel_err(go, gref, n * HC));
+
+    /* ---- a new batch every step (round 4): a dataset of member graphs batched ONCE (MLUtils.batch, transform.jl:682-709), then
+     * batch(gs[ids]) as a selection — gnnmp_plan_select must equal gnnmp_plan_create on the COO a host would have concatenated; the
+     * features come through the node map; the fused chain's wave jobs are packed on the device ---- */
+    {
+        enum { GM = 40, KSEL = 25 };
+        int64_t mn[GM], me[GM], nptr[GM + 1], eptr[GM + 1];
+        nptr[0] = eptr[0] = 0;
+        for (int g = 0; g < GM; ++g) {
+            mn[g] = 1 + rnd() % 40;
+            me[g] = rnd() % (4 * mn[g] + 1);
+            nptr[g + 1] = nptr[g] + mn[g];
+            eptr[g + 1] = eptr[g] + me[g];
+        }
+        const int64_t Nd = nptr[GM], Ed = eptr[GM];
+        int64_t *S = malloc(8 * (Ed + 1)), *T = malloc(8 * (Ed + 1));          /* the dataset's batched COO, 1-based */
+        for (int g = 0; g < GM; ++g)
+            for (int64_t k = eptr[g]; k < eptr[g + 1]; ++k) {
+                S[k] = nptr[g] + 1 + rnd() % mn[g];
+                T[k] = nptr[g] + 1 + rnd() % mn[g];
+            }
+        float *X = malloc(4 * Nd * 3);
+        for (int64_t i = 0; i < Nd * 3; ++i) X[i] = rndf();
+        int64_t *dS = dev_copy(S, 8 * Ed), *dT = dev_copy(T, 8 * Ed), *dnptr = dev_copy(nptr, 8 * (GM + 1));
+        float *dX = dev_copy(X, 4 * Nd * 3);
+        gnnmp_graph_t *pds = NULL;
+        CHECK_G(gnnmp_plan_create(&pds, dS, dT, 8, 1, Nd, Nd, Ed, 0, 1, stream));
+        int64_t ids[KSEL], nb = 0, eb = 0, mx = 0;
+        for (int k = 0; k < KSEL; ++k) { ids[k] = 1 + rnd() % GM; nb += mn[ids[k] - 1]; eb += me[ids[k] - 1]; if (mn[ids[k] - 1] > mx) mx = mn[ids[k] - 1]; }
+        int64_t *dids = dev_copy(ids, 8 * KSEL), *dseg = dev_alloc(8 * (KSEL + 1)), *dgi = dev_alloc(8 * nb);
+        int32_t *dnmap = dev_alloc(4 * nb);
+        gnnmp_graph_t *pb = NULL;
+        CHECK_G(gnnmp_plan_select(&pb, pds, dnptr, GM, dids, 8, 1, KSEL, nb, eb, dseg, dnmap, dgi, stream));
+        CHECK_G(gnnmp_plan_status(pb, stream));
+        /* what MLUtils.batch(gs[ids]) holds: members in the order of ids, local ids shifted by the nodes before them */
+        int64_t *Sb = malloc(8 * (eb + 1)), *Tb = malloc(8 * (eb + 1)), *seg = malloc(8 * (KSEL + 1)), at = 0, ro = 0;
+        for (int k = 0; k < KSEL; ++k) {
+            const int g = (int)ids[k] - 1;
+            seg[k] = ro;
+            for (int64_t q = eptr[g]; q < eptr[g + 1]; ++q, ++at) { Sb[at] = S[q] - nptr[g] + ro; Tb[at] = T[q] - nptr[g] + ro; }
+            ro += mn[g];
+        }
+        seg[KSEL] = ro;
+        int64_t *dSb = dev_copy(Sb, 8 * eb), *dTb = dev_copy(Tb, 8 * eb);
+        gnnmp_graph_t *pr = NULL;
+        CHECK_G(gnnmp_plan_create(&pr, dSb, dTb, 8, 1, nb, nb, eb, 0, 1, stream));
+        int32_t *e1[3], *e2[3];
+        for (int q = 0; q < 3; ++q) { e1[q] = dev_alloc(4 * (nb + eb + 1)); e2[q] = dev_alloc(4 * (nb + eb + 1)); }
+        CHECK_G(gnnmp_plan_export(pb, e1[0], e1[1], e1[2], stream));
+        CHECK_G(gnnmp_plan_export(pr, e2[0], e2[1], e2[2], stream));
+        CHECK_HIP(hipStreamSynchronize(stream));
+        const size_t lens[3] = {(size_t)nb + 1, (size_t)eb, (size_t)eb};
+        for (int q = 0; q < 3; ++q) {
+            int32_t *h1 = malloc(4 * lens[q] + 4), *h2 = malloc(4 * lens[q] + 4);
+            to_host(h1, e1[q], 4 * lens[q]); to_host(h2, e2[q], 4 * lens[q]);
+            REQUIRE(memcmp(h1, h2, 4 * lens[q]) == 0, "plan_select: array %d differs from plan_create on the batched COO", q);
+            free(h1); free(h2);
+        }
+        int64_t *hseg = malloc(8 * (KSEL + 1));
+        to_host(hseg, dseg, 8 * (KSEL + 1));
+        REQUIRE(memcmp(hseg, seg, 8 * (KSEL + 1)) == 0, "plan_select: seg_ptr");
+        /* s, t back from the plan = the batched COO */
+        int64_t *dS2 = dev_alloc(8 * eb), *dT2 = dev_alloc(8 * eb), *hS2 = malloc(8 * (eb + 1)), *hT2 = malloc(8 * (eb + 1));
+        CHECK_G(gnnmp_plan_edge_index(pb, 8, 1, dS2, dT2, stream));
+        CHECK_HIP(hipStreamSynchronize(stream));
+        to_host(hS2, dS2, 8 * eb); to_host(hT2, dT2, 8 * eb);
+        REQUIRE(memcmp(hS2, Sb, 8 * eb) == 0 && memcmp(hT2, Tb, 8 * eb) == 0, "plan_edge_index: the batch's COO");
+        /* features through the node map */
+        float *dXb = dev_alloc(4 * nb * 3), *hXb = malloc(4 * nb * 3);
+        CHECK_G(gnnmp_gather_f32(dX, dnmap, 4, 0, nb, dXb, 3, stream));
+        CHECK_HIP(hipStreamSynchronize(stream));
+        to_host(hXb, dXb, 4 * nb * 3);
+        for (int k = 0; k < KSEL; ++k)
+            REQUIRE(memcmp(hXb + 3 * seg[k], X + 3 * nptr[ids[k] - 1], 12 * mn[ids[k] - 1]) == 0, "collated features of member %d", k);
+        /* the wave jobs, packed on the device: every row exactly once, member graphs whole */
+        gnnmp_chain_jobs_t *jobs = NULL;
+        CHECK_G(gnnmp_chain_jobs_pack(&jobs, dseg, KSEL, nb, mx, 0, stream));
+        int32_t *dtab = dev_alloc(4 * 64 * KSEL), *dhdr = dev_alloc(4 * 32), hdr[32], *tab = malloc(4 * 64 * KSEL);
+        CHECK_HIP(hipMemset(dtab, 0xff, 4 * 64 * KSEL));
+        CHECK_G(gnnmp_chain_jobs_export(jobs, dtab, KSEL, dhdr, stream));
+        CHECK_HIP(hipStreamSynchronize(stream));
+        to_host(hdr, dhdr, 4 * 32); to_host(tab, dtab, 4 * 64 * KSEL);
+        REQUIRE(hdr[2] == 0 && hdr[0] > 0 && hdr[0] <= KSEL && hdr[5] == KSEL, "chain_jobs_pack: header %d %d %d", hdr[0], hdr[2], hdr[5]);
+        int *seen = calloc(nb, sizeof(int));
+        for (int j = 0; j < hdr[0]; ++j) {
+            int used = 0;
+            while (used < 64 && tab[64 * j + used] >= 0) ++used;
+            REQUIRE(used > 0, "job %d is empty", j);
+            for (int q = used; q < 64; ++q) REQUIRE(tab[64 * j + q] == -1, "job %d has a hole", j);
+            for (int q = 0; q < used;) {                      /* a whole member graph at a time */
+                const int r0 = tab[64 * j + q];
+                int k = 0;
+                while (k < KSEL && seg[k] != r0) ++k;
+                REQUIRE(k < KSEL, "job %d slot %d does not start a member graph", j, q);
+                for (int64_t r = seg[k]; r < seg[k + 1]; ++r, ++q) { REQUIRE(q < used && tab[64 * j + q] == r, "job %d: member %d not whole", j, k); ++seen[r]; }
+            }
+        }
+        for (int64_t r = 0; r < nb; ++r) REQUIRE(seen[r] == 1, "row %lld packed %d times", (long long)r, seen[r]);
+        CHECK_G(gnnmp_chain_jobs_release(jobs, stream));
+        CHECK_G(gnnmp_plan_release(pb, stream));               /* stream-ordered: back to the pool, no host synchronisation */
+        CHECK_G(gnnmp_plan_destroy(pr));
+        CHECK_G(gnnmp_plan_destroy(pds));
+    }
 
     /* ---- error contract: an index outside 1..n is refused with GNNMP_EBOUNDS and a message (convert.jl:47-54) ---- */
     int64_t bad = n + 1;
