@@ -292,6 +292,9 @@ static int launch_split(const SplitArgs &a, hipStream_t stream) {
     return staged ? launch_split_var<NCB, K0C, K1C, 4096>(a, stream) : launch_split_var<NCB, K0C, K1C, 0>(a, stream);
 }
 
+int dense_wreg_try(const float *x1, const float *W1, int64_t D1, int64_t ldw1, const float *x2, const float *W2, int64_t D2, int64_t ldw2,
+                   int w_layout, const float *bias, int act, float *out, int64_t N, int64_t Dout, hipStream_t stream);   // dense_wreg.hip
+
 // Returns GNNMP_OK if it launched, 1 if the shape is not one this kernel takes (the caller falls back to the fp32-MFMA kernels).
 int dense_split_try(const float *x1, const float *W1, int64_t D1, int64_t ldw1, const float *x2, const float *W2, int64_t D2,
                     int64_t ldw2, int w_layout, const float *bias, int act, float *out, int64_t N, int64_t Dout,
@@ -299,6 +302,11 @@ int dense_split_try(const float *x1, const float *W1, int64_t D1, int64_t ldw1, 
     if (knob(KNOB_DENSE_GENERIC) != 0 || knob(KNOB_DENSE_SPLIT) < 0) return 1;
     const bool two = D2 > 0;
     if ((D1 & 3) || (D2 & 3) || (Dout & 3) || Dout < 4 || N < 32) return 1;
+    {
+        // 256 outputs (SAGEConv(100 => 256)): W in registers, x through LDS once (dense_wreg.hip)
+        const int rc = dense_wreg_try(x1, W1, D1, ldw1, x2, W2, D2, ldw2, w_layout, bias, act, out, N, Dout, stream);
+        if (rc != 1) return rc;
+    }
     // column blocks are 32 wide: a Dout that pads by more than a tenth (100 -> 128) costs more MFMA work and a select per stored piece
     // than the fp32 16x16x4 kernel's 16-wide blocks (measured 2.4 M x 100 => 100: 625 us here, 549 us there)
     if (((Dout + 31) & ~(int64_t)31) * 10 > Dout * 11) return 1;
