@@ -148,6 +148,32 @@ __global__ void plan_col(const void *src, int idx_bytes, int base, int64_t E, in
     col[p] = (int32_t)s;
 }
 
+// ---- a plan straight from a compressed-sparse-column adjacency (gnnmp_plan_from_csc): no sort ---------------------------------------
+// rowptr[i] = colptr[i] - base; flags[0] |= 1 if the column pointers do not start at `base`, end at E + base or decrease
+__global__ void csc_rowptr_kernel(const void *colptr, int idx_bytes, int base, int64_t n_dst, int64_t E, uint32_t *rowptr, int *bad) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n_dst) return;
+    const int64_t v = load_index(colptr, i, idx_bytes, base);
+    bool ok = v >= 0 && v <= E;
+    if (i == 0) ok = ok && v == 0;
+    if (i == n_dst) ok = ok && v == E;
+    if (i < n_dst) ok = ok && load_index(colptr, i + 1, idx_bytes, base) >= v;
+    if (!ok) *bad = 1;
+    rowptr[i] = (uint32_t)(ok ? v : (i == n_dst ? E : 0));
+}
+// col[p] = rowval[p] - base, eid[p] = p (findnz order IS the slot order); flags[0] |= 1 for a source outside the graph
+__global__ void csc_col_kernel(const void *rowval, int idx_bytes, int base, int64_t E, int64_t n_src, int32_t *col, int32_t *eid, int *bad) {
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= E) return;
+    int64_t s = load_index(rowval, p, idx_bytes, base);
+    if (s < 0 || s >= n_src) {
+        *bad = 1;
+        s = 0;
+    }
+    col[p] = (int32_t)s;
+    eid[p] = (int32_t)(uint32_t)p;
+}
+
 // collect rows longer than `thresh` as (row, beg, end) triples; *count = how many (atomic), *maxdeg = max degree
 __global__ void plan_long_rows(const uint32_t *rowptr, int64_t n_dst, int thresh, int64_t *list,
                                int cap, int *count, unsigned long long *maxdeg) {
@@ -468,6 +494,70 @@ int gnnmp_plan_create(gnnmp_graph_t **out, const void *src, const void *dst, int
 
 done:
     if (keys_in) (void)hipFree(keys_in);   // keys_out and vals_in live in the same allocation
+    if (flags) (void)hipFree(flags);
+#undef PLAN_HIP
+    if (rc != GNNMP_OK) {
+        gnnmp_plan_destroy(p);
+        return rc;
+    }
+    *out = p;
+    return GNNMP_OK;
+}
+
+int gnnmp_plan_from_csc(gnnmp_graph_t **out, const void *colptr, const void *rowval, int idx_bytes, int index_base, int64_t n_src,
+                        int64_t n_dst, int64_t n_edges, int validate, gnnmp_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!out) return fail(GNNMP_EINVAL, "plan_from_csc: out is NULL");
+    *out = nullptr;
+    if (idx_bytes != 4 && idx_bytes != 8) return fail(GNNMP_EINVAL, "plan_from_csc: idx_bytes must be 4 or 8 (got %d)", idx_bytes);
+    if (index_base != 0 && index_base != 1) return fail(GNNMP_EINVAL, "plan_from_csc: index_base must be 0 or 1 (got %d)", index_base);
+    if (n_src < 0 || n_dst < 0 || n_edges < 0) return fail(GNNMP_EINVAL, "plan_from_csc: negative size");
+    if (!colptr || (n_edges > 0 && !rowval)) return fail(GNNMP_EINVAL, "plan_from_csc: null colptr / rowval");
+    if (n_edges >= (int64_t)GNNMP_MAX_SLOTS || n_src >= (int64_t)INT32_MAX || n_dst >= (int64_t)INT32_MAX)
+        return fail(GNNMP_EUNSUPPORTED, "plan_from_csc: E = %lld (limit 2^32 - 65536) / N = %lld (limit 2^31 - 2) exceed the plan format",
+                    (long long)n_edges, (long long)std::max(n_src, n_dst));
+    gnnmp_graph_t *p = new gnnmp_graph_t();
+    p->n_src = n_src;
+    p->n_dst = n_dst;
+    p->n_edges = n_edges;
+    p->n_total = n_edges;
+    p->long_thresh = plan_long_thresh(n_edges);
+    int *flags = nullptr;
+    int rc = GNNMP_OK;
+    const int BS = 256;
+    const size_t epad = (size_t)std::max<int64_t>(n_edges, 1);
+#define PLAN_HIP(expr)                                  \
+    do {                                                \
+        hipError_t e__ = (expr);                        \
+        if (e__ != hipSuccess) {                        \
+            rc = hip_fail(e__, #expr);                  \
+            goto done;                                  \
+        }                                               \
+    } while (0)
+    PLAN_HIP(hipMalloc((void **)&p->rowptr, sizeof(uint32_t) * (size_t)(n_dst + 1)));
+    PLAN_HIP(hipMalloc((void **)&p->col, sizeof(int32_t) * epad));
+    PLAN_HIP(hipMalloc((void **)&p->eid, sizeof(int32_t) * epad));
+    PLAN_HIP(hipMalloc((void **)&flags, sizeof(int) * 4));
+    PLAN_HIP(hipMemsetAsync(flags, 0, sizeof(int) * 4, stream));
+    p->bytes = (int64_t)(sizeof(int32_t) * ((size_t)(n_dst + 1) + 2 * epad));
+    csc_rowptr_kernel<<<nblocks(n_dst + 1, BS), BS, 0, stream>>>(colptr, idx_bytes, index_base, n_dst, n_edges, p->rowptr, flags);
+    PLAN_HIP(hipGetLastError());
+    if (n_edges > 0) {
+        csc_col_kernel<<<nblocks(n_edges, BS), BS, 0, stream>>>(rowval, idx_bytes, index_base, n_edges, n_src, p->col, p->eid, flags);
+        PLAN_HIP(hipGetLastError());
+    }
+    if (validate) {
+        int bad = 0;
+        PLAN_HIP(hipMemcpyAsync(&bad, flags, sizeof(int), hipMemcpyDeviceToHost, stream));
+        PLAN_HIP(hipStreamSynchronize(stream));
+        if (bad) {
+            rc = fail(GNNMP_EBOUNDS, "plan_from_csc: colptr is not a monotone 0..E column pointer, or a row index lies outside 1..n_src "
+                      "(n_src=%lld n_dst=%lld E=%lld)", (long long)n_src, (long long)n_dst, (long long)n_edges);
+            goto done;
+        }
+    }
+    rc = plan_build_long_rows(p, stream);
+done:
     if (flags) (void)hipFree(flags);
 #undef PLAN_HIP
     if (rc != GNNMP_OK) {

@@ -6,7 +6,7 @@ Host side only: every arithmetic step is a call into libgnnmp.so (hand-written H
 from ._lib import GnnmpError, knob, load, tune  # noqa: F401
 from . import placement  # noqa: F401
 from .graph import (GNNGraph, Plan, add_self_loops, batch, batch_arrays, check_num_edges, check_num_nodes, degree,  # noqa: F401
-                    edge_index, get_edge_weight, graph_indicator, set_edge_weight)
+                    edge_index, get_edge_weight, get_graph_type, graph_indicator, set_edge_weight)
 from .layers import (Dense, GATConv, GCNConv, GlobalPool, GNNChain, GraphConv, SAGEConv, bias_act, dense, fused_conv,  # noqa: F401
                      gat_conv, gcn_conv, global_pool, glorot_uniform, graph_conv, sage_conv)
 from .msgpass import (aggregate_neighbors, apply_edges, copy_xi, copy_xj, e_mul_xj, propagate, w_mul_xj,  # noqa: F401

@@ -20,7 +20,7 @@ LONG_ROW = 512
 # every symbol include/gnnmp.h declares (tests check the library exports exactly these)
 SYMBOLS = (
     "gnnmp_version", "gnnmp_last_error",
-    "gnnmp_plan_create", "gnnmp_plan_destroy", "gnnmp_plan_info", "gnnmp_plan_export", "gnnmp_plan_export64",
+    "gnnmp_plan_create", "gnnmp_plan_from_csc", "gnnmp_plan_destroy", "gnnmp_plan_info", "gnnmp_plan_export", "gnnmp_plan_export64",
     "gnnmp_plan_concat", "gnnmp_plan_select", "gnnmp_plan_release", "gnnmp_plan_status", "gnnmp_plan_edge_index",
     "gnnmp_chain_jobs_pack", "gnnmp_chain_jobs_release", "gnnmp_chain_jobs_export",
     "gnnmp_arena_create", "gnnmp_arena_destroy", "gnnmp_arena_alloc", "gnnmp_arena_reset", "gnnmp_arena_class_of", "gnnmp_arena_info",
@@ -71,6 +71,7 @@ def load():
     L.gnnmp_last_error.restype = ctypes.c_char_p
     sig = {
         "gnnmp_plan_create": [ctypes.POINTER(vp), vp, vp, i, i, i64, i64, i64, i, i, vp],
+        "gnnmp_plan_from_csc": [ctypes.POINTER(vp), vp, vp, i, i, i64, i64, i64, i, vp],
         "gnnmp_plan_destroy": [vp],
         "gnnmp_plan_info": [vp, ctypes.POINTER(i64)],
         "gnnmp_plan_export": [vp, vp, vp, vp, vp],

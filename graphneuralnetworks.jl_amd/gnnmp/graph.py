@@ -63,6 +63,26 @@ class Plan:
         self.device = s.device
 
     @classmethod
+    def from_csc(cls, colptr, rowval, n_src, n_dst, index_base=1, validate=True):
+        """the plan of a sparse-matrix graph (gnnmp_plan_from_csc): the CSC structure IS the dst-sorted CSR, no sort"""
+        L.require_gpu()
+        self = object.__new__(cls)
+        self._lib = L.load()
+        self._h = ctypes.c_void_p()
+        idx_bytes = 8 if colptr.dtype == torch.int64 else 4
+        rc = self._lib.gnnmp_plan_from_csc(ctypes.byref(self._h), L.ptr(colptr), L.ptr(rowval), idx_bytes, index_base, n_src, n_dst,
+                                           rowval.numel(), 1 if validate else 0, L.stream_ptr())
+        if rc == L.EBOUNDS:
+            raise AssertionError(self._lib.gnnmp_last_error().decode())
+        L.check(rc)
+        info = (ctypes.c_int64 * 8)()
+        L.check(self._lib.gnnmp_plan_info(self._h, info))
+        self.n_src, self.n_dst, self.n_edges, self.n_total = info[0], info[1], info[2], info[3]
+        self.max_degree, self.n_long, self.bytes, self.long_thresh = info[4], info[5], info[6], info[7]
+        self.device = colptr.device
+        return self
+
+    @classmethod
     def _adopt(cls, handle, device):
         """wrap a handle made by gnnmp_plan_concat / gnnmp_plan_select (a POOLED plan: released stream-ordered, no host sync)"""
         self = object.__new__(cls)
@@ -187,6 +207,47 @@ class GNNGraph:
         g._indices_validated = True
         return g
 
+    @classmethod
+    def from_sparse(cls, A=None, colptr=None, rowval=None, nzval=None, num_nodes=None, index_base=1, x=None, device=None):
+        """`GNNGraph(A::AbstractSparseMatrix)` — a graph of type :sparse (GNNGraphs/src/gnngraph.jl:108, abstracttypes.jl:5):
+        A[s, t] != 0 is an edge s -> t, and edge_index(g) = findnz(A) walks A's columns (query.jl:14, convert.jl:62-73), so the edges
+        are destination-sorted as stored and the plan is A's CSC structure itself (gnnmp_plan_from_csc: no sort).
+        get_edge_weight(g) = nzval (query.jl:18).  `A`: a scipy.sparse matrix or a torch sparse CSC / CSR / COO tensor; or the three
+        CSC arrays (colptr / rowval in `index_base`)."""
+        L.require_gpu()
+        device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        if A is not None:
+            if isinstance(A, torch.Tensor):
+                A = A.to_sparse_csc() if A.layout != torch.sparse_csc else A
+                n = int(A.shape[0])
+                assert A.shape[0] == A.shape[1], "adjacency matrix must be square"
+                colptr, rowval, nzval = A.ccol_indices() + index_base, A.row_indices() + index_base, A.values()
+            else:                                   # scipy.sparse
+                A = A.tocsc()
+                A.sort_indices()
+                n = int(A.shape[0])
+                assert A.shape[0] == A.shape[1], "adjacency matrix must be square"
+                import numpy as _np
+                colptr = torch.from_numpy(A.indptr.astype(_np.int64) + index_base)
+                rowval = torch.from_numpy(A.indices.astype(_np.int64) + index_base)
+                nzval = torch.from_numpy(A.data.astype(_np.float32))
+            num_nodes = n if num_nodes is None else num_nodes
+        colptr, rowval = _as_index(colptr, device), _as_index(rowval, device)
+        if rowval.dtype != colptr.dtype:
+            rowval = rowval.to(colptr.dtype)
+        if num_nodes is None:
+            num_nodes = int(colptr.numel()) - 1
+        assert colptr.numel() == num_nodes + 1, "length(colptr) == num_nodes + 1"
+        plan = Plan.from_csc(colptr, rowval, num_nodes, num_nodes, index_base)
+        g = cls._from_plan(plan, 1, None, None, index_base, colptr.dtype)
+        g.graph_type = "sparse"
+        g.w = _as_f32(nzval, device)
+        assert g.w is None or g.w.numel() == g.num_edges, "length(nzval) == nnz"
+        g.x = _as_f32(x, device)
+        if g.x is not None:
+            check_num_nodes(g, g.x)
+        return g
+
     def _materialise(self):
         p = self._plans.get(False) or self._plans.get(True)
         self._s, self._t = p.edge_index(self._idx_dtype, self.index_base)
@@ -239,6 +300,8 @@ class GNNGraph:
         dt = self._s.dtype if self._s is not None else self._idx_dtype
         return 8 if dt == torch.int64 else 4
 
+    graph_type = "coo"          # get_graph_type (GNNGraphs/src/query.jl:97-99); "sparse" for from_sparse graphs
+
     def __repr__(self):
         return f"GNNGraph(num_nodes={self.num_nodes}, num_edges={self.num_edges}, num_graphs={self.num_graphs})"
 
@@ -288,6 +351,11 @@ def edge_index(g: GNNGraph):
 
 def get_edge_weight(g: GNNGraph):
     return g.w
+
+
+def get_graph_type(g: GNNGraph):
+    """:coo / :sparse — GNNGraphs/src/query.jl:97-99"""
+    return g.graph_type
 
 
 def graph_indicator(g: GNNGraph, edges: bool = False):

@@ -19,9 +19,10 @@
 module GNNlibGnnmpExt
 
 using AMDGPU: AMDGPU, ROCArray, ROCVector, ROCMatrix, AnyROCMatrix
+using AMDGPU.rocSPARSE: ROCSparseMatrixCSC
 using ChainRulesCore: ChainRulesCore, NoTangent, ZeroTangent, unthunk, @non_differentiable
 using GNNlib: GNNlib, propagate, copy_xj, e_mul_xj, w_mul_xj
-using GNNGraphs: GNNGraphs, GNNGraph, COO_T, edge_index, get_edge_weight, check_num_nodes, check_num_edges
+using GNNGraphs: GNNGraphs, GNNGraph, COO_T, SPARSE_T, edge_index, get_edge_weight, check_num_nodes, check_num_edges
 using NNlib: relu
 using Statistics: mean
 
@@ -62,6 +63,16 @@ mutable struct Plan
                                                 sizeof(I)::Cint, 1::Cint, n_src::Int64, n_dst::Int64,
                                                 length(s)::Int64, self_loops::Cint, 1::Cint,
                                                 stream_ptr()::Ptr{Cvoid})::Cint)
+        p = new(h[])
+        finalizer(p -> (@ccall libgnnmp.gnnmp_plan_destroy(p.handle::Ptr{Cvoid})::Cint), p)
+        return p
+    end
+    # GNNGraph{SPARSE_T} on the device: the CSC structure of the adjacency IS the dst-sorted CSR (findnz order = slot order), no sort
+    function Plan(A::ROCSparseMatrixCSC{Tv, I}) where {Tv, I <: Union{Int32, Int64}}
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        check(@ccall libgnnmp.gnnmp_plan_from_csc(h::Ptr{Ptr{Cvoid}}, devptr(A.colPtr)::Ptr{Cvoid}, devptr(A.rowVal)::Ptr{Cvoid},
+                                                  sizeof(I)::Cint, 1::Cint, size(A, 1)::Int64, size(A, 2)::Int64,
+                                                  length(A.rowVal)::Int64, 1::Cint, stream_ptr()::Ptr{Cvoid})::Cint)
         p = new(h[])
         finalizer(p -> (@ccall libgnnmp.gnnmp_plan_destroy(p.handle::Ptr{Cvoid})::Cint), p)
         return p
@@ -143,6 +154,62 @@ end
 function GNNlib.propagate(::typeof(w_mul_xj), g::GNNGraph{<:COO_T}, aggr::FusedAggr, xi, xj::AnyROCMatrix{Float32},
                           e::Nothing)
     fused_propagate(g, aggr, xj, get_edge_weight(g))              # the CPU fast path's weighted adjacency (msgpass.jl:234-238)
+end
+
+# ---- GNNGraph{SPARSE_T}: the other half of the reference seam's Union{COO_T, SPARSE_T} (GNNlibAMDGPUExt.jl:13-32) ----------------------
+# The reference's methods gather / scatter over edge_index(g), which for a device sparse matrix is findnz on a ROCSparseMatrixCSC — the
+# cases GNNlib/test/msgpass.jl:171-196 mark `broken` on AMDGPU.  Here the adjacency's CSC arrays are the plan (gnnmp_plan_from_csc):
+# column t of A lists the sources of t's incoming edges, edge k of findnz(A) is slot k, get_edge_weight(g) is nzVal.
+const SparseDeviceGraph = GNNGraph{<:ROCSparseMatrixCSC}
+const DeviceGraph = Union{GNNGraph{<:COO_T}, SparseDeviceGraph}
+
+# (s, t) of a sparse graph in findnz order, materialised on the device from the plan (for the plans that need a COO: self loops, reversed)
+function device_edge_index(g::SparseDeviceGraph)
+    p = plan(g)
+    I = eltype(g.graph.colPtr)
+    s, t = ROCVector{I}(undef, g.num_edges), ROCVector{I}(undef, g.num_edges)
+    check(@ccall libgnnmp.gnnmp_plan_edge_index(p.handle::Ptr{Cvoid}, sizeof(I)::Cint, 1::Cint, devptr(s)::Ptr{Cvoid},
+                                                devptr(t)::Ptr{Cvoid}, stream_ptr()::Ptr{Cvoid})::Cint)
+    return s, t
+end
+
+function plan(g::SparseDeviceGraph; self_loops::Bool = false, transposed::Bool = false)
+    A = g.graph
+    key = PlanKey(objectid(A.colPtr), objectid(A.rowVal), g.num_nodes, self_loops, transposed)
+    lock(PLANS_LOCK) do
+        ent = get(PLANS, key, nothing)
+        if ent === nothing || !(@atomic ent.alive)
+            filter!(kv -> (@atomic kv.second.alive), PLANS)
+            p = if !self_loops && !transposed
+                Plan(A)
+            else
+                s, t = device_edge_index(g)                      # (recursion ends: that call asks for the plain plan)
+                transposed ? Plan(t, s, g.num_nodes, g.num_nodes, self_loops) : Plan(s, t, g.num_nodes, g.num_nodes, self_loops)
+            end
+            ent = PlanEntry(p, true)
+            let ent = ent
+                finalizer(_ -> (@atomic ent.alive = false), A.colPtr)
+                finalizer(_ -> (@atomic ent.alive = false), A.rowVal)
+            end
+            PLANS[key] = ent
+        end
+        ent.plan
+    end
+end
+
+sparse_weights(g::SparseDeviceGraph) = g.graph.nzVal isa ROCVector{Float32} ? g.graph.nzVal : Float32.(g.graph.nzVal)
+
+function GNNlib.propagate(::typeof(copy_xj), g::SparseDeviceGraph, aggr::FusedAggr, xi, xj::AnyROCMatrix{Float32}, e)
+    fused_propagate(g, aggr, xj, nothing)
+end
+function GNNlib.propagate(::typeof(e_mul_xj), g::SparseDeviceGraph, aggr::FusedAggr, xi, xj::AnyROCMatrix{Float32},
+                          e::ROCVector{Float32})
+    length(e) == g.num_edges || throw(AssertionError("Got $(length(e)) as last dimension size instead of num_edges=$(g.num_edges)"))
+    fused_propagate(g, aggr, xj, e)
+end
+function GNNlib.propagate(::typeof(w_mul_xj), g::SparseDeviceGraph, aggr::FusedAggr, xi, xj::AnyROCMatrix{Float32},
+                          e::Nothing)
+    fused_propagate(g, aggr, xj, sparse_weights(g))               # A's stored values (msgpass.jl:234-238: xj * A)
 end
 
 # in-degree counts (Float32) of the plan's rows: the mean adjoint divides by them

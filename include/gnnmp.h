@@ -115,6 +115,18 @@ const char *gnnmp_last_error(void);
 int gnnmp_plan_create(gnnmp_graph_t **out, const void *src, const void *dst, int idx_bytes,
                       int index_base, int64_t n_src, int64_t n_dst, int64_t n_edges,
                       int add_self_loops, int validate, gnnmp_stream_t stream);
+/* The plan of a GNNGraph{SPARSE_T} (GNNGraphs/src/abstracttypes.jl:5, gnngraph.jl:108): the graph IS a compressed-sparse-column
+ * adjacency A with A[s, t] != 0 for an edge s -> t, and the reference's device seam takes such graphs next to COO ones
+ * (GNNlib/ext/GNNlibAMDGPUExt.jl:13-32 dispatches on Union{COO_T, SPARSE_T}).  Column t of A lists the sources of t's incoming edges
+ * in ascending order, and edge_index(g) = findnz(A) walks the columns in order (GNNGraphs/src/query.jl:14, convert.jl:62-73): the
+ * edges of a sparse graph are ALREADY destination-sorted and the plan is the CSC structure itself — no sort:
+ *      rowptr = colptr - index_base      col = rowval - index_base      eid[p] = p   (edge k of edge_index(g) is slot k)
+ * so that edge data in findnz order (get_edge_weight(g) = nzval, query.jl:18) is what `w` / `e` of the propagate entry points take.
+ *   colptr : n_dst + 1 column pointers (SparseMatrixCSC.colptr / ROCSparseMatrixCSC.colPtr), rowval : n_edges row indices.
+ *   validate != 0: colptr[1] = 1, colptr[end] = n_edges + 1, non-decreasing, 1 <= rowval <= n_src checked on the device (GNNMP_EBOUNDS).
+ * Stored entries with value zero are edges, as in findnz.  Same limits and the same stream synchronisation as gnnmp_plan_create. */
+int gnnmp_plan_from_csc(gnnmp_graph_t **out, const void *colptr, const void *rowval, int idx_bytes, int index_base, int64_t n_src,
+                        int64_t n_dst, int64_t n_edges, int validate, gnnmp_stream_t stream);
 int gnnmp_plan_destroy(gnnmp_graph_t *plan);
 /* info[0]=n_src info[1]=n_dst info[2]=n_edges (as given) info[3]=E' (with self loops)
  * info[4]=max in-degree info[5]=number of split (long) rows info[6]=bytes of device memory held */
