@@ -245,6 +245,42 @@ def batched_setup(rank, world, dist, G=8192, forward_factory=None, device=None):
                     "of the features, gnnmp_chain_jobs_pack (1 launch), then the fused chain (2 launches); no host synchronisation in "
                     "the loop (the host prepares step k + 1 while the device runs step k)"}
         del loader, ds
+        # The TRAINING step of the same model on the same batch (the reference example is a training script,
+        # graph_classification_tudataset.jl:97-104): forward layer by layer with stored activations, every pullback a libgnnmp adjoint
+        # kernel (gnnmp/backward.py), torch for the loss and Adam.  There is no fused backward chain: reported, not claimed.
+        try:
+            import torch.nn.functional as F
+            from gnnmp.backward import dense_ad, global_pool_ad, graph_conv_ad
+            c1, c2, poolL, head = model.layers
+            tparams = [c1.weight1, c1.weight2, c1.bias, c2.weight1, c2.weight2, c2.bias, head.weight, head.bias]
+            saved = [p.detach().clone() for p in tparams]
+            for p in tparams:
+                p.requires_grad_(True)
+            opt = torch.optim.Adam(tparams, lr=1e-3)
+            Yb = torch.from_numpy(np.random.default_rng(8).integers(0, 2, g.num_graphs)).cuda()
+
+            def train_steps(n):
+                torch.cuda.synchronize(); ta = time.perf_counter()
+                for _ in range(n):
+                    opt.zero_grad(set_to_none=True)
+                    lg = dense_ad(head, global_pool_ad(poolL, g, graph_conv_ad(c2, g, graph_conv_ad(c1, g, g.x))))
+                    F.cross_entropy(lg, Yb).backward()
+                    opt.step()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - ta) / n * 1e3
+            train_steps(3)
+            t_train = train_steps(20)
+            with torch.no_grad():
+                for p, v in zip(tparams, saved):
+                    p.copy_(v)
+            for p in tparams:
+                p.requires_grad_(False)
+                p.grad = None
+            batched_setup.train = {"train_step_ms": t_train,
+                                   "what": "forward (5 launches, activations stored) + cross-entropy + the layers' HIP adjoints + Adam on "
+                                           "the static batch; no fused backward chain exists"}
+        except Exception as e:      # the side line must not take the bench line with it
+            batched_setup.train = {"error": repr(e)}
         forward = lambda: model(g, g.x)                      # noqa: E731
         device = torch.device("cuda", torch.cuda.current_device())
     else:
@@ -769,7 +805,8 @@ def main():
         extras["batched"] = {"graphs": Gb, "nodes": nb, "edges": eb, "ms_per_step": tb,
                              "graphs_per_s": Gb / tb * 1e3, "edges_per_s": 2 * eb / tb * 1e3,
                              "per_batch_prep_outside_the_timed_steps": getattr(batched_setup, "prep_ms", None),
-                             "new_batch_every_step": getattr(batched_setup, "new_batch", None)}
+                             "new_batch_every_step": getattr(batched_setup, "new_batch", None),
+                             "training_step": getattr(batched_setup, "train", None)}
         del bstep
 
     # The one path of BASELINE.json that shards (config 5): when the driver runs the default workload on N > 1 ranks, the same N ranks

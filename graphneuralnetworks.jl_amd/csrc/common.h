@@ -1,6 +1,8 @@
 // common.h — shared host/device helpers of libgnnmp (MI355X / gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <mutex>
 #include <stdint.h>
 #include "gnnmp.h"
 
@@ -20,6 +22,19 @@ int hip_fail(hipError_t e, const char *what);
     do {                                                        \
         hipError_t e__ = hipGetLastError();                     \
         if (e__ != hipSuccess) return ::gnnmp::hip_fail(e__, what); \
+    } while (0)
+
+// The opt-in of a kernel to more than 64 KB of dynamic LDS: once per process and kernel instance, thread-safe (the library promises no
+// unsynchronised mutable state besides the knobs, gnnmp.h).  GNNMP_LDS_OPTIN("name", &kernel<args...>)
+#define GNNMP_LDS_OPTIN(what, ...)                                                                                            \
+    do {                                                                                                                      \
+        static std::once_flag once__;                                                                                         \
+        static hipError_t err__ = hipSuccess;                                                                                 \
+        std::call_once(once__, [] {                                                                                           \
+            err__ = hipFuncSetAttribute(reinterpret_cast<const void *>(__VA_ARGS__), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                        160 * 1024);                                                                          \
+        });                                                                                                                   \
+        if (err__ != hipSuccess) return ::gnnmp::hip_fail(err__, "hipFuncSetAttribute(" what ")");                            \
     } while (0)
 
 // ---- tuning knobs (perf experiments; not part of the drop-in surface) -------------------------

@@ -465,13 +465,7 @@ __global__ void __launch_bounds__(512) dense_wlds_kernel(const DenseWArgs w) {
 
 template <int NT>
 static int launch_wlds(const DenseWArgs &w, size_t lds_bytes, int col_tiles, int64_t n_row_tiles, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_wlds_kernel<NT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(dense_wlds_kernel)");
-        attr_set = true;
-    }
+    GNNMP_LDS_OPTIN("dense_wlds_kernel", &dense_wlds_kernel<NT>);
     const int cus = device_cus();
     int64_t gx = (n_row_tiles + w.waves - 1) / w.waves;
     if (gx > cus) gx = cus;  // one persistent block per CU (the LDS image allows no more)

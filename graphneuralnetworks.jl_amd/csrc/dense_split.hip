@@ -236,13 +236,7 @@ static int launch_split_var(const SplitArgs &a0, hipStream_t stream) {
     SplitArgs a = a0;
     constexpr int DP = NCB * 32;
     const size_t lds = split_img_bytes(a.nkb * 16, DP) + (size_t)DP * 4 + ((VAR & 4096) ? (size_t)(split_threads<NCB, VAR>() / 64) * 4096 : 0);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_split_kernel<NCB, K0C, K1C, VAR>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(dense_split_kernel)");
-        attr_set = true;
-    }
+    GNNMP_LDS_OPTIN("dense_split_kernel", &dense_split_kernel<NCB, K0C, K1C, VAR>);
     const int cus = device_cus();
     const int64_t ntiles = (a.N + 31) / 32;
     constexpr int max_waves = split_threads<NCB, VAR>() / 64;

@@ -130,13 +130,7 @@ static int launch_t16(const T16Args &a0, hipStream_t stream) {
     constexpr int DP = NCB * 16;
     const int rows = t16_img_rows(a.K[0]) + (a.nseg > 1 ? t16_img_rows(a.K[1]) : 0);
     const size_t lds = (size_t)rows * DP * 16 + (size_t)DP * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_t16_kernel<NCB, MAXB, KQ1, KQ2>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(dense_t16_kernel)");
-        attr_set = true;
-    }
+    GNNMP_LDS_OPTIN("dense_t16_kernel", &dense_t16_kernel<NCB, MAXB, KQ1, KQ2>);
     const int cus = device_cus();
     const int64_t ntiles = (a.N + 15) / 16;
     // waves per block: 16 (four per SIMD) on large inputs; on small ones fewer, so that every CU gets a block

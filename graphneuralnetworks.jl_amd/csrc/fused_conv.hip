@@ -183,13 +183,7 @@ static int launch_fused(FusedArgs &a, size_t img_bytes, hipStream_t stream) {
     const int kw = knob(KNOB_FUSED_WAVES);
     if (kw >= 1 && kw <= waves) waves = kw;
     a.waves = waves;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_conv_kernel<NCB, KQA, OP, SCALED>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(fused_conv_kernel)");
-        attr_set = true;
-    }
+    GNNMP_LDS_OPTIN("fused_conv_kernel", &fused_conv_kernel<NCB, KQA, OP, SCALED>);
     const int ntiles = (a.r.n_rows + 15) / 16;
     const int gx = std::min(device_cus(), (ntiles + waves - 1) / waves);
     // the ticket starts every launch at zero: an 8-byte memset node on the same stream (a kernel that re-armed it itself would

@@ -542,16 +542,8 @@ extern "C" int gnnmp_graphconv_chain_f32(gnnmp_graph_t *p, const gnnmp_chain_job
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(cus, a.N / 128));
     a.waves = CHAIN_THREADS / 64;
     const size_t lds = 128 + 8 * CHAIN_DP * 4 + CHAIN_DP * 4 + img_max;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&graph_chain_kernel<true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&graph_chain_kernel<false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(graph_chain_kernel)");
-        attr_set = true;
-    }
+    GNNMP_LDS_OPTIN("graph_chain_kernel", &graph_chain_kernel<true>);
+    GNNMP_LDS_OPTIN("graph_chain_kernel", &graph_chain_kernel<false>);
     if (fullcols)
         graph_chain_kernel<true><<<blocks, CHAIN_THREADS, lds, stream>>>(a);
     else

@@ -401,13 +401,7 @@ static int launch_chunks(const SmxArgs &a0, hipStream_t stream) {
 template <int VEC>
 static int launch_smx(const SmxArgs &a, hipStream_t stream) {
     const size_t lds = (size_t)a.waves * a.wave_bytes;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&softmax_rows_lds_kernel<VEC>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(softmax_rows_lds_kernel)");
-        attr_set = true;
-    }
+    GNNMP_LDS_OPTIN("softmax_rows_lds_kernel", &softmax_rows_lds_kernel<VEC>);
     const int64_t wave_rows = ((int64_t)a.n_rows + a.rw - 1) / a.rw;
     const int64_t blocks = (wave_rows + a.waves - 1) / a.waves;
     softmax_rows_lds_kernel<VEC><<<(unsigned)blocks, 64 * a.waves, lds, stream>>>(a);
