@@ -2,6 +2,7 @@
 """The small configs of BASELINE.json alone, for rocprofv3 kernel traces and A/B runs:
     python tools/small_configs.py arxiv   [knob=value ...]   GCNConv(128=>128,relu) and GATConv(128=>16,h=8,relu) forward, arxiv shape
     python tools/small_configs.py batched [knob=value ...]   config 5: 8192 graphs, GraphConv x2 + GlobalPool(mean) + Dense
+    python tools/small_configs.py sage [noplace] [knob=value ...]   config 4: SAGEConv(100=>256, relu; mean) forward, products shape
 Prints the wall time per layer / step (median of per-call HIP events and the back-to-back average)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,7 +13,8 @@ import torch, gnnmp
 from gnnmp import synth
 
 what = sys.argv[1] if len(sys.argv) > 1 else "arxiv"
-for kv in sys.argv[2:]:
+noplace = "noplace" in sys.argv[2:]        # sage: fresh allocations instead of the placement arena (no probe launches in a kernel trace)
+for kv in [a for a in sys.argv[2:] if a != "noplace"]:
     k, v = kv.split("=")
     gnnmp.tune(int(k), int(v))
 
@@ -45,6 +47,15 @@ if what == "arxiv":
     print("arxiv shape: E' =", p.n_total, "split threshold", p.long_thresh, "split rows", p.n_long, "max degree", p.max_degree)
     measure(lambda: gcn(g, x), "GCNConv(128=>128) layer")
     measure(lambda: gat(g, x), "GATConv(128=>16,h=8) layer")
+elif what == "sage":
+    N, D = synth.PRODUCTS["N"], synth.PRODUCTS["D"]
+    s, t = synth.products_like()
+    g = gnnmp.GNNGraph(torch.from_numpy(s).cuda(), torch.from_numpy(t).cuda(), num_nodes=N, _validated=True)
+    x = torch.from_numpy(synth.features(N, D, seed=1)).cuda()
+    sage = gnnmp.SAGEConv((D, 256), "relu", aggr="mean", seed=13)
+    sage.place_outputs = not noplace
+    print("products shape: E =", g.num_edges)
+    measure(lambda: sage(g, x), "SAGEConv(100=>256, mean) layer", it=30)
 else:
     members = synth.batched_graphs(G=8192)
     rng = np.random.default_rng(4)
