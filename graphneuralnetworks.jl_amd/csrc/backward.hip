@@ -58,15 +58,40 @@ struct EdgeDotRowsArgs {
     uint32_t n_edges;
     int D, n_rows, log2g, waves;
 };
-template <int VEC, int U>
+// U dot products' partial sums, one set per lane of a G-lane group -> lane l of the group gets the TOTAL of product (l mod U): a
+// transposing butterfly.  At step s a lane keeps the products whose index has bit s equal to ITS bit s and hands the others to lane ^ 2^s:
+// U/2 + U/4 + ... + 1 exchanges, then log2(G / U) plain steps on the one value left — 9 exchanges for 8 products over 32 lanes where a
+// butterfly per product costs 40 (edge_dot_rows_kernel was bound by them: 12.1 ms at the products size, the gather itself needs 4.5).
+template <int U, int G>
+__device__ __forceinline__ float reduce_transposed(float (&d)[U], int lane) {
+    static_assert(U <= G, "one product per lane at most");
+#pragma unroll
+    for (int s = 0; (U >> s) > 1; ++s) {
+        const int o = 1 << s;
+        const bool hi = (lane & o) != 0;
+#pragma unroll
+        for (int i = 0; i < (U >> (s + 1)); ++i) {
+            const float keep = hi ? d[2 * i + 1] : d[2 * i];
+            const float send = hi ? d[2 * i] : d[2 * i + 1];
+            d[i] = keep + __shfl_xor(send, o, 64);
+        }
+    }
+    float r = d[0];
+#pragma unroll
+    for (int o = U; o < G; o <<= 1) r += __shfl_xor(r, o, 64);
+    return r;
+}
+
+template <int VEC, int LOG2G>
 __global__ void __launch_bounds__(256) edge_dot_rows_kernel(const EdgeDotRowsArgs a) {
+    constexpr int G = 1 << LOG2G;
+    constexpr int U = G < 8 ? G : 8;               // products per batch: loads in flight per lane, and the transposed reduction's width
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int G = 1 << a.log2g;
     const int lig = lane & (G - 1);
-    const int grp = lane >> a.log2g;
+    const int grp = lane >> LOG2G;
     const int gbase = lane - lig;
-    const int rpw = 64 >> a.log2g;
+    constexpr int rpw = 64 >> LOG2G;
     const int64_t v64 = ((int64_t)blockIdx.x * a.waves + wave) * rpw + grp;
     if (v64 >= (int64_t)a.n_rows + a.n_chunks) return;
     const int v = (int)v64;
@@ -110,14 +135,15 @@ __global__ void __launch_bounds__(256) edge_dot_rows_kernel(const EdgeDotRowsArg
                     for (int q = 0; q < VEC; ++q) bv[u][q] = 0.0f;
                 }
             }
+            float d[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                float d = 0.0f;
+                d[u] = 0.0f;
 #pragma unroll
-                for (int q = 0; q < VEC; ++q) d = fmaf(av[q], bv[u][q], d);
-                for (int o = 1; o < G; o <<= 1) d += __shfl_xor(d, o, 64);
-                if (lig == j + u) mine = d;
+                for (int q = 0; q < VEC; ++q) d[u] = fmaf(av[q], bv[u][q], d[u]);
             }
+            const float r = reduce_transposed<U, G>(d, lane);      // the total of product j + (lig mod U)
+            if ((lig & ~(U - 1)) == j) mine = r;
         }
         if (p < end && e < a.n_edges) a.out[e] = mine;   // plan-added self loops carry no weight: no output slot
     }
@@ -258,11 +284,19 @@ int gnnmp_edge_dot_plan_f32(gnnmp_graph_t *plan, const float *a_dst, const float
     a.waves = 4;
     const int rows_per_block = (64 >> a.log2g) * a.waves;
     const unsigned nb = (unsigned)(((int64_t)a.n_rows + a.n_chunks + rows_per_block - 1) / rows_per_block);
-    switch (vec) {
-        case 4: edge_dot_rows_kernel<4, 4><<<nb, 256, 0, stream>>>(a); break;
-        case 2: edge_dot_rows_kernel<2, 4><<<nb, 256, 0, stream>>>(a); break;
-        default: edge_dot_rows_kernel<1, 4><<<nb, 256, 0, stream>>>(a); break;
+#define EDR(V, LG) edge_dot_rows_kernel<V, LG><<<nb, 256, 0, stream>>>(a)
+#define EDR_LG(V)                                                                                                       \
+    switch (a.log2g) {                                                                                                  \
+        case 0: EDR(V, 0); break; case 1: EDR(V, 1); break; case 2: EDR(V, 2); break; case 3: EDR(V, 3); break;          \
+        case 4: EDR(V, 4); break; case 5: EDR(V, 5); break; default: EDR(V, 6); break;                                   \
     }
+    switch (vec) {
+        case 4: EDR_LG(4); break;
+        case 2: EDR_LG(2); break;
+        default: EDR_LG(1); break;
+    }
+#undef EDR_LG
+#undef EDR
     GNNMP_LAUNCH_CHECK("edge_dot_rows_kernel");
     return GNNMP_OK;
 }

@@ -64,7 +64,9 @@ def propagate_grad_w(g: GNNGraph, dy, xj, coo_order: bool = False):
     """Δw[k] = Δ[t_k] · xj[s_k]  (w_mul_xj / e_mul_xj with a vector e, aggr = +; for mean pre-scale Δ by 1/count)"""
     dyf, xf = _flat(dy), _flat(xj)
     out = torch.empty(g.num_edges, dtype=torch.float32, device=dy.device)
-    if dyf.shape[1] <= 256 and not coo_order:
+    D = dyf.shape[1]
+    lanes = D // 4 if D % 4 == 0 else (D // 2 if D % 2 == 0 else D)      # the row kernel holds a feature row in ONE lane group (<= 64 lanes)
+    if lanes <= 64 and not coo_order:
         # destination-sorted walk: Δ[t] stays in registers for all edges of a destination (half the traffic)
         L.check(L.load().gnnmp_edge_dot_plan_f32(g.plan(False).handle, L.ptr(dyf), L.ptr(xf), L.ptr(out), dyf.shape[1],
                                                  L.stream_ptr()))

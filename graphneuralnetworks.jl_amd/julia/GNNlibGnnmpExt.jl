@@ -256,8 +256,16 @@ function ChainRulesCore.rrule(::typeof(fused_propagate), g::GNNGraph, aggr, xj::
             Δs = sd === nothing ? Δ : Δ .* reshape(sd, 1, :)
             xs = scale_src === nothing ? xj : xj .* reshape(scale_src, 1, :)
             Δw = similar(w)
-            check(@ccall libgnnmp.gnnmp_edge_dot_plan_f32(plan(g).handle::Ptr{Cvoid}, devptr(Δs)::Ptr{Cvoid},
-                      devptr(xs)::Ptr{Cvoid}, devptr(Δw)::Ptr{Cvoid}, D::Int64, stream_ptr()::Ptr{Cvoid})::Cint)
+            lanes = D % 4 == 0 ? D ÷ 4 : (D % 2 == 0 ? D ÷ 2 : D)      # the row kernel keeps a feature row in ONE lane group (<= 64 lanes)
+            if lanes <= 64
+                check(@ccall libgnnmp.gnnmp_edge_dot_plan_f32(plan(g).handle::Ptr{Cvoid}, devptr(Δs)::Ptr{Cvoid},
+                          devptr(xs)::Ptr{Cvoid}, devptr(Δw)::Ptr{Cvoid}, D::Int64, stream_ptr()::Ptr{Cvoid})::Cint)
+            else                                                        # wider rows: the COO-order kernel
+                s, t = edge_index(g)
+                check(@ccall libgnnmp.gnnmp_edge_dot_f32(devptr(Δs)::Ptr{Cvoid}, devptr(xs)::Ptr{Cvoid}, devptr(s)::Ptr{Cvoid},
+                          devptr(t)::Ptr{Cvoid}, sizeof(eltype(s))::Cint, 1::Cint, length(s)::Int64, D::Int64,
+                          devptr(Δw)::Ptr{Cvoid}, stream_ptr()::Ptr{Cvoid})::Cint)
+            end
         end
         return NoTangent(), NoTangent(), NoTangent(), Δx, Δw
     end

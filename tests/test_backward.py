@@ -74,7 +74,7 @@ def dev(a):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("D", [1, 5, 16, 100, 128])
+@pytest.mark.parametrize("D", [1, 5, 8, 16, 36, 100, 128, 200, 250])      # edge_dot lane groups of 1, 8, 2, 4, 16, 32, 32, 64; COO fallback
 def test_hip_adjoints_vs_oracle(gm, oracle, D):
     from gnnmp import backward as bw
     rng = np.random.default_rng(D)
