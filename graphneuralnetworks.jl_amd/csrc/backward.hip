@@ -61,7 +61,8 @@ struct EdgeDotRowsArgs {
 // U dot products' partial sums, one set per lane of a G-lane group -> lane l of the group gets the TOTAL of product (l mod U): a
 // transposing butterfly.  At step s a lane keeps the products whose index has bit s equal to ITS bit s and hands the others to lane ^ 2^s:
 // U/2 + U/4 + ... + 1 exchanges, then log2(G / U) plain steps on the one value left — 9 exchanges for 8 products over 32 lanes where a
-// butterfly per product costs 40 (edge_dot_rows_kernel was bound by them: 12.1 ms at the products size, the gather itself needs 4.5).
+// butterfly per product costs 40.  (Measured at the products size: 6.7 -> 6.6 ms.  The kernel is bound by its 4-byte stores in original
+// edge order — a write request each — not by the reductions; the gather alone needs 4.5 ms.)
 template <int U, int G>
 __device__ __forceinline__ float reduce_transposed(float (&d)[U], int lane) {
     static_assert(U <= G, "one product per lane at most");
