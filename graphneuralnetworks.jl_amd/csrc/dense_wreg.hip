@@ -214,7 +214,7 @@ static int launch_wreg(const WregArgs &a, hipStream_t stream) {
 int dense_wreg_try(const float *x1, const float *W1, int64_t D1, int64_t ldw1, const float *x2, const float *W2, int64_t D2, int64_t ldw2,
                    int w_layout, const float *bias, int act, float *out, int64_t N, int64_t Dout, hipStream_t stream) {
     if (knob(KNOB_VARIANT) & 64) return 1;                    // knob 19 bit 6: never (A/B runs)
-    if (Dout != WR_DP || N < 4096) return 1;
+    if (Dout != WR_DP || N < 4096 || N > (int64_t)INT32_MAX - 64) return 1;      // (row numbers of a tile are 32-bit)
     const bool two = D2 > 0;
     if ((reinterpret_cast<uintptr_t>(x1) & 15) || (reinterpret_cast<uintptr_t>(out) & 127)) return 1;
     if (two && (reinterpret_cast<uintptr_t>(x2) & 15)) return 1;
