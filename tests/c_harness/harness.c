@@ -4,7 +4,8 @@
  * (Dout, Din) column-major weight = w_layout 1 with ldw = Dout, `a` (2C, H) column-major = [H][2C].
  *   plan_create(validate) -> plan_info / plan_export -> degree -> propagate(copy_xj | w_mul_xj; +, mean, max) ->
  *   dense -> fused_conv -> gat_conv -> plan_destroy, the EBOUNDS error path, and (round 4) a batch taken from a resident dataset:
- *   plan_select == plan_create on the concatenated COO, plan_edge_index, the node map, chain_jobs_pack / export, plan_release.
+ *   plan_select == plan_create on the concatenated COO, plan_edge_index, the node map, chain_jobs_pack / export, plan_release;
+ *   plan_from_csc == plan_create on findnz(A) for a sparse-matrix graph.
  * Expected values come from plain host loops in this file (edge order, separately rounded products: bit-exact where the
  * library promises bits).  Prints C_HARNESS_OK and exits 0 on success.   Built by __graft_entry__.build() / tests. */
 #include <hip/hip_runtime_api.h>
@@ -331,6 +332,51 @@ int main(void) {
         CHECK_G(gnnmp_plan_release(pb, stream));               /* stream-ordered: back to the pool, no host synchronisation */
         CHECK_G(gnnmp_plan_destroy(pr));
         CHECK_G(gnnmp_plan_destroy(pds));
+    }
+
+    /* ---- a sparse-matrix graph (GNNGraph{SPARSE_T}): the CSC arrays of A (A[s, t] != 0 for s -> t) ARE the plan — gnnmp_plan_from_csc
+     * must equal gnnmp_plan_create on findnz(A)'s COO, and slot k must be edge k (GNNGraphs/src/query.jl:14, convert.jl:62-73).  A
+     * SparseMatrixCSC has no duplicates: the multigraph above is de-duplicated column by column. ---- */
+    {
+        int64_t *colptr = malloc(8 * (n + 1)), *rowval = malloc(8 * E);
+        unsigned char *seen = calloc((size_t)n, 1);
+        int64_t nnz = 0;
+        for (int64_t j = 0; j < n; ++j) {                    /* column j = sources of j's incoming edges, ascending, once each */
+            colptr[j] = nnz + 1;
+            memset(seen, 0, (size_t)n);
+            for (int64_t p = rowptr[j]; p < rowptr[j + 1]; ++p) seen[col[p]] = 1;
+            for (int64_t i = 0; i < n; ++i)
+                if (seen[i]) rowval[nnz++] = i + 1;
+        }
+        colptr[n] = nnz + 1;
+        int64_t *fs = malloc(8 * nnz), *ft = malloc(8 * nnz);          /* findnz(A): columns in order */
+        for (int64_t j = 0, k = 0; j < n; ++j)
+            for (int64_t p = colptr[j] - 1; p < colptr[j + 1] - 1; ++p, ++k) { fs[k] = rowval[p]; ft[k] = j + 1; }
+        void *dcp = dev_copy(colptr, 8 * (n + 1)), *drv = dev_copy(rowval, 8 * nnz), *dfs = dev_copy(fs, 8 * nnz), *dft = dev_copy(ft, 8 * nnz);
+        gnnmp_graph_t *pc = NULL, *pf = NULL;
+        CHECK_G(gnnmp_plan_from_csc(&pc, dcp, drv, 8, 1, n, n, nnz, 1, stream));
+        CHECK_G(gnnmp_plan_create(&pf, dfs, dft, 8, 1, n, n, nnz, 0, 1, stream));
+        int32_t *h1 = malloc(4 * (nnz + n + 1)), *h2 = malloc(4 * (nnz + n + 1));
+        void *d1 = dev_alloc(4 * (n + 1)), *d2 = dev_alloc(4 * nnz), *d3 = dev_alloc(4 * nnz);
+        const gnnmp_graph_t *both[2] = {pc, pf};
+        int32_t *arr[2][3];
+        for (int w2 = 0; w2 < 2; ++w2) {
+            CHECK_G(gnnmp_plan_export(both[w2], d1, d2, d3, stream));
+            CHECK_HIP(hipStreamSynchronize(stream));
+            arr[w2][0] = malloc(4 * (n + 1)); arr[w2][1] = malloc(4 * nnz); arr[w2][2] = malloc(4 * nnz);
+            to_host(arr[w2][0], d1, 4 * (n + 1)); to_host(arr[w2][1], d2, 4 * nnz); to_host(arr[w2][2], d3, 4 * nnz);
+        }
+        REQUIRE(memcmp(arr[0][0], arr[1][0], 4 * (n + 1)) == 0 && memcmp(arr[0][1], arr[1][1], 4 * nnz) == 0 &&
+                memcmp(arr[0][2], arr[1][2], 4 * nnz) == 0, "plan_from_csc differs from plan_create on findnz(A)");
+        for (int64_t k = 0; k < nnz; ++k) REQUIRE(arr[0][2][k] == k, "plan_from_csc: slot %lld is not edge %lld", (long long)k, (long long)k);
+        colptr[3] = colptr[2] - 1;                               /* a decreasing column pointer is refused */
+        CHECK_HIP(hipMemcpy(dcp, colptr, 8 * (n + 1), hipMemcpyHostToDevice));
+        gnnmp_graph_t *pbadc = NULL;
+        const int stc = gnnmp_plan_from_csc(&pbadc, dcp, drv, 8, 1, n, n, nnz, 1, stream);
+        REQUIRE(stc == GNNMP_EBOUNDS && pbadc == NULL, "plan_from_csc: bad colptr gave status %d", stc);
+        CHECK_G(gnnmp_plan_destroy(pc));
+        CHECK_G(gnnmp_plan_destroy(pf));
+        (void)h1; (void)h2;
     }
 
     /* ---- error contract: an index outside 1..n is refused with GNNMP_EBOUNDS and a message (convert.jl:47-54) ---- */
