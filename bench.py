@@ -743,71 +743,74 @@ def main():
         "gat_dense_x": dense_line(f"{N}x{D}=>{H * C}", t_da, D, H * C, "dense_split_kernel (3-plane split-bf16, six bf16 MFMAs per product, fp32 accumulate)"),
         "in_step": instep.get("dense")}
     if rank == 0 and not args.no_extras and args.workload == "products":
-        # BASELINE.json config 4: SAGEConv(100 => 256) on the same graph (no self loops), aggr = mean and aggr = +
-        sage = gnnmp.SAGEConv((D, 256), "relu", aggr="mean", seed=13)
-        sage.place_outputs = not args.no_placement
-        t_sm = layer_time(lambda: sage(g, x), 5)
-        sage.aggr = "+"
-        t_ss = layer_time(lambda: sage(g, x), 5)
-        extras["sage_products"] = {"E": E, "layer_ms_mean": t_sm, "layer_ms_sum": t_ss,
-                                   "edges_per_s_mean": E / t_sm * 1e3, "edges_per_s_sum": E / t_ss * 1e3}
-        del out_p, out_g, Wx, sage
-        # SURVEY §8f "next" rows on the same graph: the standalone neighbourhood softmax (a20) and the training step of the two
-        # headline layers (f1: forward + backward through the HIP adjoints)
-        from gnnmp.backward import gat_conv_ad, gcn_conv_ad
-        e8 = torch.randn((E, H), device="cuda")
-        t_sx = layer_time(lambda: gnnmp.softmax_edge_neighbors(g, e8), 5)
-        del e8
-        xr = x.clone().requires_grad_(True)
-        dyg = torch.randn((N, D), device="cuda")
-        dya = torch.randn((N, H * C), device="cuda")
-        for prm in (gcn.weight, gcn.bias, gat.dense_x_weight, gat.a, gat.bias):
-            prm.requires_grad_(True)
+        try:      # side lines only: whatever goes wrong here must not take the bench line (or, at N > 1, the other ranks) with it
+            # BASELINE.json config 4: SAGEConv(100 => 256) on the same graph (no self loops), aggr = mean and aggr = +
+            sage = gnnmp.SAGEConv((D, 256), "relu", aggr="mean", seed=13)
+            sage.place_outputs = not args.no_placement
+            t_sm = layer_time(lambda: sage(g, x), 5)
+            sage.aggr = "+"
+            t_ss = layer_time(lambda: sage(g, x), 5)
+            extras["sage_products"] = {"E": E, "layer_ms_mean": t_sm, "layer_ms_sum": t_ss,
+                                       "edges_per_s_mean": E / t_sm * 1e3, "edges_per_s_sum": E / t_ss * 1e3}
+            del out_p, out_g, Wx, sage
+            # SURVEY §8f "next" rows on the same graph: the standalone neighbourhood softmax (a20) and the training step of the two
+            # headline layers (f1: forward + backward through the HIP adjoints)
+            from gnnmp.backward import gat_conv_ad, gcn_conv_ad
+            e8 = torch.randn((E, H), device="cuda")
+            t_sx = layer_time(lambda: gnnmp.softmax_edge_neighbors(g, e8), 5)
+            del e8
+            xr = x.clone().requires_grad_(True)
+            dyg = torch.randn((N, D), device="cuda")
+            dya = torch.randn((N, H * C), device="cuda")
+            for prm in (gcn.weight, gcn.bias, gat.dense_x_weight, gat.a, gat.bias):
+                prm.requires_grad_(True)
 
-        def train(fn, l, dy):
-            def f():
-                fn(l, g, xr).backward(dy)
-                xr.grad = None
-            return f
+            def train(fn, l, dy):
+                def f():
+                    fn(l, g, xr).backward(dy)
+                    xr.grad = None
+                return f
 
-        def median_time(fn, iters=5):   # two warm-ups (the first calls build the reversed-edge plans and grow the allocator)
-            fn(); fn()
-            torch.cuda.synchronize()
-            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
-            for a_, b_ in ev:
-                a_.record(); fn(); b_.record()
-            torch.cuda.synchronize()
-            return sorted(a_.elapsed_time(b_) for a_, b_ in ev)[iters // 2]
+            def median_time(fn, iters=5):   # two warm-ups (the first calls build the reversed-edge plans and grow the allocator)
+                fn(); fn()
+                torch.cuda.synchronize()
+                ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+                for a_, b_ in ev:
+                    a_.record(); fn(); b_.record()
+                torch.cuda.synchronize()
+                return sorted(a_.elapsed_time(b_) for a_, b_ in ev)[iters // 2]
 
-        t_tg = median_time(train(gcn_conv_ad, gcn, dyg))
-        t_ta = median_time(train(gat_conv_ad, gat, dya))
-        for prm in (gcn.weight, gcn.bias, gat.dense_x_weight, gat.a, gat.bias):
-            prm.requires_grad_(False)
-            prm.grad = None
-        extras["next_rows"] = {"softmax_edge_neighbors_h8_ms": t_sx, "gcn_fwd_bwd_ms": t_tg, "gat_fwd_bwd_ms": t_ta}
-        del xr, dyg, dya
-        # configs 2 and 3: arxiv shape
-        Na, Da = synth.ARXIV["N"], synth.ARXIV["D"]
-        sa, ta = synth.arxiv_like()
-        ga = gnnmp.GNNGraph(torch.from_numpy(sa).cuda(), torch.from_numpy(ta).cuda(), num_nodes=Na, _validated=True)
-        xa = torch.from_numpy(synth.features(Na, Da, seed=1)).cuda()
-        gcn_a = gnnmp.GCNConv((Da, Da), "relu", seed=11)
-        gat_a = gnnmp.GATConv((Da, C), "relu", heads=H, seed=12)
-        Epa = len(sa) + Na
-        tga = layer_time(lambda: gcn_a(ga, xa), 50)
-        taa = layer_time(lambda: gat_a(ga, xa), 50)
-        extras["arxiv"] = {"E_prime": Epa, "gcn_layer_ms": tga, "gat_layer_ms": taa,
-                           "gcn_edges_per_s": Epa / tga * 1e3, "gat_edges_per_s": Epa / taa * 1e3}
-        del ga, xa
-        # config 5 on this one GPU: 8192 graphs, GraphConv x2 + GlobalPool(mean) + Dense — one fused launch (csrc/graph_chain2.hip)
-        bstep, Gb, nb, eb = batched_setup(0, 1, None)
-        tb = layer_time(bstep, 50)
-        extras["batched"] = {"graphs": Gb, "nodes": nb, "edges": eb, "ms_per_step": tb,
-                             "graphs_per_s": Gb / tb * 1e3, "edges_per_s": 2 * eb / tb * 1e3,
-                             "per_batch_prep_outside_the_timed_steps": getattr(batched_setup, "prep_ms", None),
-                             "new_batch_every_step": getattr(batched_setup, "new_batch", None),
-                             "training_step": getattr(batched_setup, "train", None)}
-        del bstep
+            t_tg = median_time(train(gcn_conv_ad, gcn, dyg))
+            t_ta = median_time(train(gat_conv_ad, gat, dya))
+            for prm in (gcn.weight, gcn.bias, gat.dense_x_weight, gat.a, gat.bias):
+                prm.requires_grad_(False)
+                prm.grad = None
+            extras["next_rows"] = {"softmax_edge_neighbors_h8_ms": t_sx, "gcn_fwd_bwd_ms": t_tg, "gat_fwd_bwd_ms": t_ta}
+            del xr, dyg, dya
+            # configs 2 and 3: arxiv shape
+            Na, Da = synth.ARXIV["N"], synth.ARXIV["D"]
+            sa, ta = synth.arxiv_like()
+            ga = gnnmp.GNNGraph(torch.from_numpy(sa).cuda(), torch.from_numpy(ta).cuda(), num_nodes=Na, _validated=True)
+            xa = torch.from_numpy(synth.features(Na, Da, seed=1)).cuda()
+            gcn_a = gnnmp.GCNConv((Da, Da), "relu", seed=11)
+            gat_a = gnnmp.GATConv((Da, C), "relu", heads=H, seed=12)
+            Epa = len(sa) + Na
+            tga = layer_time(lambda: gcn_a(ga, xa), 50)
+            taa = layer_time(lambda: gat_a(ga, xa), 50)
+            extras["arxiv"] = {"E_prime": Epa, "gcn_layer_ms": tga, "gat_layer_ms": taa,
+                               "gcn_edges_per_s": Epa / tga * 1e3, "gat_edges_per_s": Epa / taa * 1e3}
+            del ga, xa
+            # config 5 on this one GPU: 8192 graphs, GraphConv x2 + GlobalPool(mean) + Dense — one fused launch (csrc/graph_chain2.hip)
+            bstep, Gb, nb, eb = batched_setup(0, 1, None)
+            tb = layer_time(bstep, 50)
+            extras["batched"] = {"graphs": Gb, "nodes": nb, "edges": eb, "ms_per_step": tb,
+                                 "graphs_per_s": Gb / tb * 1e3, "edges_per_s": 2 * eb / tb * 1e3,
+                                 "per_batch_prep_outside_the_timed_steps": getattr(batched_setup, "prep_ms", None),
+                                 "new_batch_every_step": getattr(batched_setup, "new_batch", None),
+                                 "training_step": getattr(batched_setup, "train", None)}
+            del bstep
+        except Exception as e:
+            extras["side_lines_error"] = repr(e)
 
     # The one path of BASELINE.json that shards (config 5): when the driver runs the default workload on N > 1 ranks, the same N ranks
     # also run the graph-parallel step — shard by graph, ONE all-gather of the (G_r, 2) logits over RCCL, strong scaling — so that a
