@@ -128,7 +128,7 @@ int gnnmp_arena_create(gnnmp_arena_t **out, int64_t bytes_per_class, int n_class
     if (!out || bytes_per_class <= 0 || (n_classes != 2 && n_classes != 3)) return fail(GNNMP_EINVAL, "arena_create: bad argument");
     *out = nullptr;
     gnnmp_arena *a = new gnnmp_arena();
-    (void)hipGetDevice(&a->dev);
+    a->dev = current_device();
     a->block_bytes = CHUNK;
     a->n_classes = n_classes;
     const int need = (int)((bytes_per_class + CHUNK - 1) / CHUNK);
@@ -248,8 +248,16 @@ int gnnmp_arena_create(gnnmp_arena_t **out, int64_t bytes_per_class, int n_class
     return GNNMP_OK;
 }
 
+// an arena belongs to the device it was created on: its blocks live there and the probe runs there
+static int arena_check_device(const gnnmp_arena *a, const char *who) {
+    const int dev = current_device();
+    if (dev != a->dev) return fail(GNNMP_EINVAL, "%s: the arena belongs to device %d, the current device is %d", who, a->dev, dev);
+    return GNNMP_OK;
+}
+
 int gnnmp_arena_alloc(gnnmp_arena_t *a, int cls, int64_t bytes, void **ptr) {
     if (!a || !ptr || bytes < 0 || cls < 0 || cls >= a->n_classes) return fail(GNNMP_EINVAL, "arena_alloc: bad argument");
+    if (int rc = arena_check_device(a, "arena_alloc")) return rc;
     std::lock_guard<std::mutex> lk(a->lock);
     for (auto &b : a->blocks[cls]) {                          // a buffer lies inside ONE block
         const int64_t at = (b.used + 4095) & ~(int64_t)4095;
@@ -274,6 +282,7 @@ int gnnmp_arena_reset(gnnmp_arena_t *a) {
 int gnnmp_arena_class_of(gnnmp_arena_t *a, const void *ptr, int64_t bytes, int *cls, gnnmp_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!a || !ptr || !cls) return fail(GNNMP_EINVAL, "arena_class_of: bad argument");
+    if (int rc = arena_check_device(a, "arena_class_of")) return rc;
     const unsigned char *p = static_cast<const unsigned char *>(ptr);
     for (int c = 0; c < a->n_classes; ++c)
         for (const auto &b : a->blocks[c])

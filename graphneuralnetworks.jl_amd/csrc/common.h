@@ -24,15 +24,40 @@ int hip_fail(hipError_t e, const char *what);
         if (e__ != hipSuccess) return ::gnnmp::hip_fail(e__, what); \
     } while (0)
 
-// The opt-in of a kernel to more than 64 KB of dynamic LDS: once per process and kernel instance, thread-safe (the library promises no
+// ---- per-device state ------------------------------------------------------------------------------
+// One PROCESS may drive several devices (a Julia host calling AMDGPU.device!(d) between calls; torchrun's one
+// process per GPU hides this).  Everything the library remembers about "the device" is therefore keyed on the CURRENT device of the
+// calling thread: kernel attributes (hipFuncSetAttribute acts on the current device's function object only), the compute-unit count,
+// the block pool (pool.hip), graph prep's scratch cache (graphprep.hip).
+constexpr int GNNMP_MAX_DEVICES = 32;
+// hipGetDevice clamped to [0, GNNMP_MAX_DEVICES); gnnmp_debug_mock_device (tests) overrides it for the calling thread
+int current_device();
+
+// run f() once per device (thread-safe); every later call on that device returns what the first one returned
+struct DeviceOnce {
+    std::mutex m;
+    unsigned char done[GNNMP_MAX_DEVICES] = {};
+    hipError_t err[GNNMP_MAX_DEVICES] = {};
+};
+template <class F>
+inline hipError_t device_once(DeviceOnce &o, F &&f) {
+    const int dev = current_device();
+    std::lock_guard<std::mutex> lk(o.m);     // (uncontended: ~20 ns against a kernel launch's microseconds)
+    if (!o.done[dev]) {
+        o.err[dev] = f();
+        o.done[dev] = 1;
+    }
+    return o.err[dev];
+}
+
+// The opt-in of a kernel to more than 64 KB of dynamic LDS: once per DEVICE and kernel instance, thread-safe (the library promises no
 // unsynchronised mutable state besides the knobs, gnnmp.h).  GNNMP_LDS_OPTIN("name", &kernel<args...>)
 #define GNNMP_LDS_OPTIN(what, ...)                                                                                            \
     do {                                                                                                                      \
-        static std::once_flag once__;                                                                                         \
-        static hipError_t err__ = hipSuccess;                                                                                 \
-        std::call_once(once__, [] {                                                                                           \
-            err__ = hipFuncSetAttribute(reinterpret_cast<const void *>(__VA_ARGS__), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                        160 * 1024);                                                                          \
+        static ::gnnmp::DeviceOnce once__;                                                                                    \
+        const hipError_t err__ = ::gnnmp::device_once(once__, [] {                                                            \
+            return hipFuncSetAttribute(reinterpret_cast<const void *>(__VA_ARGS__), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                       160 * 1024);                                                                           \
         });                                                                                                                   \
         if (err__ != hipSuccess) return ::gnnmp::hip_fail(err__, "hipFuncSetAttribute(" what ")");                            \
     } while (0)

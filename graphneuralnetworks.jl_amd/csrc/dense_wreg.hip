@@ -196,13 +196,7 @@ template <int K0C, int K1C>
 static int launch_wreg(const WregArgs &a, hipStream_t stream) {
     constexpr int NKB = (K0C + K1C + 15) / 16;
     const size_t lds = (size_t)2 * 3 * NKB * 2 * WR_ROW * 16 + (size_t)WR_DP * 4 + (size_t)WR_WAVES * 4096;
-    static std::once_flag once;
-    static hipError_t err = hipSuccess;
-    std::call_once(once, [] {
-        err = hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_wreg_kernel<K0C, K1C>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  160 * 1024);
-    });
-    if (err != hipSuccess) return hip_fail(err, "hipFuncSetAttribute(dense_wreg_kernel)");
+    GNNMP_LDS_OPTIN("dense_wreg_kernel", &dense_wreg_kernel<K0C, K1C>);
     const int64_t ntiles = (a.N + 31) / 32;
     const int64_t gx = std::min<int64_t>(device_cus(), ntiles);
     dense_wreg_kernel<K0C, K1C><<<(unsigned)gx, WR_THREADS, lds, stream>>>(a);

@@ -1014,14 +1014,8 @@ int graph_chain2_try(gnnmp_graph_t *p, const gnnmp_chain_jobs_t *J, const int64_
     const int waves = (knob(KNOB_VARIANT) & 3) == 1 ? 8 : 12;
     const size_t lds = (size_t)3 * C2_UNITS1 * 16 + (size_t)3 * C2_UNITS2 * 16 + C2_D1 * 4 + C2_SLAB * 4 + 8 * C2_SLAB * 4 +
                        (size_t)(waves / 2) * C2_STAGE_BYTES + 4 * 2 * (size_t)waves;
-    static std::once_flag attr_once;
-    static hipError_t attr_err = hipSuccess;
-    std::call_once(attr_once, [] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(&graph_chain2_kernel<768>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (attr_err == hipSuccess)
-            attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(&graph_chain2_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    });
-    if (attr_err != hipSuccess) return hip_fail(attr_err, "hipFuncSetAttribute(graph_chain2_kernel)");
+    GNNMP_LDS_OPTIN("graph_chain2_kernel<768>", &graph_chain2_kernel<768>);
+    GNNMP_LDS_OPTIN("graph_chain2_kernel<512>", &graph_chain2_kernel<512>);
     const int cus = device_cus();
     const int gx = std::max(1, std::min(cus / 2, (a.njobs + waves / 2 - 1) / (waves / 2)));     // one block a CU: half of them per slab
     const dim3 grid((unsigned)gx, 2);

@@ -84,16 +84,21 @@ done:
 // Scratch for the per-mini-batch entry points (sample_neighbors, unique_append, induced_subgraph): hipMalloc / hipFree cost
 // ~0.1-1 ms each and a NeighborLoader batch made ~50 of them.  Freed blocks are parked in a small per-thread cache and
 // handed out again (every entry point synchronises its stream before returning, so a parked block is idle).
-struct PrepBlock { void *p; size_t cap; };
+// A block is only handed out on the device it was allocated on (dev = common.h's current_device at allocation; alloc and free of one
+// entry point run under the same current device).
+struct PrepBlock { void *p; size_t cap; int dev; };
 static thread_local PrepBlock g_prep_cache[8] = {};
 static hipError_t prep_alloc(void **out, size_t bytes) {
     bytes = std::max<size_t>(bytes, 256);
+    const int dev = current_device();
     int best = -1;
     for (int i = 0; i < 8; ++i)
-        if (g_prep_cache[i].p && g_prep_cache[i].cap >= bytes && (best < 0 || g_prep_cache[i].cap < g_prep_cache[best].cap)) best = i;
+        if (g_prep_cache[i].p && g_prep_cache[i].dev == dev && g_prep_cache[i].cap >= bytes &&
+            (best < 0 || g_prep_cache[i].cap < g_prep_cache[best].cap))
+            best = i;
     if (best >= 0 && g_prep_cache[best].cap <= 4 * bytes + (1 << 20)) {
         *out = g_prep_cache[best].p;
-        g_prep_cache[best] = PrepBlock{nullptr, 0};
+        g_prep_cache[best] = PrepBlock{nullptr, 0, 0};
         return hipSuccess;
     }
     return hipMalloc(out, bytes);
@@ -101,6 +106,7 @@ static hipError_t prep_alloc(void **out, size_t bytes) {
 static void prep_free(void *p, size_t bytes) {
     if (!p) return;
     bytes = std::max<size_t>(bytes, 256);
+    const int dev = current_device();
     int slot = -1;
     for (int i = 0; i < 8; ++i)
         if (!g_prep_cache[i].p) { slot = i; break; }
@@ -114,7 +120,7 @@ static void prep_free(void *p, size_t bytes) {
         }
         (void)hipFree(g_prep_cache[slot].p);
     }
-    g_prep_cache[slot] = PrepBlock{p, bytes};
+    g_prep_cache[slot] = PrepBlock{p, bytes, dev};
 }
 
 // ---- neighbour sampling ---------------------------------------------------------------------------

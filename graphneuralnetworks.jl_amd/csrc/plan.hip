@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
 #include <vector>
 
 
@@ -30,16 +31,23 @@ int hip_fail(hipError_t e, const char *what) {
     return e == hipErrorOutOfMemory ? GNNMP_EALLOC : GNNMP_ELAUNCH;
 }
 int knob(int k) { return (k >= 0 && k < KNOB_COUNT) ? g_knobs[k] : 0; }
-int device_cus() {
-    static int cached[16] = {0};
+static thread_local int g_mock_device = -1;
+int current_device() {
+    if (g_mock_device >= 0) return g_mock_device < GNNMP_MAX_DEVICES ? g_mock_device : GNNMP_MAX_DEVICES - 1;
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
-    if (cached[dev] == 0) {
-        int cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    return dev < GNNMP_MAX_DEVICES ? dev : GNNMP_MAX_DEVICES - 1;
+}
+int device_cus() {
+    static std::atomic<int> cached[GNNMP_MAX_DEVICES] = {};
+    const int dev = current_device();
+    int cus = cached[dev].load(std::memory_order_relaxed);
+    if (cus == 0) {
+        cus = 256;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-        cached[dev] = cus;
+        cached[dev].store(cus, std::memory_order_relaxed);
     }
-    return cached[dev];
+    return cus;
 }
 
 int plan_dispose(gnnmp_graph_t *p, hipStream_t stream, bool stream_known);
@@ -367,6 +375,41 @@ int gnnmp_tune(int k, int value) {
     if (k < 0 || k >= KNOB_COUNT) return fail(GNNMP_EINVAL, "gnnmp_tune: bad knob %d", k);
     g_knobs[k] = value;
     return GNNMP_OK;
+}
+
+// test hooks (like gnnmp_tune: exported, not part of the drop-in surface).  gnnmp_debug_mock_device(d >= 0) makes `d` the calling
+// thread's "current device" for every per-device table of the library (common.h: current_device), d < 0 restores hipGetDevice.
+int gnnmp_debug_mock_device(int dev) {
+    g_mock_device = dev;
+    return current_device();
+}
+// Runs the per-device machinery with a counting stand-in for hipFuncSetAttribute and returns how often it ran: the sequence of mocked
+// devices devs[0..n) must run it once per DISTINCT device (tests/test_multi_device_cpu.py).  fail_on >= 0: the stand-in fails on that
+// device; *n_failed = calls that reported the failure (every call on that device must, not only the first).
+int gnnmp_debug_device_once(const int *devs, int n, int fail_on, int *n_failed) {
+    DeviceOnce once;
+    int ran = 0, failed = 0;
+    const int keep = g_mock_device;
+    for (int k = 0; k < n; ++k) {
+        g_mock_device = devs[k];
+        const hipError_t e = device_once(once, [&] {
+            ++ran;
+            return current_device() == fail_on ? hipErrorInvalidValue : hipSuccess;
+        });
+        if (e != hipSuccess) ++failed;
+    }
+    g_mock_device = keep;
+    if (n_failed) *n_failed = failed;
+    return ran;
+}
+// the pooled block of a plan made by gnnmp_plan_concat / gnnmp_plan_select (NULL for other plans): lets a test see WHICH block a plan got
+void *gnnmp_debug_plan_block(const gnnmp_graph_t *p) { return p ? p->block : nullptr; }
+// pool.h's slot choice on host arrays
+int gnnmp_debug_pool_pick(const uint64_t *caps, int n, uint64_t bytes) {
+    size_t c[64];
+    if (n < 0 || n > 64) return -2;
+    for (int i = 0; i < n; ++i) c[i] = (size_t)caps[i];
+    return pool_pick(c, n, (size_t)bytes);
 }
 
 int gnnmp_plan_destroy(gnnmp_graph_t *p) { return plan_dispose(p, nullptr, false); }

@@ -4,6 +4,9 @@
 // last work was enqueued on; the next taker waits for that event ON ITS STREAM (hipStreamWaitEvent: no host synchronisation), or not at
 // all when it is the same stream.  Blocks parked without a stream (plain destroy) are handed out again only after a device-wide
 // synchronisation — what hipFree would have cost.
+// The pool is one table PER DEVICE (common.h: current_device): a taker sees only blocks allocated on its current device, events are
+// created and recycled on their own device, and stream handles are compared inside one device only — a process that drives eight
+// devices gets eight independent pools.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
@@ -13,6 +16,9 @@ namespace gnnmp {
 bool pool_take(void **out, size_t *cap, size_t bytes, hipStream_t stream);
 // stream_known: work that touches the block was last enqueued on `stream` (an event is recorded there); otherwise unknown streams.
 void pool_park(void *p, size_t cap, hipStream_t stream, bool stream_known);
-// free every parked block (tests / process teardown)
+// the slot pool_take hands out for a request of `bytes` among blocks of capacities caps[0..n) (0 = empty slot): the smallest block that
+// fits, unless it is more than twice the request (+ 1 MiB); -1 = none.  Pure host logic (tests/test_multi_device_cpu.py).
+int pool_pick(const size_t *caps, int n, size_t bytes);
+// free every parked block of every device (tests / process teardown)
 void pool_trim();
 }  // namespace gnnmp

@@ -89,6 +89,7 @@ class Plan:
         self._lib = L.load()
         self._h = handle
         self._pooled = True
+        self._last_stream = torch.cuda.current_stream()      # the stream gnnmp_plan_concat / _select ran on
         info = (ctypes.c_int64 * 8)()
         L.check(self._lib.gnnmp_plan_info(self._h, info))
         self.n_src, self.n_dst, self.n_edges, self.n_total = info[0], info[1], info[2], info[3]
@@ -98,6 +99,10 @@ class Plan:
 
     @property
     def handle(self):
+        # every compute call reads the handle right before it passes the current stream to the library: remember that stream, so that a
+        # pooled plan is released BEHIND its last use even when the garbage collector runs while another stream is current
+        if getattr(self, "_pooled", False):
+            self._last_stream = torch.cuda.current_stream()
         return self._h
 
     def status(self):
@@ -132,8 +137,13 @@ class Plan:
         try:
             if self._h:
                 if getattr(self, "_pooled", False):
-                    # stream-ordered: the block goes back to the library's pool behind the work enqueued so far (no host synchronisation)
-                    self._lib.gnnmp_plan_release(self._h, L.stream_ptr())
+                    # stream-ordered: the block goes back to the library's pool behind the work enqueued so far ON THE STREAM THE PLAN
+                    # WAS LAST USED ON (no host synchronisation); a plan that never saw a stream of ours takes the unknown-streams path
+                    st = getattr(self, "_last_stream", None)
+                    if st is not None:
+                        self._lib.gnnmp_plan_release(self._h, ctypes.c_void_p(st.cuda_stream))
+                    else:
+                        self._lib.gnnmp_plan_destroy(self._h)
                 else:
                     self._lib.gnnmp_plan_destroy(self._h)
                 self._h = ctypes.c_void_p()

@@ -571,18 +571,26 @@ class ChainJobs:
 
     def __init__(self, seg_ptr, G, member_stats=None):
         import ctypes
-        self.handle = ctypes.c_void_p()
+        self._h = ctypes.c_void_p()
         self._packed = member_stats is not None
         self._keep = seg_ptr
+        self._last_stream = torch.cuda.current_stream()
         if self._packed:
             n_rows, max_graph, has_empty = member_stats
-            L.check(L.load().gnnmp_chain_jobs_pack(ctypes.byref(self.handle), L.ptr(seg_ptr), G, int(n_rows), int(max_graph),
+            L.check(L.load().gnnmp_chain_jobs_pack(ctypes.byref(self._h), L.ptr(seg_ptr), G, int(n_rows), int(max_graph),
                                                    1 if has_empty else 0, L.stream_ptr()))
             self.G, self.N, self.max_graph = G, int(n_rows), int(max_graph)
             self._info = None
         else:
-            L.check(L.load().gnnmp_chain_jobs_create(ctypes.byref(self.handle), L.ptr(seg_ptr), G, L.stream_ptr()))
+            L.check(L.load().gnnmp_chain_jobs_create(ctypes.byref(self._h), L.ptr(seg_ptr), G, L.stream_ptr()))
             self._info = self._read_info()
+
+    @property
+    def handle(self):
+        # read right before every call that passes the current stream: a device-packed handle is released behind its LAST use
+        # (the stream remembered here), whatever stream is current when the garbage collector runs
+        self._last_stream = torch.cuda.current_stream()
+        return self._h
 
     def _read_info(self):
         import ctypes
@@ -613,12 +621,13 @@ class ChainJobs:
 
     def __del__(self):
         try:
-            if self.handle:
+            if self._h:
                 if self._packed:
-                    L.load().gnnmp_chain_jobs_release(self.handle, L.stream_ptr())
+                    import ctypes
+                    L.load().gnnmp_chain_jobs_release(self._h, ctypes.c_void_p(self._last_stream.cuda_stream))
                 else:
-                    L.load().gnnmp_chain_jobs_destroy(self.handle)
-                self.handle = None
+                    L.load().gnnmp_chain_jobs_destroy(self._h)
+                self._h = None
         except Exception:
             pass
 

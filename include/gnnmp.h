@@ -24,8 +24,15 @@
  *   - a plan carries scratch of its own (the partials of split rows, the tile ticket of the fused layer kernel, cached
  *     orderings): calls that take the SAME plan must be ordered on ONE stream (or by events) — two streams may run
  *     different plans, or read-only queries of one plan, concurrently, but not two compute calls on one plan.  The
- *     reference has the same shape: one GNNGraph, one task.  Host threads: the library keeps no global mutable state
- *     besides the tuning knobs (gnnmp_tune, experiments only) and the thread-local error string.
+ *     reference has the same shape: one GNNGraph, one task.  Host threads: besides the tuning knobs (gnnmp_tune, experiments
+ *     only) and the thread-local error string, the library's only process-wide state is (i) the per-DEVICE tables behind a mutex —
+ *     which kernels have been opted into large LDS on which device, and the stream-ordered block pool that backs
+ *     gnnmp_plan_concat / gnnmp_plan_select / gnnmp_chain_jobs_pack (one table per device: a block, its event and its stream are
+ *     only ever matched against takers of the SAME device) — and (ii) a per-thread scratch cache of graph prep, keyed on the device.
+ *   - several devices in one process (a Julia host calling AMDGPU.device!(d) between calls): supported.  Every entry point acts on
+ *     the calling thread's CURRENT device (hipGetDevice) — the one `stream` and every pointer of the call must belong to.  Plans,
+ *     job handles and arenas belong to the device they were created on; gnnmp_arena_* refuse a foreign current device with
+ *     GNNMP_EINVAL.  Release a pooled object (gnnmp_plan_release, gnnmp_chain_jobs_release) with a stream of ITS device.
  *   - return value: 0 = ok, negative = gnnmp_status; nothing throws, nothing aborts.
  *     gnnmp_last_error() gives a thread-local message for the last failing call.
  *   - determinism: no entry point except *_atomic_* uses floating-point atomics.  Per-destination

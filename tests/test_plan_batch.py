@@ -170,6 +170,53 @@ def test_pooled_blocks_are_reused_across_streams(gm):
         assert torch.equal(y, yr), it
 
 
+def test_pool_is_keyed_on_the_device_and_release_follows_the_last_use(gm):
+    """(i) a block parked on device 0 is not handed to a taker whose current device is another one (mocked through the library's test
+    hook: the box has one GPU), and comes back to device 0's next taker; (ii) a pooled plan is released on the stream it was LAST USED on,
+    not on whatever stream is current when the garbage collector runs"""
+    import torch
+    from gnnmp import _lib as L
+    lib = L.load()
+    lib.gnnmp_debug_mock_device.argtypes = [ctypes.c_int]
+    lib.gnnmp_debug_plan_block.restype = ctypes.c_void_p
+    lib.gnnmp_debug_plan_block.argtypes = [ctypes.c_void_p]
+    rng = np.random.default_rng(5)
+    members = random_members(200, rng)
+    xs = [rng.standard_normal((n, 4), dtype=np.float32) for _, _, n in members]
+    ds = gm.GraphDataset.from_members(members, xs)
+    ids = rng.integers(0, len(members), 150)
+    torch.cuda.synchronize()
+    try:
+        g = ds.batch(ids, with_x=False)
+        blk0 = lib.gnnmp_debug_plan_block(g.plan().handle)
+        assert blk0
+        del g                                               # parked in device 0's table
+        assert lib.gnnmp_debug_mock_device(1) == 1
+        g1 = ds.batch(ids, with_x=False)
+        blk1 = lib.gnnmp_debug_plan_block(g1.plan().handle)
+        assert blk1 and blk1 != blk0, "a block parked on device 0 was handed out under device 1"
+        lib.gnnmp_debug_mock_device(-1)
+        g2 = ds.batch(ids, with_x=False)
+        assert lib.gnnmp_debug_plan_block(g2.plan().handle) == blk0      # same size, same device: the parked block
+        del g1, g2
+    finally:
+        lib.gnnmp_debug_mock_device(-1)
+    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    with torch.cuda.stream(a):
+        g = ds.batch(ids)
+        y = gm.propagate(gm.copy_xj, g, "+", xj=g.x)
+    assert g.plan()._last_stream == a
+    with torch.cuda.stream(b):
+        plan = g.plan()
+        del g
+        assert plan._last_stream == a                      # reading attributes does not move it; only compute calls do
+        del plan                                           # released behind the propagate on stream a
+        g = ds.batch(ids)                                  # stream b takes the block: must wait for a's event inside the library
+        y2 = gm.propagate(gm.copy_xj, g, "+", xj=g.x)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y2)
+
+
 # ---- the chain's wave jobs packed on the device -------------------------------------------------------------------------------------------
 def check_packing(tab, hdr, sizes):
     """tab [cap][64]: every row of the batch exactly once, member graphs whole and contiguous, jobs filled from slot 0 without holes"""
