@@ -173,6 +173,32 @@ def julia_reference_baseline():
     return None
 
 
+def timed_region(step, steps, warmup, barrier, dist, device="cuda", before=None, after=None):
+    """The driver's protocol, in one place for every workload: `warmup` untimed steps, then EXACTLY `steps` steps bracketed by
+    barrier() (dist.barrier + device synchronise) on both sides, wall clock, MAX over the ranks.  Returns (seconds, last output).
+    `before` / `after` run inside the brackets, right around the timed loop (the kernel event probe).  Shared by the GPU run and by the
+    world-2 / world-8 gloo rehearsals of tests/test_parallel_gloo.py (device = "cpu" there)."""
+    import torch
+    out = None
+    for _ in range(warmup):
+        step()
+    barrier()
+    if before is not None:
+        before()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if after is not None:
+        after()
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    return dt, out
+
+
 def batched_setup(rank, world, dist, G=8192, forward_factory=None, device=None):
     """BASELINE.json config 5 on this rank: its shard of the G synthetic graphs batched on the device, the model, and the static part of
     the exchange (gnnmp.parallel.ShardPlan: send / receive buffers and the inverse permutation, built ONCE).  Returns step() — model
@@ -301,18 +327,7 @@ def run_batched(args, rank, world, dist, barrier):
     (gnnmp.parallel), one all-gather of the (G_r, 2) logits per step.  Total work is fixed: strong scaling."""
     import torch
     step, G, n_tot, e_tot = batched_setup(rank, world, dist)
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt, out = timed_region(step, args.steps, args.warmup, barrier, dist)
     assert out.shape == (G, 2)
     result = {
         "metric": "graphs/sec (fwd) batched graph classification, GraphConv x2 + GlobalPool(mean) + Dense",
@@ -375,18 +390,7 @@ def run_rowpart(args, rank, world, dist, barrier):
     def step():
         return RP.row_parallel_forward(fs, x, bounds, rank, world, dist)
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt, out = timed_region(step, args.steps, args.warmup, barrier, dist)
     assert out.shape == (N, D)
     Ep = E + N
     result = {
@@ -582,18 +586,7 @@ def main():
     # event records per launch, ~1 us each): roofline.avg_ms below is the in-step duration, the one a rocprofv3 kernel trace of this
     # command shows — not the kernel timed alone back to back (the two differed by 8 %)
     probe = L.EventProbe()
-    barrier()
-    L.set_probe(probe)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    L.set_probe(None)
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt, _ = timed_region(step, args.steps, 0, barrier, dist, before=lambda: L.set_probe(probe), after=lambda: L.set_probe(None))
     ms_per_step = dt / args.steps * 1e3
     value = world * 2 * Ep / (dt / args.steps)
     instep = {}
@@ -821,17 +814,8 @@ def main():
         del x, g, plan
         torch.cuda.empty_cache()
         bstep, Gb, nb, eb = batched_setup(rank, world, dist)
-        for _ in range(10):
-            bstep()
-        barrier()
-        t0b = time.perf_counter()
-        for _ in range(100):
-            outb = bstep()
-        barrier()
-        dtb = time.perf_counter() - t0b
-        ttb = torch.tensor([dtb], dtype=torch.float64, device="cuda")
-        dist.all_reduce(ttb, op=dist.ReduceOp.MAX)
-        dtb = float(ttb.item()) / 100
+        dtb, outb = timed_region(bstep, 100, 10, barrier, dist)
+        dtb /= 100
         assert outb.shape == (Gb, 2)
         extras["batched_strong"] = {"graphs": Gb, "world": world, "ms_per_step": dtb * 1e3, "graphs_per_s": Gb / dtb,
                                     "scaling": "strong", "parallelism": f"graph-parallel x{world}: shard by graph, one all-gather of "

@@ -200,14 +200,29 @@ def _worker_bench(rank, world, port, ret):
         a = step().clone()
         b = step().clone()
         assert torch.equal(a, b) and a.shape == (G, 2)
-        ret[rank] = a.numpy()
+        # the driver's timing protocol exactly as bench.py runs it for extras.batched_strong / --workload batched: warm-up, barrier, K
+        # steps, barrier, MAX over the ranks.  Rank 1 is made slow: every rank must report ITS time, i.e. the maximum.
+        import time
+        calls = [0]
+
+        def slow_step():
+            calls[0] += 1
+            if rank == 1:
+                time.sleep(0.02)
+            return step()
+        dt, out = bench.timed_region(slow_step, 3, 2, dist.barrier, dist, device="cpu")
+        assert calls[0] == 5 and torch.equal(out, a)
+        assert dt >= 3 * 0.02
+        ret[rank] = (a.numpy(), dt)
     finally:
         dist.destroy_process_group()
 
 
-def test_bench_batched_strong_code_path_world2_gloo():
-    """the step bench.py times for extras.batched_strong / --workload batched (batched_setup: shard, forward, ShardPlan.gather), dry-run
-    on the CPU with world 2 over gloo and the oracle as the forward: both ranks end with the unsharded logits, bit for bit"""
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_batched_strong_code_path_gloo(world):
+    """the step bench.py times for extras.batched_strong / --workload batched (batched_setup: shard, forward, ShardPlan.gather) and the
+    timing protocol around it (bench.timed_region), dry-run on the CPU over gloo with the oracle as the forward — at world 2 and at the
+    world 8 of the driver's scaling run: every rank ends with the unsharded logits, bit for bit, and with the same (maximum) time"""
     import sys
     import torch.multiprocessing as mp
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -215,14 +230,15 @@ def test_bench_batched_strong_code_path_world2_gloo():
     mgr = ctx.Manager()
     ret = mgr.dict()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_bench, args=(r, 2, port, ret)) for r in range(2)]
+    procs = [ctx.Process(target=_worker_bench, args=(r, world, port, ret)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(300)
+        p.join(600)
         assert p.exitcode == 0
     import bench
     step, G, _, _ = bench.batched_setup(0, 1, None, G=96, forward_factory=_oracle_forward_factory, device=torch.device("cpu"))
     full = step().numpy()
-    np.testing.assert_array_equal(ret[0], full)
-    np.testing.assert_array_equal(ret[1], full)
+    for r in range(world):
+        np.testing.assert_array_equal(ret[r][0], full)
+        assert ret[r][1] == ret[0][1]                  # the all-reduced maximum, identical on every rank
