@@ -91,7 +91,9 @@ enum Knob {
     KNOB_CHAIN = 18,           // fused GraphConv chain kernel (graph_chain.hip): 0 = auto, < 0 = never (layer-by-layer path)
     KNOB_VARIANT = 19,         // A/B switches of round 3 (all variants are correct code): low 2 bits = 1: the wave-pair chain kernel with 8 waves
                                // a block (default 12); 16: dense_split runs its column tiles one after the other; 32: dense_split stores
-                               // straight from the accumulator layout (default: through the per-wave LDS stage)
+                               // straight from the accumulator layout (default: through the per-wave LDS stage); 64: never dense_wreg;
+                               // 128: split rows folded by a second kernel (csr_combine / gat_fused_combine) as in rounds 1-4 instead of
+                               // by the last chunk to arrive inside the row kernel (round 5, use_fold)
     KNOB_COUNT = 20
 };
 int knob(int k);
@@ -291,6 +293,13 @@ struct gnnmp_graph {
     // rows of a power-law graph are not, and a wave runs as long as its longest row (products shape: 1.43x the instruction
     // issue of perfectly packed rows with adjacent pairing, 1.13x with this order)
     int32_t *row_order = nullptr;
+    // fold-in-kernel (round 5): the long row (index into long_rows) of every chunk, and the arrival counters of the long rows — zero
+    // between launches (the last arriver resets its counter), grown on demand like ws (ensure_arrive)
+    int32_t *chunk_lrow = nullptr;  // [n_chunks]
+    uint32_t *arrive = nullptr;
+    size_t arrive_n = 0;
+    float *spart = nullptr;         // slice partials of the long rows (csr_reduce.h: long_geom)
+    size_t spart_floats = 0;
     // plans made by gnnmp_plan_concat / gnnmp_plan_select (plan_batch.hip): rowptr, col, eid (and the member table) live in ONE block taken
     // from the stream-ordered pool (pool.h); gnnmp_plan_release hands it back without a host synchronisation
     void *block = nullptr;
@@ -301,6 +310,10 @@ struct gnnmp_graph {
 namespace gnnmp {
 // make sure plan->ws holds at least `floats` floats (hipMalloc on growth; hipFree waits for in-flight work)
 int ensure_workspace(gnnmp_graph *p, size_t floats);
+// make sure plan->arrive holds at least n zeroed counters and plan->spart at least `floats` floats
+int ensure_arrive(gnnmp_graph *p, size_t n, size_t floats, hipStream_t stream);
+// split rows folded inside the row kernels (default) or by the combine kernels of rounds 1-4 (knob 19 bit 7)?
+inline bool use_fold() { return (knob(KNOB_VARIANT) & 128) == 0; }
 // allocate + zero plan->ticket on first use
 int ensure_ticket(gnnmp_graph *p, hipStream_t stream);
 // build plan->row_order on first use

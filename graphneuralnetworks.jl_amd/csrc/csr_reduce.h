@@ -47,6 +47,11 @@ struct ReduceArgs {
     int nbc;                 // leading blocks (chunk virtual rows) that are not remapped
     int waves;               // waves per block
     int compact_long;        // csr_combine_kernel writes long row r to out[r] (a compact [n_long][D] buffer), not out[row]
+    // fold-in-kernel (FOLD instances of csr_rows_kernel, see long_geom below): chunk v belongs to long row chunk_lrow[v]; arrival
+    // counters per slice of the row's chunks and per row — the LAST one to arrive folds, and resets the counter for the next launch
+    const int32_t *chunk_lrow;
+    uint32_t *arrive;        // [n_long][tiles][256 / G + 1]: per slice, then the row's own
+    float *spart;            // [n_long][256 / G][D] slice partials
 };
 
 // The gated functors evaluate their activations once per edge and feature (6e9 times on the products shape): with libm's
@@ -244,6 +249,65 @@ __device__ __forceinline__ void finalize_store(const ReduceArgs &a, int row, uin
         for (int q = 0; q < VEC; ++q) acc[q] = acc[q] < 0.0f ? 0.0f : acc[q];
     }
     if (active) Vec<VEC>::store(a.out + (int64_t)(out_row < 0 ? row : out_row) * a.D + f0, acc);
+}
+
+// The fold of csr_combine_kernel (propagate.hip) INSIDE the row kernel, by whoever arrives last — in the combine kernel's own two levels,
+// so a row comes out bit-identical to the two-kernel path and no lane group walks a hub's 200 partials alone:
+//   level 1  the chunks of long row r fall into 256 / G contiguous SLICES of `per` chunks (csr_combine_kernel's lane groups); the last chunk
+//            of a slice to store its partial folds the slice from the identity, in chunk order, into a slice partial (fold_slice);
+//   level 2  the last slice of the row to finish folds the slice partials in slice order and runs the row's epilogue (fold_slices).
+// A 12 800-edge hub (200 chunks, G = 32): 8 slices of 25 partials folded by 8 different lane groups + 8 slice partials, instead of one
+// chain of 200.  The loads are 4 deep (the row kernel's register count — its occupancy — is set by its main loop, not by this tail).
+struct LongGeom {
+    int c0, c1, per, ns;      // chunk range of the row, chunks per slice, non-empty slices
+};
+__device__ __forceinline__ LongGeom long_geom(const int32_t *long_cptr, int r, int log2g) {
+    LongGeom g;
+    const int NG = 256 >> log2g;
+    g.c0 = long_cptr[r];
+    g.c1 = long_cptr[r + 1];
+    g.per = (g.c1 - g.c0 + NG - 1) / NG;
+    g.ns = (g.c1 - g.c0 + g.per - 1) / g.per;
+    return g;
+}
+template <int VEC, int OP>
+__device__ __forceinline__ void fold_rows(const float *__restrict__ base, int64_t stride, int n, int f0, bool active, float acc[VEC],
+                                          bool from_identity) {
+    // acc = (from_identity ? identity : row 0) folded with the following rows in order; rows are `stride` floats apart
+    constexpr int CB = 4;
+    int c = 0;
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) acc[q] = op_identity<OP>();
+    if (!active) return;
+    if (!from_identity) {
+        Vec<VEC>::load(base + f0, acc);
+        c = 1;
+    }
+    for (; c < n; c += CB) {
+        float v[CB][VEC];
+#pragma unroll
+        for (int u = 0; u < CB; ++u) Vec<VEC>::load(base + (int64_t)min(c + u, n - 1) * stride + f0, v[u]);
+#pragma unroll
+        for (int u = 0; u < CB; ++u) {
+            if (c + u < n) {
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) acc[q] = op_apply<OP>(acc[q], v[u][q]);
+            }
+        }
+    }
+}
+
+// A chunk's lane group has stored its partial: count it in; true for the group that completes its long row (it then folds the row).
+// release: the partial is visible device-wide before the count; acquire: the last arriver sees every other chunk's partial.
+__device__ __forceinline__ bool chunk_arrive(uint32_t *counter, int nchunks, int lig, int gbase) {
+    __threadfence();
+    unsigned prev = 0;
+    if (lig == 0) prev = atomicAdd(counter, 1u);
+    prev = (unsigned)__shfl((int)prev, gbase, 64);
+    if (prev != (unsigned)(nchunks - 1)) return false;
+    __threadfence();
+    if (lig == 0) *counter = 0u;          // ready for the plan's next launch (every chunk of this row has arrived: nobody touches it again)
+    return true;
 }
 
 }  // namespace gnnmp

@@ -62,6 +62,11 @@ struct GatFusedArgs {
     int nbc;              // leading blocks (chunk virtual rows) that are not remapped
     int waves;
     DropArgs drop;        // ATTN_GAT_DROP / ATTN_GATV2_DROP only
+    // fold-in-kernel (FOLD instances of gat_fused_rows_kernel; csr_reduce.h's scheme): chunk v belongs to long row chunk_lrow[v];
+    // arrive[r] counts the chunks of long row r whose partial is stored — the last one to arrive merges the row (gat_fold_row)
+    const int32_t *chunk_lrow;
+    uint32_t *arrive;     // [n_long][256 / G + 1]
+    float *spart;         // [n_long][256 / G][partial row]
 };
 
 // internal fifth mode: GAT with the per-edge logit term (gnnmp_gat_conv_edge_f32) — a compile-time property, so the headline
@@ -245,7 +250,140 @@ __device__ __forceinline__ void gat_fused_store(const GatFusedArgs &a, int row, 
     Vec<VEC>::store(a.out + (int64_t)row * a.D + f0, acc);
 }
 
-template <int VEC, int U, int LPH, int MODE>
+// the end of a split row, given its merged state (active lanes only): normalise, statistics, o+ / P, epilogue + store
+template <int VEC, bool PLUS>
+__device__ __forceinline__ void gat_long_row_finish(const GatFusedArgs &a, int row, int f0, float acc[VEC], float Mt, float den,
+                                                    float acc2[VEC], float den2) {
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) acc[q] = acc[q] / den;
+    if (a.stats && (f0 % a.C) == 0) {
+        float *st = a.stats + ((int64_t)row * a.H + f0 / a.C) * 2;
+        st[0] = Mt;
+        st[1] = den;
+        if (PLUS) a.pplus[(int64_t)row * a.H + f0 / a.C] = den2 / den;
+    }
+    if (PLUS) {
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) acc2[q] = acc2[q] / den;
+        Vec<VEC>::store(a.oplus + (int64_t)row * a.D + f0, acc2);
+    }
+    gat_fused_store<VEC>(a, row, f0, true, acc);
+}
+
+// gat_fused_combine_kernel's merge INSIDE the row kernel, in the combine kernel's own two levels (csr_reduce.h: long_geom) — the same
+// slices, the same log-sum-exp rescales, the same fma order, so a split row comes out bit-identical to the two-kernel path.  Active lanes
+// only.  Level 1: the last chunk of a slice to arrive merges the slice's chunk partials relative to the slice's maximum and stores
+// (acc, M, den [, acc2, den2]) in the chunk-partial layout to the slice partials.
+template <int VEC, bool PLUS>
+__device__ __forceinline__ void gat_fold_slice(const GatFusedArgs &a, int s0, int s1, int f0, float *__restrict__ sp) {
+    const int LN = a.D / VEC;
+    const int64_t S = PLUS ? 2 * a.D + 3 * LN : a.D + 2 * LN;
+    constexpr int CB = 4;
+    const int li = f0 / VEC;
+    float M = -__builtin_inff();
+    for (int c = s0; c < s1; c += CB) {
+        float mv[CB];
+#pragma unroll
+        for (int u = 0; u < CB; ++u) mv[u] = a.partial[(int64_t)min(c + u, s1 - 1) * S + a.D + li];
+#pragma unroll
+        for (int u = 0; u < CB; ++u) M = fmaxf(M, mv[u]);
+    }
+    float den = 0.0f, den2 = 0.0f, acc[VEC], acc2[VEC];
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) acc[q] = acc2[q] = 0.0f;
+    for (int c = s0; c < s1; c += CB) {
+        float mv[CB], dv[CB], v[CB][VEC], dv2[PLUS ? CB : 1], v2[PLUS ? CB : 1][VEC];
+#pragma unroll
+        for (int u = 0; u < CB; ++u) {
+            const float *pc = a.partial + (int64_t)min(c + u, s1 - 1) * S;
+            mv[u] = pc[a.D + li];
+            dv[u] = pc[a.D + LN + li];
+            Vec<VEC>::load(pc + f0, v[u]);
+            if (PLUS) {
+                Vec<VEC>::load(pc + a.D + 2 * LN + f0, v2[PLUS ? u : 0]);
+                dv2[PLUS ? u : 0] = pc[2 * a.D + 2 * LN + li];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < CB; ++u) {
+            if (c + u < s1) {
+                const float sc = expf(mv[u] - M);
+                den = fmaf(dv[u], sc, den);
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) acc[q] = fmaf(v[u][q], sc, acc[q]);
+                if (PLUS) {
+                    den2 = fmaf(dv2[PLUS ? u : 0], sc, den2);
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) acc2[q] = fmaf(v2[PLUS ? u : 0][q], sc, acc2[q]);
+                }
+            }
+        }
+    }
+    Vec<VEC>::store(sp + f0, acc);
+    sp[a.D + li] = M;
+    sp[a.D + LN + li] = den;
+    if (PLUS) {
+        Vec<VEC>::store(sp + a.D + 2 * LN + f0, acc2);
+        sp[2 * a.D + 2 * LN + li] = den2;
+    }
+}
+// Level 2: the last slice of the row to finish merges the ns slice partials (slice 0 rescaled by a multiplication, the others folded in
+// with an fma each — group 0 of the combine kernel) and finishes the row.
+template <int VEC, bool PLUS>
+__device__ __forceinline__ void gat_fold_slices(const GatFusedArgs &a, int row, int ns, int f0, const float *__restrict__ sp) {
+    const int LN = a.D / VEC;
+    const int64_t S = PLUS ? 2 * a.D + 3 * LN : a.D + 2 * LN;
+    const int li = f0 / VEC;
+    float Mt = -__builtin_inff();
+    for (int k = 0; k < ns; ++k) Mt = fmaxf(Mt, sp[(int64_t)k * S + a.D + li]);
+    float den = 0.0f, den2 = 0.0f, acc[VEC], acc2[VEC];
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) acc[q] = acc2[q] = 0.0f;
+    for (int k = 0; k < ns; ++k) {
+        const float *o = sp + (int64_t)k * S;
+        float sa[VEC], sa2[VEC];
+        Vec<VEC>::load(o + f0, sa);
+        const float sc = expf(o[a.D + li] - Mt);
+        const float sd = o[a.D + LN + li];
+        float sd2 = 0.0f;
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) sa2[q] = 0.0f;
+        if (PLUS) {
+            Vec<VEC>::load(o + a.D + 2 * LN + f0, sa2);
+            sd2 = o[2 * a.D + 2 * LN + li];
+        }
+        if (k == 0) {
+            den = sd * sc;
+            den2 = sd2 * sc;
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) { acc[q] = sa[q] * sc; acc2[q] = sa2[q] * sc; }
+        } else {
+            den = fmaf(sd, sc, den);
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) acc[q] = fmaf(sa[q], sc, acc[q]);
+            if (PLUS) {
+                den2 = fmaf(sd2, sc, den2);
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) acc2[q] = fmaf(sa2[q], sc, acc2[q]);
+            }
+        }
+    }
+    gat_long_row_finish<VEC, PLUS>(a, row, f0, acc, Mt, den, acc2, den2);
+}
+
+// A chunk's lane group has stored its partial: count it in; true for the group that completes its long row (csr_reduce.h: chunk_arrive)
+__device__ __forceinline__ bool gat_chunk_arrive(uint32_t *counter, int nchunks, int lig, int gbase) {
+    __threadfence();
+    unsigned prev = 0;
+    if (lig == 0) prev = atomicAdd(counter, 1u);
+    prev = (unsigned)__shfl((int)prev, gbase, 64);
+    if (prev != (unsigned)(nchunks - 1)) return false;
+    __threadfence();
+    if (lig == 0) *counter = 0u;
+    return true;
+}
+
+template <int VEC, int U, int LPH, int MODE, bool FOLD = false>
 __global__ void __launch_bounds__(256) gat_fused_rows_kernel(const GatFusedArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -334,6 +472,22 @@ __global__ void __launch_bounds__(256) gat_fused_rows_kernel(const GatFusedArgs 
                 Vec<VEC>::store(pc + a.D + 2 * LN + f0, acc2);
                 pc[2 * a.D + 2 * LN + f0 / VEC] = den2;
             }
+        }
+        if (FOLD) {
+            const int lr = a.chunk_lrow[v];
+            const int NG = 256 >> a.log2g;
+            const int c0 = a.long_cptr[lr], c1 = a.long_cptr[lr + 1];
+            const int per = (c1 - c0 + NG - 1) / NG, ns = (c1 - c0 + per - 1) / per;
+            const int k = (v - c0) / per;
+            const int s0 = c0 + k * per, s1 = min(c1, s0 + per);
+            const int LN = a.D / VEC;
+            const int64_t S = plus ? 2 * a.D + 3 * LN : a.D + 2 * LN;
+            uint32_t *cnt = a.arrive + (int64_t)lr * (NG + 1);
+            float *sp = a.spart + (int64_t)lr * NG * S;
+            if (!gat_chunk_arrive(cnt + k, s1 - s0, lig, gbase)) return;
+            if (active) gat_fold_slice<VEC, plus>(a, s0, s1, f0, sp + (int64_t)k * S);
+            if (!gat_chunk_arrive(cnt + NG, ns, lig, gbase)) return;
+            if (active) gat_fold_slices<VEC, plus>(a, row, ns, f0, sp);
         }
         return;
     }
@@ -454,42 +608,29 @@ __global__ void __launch_bounds__(256) gat_fused_combine_kernel(const GatFusedAr
             for (int q = 0; q < VEC; ++q) acc2[q] = fmaf(o[VEC + 2 + q], sc, acc2[q]);
         }
     }
-#pragma unroll
-    for (int q = 0; q < VEC; ++q) acc[q] = acc[q] / den;
-    if (a.stats && (f0 % a.C) == 0) {
-        float *st = a.stats + ((int64_t)row * a.H + f0 / a.C) * 2;
-        st[0] = Mt;
-        st[1] = den;
-        if (PLUS) a.pplus[(int64_t)row * a.H + f0 / a.C] = den2 / den;
-    }
-    if (PLUS) {
-#pragma unroll
-        for (int q = 0; q < VEC; ++q) acc2[q] = acc2[q] / den;
-        Vec<VEC>::store(a.oplus + (int64_t)row * a.D + f0, acc2);
-    }
-    gat_fused_store<VEC>(a, row, f0, true, acc);
+    gat_long_row_finish<VEC, PLUS>(a, row, f0, acc, Mt, den, acc2, den2);
 }
 
-template <int VEC, int U, int MODE>
+template <int VEC, int U, int MODE, bool FOLD = false>
 static void launch_rows_lph(const GatFusedArgs &a, dim3 grid, int blk, hipStream_t stream) {
     // compile-time lane count per head for the usual VEC = 4 shapes (DPP butterflies); anything else walks the xor
     // butterfly with the run-time count
     if (VEC == 4 && a.lph == 1)
-        gat_fused_rows_kernel<VEC, U, 1, MODE><<<grid, blk, 0, stream>>>(a);
+        gat_fused_rows_kernel<VEC, U, 1, MODE, FOLD><<<grid, blk, 0, stream>>>(a);
     else if (VEC == 4 && a.lph == 2)
-        gat_fused_rows_kernel<VEC, U, 2, MODE><<<grid, blk, 0, stream>>>(a);
+        gat_fused_rows_kernel<VEC, U, 2, MODE, FOLD><<<grid, blk, 0, stream>>>(a);
     else if (VEC == 4 && a.lph == 4)
-        gat_fused_rows_kernel<VEC, U, 4, MODE><<<grid, blk, 0, stream>>>(a);
+        gat_fused_rows_kernel<VEC, U, 4, MODE, FOLD><<<grid, blk, 0, stream>>>(a);
     else if (VEC == 4 && a.lph == 8)
-        gat_fused_rows_kernel<VEC, U, 8, MODE><<<grid, blk, 0, stream>>>(a);
+        gat_fused_rows_kernel<VEC, U, 8, MODE, FOLD><<<grid, blk, 0, stream>>>(a);
     else if (VEC == 4 && a.lph == 16)
-        gat_fused_rows_kernel<VEC, U, 16, MODE><<<grid, blk, 0, stream>>>(a);
+        gat_fused_rows_kernel<VEC, U, 16, MODE, FOLD><<<grid, blk, 0, stream>>>(a);
     else if (VEC == 4 && a.lph == 32)
-        gat_fused_rows_kernel<VEC, U, 32, MODE><<<grid, blk, 0, stream>>>(a);
+        gat_fused_rows_kernel<VEC, U, 32, MODE, FOLD><<<grid, blk, 0, stream>>>(a);
     else if (VEC == 4 && a.lph == 64)
-        gat_fused_rows_kernel<VEC, U, 64, MODE><<<grid, blk, 0, stream>>>(a);
+        gat_fused_rows_kernel<VEC, U, 64, MODE, FOLD><<<grid, blk, 0, stream>>>(a);
     else
-        gat_fused_rows_kernel<VEC, U, 0, MODE><<<grid, blk, 0, stream>>>(a);
+        gat_fused_rows_kernel<VEC, U, 0, MODE, FOLD><<<grid, blk, 0, stream>>>(a);
 }
 
 template <int VEC, int MODE>
@@ -520,6 +661,12 @@ static int launch_gat_fused(GatFusedArgs a, hipStream_t stream) {
             gat_fused_rows_kernel<VEC, 4, 0, MODE><<<grid, blk, 0, stream>>>(a);
         } else if (is_gat(MODE) && U == 2) {
             gat_fused_rows_kernel<VEC, 2, 0, MODE><<<grid, blk, 0, stream>>>(a);
+        } else if (MODE == GNNMP_ATTN_GAT && a.arrive && a.n_long > 0) {
+            // GATConv's forward merges its split rows inside the row kernel: no second launch.  (Not the training forward: with the o+ / P
+            // accumulators the merge code took the kernel from 86 to 101 registers — 5 -> 4 waves a SIMD.)
+            launch_rows_lph<VEC, 8, MODE, MODE == GNNMP_ATTN_GAT>(a, grid, blk, stream);
+            GNNMP_LAUNCH_CHECK("gat_fused_rows_kernel<FOLD>");
+            return GNNMP_OK;
         } else {
             launch_rows_lph<VEC, 8, MODE>(a, grid, blk, stream);
         }
@@ -641,6 +788,17 @@ static int attn_conv_impl(gnnmp_graph_t *plan, int mode, const float *Q, const f
     g.waves = 4;
     g.off24 = plan->n_src < (1 << 24) && D < (1 << 24) && (int64_t)plan->n_src * D < (1ll << 32);
     g.drop = make_drop(drop_p, drop_seed);
+    g.chunk_lrow = plan->chunk_lrow;
+    g.arrive = nullptr;
+    g.spart = nullptr;
+    if (plan->n_long > 0 && use_fold() && (mode == GNNMP_ATTN_GAT && !escore && drop_p == 0.0f && !plus)) {   // (plain GAT only)
+        const size_t NG = (size_t)(256 >> log2g);
+        if (int rc = ensure_arrive(plan, (size_t)plan->n_long * (NG + 1),
+                                   (size_t)plan->n_long * NG * (size_t)(plus ? 2 * D + 3 * lanes : D + 2 * lanes), stream))
+            return rc;
+        g.arrive = plan->arrive;
+        g.spart = plan->spart;
+    }
     if (drop_p > 0.0f)
         return mode == GNNMP_ATTN_GATV2 ? launch_mode<ATTN_GATV2_DROP>(g, vec, stream) : launch_mode<ATTN_GAT_DROP>(g, vec, stream);
     if (plus) return launch_mode<ATTN_GAT_PLUS>(g, vec, stream);

@@ -63,6 +63,27 @@ int ensure_workspace(gnnmp_graph *p, size_t floats) {
     return GNNMP_OK;
 }
 
+int ensure_arrive(gnnmp_graph *p, size_t n, size_t floats, hipStream_t stream) {
+    if (floats > p->spart_floats) {
+        if (p->spart) (void)hipFree(p->spart);   // (waits for in-flight work)
+        p->spart = nullptr;
+        p->spart_floats = 0;
+        hipError_t e = hipMalloc((void **)&p->spart, sizeof(float) * floats);
+        if (e != hipSuccess) return hip_fail(e, "hipMalloc(plan slice partials)");
+        p->spart_floats = floats;
+    }
+    if (n <= p->arrive_n) return GNNMP_OK;
+    if (p->arrive) (void)hipFree(p->arrive);   // (waits for in-flight work; counters are zero between launches, nothing to carry over)
+    p->arrive = nullptr;
+    p->arrive_n = 0;
+    hipError_t e = hipMalloc((void **)&p->arrive, sizeof(uint32_t) * n);
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc(plan arrival counters)");
+    e = hipMemsetAsync(p->arrive, 0, sizeof(uint32_t) * n, stream);
+    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(plan arrival counters)");
+    p->arrive_n = n;
+    return GNNMP_OK;
+}
+
 int ensure_ticket(gnnmp_graph *p, hipStream_t stream) {
     if (p->ticket) return GNNMP_OK;
     hipError_t e = hipMalloc((void **)&p->ticket, 2 * sizeof(uint32_t));
@@ -315,7 +336,7 @@ int plan_build_long_rows(gnnmp_graph *p, hipStream_t stream) {
             PLAN_HIP(hipMemcpy(h.data(), long_tmp, sizeof(Tri) * h.size(), hipMemcpyDeviceToHost));
             // atomics filled the list in arbitrary order: make it canonical (ascending row)
             std::sort(h.begin(), h.end(), [](const Tri &a, const Tri &b) { return a.row < b.row; });
-            std::vector<int32_t> rows, cptr, crow;
+            std::vector<int32_t> rows, cptr, crow, clrow;
             std::vector<uint32_t> cbeg, cend;
             cptr.push_back(0);
             for (const Tri &t : h) {
@@ -324,6 +345,7 @@ int plan_build_long_rows(gnnmp_graph *p, hipStream_t stream) {
                 const int64_t csz = (len + nch - 1) / nch;  // balanced chunks, each <= long_thresh slots
                 for (int64_t c = 0; c < nch; ++c) {
                     crow.push_back((int32_t)t.row);
+                    clrow.push_back((int32_t)rows.size());
                     cbeg.push_back((uint32_t)(t.beg + c * csz));
                     cend.push_back((uint32_t)std::min(t.beg + (c + 1) * csz, t.end));
                 }
@@ -344,6 +366,7 @@ int plan_build_long_rows(gnnmp_graph *p, hipStream_t stream) {
             PLAN_HIP(upload(&p->long_rows, rows));
             PLAN_HIP(upload(&p->long_cptr, cptr));
             PLAN_HIP(upload(&p->chunk_row, crow));
+            PLAN_HIP(upload(&p->chunk_lrow, clrow));
             auto upload_u = [&](uint32_t **dst, const std::vector<uint32_t> &v) -> hipError_t {
                 hipError_t e = hipMalloc((void **)dst, sizeof(uint32_t) * v.size());
                 if (e != hipSuccess) return e;
@@ -435,6 +458,9 @@ int plan_dispose(gnnmp_graph_t *p, hipStream_t stream, bool stream_known) {
     if (p->long_rows) (void)hipFree(p->long_rows);
     if (p->long_cptr) (void)hipFree(p->long_cptr);
     if (p->chunk_row) (void)hipFree(p->chunk_row);
+    if (p->chunk_lrow) (void)hipFree(p->chunk_lrow);
+    if (p->arrive) (void)hipFree(p->arrive);
+    if (p->spart) (void)hipFree(p->spart);
     if (p->chunk_beg) (void)hipFree(p->chunk_beg);
     if (p->chunk_end) (void)hipFree(p->chunk_end);
     if (p->ws) (void)hipFree(p->ws);

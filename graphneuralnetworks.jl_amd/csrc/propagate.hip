@@ -20,7 +20,10 @@
 namespace gnnmp {
 
 // virtual rows: [0, n_chunks) are chunks of long rows (raw partials), [n_chunks, n_chunks + n_rows) ordinary rows.
-template <int VEC, int OP, bool SCALED, int U, bool EMAT = false, bool EXPSUB = false, int GATED = 0>
+// FOLD: no second kernel for the split rows — the last chunk of a long row to arrive folds the row's partials itself, in the order of
+// csr_combine_kernel (csr_reduce.h: chunk_arrive, fold_long_row).  One launch and one launch seam less per call: 5.6 us + the seam of a
+// 107 us arxiv-shaped propagate.
+template <int VEC, int OP, bool SCALED, int U, bool EMAT = false, bool EXPSUB = false, int GATED = 0, bool FOLD = false>
 __global__ void __launch_bounds__(256) csr_rows_kernel(const ReduceArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -42,6 +45,22 @@ __global__ void __launch_bounds__(256) csr_rows_kernel(const ReduceArgs a) {
         reduce_range<VEC, OP, SCALED, U, EMAT, EXPSUB, GATED>(a, a.chunk_beg[v], a.chunk_end[v], lig, gbase, G, f0, active, acc,
                                                               (EXPSUB || GATED) ? a.chunk_row[v] : 0);
         if (active) Vec<VEC>::store(a.partial + (int64_t)v * a.D + f0, acc);
+        if (FOLD) {
+            const int r = a.chunk_lrow[v];
+            const LongGeom lg = long_geom(a.long_cptr, r, a.log2g);
+            const int NG = 256 >> a.log2g;
+            const int k = (v - lg.c0) / lg.per;
+            const int s0 = lg.c0 + k * lg.per, s1 = min(lg.c1, s0 + lg.per);
+            uint32_t *cnt = a.arrive + ((int64_t)r * gridDim.y + blockIdx.y) * (NG + 1);
+            if (!chunk_arrive(cnt + k, s1 - s0, lig, gbase)) return;
+            fold_rows<VEC, OP>(a.partial + (int64_t)s0 * a.D, a.D, s1 - s0, f0, active, acc, true);
+            float *sp = a.spart + (int64_t)r * NG * a.D;
+            if (active) Vec<VEC>::store(sp + (int64_t)k * a.D + f0, acc);
+            if (!chunk_arrive(cnt + NG, lg.ns, lig, gbase)) return;
+            fold_rows<VEC, OP>(sp, a.D, lg.ns, f0, active, acc, false);
+            const int lrow = a.long_rows[r];
+            finalize_store<VEC, OP>(a, lrow, a.rowptr[lrow + 1] - a.rowptr[lrow], f0, active, acc, a.compact_long ? r : -1);
+        }
         return;
     }
     int row = v - a.n_chunks;
@@ -270,6 +289,13 @@ static int launch_reduce(const ReduceArgs &a0, hipStream_t stream) {
             gx = (int64_t)a.nbc + (int64_t)a.cpx * 8;
         }
         dim3 grid((unsigned)gx, (unsigned)tiles);
+        // the plain propagate / scatter instances fold their split rows themselves (a.arrive set by run_reduce when it may)
+        constexpr bool CAN_FOLD = !EMAT && !EXPSUB && GATED == 0 && U == 8;
+        if (CAN_FOLD && a.arrive && a.n_long > 0) {
+            csr_rows_kernel<VEC, OP, SCALED, U, EMAT, EXPSUB, GATED, CAN_FOLD><<<grid, 64 * waves, 0, stream>>>(a);
+            GNNMP_LAUNCH_CHECK("csr_rows_kernel<FOLD>");
+            return GNNMP_OK;
+        }
         csr_rows_kernel<VEC, OP, SCALED, U, EMAT, EXPSUB, GATED><<<grid, 64 * waves, 0, stream>>>(a);
         GNNMP_LAUNCH_CHECK("csr_rows_kernel");
     }
@@ -374,6 +400,8 @@ int run_reduce(gnnmp_graph_t *p, const int32_t *idx, int aggr, const float *x, c
     a.cpx = 0;
     a.nbc = 0;
     a.waves = 4;
+    a.chunk_lrow = p->chunk_lrow;
+    a.arrive = nullptr;
     int vec = pick_vec(D, x, out);
     if (emat && (reinterpret_cast<uintptr_t>(emat) & (4 * vec - 1)) != 0) vec = 1;
     if (gate_i && (reinterpret_cast<uintptr_t>(gate_i) & (4 * vec - 1)) != 0) vec = 1;
@@ -387,6 +415,14 @@ int run_reduce(gnnmp_graph_t *p, const int32_t *idx, int aggr, const float *x, c
     }
     const int op = (aggr == GNNMP_MAX) ? OP_MAX : (aggr == GNNMP_MIN ? OP_MIN : OP_SUM);
     const bool scaled = w || ss || w_slot || ss_slot;
+    a.spart = nullptr;
+    if (p->n_long > 0 && use_fold()) {      // split rows folded inside the row kernel: arrival counters per (long row, feature tile, slice)
+        const int G = 1 << a.log2g, NG = 256 >> a.log2g;
+        const size_t tiles = (size_t)(((D + vec - 1) / vec + G - 1) / G);
+        if (int rc = ensure_arrive(p, (size_t)p->n_long * tiles * (size_t)(NG + 1), (size_t)p->n_long * (size_t)NG * (size_t)D, stream)) return rc;
+        a.arrive = p->arrive;
+        a.spart = p->spart;
+    }
     switch (vec) {
         case 4: return dispatch_op<4>(a, op, scaled, stream);
         case 2: return dispatch_op<2>(a, op, scaled, stream);

@@ -9,6 +9,8 @@ paths: non-power-of-two heads, K > 128, D % 4 != 0, small graphs).  Here a core 
   19=1             the wave-pair chain kernel with 8 waves a block (4 pairs, the 512-thread instantiation; default 12 waves)
   19=48            the split-bf16 dense kernel storing straight from the accumulator layout and running its column tiles one after
                    the other (default: through the per-wave LDS stage, column tiles side by side)
+  19=128           split rows folded by the combine kernels of rounds 1-4 (default since round 5: by the last chunk to arrive, inside
+                   the row kernel)
 Each case IS the original test function, called with the knobs set."""
 import numpy as np
 import pytest
@@ -25,6 +27,7 @@ KNOB_SETS = {
     "chain-off(18=-1)": [(18, -1)],
     "chain-8-waves(19=1)": [(19, 1)],
     "dense-split-direct-stores-serial-column-tiles(19=48)": [(19, 48)],
+    "two-kernel-long-rows(19=128)": [(19, 128)],
 }
 
 
