@@ -209,6 +209,47 @@ struct Vec<1> {
     static __device__ __forceinline__ void store(float *p, const float v[1]) { *p = v[0]; }
 };
 
+// Device-coherent accesses WITHOUT cache maintenance — for the few values that cross from one workgroup to another inside a kernel (the
+// partials of split rows, csr_reduce.h).  The eight XCDs' L2s are not coherent with each other; a __threadfence() makes ordinary stores
+// visible by writing back / invalidating the WHOLE L2 of the issuing XCD (buffer_wbl2 / buffer_inv) — measured: 4 000 of those turned a
+// 101 us arxiv-shaped propagate into 270 us.  Relaxed agent-scope atomics instead compile to loads / stores with the sc1 bit: they go
+// through to the coherence point themselves and leave every other line of the cache alone.  Ordering is then the program's job:
+// coh_publish() waits until this lane's stores have been acknowledged before the arrival counter is bumped, and the consumer reads only
+// through coh_load after it saw the count (a control dependency: no load is issued before the counter's value is back).
+template <int VEC>
+__device__ __forceinline__ void coh_store(float *p, const float v[VEC]) {
+    if (VEC == 1) {
+        __hip_atomic_store(reinterpret_cast<unsigned int *>(p), __float_as_uint(v[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+#pragma unroll
+        for (int q = 0; q < VEC; q += 2) {
+            const unsigned long long b = (unsigned long long)__float_as_uint(v[q]) | ((unsigned long long)__float_as_uint(v[q + 1 < VEC ? q + 1 : q]) << 32);
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(p + q), b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+template <int VEC>
+__device__ __forceinline__ void coh_load(const float *p, float v[VEC]) {
+    if (VEC == 1) {
+        v[0] = __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned int *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    } else {
+#pragma unroll
+        for (int q = 0; q < VEC; q += 2) {
+            const unsigned long long b = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p + q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v[q] = __uint_as_float((unsigned int)b);
+            if (q + 1 < VEC) v[q + 1] = __uint_as_float((unsigned int)(b >> 32));
+        }
+    }
+}
+__device__ __forceinline__ void coh_store1(float *p, float v) {
+    __hip_atomic_store(reinterpret_cast<unsigned int *>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float coh_load1(const float *p) {
+    return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned int *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+// every memory operation this lane has issued so far has completed (stores acknowledged by the coherence point)
+__device__ __forceinline__ void coh_publish() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
+
 // Sum over aligned groups of LPH adjacent lanes (LPH a power of two; the lanes that hold one attention head).  Every lane
 // of the group ends with the same bits.  Stages 1, 2 are quad permutes, 4 and 8 the half-row / row mirrors (after the
 // quad stages the mirror partner holds the other half's sum, so it is as good as xor) — all DPP modifiers folded into

@@ -280,13 +280,13 @@ __device__ __forceinline__ void fold_rows(const float *__restrict__ base, int64_
     for (int q = 0; q < VEC; ++q) acc[q] = op_identity<OP>();
     if (!active) return;
     if (!from_identity) {
-        Vec<VEC>::load(base + f0, acc);
+        coh_load<VEC>(base + f0, acc);
         c = 1;
     }
     for (; c < n; c += CB) {
         float v[CB][VEC];
 #pragma unroll
-        for (int u = 0; u < CB; ++u) Vec<VEC>::load(base + (int64_t)min(c + u, n - 1) * stride + f0, v[u]);
+        for (int u = 0; u < CB; ++u) coh_load<VEC>(base + (int64_t)min(c + u, n - 1) * stride + f0, v[u]);
 #pragma unroll
         for (int u = 0; u < CB; ++u) {
             if (c + u < n) {
@@ -297,16 +297,16 @@ __device__ __forceinline__ void fold_rows(const float *__restrict__ base, int64_
     }
 }
 
-// A chunk's lane group has stored its partial: count it in; true for the group that completes its long row (it then folds the row).
-// release: the partial is visible device-wide before the count; acquire: the last arriver sees every other chunk's partial.
-__device__ __forceinline__ bool chunk_arrive(uint32_t *counter, int nchunks, int lig, int gbase) {
-    __threadfence();
+// A chunk's lane group has stored its partial (coh_store): count it in; true for the group that completes its slice / row (it then folds,
+// reading through coh_load).  No fence: see common.h coh_store.
+__device__ __forceinline__ bool chunk_arrive(uint32_t *counter, int n, int lig, int gbase) {
+    coh_publish();
     unsigned prev = 0;
-    if (lig == 0) prev = atomicAdd(counter, 1u);
+    if (lig == 0) prev = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     prev = (unsigned)__shfl((int)prev, gbase, 64);
-    if (prev != (unsigned)(nchunks - 1)) return false;
-    __threadfence();
-    if (lig == 0) *counter = 0u;          // ready for the plan's next launch (every chunk of this row has arrived: nobody touches it again)
+    if (prev != (unsigned)(n - 1)) return false;
+    // ready for the plan's next launch (every participant has arrived: nobody touches the counter again in this one)
+    if (lig == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return true;
 }
 

@@ -284,7 +284,7 @@ __device__ __forceinline__ void gat_fold_slice(const GatFusedArgs &a, int s0, in
     for (int c = s0; c < s1; c += CB) {
         float mv[CB];
 #pragma unroll
-        for (int u = 0; u < CB; ++u) mv[u] = a.partial[(int64_t)min(c + u, s1 - 1) * S + a.D + li];
+        for (int u = 0; u < CB; ++u) mv[u] = coh_load1(a.partial + (int64_t)min(c + u, s1 - 1) * S + a.D + li);
 #pragma unroll
         for (int u = 0; u < CB; ++u) M = fmaxf(M, mv[u]);
     }
@@ -296,12 +296,12 @@ __device__ __forceinline__ void gat_fold_slice(const GatFusedArgs &a, int s0, in
 #pragma unroll
         for (int u = 0; u < CB; ++u) {
             const float *pc = a.partial + (int64_t)min(c + u, s1 - 1) * S;
-            mv[u] = pc[a.D + li];
-            dv[u] = pc[a.D + LN + li];
-            Vec<VEC>::load(pc + f0, v[u]);
+            mv[u] = coh_load1(pc + a.D + li);
+            dv[u] = coh_load1(pc + a.D + LN + li);
+            coh_load<VEC>(pc + f0, v[u]);
             if (PLUS) {
-                Vec<VEC>::load(pc + a.D + 2 * LN + f0, v2[PLUS ? u : 0]);
-                dv2[PLUS ? u : 0] = pc[2 * a.D + 2 * LN + li];
+                coh_load<VEC>(pc + a.D + 2 * LN + f0, v2[PLUS ? u : 0]);
+                dv2[PLUS ? u : 0] = coh_load1(pc + 2 * a.D + 2 * LN + li);
             }
         }
 #pragma unroll
@@ -319,12 +319,12 @@ __device__ __forceinline__ void gat_fold_slice(const GatFusedArgs &a, int s0, in
             }
         }
     }
-    Vec<VEC>::store(sp + f0, acc);
-    sp[a.D + li] = M;
-    sp[a.D + LN + li] = den;
+    coh_store<VEC>(sp + f0, acc);
+    coh_store1(sp + a.D + li, M);
+    coh_store1(sp + a.D + LN + li, den);
     if (PLUS) {
-        Vec<VEC>::store(sp + a.D + 2 * LN + f0, acc2);
-        sp[2 * a.D + 2 * LN + li] = den2;
+        coh_store<VEC>(sp + a.D + 2 * LN + f0, acc2);
+        coh_store1(sp + 2 * a.D + 2 * LN + li, den2);
     }
 }
 // Level 2: the last slice of the row to finish merges the ns slice partials (slice 0 rescaled by a multiplication, the others folded in
@@ -335,22 +335,22 @@ __device__ __forceinline__ void gat_fold_slices(const GatFusedArgs &a, int row, 
     const int64_t S = PLUS ? 2 * a.D + 3 * LN : a.D + 2 * LN;
     const int li = f0 / VEC;
     float Mt = -__builtin_inff();
-    for (int k = 0; k < ns; ++k) Mt = fmaxf(Mt, sp[(int64_t)k * S + a.D + li]);
+    for (int k = 0; k < ns; ++k) Mt = fmaxf(Mt, coh_load1(sp + (int64_t)k * S + a.D + li));
     float den = 0.0f, den2 = 0.0f, acc[VEC], acc2[VEC];
 #pragma unroll
     for (int q = 0; q < VEC; ++q) acc[q] = acc2[q] = 0.0f;
     for (int k = 0; k < ns; ++k) {
         const float *o = sp + (int64_t)k * S;
         float sa[VEC], sa2[VEC];
-        Vec<VEC>::load(o + f0, sa);
-        const float sc = expf(o[a.D + li] - Mt);
-        const float sd = o[a.D + LN + li];
+        coh_load<VEC>(o + f0, sa);
+        const float sc = expf(coh_load1(o + a.D + li) - Mt);
+        const float sd = coh_load1(o + a.D + LN + li);
         float sd2 = 0.0f;
 #pragma unroll
         for (int q = 0; q < VEC; ++q) sa2[q] = 0.0f;
         if (PLUS) {
-            Vec<VEC>::load(o + a.D + 2 * LN + f0, sa2);
-            sd2 = o[2 * a.D + 2 * LN + li];
+            coh_load<VEC>(o + a.D + 2 * LN + f0, sa2);
+            sd2 = coh_load1(o + 2 * a.D + 2 * LN + li);
         }
         if (k == 0) {
             den = sd * sc;
@@ -371,15 +371,15 @@ __device__ __forceinline__ void gat_fold_slices(const GatFusedArgs &a, int row, 
     gat_long_row_finish<VEC, PLUS>(a, row, f0, acc, Mt, den, acc2, den2);
 }
 
-// A chunk's lane group has stored its partial: count it in; true for the group that completes its long row (csr_reduce.h: chunk_arrive)
-__device__ __forceinline__ bool gat_chunk_arrive(uint32_t *counter, int nchunks, int lig, int gbase) {
-    __threadfence();
+// A chunk's lane group has stored its partial (coh_store): count it in; true for the group that completes its slice / row
+// (csr_reduce.h: chunk_arrive — no fence, coherent accesses only)
+__device__ __forceinline__ bool gat_chunk_arrive(uint32_t *counter, int n, int lig, int gbase) {
+    coh_publish();
     unsigned prev = 0;
-    if (lig == 0) prev = atomicAdd(counter, 1u);
+    if (lig == 0) prev = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     prev = (unsigned)__shfl((int)prev, gbase, 64);
-    if (prev != (unsigned)(nchunks - 1)) return false;
-    __threadfence();
-    if (lig == 0) *counter = 0u;
+    if (prev != (unsigned)(n - 1)) return false;
+    if (lig == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return true;
 }
 
@@ -465,9 +465,15 @@ __global__ void __launch_bounds__(256) gat_fused_rows_kernel(const GatFusedArgs 
         if (active) {
             const int LN = a.D / VEC;
             float *pc = a.partial + (int64_t)v * (plus ? 2 * a.D + 3 * LN : a.D + 2 * LN);
-            Vec<VEC>::store(pc + f0, acc);
-            pc[a.D + f0 / VEC] = m;
-            pc[a.D + LN + f0 / VEC] = den;
+            if (FOLD) {           // read by another workgroup of this launch: coherent stores (common.h)
+                coh_store<VEC>(pc + f0, acc);
+                coh_store1(pc + a.D + f0 / VEC, m);
+                coh_store1(pc + a.D + LN + f0 / VEC, den);
+            } else {
+                Vec<VEC>::store(pc + f0, acc);
+                pc[a.D + f0 / VEC] = m;
+                pc[a.D + LN + f0 / VEC] = den;
+            }
             if (plus) {
                 Vec<VEC>::store(pc + a.D + 2 * LN + f0, acc2);
                 pc[2 * a.D + 2 * LN + f0 / VEC] = den2;

@@ -44,7 +44,10 @@ __global__ void __launch_bounds__(256) csr_rows_kernel(const ReduceArgs a) {
     if (v < a.n_chunks) {
         reduce_range<VEC, OP, SCALED, U, EMAT, EXPSUB, GATED>(a, a.chunk_beg[v], a.chunk_end[v], lig, gbase, G, f0, active, acc,
                                                               (EXPSUB || GATED) ? a.chunk_row[v] : 0);
-        if (active) Vec<VEC>::store(a.partial + (int64_t)v * a.D + f0, acc);
+        if (active) {
+            if (FOLD) coh_store<VEC>(a.partial + (int64_t)v * a.D + f0, acc);      // read by another workgroup of this launch
+            else Vec<VEC>::store(a.partial + (int64_t)v * a.D + f0, acc);
+        }
         if (FOLD) {
             const int r = a.chunk_lrow[v];
             const LongGeom lg = long_geom(a.long_cptr, r, a.log2g);
@@ -55,7 +58,7 @@ __global__ void __launch_bounds__(256) csr_rows_kernel(const ReduceArgs a) {
             if (!chunk_arrive(cnt + k, s1 - s0, lig, gbase)) return;
             fold_rows<VEC, OP>(a.partial + (int64_t)s0 * a.D, a.D, s1 - s0, f0, active, acc, true);
             float *sp = a.spart + (int64_t)r * NG * a.D;
-            if (active) Vec<VEC>::store(sp + (int64_t)k * a.D + f0, acc);
+            if (active) coh_store<VEC>(sp + (int64_t)k * a.D + f0, acc);
             if (!chunk_arrive(cnt + NG, lg.ns, lig, gbase)) return;
             fold_rows<VEC, OP>(sp, a.D, lg.ns, f0, active, acc, false);
             const int lrow = a.long_rows[r];

@@ -66,7 +66,7 @@ def test_propagate_fold_is_bit_identical_to_the_combine_kernel(gm, D, aggr):
     a1, a2, b = both(gm, lambda: gm.propagate(gm.copy_xj, g, aggr, xj=x))
     assert torch.equal(a1.view(torch.int32), b.view(torch.int32)) and torch.equal(a2.view(torch.int32), b.view(torch.int32))
     if aggr in ("+", "mean"):
-        a1, a2, b = both(gm, lambda: gm.propagate(gm.w_mul_xj, g, aggr, xj=x, w=w))
+        a1, a2, b = both(gm, lambda: gm.propagate(gm.e_mul_xj, g, aggr, xj=x, e=w))
         assert torch.equal(a1.view(torch.int32), b.view(torch.int32)) and torch.equal(a2.view(torch.int32), b.view(torch.int32))
 
 
