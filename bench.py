@@ -679,7 +679,9 @@ def main():
                            "trials_ms": {name: {k[0]: ch.times_ms for k, ch in getattr(layer, "_placed", {}).items() if hasattr(ch, "times_ms")}
                                          for name, layer in (("gcn", gcn), ("gat", gat))},
                            "note": "outputs of the two gather kernels live in a placement class other than their gathered matrix's "
-                                   "(csrc/arena.hip: 2 GiB physical chunks classified by a 140 us probe)"}
+                                   "(csrc/arena.hip: 2 GiB blocks classified by a 0.6 ms probe inside a budget of 32 GiB held / ~0.3 s; fewer "
+                                   "than two classes found = no placement, ordinary allocations)",
+                           "no_arena_because": (gnnmp.placement._arena[2] if ar is None and len(gnnmp.placement._arena) > 2 else None)}
     if not args.no_placement:
         gcn.place_outputs = gat.place_outputs = False
         extras["placement"]["gcn_layer_ms_fresh_allocations"] = layer_time(lambda: gcn(g, x), 5)
@@ -744,7 +746,8 @@ def main():
             sage.aggr = "+"
             t_ss = layer_time(lambda: sage(g, x), 5)
             extras["sage_products"] = {"E": E, "layer_ms_mean": t_sm, "layer_ms_sum": t_ss,
-                                       "edges_per_s_mean": E / t_sm * 1e3, "edges_per_s_sum": E / t_ss * 1e3}
+                                       "edges_per_s_mean": E / t_sm * 1e3, "edges_per_s_sum": E / t_ss * 1e3,
+                                       "placed_buffers": sorted(k[0] for k in getattr(sage, "_placed", {}))}
             del out_p, out_g, Wx, sage
             # SURVEY §8f "next" rows on the same graph: the standalone neighbourhood softmax (a20) and the training step of the two
             # headline layers (f1: forward + backward through the HIP adjoints)

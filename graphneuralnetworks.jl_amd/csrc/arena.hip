@@ -16,7 +16,15 @@
 //     gnnmp_arena_alloc(arena, 1 - cls, bytes)  -> the output buffer
 // The C ABI's rule — the caller allocates — stands: this is an allocator the caller MAY use.  Creation synchronises (graph prep); alloc
 // and class_of on arena memory do not; class_of on foreign memory runs the probe (synchronises).
+//
+// Round 5 — an allocator a caller can leave on.  Creation works inside a BUDGET: at most max_probe_bytes of device memory held at any moment
+// (default 32 GiB = 16 blocks) and at most ~0.3 s (GNNMP_ARENA_BUDGET_MS); a block is first screened at ONE window (1 warm-up + 3 timed
+// probes, ~2.5 ms) and only the blocks that are kept are checked at all four.  When the budget runs out the arena is returned with the classes
+// it found (gnnmp_arena_info: [7] = classes, [9] = 1 "gave up") instead of an error: two classes still separate a gather's source from
+// its output, one class means "no placement on this device today" (the caller allocates as usual).  A buffer larger than a block is served
+// from VIRTUALLY ADJACENT blocks of one class (sequential hipMallocs of one size usually are; checked, never assumed).
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
@@ -35,6 +43,8 @@ struct gnnmp_arena {
     int dev = 0;
     int64_t created = 0, released = 0;                 // blocks made / given back during classification
     float probe_same_us = 0.0f, probe_other_us = 0.0f; // what the probe measured (info)
+    int gave_up = 0;                                   // the budget ran out before every class held its blocks
+    int64_t create_us = 0;                             // wall time of gnnmp_arena_create
     std::mutex lock;
 };
 
@@ -51,14 +61,15 @@ __global__ void probe_edges_kernel(int64_t n_src, int64_t *src, int64_t *dst) {
     dst[e] = e / PROBE_DEG + 1;
 }
 
-// median of `reps` timed launches of the probe: source rows at `src`, output at `out` (PROBE_ROWS x PROBE_D floats); microseconds
-int probe_us(gnnmp_arena *a, const float *src, float *out, hipStream_t stream, float *us) {
+// median of `reps` (odd, <= 5) timed launches of the probe after `warm` untimed ones: source rows at `src`, output at `out` (PROBE_ROWS x
+// PROBE_D floats); microseconds
+int probe_us(gnnmp_arena *a, const float *src, float *out, hipStream_t stream, float *us, int warm = 2, int reps = 5) {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     GNNMP_HIP(hipEventCreate(&e0));
     GNNMP_HIP(hipEventCreate(&e1));
     float t[5];
     int rc = GNNMP_OK;
-    for (int it = -2; it < 5 && rc == GNNMP_OK; ++it) {
+    for (int it = -warm; it < reps && rc == GNNMP_OK; ++it) {
         hipError_t e = hipEventRecord(e0, stream);
         if (e == hipSuccess) {
             rc = gnnmp_propagate_f32(a->probe_plan, GNNMP_COPY_XJ, GNNMP_SUM, src, nullptr, nullptr, nullptr, out, PROBE_D, stream);
@@ -74,24 +85,28 @@ int probe_us(gnnmp_arena *a, const float *src, float *out, hipStream_t stream, f
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     if (rc != GNNMP_OK) return rc;
-    std::sort(t, t + 5);
-    *us = t[2];
+    std::sort(t, t + reps);
+    *us = t[reps / 2];
     return GNNMP_OK;
 }
 
-// a block under test, probed at its start and at its middle (an allocation is a patchwork of whatever physical blocks were free: only
-// blocks whose two halves agree are used); *lo / *hi = the smaller / larger of the two times
+// a block probed at four places, every 512 MiB (an allocation is a patchwork of whatever physical blocks were free: only blocks whose
+// windows agree are used); *lo / *hi = the smallest / largest of the four times
 int probe_chunk(gnnmp_arena *a, const float *src, unsigned char *chunk, hipStream_t stream, float *lo, float *hi) {
     *lo = 1e30f;
     *hi = 0.0f;
     for (int k = 0; k < 4; ++k) {
         float t = 0.0f;
-        int rc = probe_us(a, src, reinterpret_cast<float *>(chunk + (int64_t)k * (CHUNK / 4)), stream, &t);
+        int rc = probe_us(a, src, reinterpret_cast<float *>(chunk + (int64_t)k * (CHUNK / 4)), stream, &t, 1, 3);
         if (rc != GNNMP_OK) return rc;
         *lo = std::min(*lo, t);
         *hi = std::max(*hi, t);
     }
     return GNNMP_OK;
+}
+// the screening probe: one window (the block's second quarter), 1 warm-up + 3 timed launches
+int probe_quick(gnnmp_arena *a, const float *src, unsigned char *chunk, hipStream_t stream, float *us) {
+    return probe_us(a, src, reinterpret_cast<float *>(chunk + CHUNK / 4), stream, us, 1, 3);
 }
 
 int make_probe_plan(gnnmp_arena *a, int64_t n_src, hipStream_t stream) {
@@ -127,19 +142,25 @@ int gnnmp_arena_create(gnnmp_arena_t **out, int64_t bytes_per_class, int n_class
     hipStream_t stream = (hipStream_t)stream_;
     if (!out || bytes_per_class <= 0 || (n_classes != 2 && n_classes != 3)) return fail(GNNMP_EINVAL, "arena_create: bad argument");
     *out = nullptr;
+    const auto t_start = std::chrono::steady_clock::now();
+    auto elapsed_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
     gnnmp_arena *a = new gnnmp_arena();
     a->dev = current_device();
     a->block_bytes = CHUNK;
     a->n_classes = n_classes;
     const int need = (int)((bytes_per_class + CHUNK - 1) / CHUNK);
     a->cap = (int64_t)need * CHUNK;
-    if (max_probe_bytes <= 0) max_probe_bytes = (int64_t)160 << 30;
-    const int max_blocks = (int)std::max<int64_t>((int64_t)n_classes * need, max_probe_bytes / CHUNK);
+    if (max_probe_bytes <= 0) max_probe_bytes = (int64_t)32 << 30;
+    // at any moment the arena holds what it probed so far (a freed block would come straight back from hipMalloc): the budget bounds that
+    const int max_blocks = (int)std::max<int64_t>(2, max_probe_bytes / CHUNK);
+    double budget_ms = 300.0;
+    if (const char *e = getenv("GNNMP_ARENA_BUDGET_MS")) budget_ms = std::max(1.0, atof(e));
+    const bool debug = getenv("GNNMP_ARENA_DEBUG") != nullptr;
     // Blocks are plain hipMalloc allocations, each classified where it lies and then kept or freed — no remapping.  (A first version built
     // the ranges out of hipMemCreate chunks moved between addresses with hipMemMap / hipMemUnmap: translations of an unmapped range
     // outlived the unmap — 80 different chunks probed through one address measured alike — and two runs in six ended in a GPU memory
-    // fault.)  A block is used only if its four windows probe alike (an allocation of 2 GiB is usually one physical block, but need not be).
-    struct Pend { unsigned char *p; float lo, hi; };
+    // fault.)
+    struct Pend { unsigned char *p; float t; };
     std::vector<Pend> pending;
     std::vector<unsigned char *> spare;                      // blocks of a class that is full / mixed blocks: freed at the end (freeing
                                                              // one earlier would hand the same physical memory out again)
@@ -150,22 +171,24 @@ int gnnmp_arena_create(gnnmp_arena_t **out, int64_t bytes_per_class, int n_class
         if (cls < a->n_classes && (int)a->blocks[cls].size() < need) a->blocks[cls].push_back({p, 0});
         else spare.push_back(p);
     };
+    // (consumes q.p on every path: kept, spare, or — on an error — spare)
     auto classify = [&](const Pend &q) -> int {
         int cls;
-        if (q.lo > thr) {
-            cls = 0;                                         // both halves as slow as block 0's own class
-        } else if (q.hi > thr) {
-            cls = 3;                                         // the halves disagree: a mixed block, not used
+        if (q.t > thr) {
+            cls = 0;                                         // as slow as block 0's own class
         } else if (!ref1) {
             cls = 1;
             ref1 = reinterpret_cast<const float *>(q.p);
-            if (hipMemsetAsync(q.p, 0, (size_t)CHUNK / 2, stream) != hipSuccess) return fail(GNNMP_ELAUNCH, "arena: memset of the second reference");
+            if (hipMemsetAsync(q.p, 0, (size_t)CHUNK / 2, stream) != hipSuccess) {
+                spare.push_back(q.p);
+                return fail(GNNMP_ELAUNCH, "arena: memset of the second reference");
+            }
         } else {
-            float lo1 = 0.0f, hi1 = 0.0f;
-            int r2 = probe_chunk(a, ref1, q.p, stream, &lo1, &hi1);
-            if (r2 != GNNMP_OK) return r2;
-            cls = lo1 > thr ? 1 : (hi1 > thr ? 3 : 2);
-            if (getenv("GNNMP_ARENA_DEBUG")) fprintf(stderr, "[arena]   against the class-1 reference %.1f / %.1f us -> class %d\n", lo1, hi1, cls);
+            float t1 = 0.0f;
+            const int r2 = probe_quick(a, ref1, q.p, stream, &t1);
+            if (r2 != GNNMP_OK) { spare.push_back(q.p); return r2; }
+            cls = t1 > thr ? 1 : 2;
+            if (debug) fprintf(stderr, "[arena]   against the class-1 reference %.1f us -> class %d\n", t1, cls);
         }
         keep(q.p, cls);
         return GNNMP_OK;
@@ -189,28 +212,24 @@ int gnnmp_arena_create(gnnmp_arena_t **out, int64_t bytes_per_class, int n_class
         }
     }
     while (rc == GNNMP_OK && !all_full()) {
-        if (a->created >= max_blocks) {
-            rc = fail(GNNMP_EUNSUPPORTED, "arena_create: %lld blocks of 2 GiB probed (probe %.0f..%.0f us), classes hold %zu / %zu / %zu of %d blocks "
-                                          "(raise max_probe_bytes or free device memory)", (long long)a->created, lo, hi,
-                      a->blocks[0].size(), a->blocks[1].size(), a->blocks[2].size(), need);
+        if (a->created >= max_blocks || elapsed_ms() > budget_ms) {      // out of budget: the caller gets what was found
+            a->gave_up = 1;
             break;
         }
         unsigned char *p = nullptr;
         hipError_t e = hipMalloc((void **)&p, (size_t)CHUNK);
         if (e != hipSuccess) {
             (void)hipGetLastError();
-            rc = fail(GNNMP_EALLOC, "arena_create: device memory exhausted after %lld blocks while looking for %d placement classes",
-                      (long long)a->created, a->n_classes);
+            a->gave_up = 1;                                  // device memory exhausted: the same graceful end
             break;
         }
         ++a->created;
-        Pend q = {p, 0.0f, 0.0f};
-        rc = probe_chunk(a, ref0, p, stream, &q.lo, &q.hi);
+        Pend q = {p, 0.0f};
+        rc = probe_quick(a, ref0, p, stream, &q.t);
         if (rc != GNNMP_OK) { spare.push_back(p); break; }
-        if (getenv("GNNMP_ARENA_DEBUG"))
-            fprintf(stderr, "[arena] block %lld @ %p: probe against block 0 %.1f / %.1f us\n", (long long)a->created - 1, (void *)p, q.lo, q.hi);
-        lo = lo == 0.0f ? q.lo : std::min(lo, q.lo);
-        hi = std::max(hi, q.hi);
+        if (debug) fprintf(stderr, "[arena] block %lld @ %p: probe against block 0 %.1f us (%.0f ms)\n", (long long)a->created - 1, (void *)p, q.t, elapsed_ms());
+        lo = lo == 0.0f ? q.t : std::min(lo, q.t);
+        hi = std::max(hi, q.t);
         if (thr == 0.0f) {
             pending.push_back(q);
             if (hi > 1.06f * lo) {                        // both clusters seen (pure pairs are 10 % apart): decide everything held back
@@ -226,17 +245,27 @@ int gnnmp_arena_create(gnnmp_arena_t **out, int64_t bytes_per_class, int n_class
             rc = classify(q);
         }
     }
-    for (const Pend &q : pending) spare.push_back(q.p);
+    // no second cluster seen: everything probed so far lies in block 0's class (keep what class 0 still needs of it)
+    for (const Pend &q : pending) keep(q.p, 0);
     pending.clear();
-    // the finished classes against the reference once more: every block of class 0 slow, every other block fast
-    for (int c = 0; c < a->n_classes && rc == GNNMP_OK; ++c)
-        for (size_t i = (c == 0 ? 1 : 0); i < a->blocks[c].size() && rc == GNNMP_OK; ++i) {
-            float l2 = 0.0f, h2 = 0.0f;
-            rc = probe_chunk(a, ref0, a->blocks[c][i].p, stream, &l2, &h2);
-            if (rc == GNNMP_OK && (c == 0 ? l2 <= thr : h2 > thr))
-                rc = fail(GNNMP_EUNSUPPORTED, "arena_create: class %d block %zu probes %.0f / %.0f us against a threshold of %.0f: the "
-                                              "placement classes of this device are not stable enough to use", c, i, l2, h2, thr);
-        }
+    // the kept blocks at all four windows against the reference: every window of a class-0 block slow, of any other block fast; a block
+    // that fails is a patchwork (or was mis-screened) and is dropped
+    if (thr > 0.0f) {
+        for (int c = 0; c < a->n_classes && rc == GNNMP_OK; ++c)
+            for (size_t i = (c == 0 ? 1 : 0); i < a->blocks[c].size() && rc == GNNMP_OK;) {
+                float l2 = 0.0f, h2 = 0.0f;
+                rc = probe_chunk(a, ref0, a->blocks[c][i].p, stream, &l2, &h2);
+                const bool bad = rc == GNNMP_OK && (c == 0 ? l2 <= thr : h2 > thr);
+                if (debug) fprintf(stderr, "[arena] class %d block %zu: four windows %.1f .. %.1f us%s\n", c, i, l2, h2, bad ? " -> dropped" : "");
+                if (bad && reinterpret_cast<const float *>(a->blocks[c][i].p) != ref1) {
+                    spare.push_back(a->blocks[c][i].p);
+                    a->blocks[c].erase(a->blocks[c].begin() + (long)i);
+                    a->gave_up = 1;
+                } else {
+                    ++i;
+                }
+            }
+    }
     if (rc == GNNMP_OK && hipStreamSynchronize(stream) != hipSuccess) rc = fail(GNNMP_ELAUNCH, "arena_create: stream synchronisation failed");
     (void)hipDeviceSynchronize();
     for (unsigned char *p : spare) { (void)hipFree(p); ++a->released; }
@@ -244,6 +273,16 @@ int gnnmp_arena_create(gnnmp_arena_t **out, int64_t bytes_per_class, int n_class
         gnnmp_arena_destroy(a);
         return rc;
     }
+    // classes that exist: the non-empty ones, renumbered 0 .. n - 1 in their order; blocks of a class sorted by address (adjacency: alloc)
+    int found = 0;
+    for (int c = 0; c < 3; ++c) {
+        if (a->blocks[c].empty()) continue;
+        std::sort(a->blocks[c].begin(), a->blocks[c].end(), [](const gnnmp_arena::Block &x, const gnnmp_arena::Block &y) { return x.p < y.p; });
+        if (found != c) { a->blocks[found] = std::move(a->blocks[c]); a->blocks[c].clear(); }
+        ++found;
+    }
+    a->n_classes = found;
+    a->create_us = (int64_t)(elapsed_ms() * 1e3);
     *out = a;
     return GNNMP_OK;
 }
@@ -259,16 +298,32 @@ int gnnmp_arena_alloc(gnnmp_arena_t *a, int cls, int64_t bytes, void **ptr) {
     if (!a || !ptr || bytes < 0 || cls < 0 || cls >= a->n_classes) return fail(GNNMP_EINVAL, "arena_alloc: bad argument");
     if (int rc = arena_check_device(a, "arena_alloc")) return rc;
     std::lock_guard<std::mutex> lk(a->lock);
-    for (auto &b : a->blocks[cls]) {                          // a buffer lies inside ONE block
-        const int64_t at = (b.used + 4095) & ~(int64_t)4095;
-        if (at + bytes <= a->block_bytes) {
-            *ptr = b.p + at;
-            b.used = at + bytes;
+    auto &bl = a->blocks[cls];
+    if (bytes <= a->block_bytes) {
+        for (auto &b : bl) {                                  // inside ONE block
+            const int64_t at = (b.used + 4095) & ~(int64_t)4095;
+            if (at + bytes <= a->block_bytes) {
+                *ptr = b.p + at;
+                b.used = at + bytes;
+                return GNNMP_OK;
+            }
+        }
+    } else {
+        // larger than a block (SAGEConv's 2.5 GB output on the products shape): a run of unused blocks of this class that are adjacent
+        // in the address space (the list is sorted by address) — one buffer, one placement class
+        const int64_t k = (bytes + a->block_bytes - 1) / a->block_bytes;
+        for (size_t i = 0; i + (size_t)k <= bl.size(); ++i) {
+            bool ok = true;
+            for (int64_t j = 0; j < k && ok; ++j)
+                ok = bl[i + (size_t)j].used == 0 && (j == 0 || bl[i + (size_t)j].p == bl[i + (size_t)j - 1].p + a->block_bytes);
+            if (!ok) continue;
+            for (int64_t j = 0; j < k; ++j) bl[i + (size_t)j].used = std::min<int64_t>(a->block_bytes, bytes - j * a->block_bytes);
+            *ptr = bl[i].p;
             return GNNMP_OK;
         }
     }
-    return fail(GNNMP_EALLOC, "arena_alloc: no block of class %d has %lld bytes left (blocks of %lld bytes)", cls, (long long)bytes,
-                (long long)a->block_bytes);
+    return fail(GNNMP_EALLOC, "arena_alloc: class %d cannot hold %lld bytes (blocks of %lld bytes, %zu of them; a larger buffer needs "
+                              "adjacent unused blocks)", cls, (long long)bytes, (long long)a->block_bytes, bl.size());
 }
 
 int gnnmp_arena_reset(gnnmp_arena_t *a) {
@@ -299,7 +354,7 @@ int gnnmp_arena_class_of(gnnmp_arena_t *a, const void *ptr, int64_t bytes, int *
     float us[3] = {0.0f, 0.0f, 0.0f};
     for (int c = 0; c < a->n_classes; ++c) {
         const auto &b = a->blocks[c].back();
-        if (a->block_bytes - b.used < out_bytes + 4096) return fail(GNNMP_EALLOC, "arena_class_of: no room for the probe's output in class %d", c);
+        if (a->block_bytes - b.used < out_bytes + 4096) { *cls = none; return GNNMP_OK; }      // no room for the probe's output: cannot tell
         float *o = reinterpret_cast<float *>(b.p + a->block_bytes - out_bytes);      // the top of the block: free by the check above
         rc = probe_us(a, static_cast<const float *>(ptr), o, stream, &us[c]);
         if (rc != GNNMP_OK) return rc;
@@ -316,8 +371,10 @@ int gnnmp_arena_class_of(gnnmp_arena_t *a, const void *ptr, int64_t bytes, int *
     return GNNMP_OK;
 }
 
-/* info[0] = bytes per class, [1] = bytes used in range 0, [2] = in range 1, [3] = chunks created while classifying, [4] = released again,
- * [5] = probe microseconds with source and output in one class, [6] = in two, [7] = ranges (2 | 3), [8] = bytes used in range 2 */
+/* info[0] = bytes per class asked for, [1] = bytes used in range 0, [2] = in range 1, [3] = blocks created while classifying, [4] = released
+ * again, [5] = probe microseconds with source and output in one class, [6] = in two, [7] = classes the arena HOLDS (0 .. 3: fewer than asked
+ * for when the budget ran out), [8] = bytes used in range 2, [9] = 1 if creation gave up on its budget (bytes or time) before every class
+ * held its blocks, [10] / [11] / [12] = blocks held in range 0 / 1 / 2, [13] = microseconds gnnmp_arena_create took */
 int gnnmp_arena_info(const gnnmp_arena_t *a, int64_t *info) {
     if (!a || !info) return fail(GNNMP_EINVAL, "arena_info: null argument");
     int64_t used[3] = {0, 0, 0};
@@ -326,6 +383,9 @@ int gnnmp_arena_info(const gnnmp_arena_t *a, int64_t *info) {
     info[0] = a->cap; info[1] = used[0]; info[2] = used[1]; info[3] = a->created; info[4] = a->released;
     info[5] = (int64_t)(a->probe_same_us + 0.5f); info[6] = (int64_t)(a->probe_other_us + 0.5f);
     info[7] = a->n_classes; info[8] = used[2];
+    info[9] = a->gave_up;
+    for (int c = 0; c < 3; ++c) info[10 + c] = (int64_t)a->blocks[c].size();
+    info[13] = a->create_us;
     return GNNMP_OK;
 }
 

@@ -316,7 +316,13 @@ def sage_conv(l, g: GNNGraph, x):
     m = _fused(g, L.COPY_XJ, l.aggr, xj, None, out=mb)
     if ch is not None:
         ch.end(tok)
-    return dense(xi, W[:, :Din], l.bias, l.sigma, x2=m, W2=W[:, Din:])
+    # opt-in, end to end: the layer's output too is a persistent arena buffer (a buffer larger than one 2 GiB block — (N, 256) on the
+    # products shape — takes adjacent blocks of one class, gnnmp_arena_alloc), in a class other than the aggregate's
+    ob = None
+    if mb is not None:
+        ar = placement.arena()
+        ob, _ = placement.buffer_for(l, "out", (m.shape[0], W.shape[0]), [ar.class_of(m)])
+    return dense(xi, W[:, :Din], l.bias, l.sigma, x2=m, W2=W[:, Din:], out=ob)
 
 
 def _placed_aggregate(l, xj, n_dst):

@@ -58,23 +58,26 @@ class _Raw:
 class Arena:
     """gnnmp_arena_t: ranges of device memory in different placement classes"""
 
-    def __init__(self, gib_per_class=None, n_classes=3, max_probe_gib=160):
+    def __init__(self, gib_per_class=None, n_classes=3, max_probe_gib=None):
         L.require_gpu()
         if gib_per_class is None:
             gib_per_class = float(os.environ.get("GNNMP_ARENA_GIB", "4"))
+        if max_probe_gib is None:          # 0: the library's default budget (32 GiB held while probing, ~0.3 s)
+            max_probe_gib = float(os.environ.get("GNNMP_ARENA_PROBE_GIB", "0"))
         self._lib = L.load()
         self.handle = ctypes.c_void_p()
-        L.check(self._lib.gnnmp_arena_create(ctypes.byref(self.handle), int(gib_per_class * (1 << 30)), int(n_classes), int(max_probe_gib) << 30,
-                                             L.stream_ptr()))
-        self.n_classes = int(n_classes)
+        L.check(self._lib.gnnmp_arena_create(ctypes.byref(self.handle), int(gib_per_class * (1 << 30)), int(n_classes),
+                                             int(max_probe_gib * (1 << 30)), L.stream_ptr()))
         self._classes = {}
         self.device = torch.device("cuda", torch.cuda.current_device())
+        self.n_classes = self.info()["ranges"]      # the classes the device showed within the budget: 0 .. n_classes
 
     def info(self):
-        v = (ctypes.c_int64 * 9)()
+        v = (ctypes.c_int64 * 14)()
         L.check(self._lib.gnnmp_arena_info(self.handle, v))
         return {"bytes_per_class": v[0], "ranges": v[7], "used": (v[1], v[2], v[8])[: v[7]], "chunks_created": v[3], "chunks_released": v[4],
-                "probe_us_same_class": v[5], "probe_us_two_classes": v[6]}
+                "probe_us_same_class": v[5], "probe_us_two_classes": v[6], "gave_up_on_budget": bool(v[9]),
+                "blocks_per_range": (v[10], v[11], v[12])[: v[7]], "create_ms": v[13] / 1e3}
 
     def alloc(self, shape, cls):
         """a float32 tensor of `shape` in range `cls` (0 .. n_classes - 1); None when the range is full"""
@@ -117,21 +120,28 @@ _arena = [None, False]      # the arena, "creation was tried and failed"
 
 
 def arena():
-    """the process-wide arena, created at first use (three ranges if the device shows three classes within the probing budget, else two);
-    None if this device does not yield two classes (the layers then allocate as usual)"""
+    """the process-wide arena, created at first use inside the library's probing budget (32 GiB held, ~0.3 s: gnnmp.h); None if the device
+    did not show two placement classes within it (the layers then allocate as usual)"""
     if _arena[0] is None and not _arena[1]:
-        err = None
-        for n in (3, 2):
-            try:
-                _arena[0] = Arena(n_classes=n)
-                break
-            except L.GnnmpError as e:
-                err = e
-        if _arena[0] is None:
+        try:
+            a = Arena(n_classes=3)
+            if a.n_classes >= 2:
+                _arena[0] = a
+            else:
+                _arena[1] = True
+                _arena.append(a.info())           # (kept for reports: why there is no placement)
+                del a
+        except L.GnnmpError as e:
             _arena[1] = True
             import warnings
-            warnings.warn(f"gnnmp.placement: no arena ({err}); outputs are allocated as usual")
+            warnings.warn(f"gnnmp.placement: no arena ({e}); outputs are allocated as usual")
     return _arena[0]
+
+
+def trials(on=True):
+    """Choice's self-timing (every candidate buffer used three times, the fastest kept) on or off.  Off: a layer takes its first candidate —
+    the arena's own classification — and never times itself (no events, no round-robin over buffers in its first calls)."""
+    Choice.TRIALS = 2 if on else 0
 
 
 class Choice:
@@ -146,7 +156,8 @@ class Choice:
         self.spans = [[] for _ in bufs]
         self.rr = 0
         self.times_ms = None
-        if len(bufs) == 1:
+        if len(bufs) == 1 or self.TRIALS <= 0:      # nothing to choose between / self-timing switched off (placement.trials(False))
+            self.bufs = bufs[:1]
             self.spans = None
 
     def _resolve(self):

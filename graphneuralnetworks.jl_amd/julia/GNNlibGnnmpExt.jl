@@ -107,6 +107,10 @@ end
 const PLANS = Dict{PlanKey, PlanEntry}()
 const PLANS_LOCK = ReentrantLock()
 
+# (s, t) of any device graph on the device: the COO vectors themselves, or findnz order materialised from a sparse graph's plan
+# (device_edge_index below — `edge_index` of a ROCSparseMatrixCSC graph is findnz on the device, which AMDGPU.jl does not provide)
+coo_index(g::GNNGraph{<:COO_T}) = edge_index(g)
+
 function plan(g::GNNGraph{<:COO_T}; self_loops::Bool = false, transposed::Bool = false)
     s, t = edge_index(g)
     key = PlanKey(objectid(s), objectid(t), g.num_nodes, self_loops, transposed)
@@ -172,6 +176,8 @@ function device_edge_index(g::SparseDeviceGraph)
                                                 devptr(t)::Ptr{Cvoid}, stream_ptr()::Ptr{Cvoid})::Cint)
     return s, t
 end
+
+coo_index(g::SparseDeviceGraph) = device_edge_index(g)
 
 function plan(g::SparseDeviceGraph; self_loops::Bool = false, transposed::Bool = false)
     A = g.graph
@@ -256,12 +262,14 @@ function ChainRulesCore.rrule(::typeof(fused_propagate), g::GNNGraph, aggr, xj::
             Δs = sd === nothing ? Δ : Δ .* reshape(sd, 1, :)
             xs = scale_src === nothing ? xj : xj .* reshape(scale_src, 1, :)
             Δw = similar(w)
-            lanes = D % 4 == 0 ? D ÷ 4 : (D % 2 == 0 ? D ÷ 2 : D)      # the row kernel keeps a feature row in ONE lane group (<= 64 lanes)
-            if lanes <= 64
-                check(@ccall libgnnmp.gnnmp_edge_dot_plan_f32(plan(g).handle::Ptr{Cvoid}, devptr(Δs)::Ptr{Cvoid},
-                          devptr(xs)::Ptr{Cvoid}, devptr(Δw)::Ptr{Cvoid}, D::Int64, stream_ptr()::Ptr{Cvoid})::Cint)
-            else                                                        # wider rows: the COO-order kernel
-                s, t = edge_index(g)
+            # the row kernel keeps a feature row in ONE lane group (<= 64 lanes of 4 / 2 / 1 floats, by width AND pointer alignment: the
+            # library decides, GNNMP_EUNSUPPORTED = -5 says "not this one"); wider rows take the COO-order kernel
+            st = @ccall libgnnmp.gnnmp_edge_dot_plan_f32(plan(g).handle::Ptr{Cvoid}, devptr(Δs)::Ptr{Cvoid},
+                          devptr(xs)::Ptr{Cvoid}, devptr(Δw)::Ptr{Cvoid}, D::Int64, stream_ptr()::Ptr{Cvoid})::Cint
+            if st != -5
+                check(st)
+            else
+                s, t = coo_index(g)                                     # (a sparse device graph: from its plan, not findnz on the device)
                 check(@ccall libgnnmp.gnnmp_edge_dot_f32(devptr(Δs)::Ptr{Cvoid}, devptr(xs)::Ptr{Cvoid}, devptr(s)::Ptr{Cvoid},
                           devptr(t)::Ptr{Cvoid}, sizeof(eltype(s))::Cint, 1::Cint, length(s)::Int64, D::Int64,
                           devptr(Δw)::Ptr{Cvoid}, stream_ptr()::Ptr{Cvoid})::Cint)
@@ -311,7 +319,7 @@ function ChainRulesCore.rrule(::typeof(scatter_edges), g, aggr, m::ROCArray{Floa
     y = scatter_edges(g, aggr, m)
     function scatter_edges_pullback(Δ̄)
         Δ = convert(typeof(y), unthunk(Δ̄))
-        _, t = edge_index(g)
+        _, t = coo_index(g)
         Δs = aggr === mean ? Δ ./ reshape(max.(in_count(g, false), 1f0), ntuple(_ -> 1, ndims(Δ) - 1)..., :) : Δ
         return NoTangent(), NoTangent(), NoTangent(), GNNGraphs._gather(Δs, t)
     end
@@ -807,20 +815,26 @@ mutable struct Arena
     n_classes::Int
 end
 const ARENA = Ref{Union{Nothing, Arena}}(nothing)
+const ARENA_TRIED = Ref(false)
 function arena(; gib_per_class::Real = parse(Float64, get(ENV, "GNNMP_ARENA_GIB", "4")))
-    ARENA[] === nothing || return ARENA[]
-    for n in (3, 2)
-        h = Ref{Ptr{Cvoid}}(C_NULL)
-        st = @ccall libgnnmp.gnnmp_arena_create(h::Ptr{Ptr{Cvoid}}, round(Int64, gib_per_class * 2.0^30)::Int64, n::Cint,
-                                                0::Int64, stream_ptr()::Ptr{Cvoid})::Cint
-        if st == 0
-            a = Arena(h[], n)
-            finalizer(q -> (@ccall libgnnmp.gnnmp_arena_destroy(q.handle::Ptr{Cvoid})::Cint), a)
-            ARENA[] = a
-            return a
-        end
+    (ARENA[] === nothing && !ARENA_TRIED[]) || return ARENA[]
+    ARENA_TRIED[] = true
+    # creation works inside the library's probing budget (32 GiB of blocks held, ~0.3 s) and comes back with the classes it found:
+    # info[8] (1-based: C's info[7]) = 0 .. 3 of them.  Fewer than two: no placement on this device today, allocate as usual.
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    st = @ccall libgnnmp.gnnmp_arena_create(h::Ptr{Ptr{Cvoid}}, round(Int64, gib_per_class * 2.0^30)::Int64, 3::Cint,
+                                            0::Int64, stream_ptr()::Ptr{Cvoid})::Cint
+    st == 0 || return nothing
+    info = zeros(Int64, 14)
+    check(@ccall libgnnmp.gnnmp_arena_info(h[]::Ptr{Cvoid}, info::Ptr{Int64})::Cint)
+    if info[8] < 2
+        @ccall libgnnmp.gnnmp_arena_destroy(h[]::Ptr{Cvoid})::Cint
+        return nothing
     end
-    return nothing                                                 # this device does not show two classes: allocate as usual
+    a = Arena(h[], Int(info[8]))
+    finalizer(q -> (@ccall libgnnmp.gnnmp_arena_destroy(q.handle::Ptr{Cvoid})::Cint), a)
+    ARENA[] = a
+    return a
 end
 function arena_class_of(x::ROCArray{Float32})
     a = arena()

@@ -130,8 +130,11 @@ int gnnmp_plan_create(gnnmp_graph_t **out, const void *src, const void *dst, int
  *      rowptr = colptr - index_base      col = rowval - index_base      eid[p] = p   (edge k of edge_index(g) is slot k)
  * so that edge data in findnz order (get_edge_weight(g) = nzval, query.jl:18) is what `w` / `e` of the propagate entry points take.
  *   colptr : n_dst + 1 column pointers (SparseMatrixCSC.colptr / ROCSparseMatrixCSC.colPtr), rowval : n_edges row indices.
- *   validate != 0: colptr[1] = 1, colptr[end] = n_edges + 1, non-decreasing, 1 <= rowval <= n_src checked on the device (GNNMP_EBOUNDS).
- * Stored entries with value zero are edges, as in findnz.  Same limits and the same stream synchronisation as gnnmp_plan_create. */
+ *   colptr[1] = 1, colptr[end] = n_edges + 1, non-decreasing, 1 <= rowval <= n_src are ALWAYS checked on the device (GNNMP_EBOUNDS) —
+ *   the build synchronises the stream anyway; `validate` is accepted for symmetry with gnnmp_plan_create and ignored.
+ * Stored entries whose VALUE is zero are edges: a sparse graph's num_edges is nnz(A) (convert.jl:199) and its edge_index is
+ * to_coo(A::SPARSE_T) = findnz(A) (convert.jl:62-73), which walks the STORED entries, explicit zeros included — the `findall(!=(0), A)` of
+ * convert.jl:75-79 is the dense-matrix method.  Same limits and the same stream synchronisation as gnnmp_plan_create. */
 int gnnmp_plan_from_csc(gnnmp_graph_t **out, const void *colptr, const void *rowval, int idx_bytes, int index_base, int64_t n_src,
                         int64_t n_dst, int64_t n_edges, int validate, gnnmp_stream_t stream);
 int gnnmp_plan_destroy(gnnmp_graph_t *plan);
@@ -199,17 +202,25 @@ int gnnmp_plan_edge_index(const gnnmp_graph_t *plan, int idx_bytes, int index_ba
  * 0.6 ms probe (a propagate over a synthetic random graph, timed with the block as its output at four places: 10 % apart between the two
  * cases) and keeps blocks of n_classes = 2 or 3 different classes (three let a pipeline keep the PREVIOUS kernel's output — whose dirty
  * lines are still being written back — out of the class the next kernel gathers from); the other blocks are freed:
- *   gnnmp_arena_create(&a, bytes_per_class, n_classes, max_probe_bytes, stream)   bytes_per_class rounded up to 2 GiB blocks; up to max_probe_bytes
- *                        (<= 0: 160 GiB) of blocks may be held transiently while the classes are being found (they come in runs of tens of
- *                        GiB); synchronises; GNNMP_EUNSUPPORTED / GNNMP_EALLOC when device memory does not show two classes in that budget
- *   gnnmp_arena_class_of(a, ptr, bytes, &cls, stream)   arena memory: its range (0 .. n_classes - 1), no launch.  Foreign memory (bytes >= 128 MiB):
+ *   gnnmp_arena_create(&a, bytes_per_class, n_classes, max_probe_bytes, stream)   bytes_per_class rounded up to 2 GiB blocks.  Creation works
+ *                        inside a BUDGET: at most max_probe_bytes (<= 0: 32 GiB) of blocks held at any moment while the classes are being
+ *                        looked for (they come in runs of GiB to tens of GiB) and ~0.3 s (env GNNMP_ARENA_BUDGET_MS); a block is screened at
+ *                        one window, the kept ones checked at four.  Out of budget is NOT an error: the arena comes back with the classes
+ *                        it found — info[7] = 0 .. n_classes of them, info[9] = 1 — and the caller places what it can (two classes still
+ *                        separate a gather's source from its output; fewer: allocate as usual).  Synchronises.
+ *   gnnmp_arena_class_of(a, ptr, bytes, &cls, stream)   arena memory: its range (0 .. classes - 1), no launch.  Foreign memory (bytes >= 128 MiB):
  *                        the probe with `ptr` as the gathered matrix and the output in every range — c = it shares range c's class,
- *                        n_classes = none of them / mixed / too small to tell; synchronises
- *   gnnmp_arena_alloc(a, cls, bytes, &ptr)   bump allocation (4 KiB aligned) inside ONE block of class cls (bytes <= 2 GiB); GNNMP_EALLOC when
- *                        no block of the class has room
+ *                        classes = none of them / mixed / too small to tell / no room left for the probe's output; synchronises
+ *   gnnmp_arena_alloc(a, cls, bytes, &ptr)   bump allocation (4 KiB aligned) inside one block of class cls; a buffer LARGER than a block
+ *                        (SAGEConv's 2.5 GB output on the products shape) takes a run of unused blocks of the class that are adjacent in the
+ *                        address space; GNNMP_EALLOC when the class cannot hold it (the caller then allocates as usual)
  *   gnnmp_arena_reset(a)  forget every allocation (the caller knows nothing uses them any more)
- *   gnnmp_arena_info      info[9]: [0] bytes per class [1], [2] bytes used in range 0 / 1 [3] chunks created while classifying [4] released again
- *                         [5], [6] the probe's microseconds with source and output in one class / in two [7] ranges [8] bytes used in range 2
+ *   gnnmp_arena_info      info[14]: [0] bytes per class asked for [1], [2], [8] bytes used in range 0 / 1 / 2 [3] blocks created while classifying
+ *                         [4] released again [5], [6] the probe's microseconds with source and output in one class / in two [7] classes held
+ *                         [9] 1 = gave up on the budget [10], [11], [12] blocks held per range [13] microseconds creation took
+ * ALIASING: the arena is a bump allocator — memory it hands out stays handed out until gnnmp_arena_reset.  A caller that keeps a layer's
+ * output buffer in the arena and passes the SAME buffer to the layer's next call (gnnmp/placement.py's persistent outputs, the static
+ * outputs of a captured graph) overwrites the previous result; a caller that needs both alive allocates both.
  * Usage: cls = class_of(gathered matrix); out = alloc(any range != cls).  Results do not depend on where buffers lie.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct gnnmp_arena gnnmp_arena_t;

@@ -13,35 +13,73 @@ def ar():
     import gnnmp
     from gnnmp import _lib as L, placement
     free, _ = torch.cuda.mem_get_info()
-    if free < (200 << 30):
-        pytest.skip("the arena may hold up to 160 GiB of chunks while it looks for two placement classes; this device has less free")
-    try:
-        return placement.Arena(gib_per_class=4, n_classes=3)
-    except L.GnnmpError as e:
-        if e.status in (L.EUNSUPPORTED, L.EALLOC):
-            pytest.skip(f"this device does not show two placement classes: {e}")
-        raise
+    if free < (48 << 30):
+        pytest.skip("the arena holds up to 32 GiB of blocks while it looks for the placement classes; this device has less free")
+    a = placement.Arena(gib_per_class=4, n_classes=3)        # never raises for want of classes: it comes back with what it found
+    if a.n_classes < 2:
+        pytest.skip(f"this device did not show two placement classes within the probing budget: {a.info()}")
+    return a
 
 
-def test_arena_finds_two_classes_and_tells_them_apart(ar):
+def test_arena_finds_classes_inside_its_budget_and_tells_them_apart(ar):
     import torch
     info = ar.info()
-    assert info["bytes_per_class"] == 4 << 30 and info["chunks_created"] >= 3 and info["ranges"] == 3
-    # the probe saw two clusters at least 3 % apart (that is what makes two classes)
+    assert info["bytes_per_class"] == 4 << 30 and info["ranges"] in (2, 3) and info["ranges"] == ar.n_classes
+    assert 3 <= info["chunks_created"] <= 16, info            # the default budget: 32 GiB of 2 GiB blocks held while probing
+    assert info["create_ms"] < 1500, info                     # (~0.3 s of probing + the hipMallocs / hipFrees around it)
+    assert info["gave_up_on_budget"] == (min(info["blocks_per_range"]) < 2 or info["ranges"] < 3)
+    # the probe saw two clusters at least 6 % apart (that is what makes two classes)
     assert info["probe_us_same_class"] > 1.06 * info["probe_us_two_classes"] > 0
-    a0, a1, a2 = ar.alloc((1 << 20, 128), 0), ar.alloc((1 << 20, 128), 1), ar.alloc((1 << 20, 128), 2)
-    assert ar.class_of(a0) == 0 and ar.class_of(a1) == 1 and ar.class_of(a2) == 2
-    a0.fill_(1.0); a1.fill_(2.0)
-    assert float(a0.sum()) == float(1 << 27) and float(a1.sum()) == float(2 << 27)
-    # memory of either range, copied through the probe's eyes: a buffer that IS arena memory of class c, seen as foreign memory
-    # (an offset view is outside the cache of known addresses), must come out as class c
-    for c, t in ((0, a0), (1, a1)):
-        view = t[4096:]
-        got = ctypes_class(ar, view)
-        assert got == c, (c, got)
-    assert ar.alloc((1 << 30, 1), 0) is None          # 4 GiB do not fit a 2 GiB block: the caller allocates as usual
+    bufs = [ar.alloc((1 << 20, 128), c) for c in range(ar.n_classes)]
+    for c, b in enumerate(bufs):
+        assert ar.class_of(b) == c
+    bufs[0].fill_(1.0); bufs[1].fill_(2.0)
+    assert float(bufs[0].sum()) == float(1 << 27) and float(bufs[1].sum()) == float(2 << 27)
+    # an address INSIDE a range answers from the range (an offset view is outside the cache of known addresses)
+    for c, t in enumerate(bufs[:2]):
+        assert ctypes_class(ar, t[4096:]) == c
+    with pytest.raises(Exception):
+        ar.alloc((16, 16), ar.n_classes)                      # no such range
     ar.reset()
-    assert ar.info()["used"] == (0, 0, 0)
+    assert ar.info()["used"] == (0,) * ar.n_classes
+
+
+def test_a_buffer_larger_than_a_block_takes_adjacent_blocks(ar):
+    """gnnmp_arena_alloc: SAGEConv's (N, 256) output on the products shape is 2.5 GB — more than a 2 GiB block.  It is served from a run of
+    unused, address-adjacent blocks of one class, or refused (None: the caller allocates as usual); never from blocks of two classes"""
+    import torch
+    ar.reset()
+    info = ar.info()
+    served = 0
+    for c in range(ar.n_classes):
+        if info["blocks_per_range"][c] < 2:
+            assert ar.alloc((3 << 28, 1), c) is None
+            continue
+        big = ar.alloc((3 << 28, 1), c)                       # 3 GiB
+        if big is None:
+            continue                                          # the class's blocks are not adjacent in the address space on this box
+        served += 1
+        assert ar.class_of(big) == c
+        big[0] = 1.0; big[-1] = 2.0; big[(1 << 29) - 1] = 3.0; big[1 << 29] = 4.0      # both sides of the block boundary (2 GiB = 2^29 floats)
+        torch.cuda.synchronize()
+        assert (float(big[0]), float(big[-1]), float(big[(1 << 29) - 1]), float(big[1 << 29])) == (1.0, 2.0, 3.0, 4.0)
+        assert ar.alloc((1 << 28, 1), c) is not None          # the rest of the second block is still there (1 GiB of 2 - 1)
+        assert ar.alloc((1 << 29, 1), c) is None              # ... but not a whole block
+    ar.reset()
+    assert ar.info()["used"] == (0,) * ar.n_classes
+    print("multi-block buffers served in", served, "of", ar.n_classes, "classes")
+
+
+def test_a_tiny_budget_is_not_an_error():
+    """out of budget = the arena comes back with what it found (gnnmp.h): two blocks can show at most two classes"""
+    import torch
+    from gnnmp import placement
+    a = placement.Arena(gib_per_class=2, n_classes=3, max_probe_gib=4)
+    info = a.info()
+    assert info["chunks_created"] <= 2 and info["ranges"] in (1, 2) and info["gave_up_on_budget"]
+    assert a.n_classes == info["ranges"]
+    b = a.alloc((1 << 20, 16), 0)
+    assert b is not None and a.class_of(b) == 0
 
 
 def ctypes_class(ar, t):
@@ -59,9 +97,9 @@ def test_foreign_buffers_are_probed(ar):
     import torch
     x = torch.randn((1 << 21, 128), device="cuda")        # 1 GiB of ordinary (torch) memory
     c = ar.class_of(x)
-    assert c in (0, 1, 2, 3)
+    assert c in range(ar.n_classes + 1)
     assert ar.class_of(x) == c                            # cached per buffer
-    assert ar.class_of(torch.zeros(16, device="cuda")) == 3      # too small to matter
+    assert ar.class_of(torch.zeros(16, device="cuda")) == ar.n_classes      # too small to matter
 
 
 def test_placed_layers_are_bit_identical(ar, monkeypatch):
@@ -86,12 +124,13 @@ def test_placed_layers_are_bit_identical(ar, monkeypatch):
             assert torch.equal(y1, ref_gcn) and torch.equal(y2, ref_gat), it
             torch.cuda.synchronize()        # (lets the polled events complete; the layers themselves never wait)
         # where the buffers lie: GCN's output not in x's class; Wx and the attention output in different classes; the trials are over
-        assert ar.class_of(y1) in (0, 1, 2) and ar.class_of(y1) != cx
+        assert ar.class_of(y1) in range(ar.n_classes) and ar.class_of(y1) != cx
         (wx,) = [b for k, b in gat._placed.items() if k[0] == "Wx"]
         assert ar.class_of(wx) != cx and ar.class_of(y2) != ar.class_of(wx)
         for layer in (gcn, gat):
             (ch,) = [c for k, c in layer._placed.items() if k[0] == "out"]
-            assert ch.settled and len(ch.times_ms) in (2, 3)      # (x is ordinary torch memory here: its class may be none of the arena's)
+            assert ch.settled      # (x is ordinary torch memory here: its class may be none of the arena's)
+            assert ch.times_ms is None or len(ch.times_ms) in (2, 3)      # (None: one candidate only — a two-class arena)
         a, b = gat(g, x), gat(g, x)
         assert a.data_ptr() == b.data_ptr()     # persistent: the documented aliasing of the opt-in
         gcn.place_outputs = gat.place_outputs = False

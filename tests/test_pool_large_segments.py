@@ -1,39 +1,66 @@
 """reduce_nodes / GlobalPool when the batch holds few, LARGE graphs (a whole-graph readout is num_graphs = 1): the segments
 must be reduced in parallel chunks, not by one lane group walking millions of rows (283 ms at N = 2.4 M before the fix).
-Values against float64 numpy; max / min exactly; and a loose wall-clock bound that the serial walk could not meet."""
+GNNlib/src/utils.jl:12-16 (reduce_nodes = NNlib.scatter over the graph indicator).  Two checks, both at north_star's 1e-5:
+  * against the ORACLE's sequential fp32 scatter (oracle.reduce_nodes: the reference's own loop order) on 50 000-row segments — the chunked
+    reduction is a different association of the same sum, so norm-wise and element-wise (against the array scale) 1e-5, max / min exactly;
+  * at 600 000 rows against float64 numpy, norm-wise 1e-5 (Julia's isapprox, the criterion of the reference's own tests) — there the
+    sequential fp32 sum is itself ~1e-5 away from the exact value and stops being a usable yardstick;
+and a loose wall-clock bound that the serial walk could not meet."""
 import time
 
 import numpy as np
 import pytest
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("G", [1, 2, 3])
-@pytest.mark.parametrize("form", ["graph", "indicator"])
-def test_reduce_nodes_with_large_segments(oracle, G, form):
+def _setup(N, D, G, seed):
     import torch
     import gnnmp
     gnnmp.load()
-    rng = np.random.default_rng(G)
-    N, D = 600_000, 20
+    rng = np.random.default_rng(seed)
     cuts = np.sort(rng.choice(np.arange(1, N), G - 1, replace=False)) if G > 1 else np.array([], np.int64)
     gi = np.searchsorted(cuts, np.arange(N), side="right") + 1
     x = rng.standard_normal((N, D)).astype(np.float32)
     dev = lambda v: torch.from_numpy(np.ascontiguousarray(v)).cuda()
     X, GI = dev(x), dev(gi)
     g = gnnmp.GNNGraph(dev(np.array([1, 2])), dev(np.array([2, 1])), num_nodes=N, graph_indicator=GI, num_graphs=G)
+    return gnnmp, x, gi, X, GI, g
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("G", [1, 2, 3])
+@pytest.mark.parametrize("form", ["graph", "indicator"])
+def test_reduce_nodes_50k_row_segments_vs_oracle(oracle, G, form):
+    gnnmp, x, gi, X, GI, g = _setup(50_000 * G, 20, G, 40 + G)
     arg = g if form == "graph" else GI
     kw = {} if form == "graph" else {"num_graphs": G}
     for aggr in ("+", "mean", "max", "min"):
         y = gnnmp.reduce_nodes(aggr, arg, X, **kw).cpu().numpy()
-        assert y.shape == (G, D)
-        for k in range(G):
-            seg = x[gi == k + 1].astype(np.float64)
-            ref = {"+": seg.sum(0), "mean": seg.mean(0), "max": seg.max(0), "min": seg.min(0)}[aggr]
-            if aggr in ("max", "min"):
-                np.testing.assert_array_equal(y[k], ref.astype(np.float32))
-            else:
-                assert np.abs(y[k] - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()) * (30 if aggr == "+" else 1)
+        ref = oracle.reduce_nodes(aggr, gi, x, G)
+        assert y.shape == ref.shape == (G, 20)
+        if aggr in ("max", "min"):
+            np.testing.assert_array_equal(y, ref)
+        else:
+            assert np.linalg.norm(y - ref) <= 1e-5 * np.linalg.norm(ref), aggr
+            assert np.abs(y - ref).max() <= 1e-5 * np.abs(ref).max(), aggr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("G", [1, 2, 3])
+@pytest.mark.parametrize("form", ["graph", "indicator"])
+def test_reduce_nodes_with_large_segments(G, form):
+    import torch
+    gnnmp, x, gi, X, GI, g = _setup(600_000, 20, G, G)
+    arg = g if form == "graph" else GI
+    kw = {} if form == "graph" else {"num_graphs": G}
+    for aggr in ("+", "mean", "max", "min"):
+        y = gnnmp.reduce_nodes(aggr, arg, X, **kw).cpu().numpy()
+        assert y.shape == (G, 20)
+        ref = np.stack([{"+": seg.sum(0), "mean": seg.mean(0), "max": seg.max(0), "min": seg.min(0)}[aggr]
+                        for seg in (x[gi == k + 1].astype(np.float64) for k in range(G))])
+        if aggr in ("max", "min"):
+            np.testing.assert_array_equal(y, ref.astype(np.float32))
+        else:
+            assert np.linalg.norm(y - ref) <= 1e-5 * np.linalg.norm(ref), aggr
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(5):

@@ -80,8 +80,27 @@ def test_zero_based_and_empty(gm):
                                            ([1, 2, 3, 4], [0, 1, 3])])        # row index < 1
 def test_validation(gm, colptr, rowval):
     import torch
-    with pytest.raises(AssertionError):
-        gm.Plan.from_csc(torch.tensor(colptr, dtype=torch.int64).cuda(), torch.tensor(rowval, dtype=torch.int64).cuda(), 3, 3)
+    for validate in (True, False):      # the structure is checked either way (a sanitised colptr [0,2,5,3,7] left row 1 unwritten)
+        with pytest.raises(AssertionError):
+            gm.Plan.from_csc(torch.tensor(colptr, dtype=torch.int64).cuda(), torch.tensor(rowval, dtype=torch.int64).cuda(), 3, 3,
+                             validate=validate)
+
+
+def test_stored_zeros_are_edges_like_findnz(gm):
+    """num_edges of a sparse graph is nnz(A) (GNNGraphs/src/convert.jl:199) and edge_index is findnz(A) (convert.jl:62-73): an explicitly
+    stored zero is an edge — it is counted, numbered, and contributes 0 * x_j to a weighted propagate and x_j to an unweighted one"""
+    import scipy.sparse as sp
+    import torch
+    A = sp.csc_matrix((np.array([1.0, 0.0, 2.0], np.float32), np.array([1, 2, 0]), np.array([0, 2, 2, 3])), shape=(3, 3))
+    assert A.nnz == 3                                     # scipy keeps the explicit zero at (2, 0)
+    g = gm.GNNGraph.from_sparse(A)
+    assert g.num_edges == 3
+    s, t = g.plan().edge_index()
+    assert (s.cpu().tolist(), t.cpu().tolist()) == ([2, 3, 1], [1, 1, 3])
+    x = torch.tensor([[1.0], [10.0], [100.0]], device="cuda")
+    assert gm.propagate(gm.copy_xj, g, "+", xj=x).cpu().flatten().tolist() == [110.0, 0.0, 1.0]
+    assert gm.propagate(gm.w_mul_xj, g, "+", xj=x).cpu().flatten().tolist() == [10.0, 0.0, 2.0]
+    assert gm.degree(g, dir="in", edge_weight=False).cpu().tolist() == [2, 0, 1]
 
 
 def test_reference_known_answers_for_sparse_graphs(gm):
