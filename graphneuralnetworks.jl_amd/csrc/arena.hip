@@ -21,8 +21,8 @@
 // (default 32 GiB = 16 blocks) and at most ~0.3 s (GNNMP_ARENA_BUDGET_MS); a block is first screened at ONE window (1 warm-up + 3 timed
 // probes, ~2.5 ms) and only the blocks that are kept are checked at all four.  When the budget runs out the arena is returned with the classes
 // it found (gnnmp_arena_info: [7] = classes, [9] = 1 "gave up") instead of an error: two classes still separate a gather's source from
-// its output, one class means "no placement on this device today" (the caller allocates as usual).  A buffer larger than a block is served
-// from VIRTUALLY ADJACENT blocks of one class (sequential hipMallocs of one size usually are; checked, never assumed).
+// its output, one class means "no placement on this device today" (the caller allocates as usual).  A buffer larger than a block is an
+// allocation of its own, classified window by window when it is asked for (gnnmp_arena_alloc).
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -45,6 +45,11 @@ struct gnnmp_arena {
     float probe_same_us = 0.0f, probe_other_us = 0.0f; // what the probe measured (info)
     int gave_up = 0;                                   // the budget ran out before every class held its blocks
     int64_t create_us = 0;                             // wall time of gnnmp_arena_create
+    // buffers larger than a block: allocations of their own, classified window by window when they are made (gnnmp_arena_alloc)
+    struct Big { unsigned char *p; int64_t bytes; int cls; bool used; };
+    std::vector<Big> big;
+    float thr = 0.0f;                                  // the probe time that separates "same class as the source" from "another"
+    const float *ref[2] = {nullptr, nullptr};          // the probe's sources: the first GiB of a block of class 0 / class 1
     std::mutex lock;
 };
 
@@ -133,6 +138,7 @@ int gnnmp_arena_destroy(gnnmp_arena_t *a) {
     if (!a) return GNNMP_OK;
     for (int c = 0; c < 3; ++c)
         for (auto &b : a->blocks[c]) (void)hipFree(b.p);      // (hipFree waits for the device)
+    for (auto &b : a->big) (void)hipFree(b.p);
     if (a->probe_plan) gnnmp_plan_destroy(a->probe_plan);
     delete a;
     return GNNMP_OK;
@@ -282,6 +288,9 @@ int gnnmp_arena_create(gnnmp_arena_t **out, int64_t bytes_per_class, int n_class
         ++found;
     }
     a->n_classes = found;
+    a->thr = thr;
+    a->ref[0] = ref0;                                        // (block 0 is never dropped; ref1's block is kept even if a window of it failed)
+    a->ref[1] = ref1;
     a->create_us = (int64_t)(elapsed_ms() * 1e3);
     *out = a;
     return GNNMP_OK;
@@ -309,21 +318,52 @@ int gnnmp_arena_alloc(gnnmp_arena_t *a, int cls, int64_t bytes, void **ptr) {
             }
         }
     } else {
-        // larger than a block (SAGEConv's 2.5 GB output on the products shape): a run of unused blocks of this class that are adjacent
-        // in the address space (the list is sorted by address) — one buffer, one placement class
-        const int64_t k = (bytes + a->block_bytes - 1) / a->block_bytes;
-        for (size_t i = 0; i + (size_t)k <= bl.size(); ++i) {
-            bool ok = true;
-            for (int64_t j = 0; j < k && ok; ++j)
-                ok = bl[i + (size_t)j].used == 0 && (j == 0 || bl[i + (size_t)j].p == bl[i + (size_t)j - 1].p + a->block_bytes);
-            if (!ok) continue;
-            for (int64_t j = 0; j < k; ++j) bl[i + (size_t)j].used = std::min<int64_t>(a->block_bytes, bytes - j * a->block_bytes);
-            *ptr = bl[i].p;
-            return GNNMP_OK;
+        // Larger than a block (SAGEConv's 2.5 GB output on the products shape).  Separate hipMallocs are never adjacent in the address space
+        // (measured: 2 GiB + 2 MiB apart), so such a buffer is an allocation of its own, classified where it lies — every 512 MiB window
+        // probed against the class references, all windows must agree — and kept if it came out in class `cls`; up to three tries, the
+        // rejects held until the end (freed earlier they would come straight back).  Synchronises (this is set-up: the buffers are
+        // persistent); GNNMP_EALLOC = not today, the caller allocates as usual.
+        for (auto &b : a->big)
+            if (!b.used && b.cls == cls && b.bytes >= bytes && b.bytes <= bytes + (bytes >> 2)) { b.used = true; *ptr = b.p; return GNNMP_OK; }
+        if (a->thr <= 0.0f || !a->ref[0]) return fail(GNNMP_EALLOC, "arena_alloc: no class references to classify a %lld-byte buffer", (long long)bytes);
+        const int64_t win = CHUNK / 4, nb = (bytes + win - 1) / win * win;
+        std::vector<unsigned char *> rejects;
+        int rc = GNNMP_EALLOC;
+        for (int attempt = 0; attempt < 3 && rc == GNNMP_EALLOC; ++attempt) {
+            unsigned char *p = nullptr;
+            if (hipMalloc((void **)&p, (size_t)nb) != hipSuccess) { (void)hipGetLastError(); break; }
+            int got = -1;                                    // the class all windows agree on; -2 = they do not
+            for (int64_t w = 0; w < nb / win && got != -2; ++w) {
+                float t0 = 0.0f, t1 = 0.0f;
+                int c = -1;
+                int r = probe_us(a, a->ref[0], reinterpret_cast<float *>(p + w * win), nullptr, &t0, 1, 3);
+                if (r == GNNMP_OK && t0 > a->thr) c = 0;
+                else if (r == GNNMP_OK && a->ref[1]) {
+                    r = probe_us(a, a->ref[1], reinterpret_cast<float *>(p + w * win), nullptr, &t1, 1, 3);
+                    if (r == GNNMP_OK) c = t1 > a->thr ? 1 : 2;
+                } else if (r == GNNMP_OK) c = 1;              // not class 0, and no second reference: "the other one"
+                if (r != GNNMP_OK) { got = -2; rc = r; break; }
+                got = got == -1 ? c : (got == c ? got : -2);
+            }
+            if (getenv("GNNMP_ARENA_DEBUG")) fprintf(stderr, "[arena] big buffer of %lld bytes, attempt %d: class %d (wanted %d)\n", (long long)nb, attempt, got, cls);
+            if (got == cls) {
+                a->big.push_back({p, nb, cls, true});
+                *ptr = p;
+                rc = GNNMP_OK;
+            } else if (got >= 0 && got < a->n_classes) {
+                a->big.push_back({p, nb, got, false});       // a pure buffer of another class: somebody may ask for it
+            } else {
+                rejects.push_back(p);
+            }
         }
+        (void)hipDeviceSynchronize();
+        for (unsigned char *p : rejects) (void)hipFree(p);
+        if (rc == GNNMP_OK) return GNNMP_OK;
+        if (rc != GNNMP_EALLOC) return rc;
     }
-    return fail(GNNMP_EALLOC, "arena_alloc: class %d cannot hold %lld bytes (blocks of %lld bytes, %zu of them; a larger buffer needs "
-                              "adjacent unused blocks)", cls, (long long)bytes, (long long)a->block_bytes, bl.size());
+    return fail(GNNMP_EALLOC, "arena_alloc: class %d cannot hold %lld bytes (blocks of %lld bytes, %zu of them; a larger buffer is an "
+                              "allocation of its own that did not come out in that class)", cls, (long long)bytes, (long long)a->block_bytes,
+                bl.size());
 }
 
 int gnnmp_arena_reset(gnnmp_arena_t *a) {
@@ -331,6 +371,7 @@ int gnnmp_arena_reset(gnnmp_arena_t *a) {
     std::lock_guard<std::mutex> lk(a->lock);
     for (int c = 0; c < 3; ++c)
         for (auto &b : a->blocks[c]) b.used = 0;
+    for (auto &b : a->big) b.used = false;
     return GNNMP_OK;
 }
 
@@ -342,6 +383,8 @@ int gnnmp_arena_class_of(gnnmp_arena_t *a, const void *ptr, int64_t bytes, int *
     for (int c = 0; c < a->n_classes; ++c)
         for (const auto &b : a->blocks[c])
             if (p >= b.p && p < b.p + a->block_bytes) { *cls = c; return GNNMP_OK; }
+    for (const auto &b : a->big)
+        if (p >= b.p && p < b.p + b.bytes) { *cls = b.cls; return GNNMP_OK; }
     // foreign memory: the probe with the buffer as the gathered matrix, the output in a spare corner of each arena range
     const int none = a->n_classes;                         // "in none of the ranges' classes / cannot tell"
     const int64_t n_src = std::min<int64_t>(bytes, CHUNK / 2) / (PROBE_D * 4);

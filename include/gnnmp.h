@@ -212,8 +212,9 @@ int gnnmp_plan_edge_index(const gnnmp_graph_t *plan, int idx_bytes, int index_ba
  *                        the probe with `ptr` as the gathered matrix and the output in every range — c = it shares range c's class,
  *                        classes = none of them / mixed / too small to tell / no room left for the probe's output; synchronises
  *   gnnmp_arena_alloc(a, cls, bytes, &ptr)   bump allocation (4 KiB aligned) inside one block of class cls; a buffer LARGER than a block
- *                        (SAGEConv's 2.5 GB output on the products shape) takes a run of unused blocks of the class that are adjacent in the
- *                        address space; GNNMP_EALLOC when the class cannot hold it (the caller then allocates as usual)
+ *                        (SAGEConv's 2.5 GB output on the products shape) is an allocation of its own, classified where it lies when it
+ *                        is asked for (every 512 MiB window probed, all must agree; up to three tries; synchronises — set-up work for a
+ *                        persistent buffer); GNNMP_EALLOC when the class cannot serve it (the caller then allocates as usual)
  *   gnnmp_arena_reset(a)  forget every allocation (the caller knows nothing uses them any more)
  *   gnnmp_arena_info      info[14]: [0] bytes per class asked for [1], [2], [8] bytes used in range 0 / 1 / 2 [3] blocks created while classifying
  *                         [4] released again [5], [6] the probe's microseconds with source and output in one class / in two [7] classes held
