@@ -30,6 +30,9 @@ struct ReduceArgs {
     float *out;              // [n_dst][D]
     const float *bias;       // [D] or null: added to the finished row (after the destination scaling) ...
     int bias_relu;           // ... and then relu, if set: the layer epilogue σ.(x .+ b) of gcn_conv's W-first branch (conv.jl:36-40,71)
+    const float *addend;     // [n_dst][D] or null: out = row + addend[row] — the other summand of graph_conv's pullback
+                             //   Δx = Δz W_root + Aᵀ(Δz W_agg) (conv.jl:102-108), added where the row is finished instead of in a pass of its own
+    const float *mask_y;     // [n_dst][D] or null: out = mask_y[row] > 0 ? out : 0 — relu' of the layer below (its stored output), ditto
     float *partial;          // [n_chunks][D]
     const int32_t *chunk_row;
     const uint32_t *chunk_beg, *chunk_end;
@@ -247,6 +250,18 @@ __device__ __forceinline__ void finalize_store(const ReduceArgs &a, int row, uin
     if (a.bias_relu) {
 #pragma unroll
         for (int q = 0; q < VEC; ++q) acc[q] = acc[q] < 0.0f ? 0.0f : acc[q];
+    }
+    if (a.addend && active) {
+        float ad[VEC];
+        Vec<VEC>::load(a.addend + (int64_t)row * a.D + f0, ad);
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) acc[q] = ad[q] + acc[q];
+    }
+    if (a.mask_y && active) {
+        float my[VEC];
+        Vec<VEC>::load(a.mask_y + (int64_t)row * a.D + f0, my);
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) acc[q] = my[q] > 0.0f ? acc[q] : 0.0f;
     }
     if (active) Vec<VEC>::store(a.out + (int64_t)(out_row < 0 ? row : out_row) * a.D + f0, acc);
 }

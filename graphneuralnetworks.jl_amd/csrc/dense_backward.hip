@@ -25,6 +25,37 @@ __global__ void __launch_bounds__(256) act_grad_kernel(const float *dy, const fl
     dz[i] = (act == GNNMP_ACT_RELU) ? (y[i] > 0.0f ? g : 0.0f) : g;
 }
 
+// reduce_nodes' pullback (GNNlib/src/utils.jl:12-16 = scatter over the graph indicator: Δx_i = Δpool[g(i)], ./ the member graph's node
+// count for mean) and the relu' of the layer that produced x, in one pass: dz[i][:] = (y[i][:] > 0) ? Δpool[g(i)][:] * inv[g(i)] : 0.
+// Same operations as gnnmp_mul_rows_f32 + gnnmp_gather_f32 + gnnmp_act_grad_f32 (bit-identical), one read of y and one write of dz
+// instead of three passes over (N, D).
+template <int V>
+__global__ void __launch_bounds__(256) pool_grad_act_kernel(const float *__restrict__ dpool, const void *__restrict__ gi, int idx_bytes, int base,
+                                                            const float *__restrict__ inv, const float *__restrict__ y, int act,
+                                                            float *__restrict__ dz, int64_t N, int64_t G, int D) {
+    const int per = D / V;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N * per) return;
+    const int64_t i = t / per;
+    const int c = (int)(t - i * per) * V;
+    int64_t g = load_index(gi, i, idx_bytes, base);
+    const bool ok = g >= 0 && g < G;                       // (an indicator outside 1..G: the row gets zeros, like a gather's bounds guard)
+    if (!ok) g = 0;
+    const float sc = inv ? inv[g] : 1.0f;
+    float v[V], yy[V];
+    Vec<V>::load(dpool + g * D + c, v);
+#pragma unroll
+    for (int q = 0; q < V; ++q) yy[q] = 1.0f;
+    if (act == GNNMP_ACT_RELU) Vec<V>::load(y + i * D + c, yy);
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+        float r = inv ? sc * v[q] : v[q];                   // mul_rows: a .* b with the 1-channel factor first
+        r = ok ? r : 0.0f;
+        v[q] = (act == GNNMP_ACT_RELU) ? (yy[q] > 0.0f ? r : 0.0f) : r;
+    }
+    Vec<V>::store(dz + i * D + c, v);
+}
+
 // stage 1: block b sums rows [b*R, (b+1)*R) of x[N][D] for every column -> part[b][D]
 __global__ void __launch_bounds__(256) colsum_partial_kernel(const float *x, int64_t N, int D, int64_t R,
                                                              float *part) {
@@ -196,12 +227,18 @@ __global__ void __launch_bounds__(256) dense_gradw_kernel(const GradWArgs a) {
 struct GradW16Args {
     const float *dz;   // [N][Dout]
     const float *x;    // [N][K]
-    float *part;       // [slabs][Dout][K]
-    float *part_db;    // [slabs][Dout] column sums of Δz (Δb), or null
+    float *part;       // [slabs][part_stride]: the slab's [Dout][K] partial (then, two operands: its [Dout][K2] partial)
+    float *part_db;    // [slabs][db_stride] column sums of Δz (Δb), or null
     int64_t N;
     int64_t rows_per_slab;   // multiple of 4
     int Dout, K;
     int tiles_per_wave;      // k-tiles (16 columns of ΔW) per wave, <= TK
+    // a SECOND operand sharing the pass over Δz (round 5: ΔW_root and ΔW_agg of graph_conv / sage_conv, conv.jl:102-108, from one read
+    // of Δz): ΔW2[o][k] = Σ_n Δz[n][o] x2[n][k].  The waves of a block split the columns of the CONCATENATED [x | x2]; a wave's
+    // tiles lie in one operand (the host picks tiles_per_wave so that K % (16 tiles_per_wave) == 0).  K2 = 0: one operand.
+    const float *x2;   // [N][K2] or null
+    int K2;
+    int64_t part_stride, db_stride;
 };
 
 template <int TO, int TK, int NB, int WPE>
@@ -209,17 +246,21 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, W
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
     const int o0 = (int)blockIdx.y * 128;
-    const int k0 = ((int)blockIdx.z * (int)(blockDim.x >> 6) + wave) * 16 * a.tiles_per_wave;
-    if (k0 >= a.K) return;
+    const int kv0 = ((int)blockIdx.z * (int)(blockDim.x >> 6) + wave) * 16 * a.tiles_per_wave;      // column of [x | x2]
+    if (kv0 >= a.K + a.K2) return;
+    const bool second = kv0 >= a.K;
+    const float *xop = second ? a.x2 : a.x;
+    const int Kop = second ? a.K2 : a.K;
+    const int k0 = second ? kv0 - a.K : kv0;
     const int nto = min(TO, (a.Dout - o0 + 15) >> 4);
-    const int ntk = min(a.tiles_per_wave, (a.K - k0 + 15) >> 4);
+    const int ntk = min(a.tiles_per_wave, (Kop - k0 + 15) >> 4);
     // columns that do not exist read column 0 of the row instead (valid memory); their accumulator rows / columns are never
     // stored.  No select on the loaded values: see the note in dense_gradw_kernel.
     int ocol[TO], kcol[TK];
 #pragma unroll
     for (int t = 0; t < TO; ++t) ocol[t] = (o0 + 16 * t + i < a.Dout) ? o0 + 16 * t + i : 0;
 #pragma unroll
-    for (int t = 0; t < TK; ++t) kcol[t] = (k0 + 16 * t + i < a.K) ? k0 + 16 * t + i : 0;
+    for (int t = 0; t < TK; ++t) kcol[t] = (k0 + 16 * t + i < Kop) ? k0 + 16 * t + i : 0;
     f32x4 acc[TO][TK];
 #pragma unroll
     for (int t = 0; t < TO; ++t)
@@ -254,7 +295,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, W
             auto load_batch = [&](int slot, int64_t b) {
                 const int64_t row = n0 + 4 * (b < nfull ? b : nfull - 1) + q;
                 const float *pa = a.dz + row * a.Dout;
-                const float *pb = a.x + row * a.K;
+                const float *pb = xop + row * Kop;
 #pragma unroll
                 for (int t = 0; t < TO; ++t) av[slot][t] = pa[ocol[t]];
 #pragma unroll
@@ -277,7 +318,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, W
             const bool in = row < n1;   // a SELECT, not a multiplication by 0: 0 * Inf = NaN would poison whole rows / columns of ΔW and Δb
                                         // when the last row holds a non-finite value; outside the pipelined loop it costs nothing
             const float *pa = a.dz + min(row, n1 - 1) * a.Dout;
-            const float *pb = a.x + min(row, n1 - 1) * a.K;
+            const float *pb = xop + min(row, n1 - 1) * Kop;
             float av[TO], bv[TK];
 #pragma unroll
             for (int t = 0; t < TO; ++t) av[t] = in ? pa[ocol[t]] : 0.0f;
@@ -292,11 +333,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, W
             float v = dbacc[t];
             v = v + __shfl_xor(v, 16, 64);
             v = v + __shfl_xor(v, 32, 64);
-            if (q == 0 && o0 + 16 * t + i < a.Dout) a.part_db[(int64_t)blockIdx.x * a.Dout + o0 + 16 * t + i] = v;
+            if (q == 0 && o0 + 16 * t + i < a.Dout) a.part_db[(int64_t)blockIdx.x * a.db_stride + o0 + 16 * t + i] = v;
         }
     }
     // C/D layout: col = lane & 15, row = 4 (lane >> 4) + reg
-    float *part = a.part + (int64_t)blockIdx.x * a.Dout * a.K;
+    float *part = a.part + (int64_t)blockIdx.x * a.part_stride + (second ? (int64_t)a.Dout * a.K : 0);
 #pragma unroll
     for (int t = 0; t < TO; ++t) {
         if (t >= nto) continue;
@@ -304,11 +345,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, W
         for (int u = 0; u < TK; ++u) {
             if (u >= ntk) continue;
             const int col = k0 + 16 * u + i;
-            if (col >= a.K) continue;
+            if (col >= Kop) continue;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = o0 + 16 * t + 4 * q + r;
-                if (row < a.Dout) part[(int64_t)row * a.K + col] = acc[t][u][r];
+                if (row < a.Dout) part[(int64_t)row * Kop + col] = acc[t][u][r];
             }
         }
     }
@@ -389,6 +430,10 @@ int gnnmp_dense_grad_w_f32(const float *dz, const float *x, int64_t N, int64_t D
             a.rows_per_slab = rps;
             a.Dout = (int)Dout;
             a.K = (int)K;
+            a.x2 = nullptr;
+            a.K2 = 0;
+            a.part_stride = Dout * K;
+            a.db_stride = Dout;
             // 16 x 16 tiles of ΔW per wave: 8 x 4 (128 rows x 64 columns, 128 accumulator registers), two waves per SIMD; the
             // waves of a block share the Δz rows and split the columns.  (ONE wave per SIMD holding all of a 7 x 7 or 8 x 7-tile
             // ΔW in AGPRs — equal work for every wave — was slower: 756 vs 723 us at 100 x 100, 889 vs 807 us at 128 x 100; one
@@ -429,6 +474,83 @@ int gnnmp_dense_grad_w_f32(const float *dz, const float *x, int64_t N, int64_t D
         GNNMP_LAUNCH_CHECK("colsum_partial_kernel");
         if (int rc = fold_partials(workspace, slabs, Dout, db, workspace + (int64_t)slabs * Dout, stream)) return rc;
     }
+    return GNNMP_OK;
+}
+
+/* Two weight gradients and the bias gradient from ONE pass over Δz (gnnmp.h): out = [ΔW1 (Dout x K1) | ΔW2 (Dout x K2) | Δb (Dout)] */
+int64_t gnnmp_dense_grad_w2_workspace(int64_t N, int64_t Dout, int64_t K1, int64_t K2) {
+    if (N <= 0 || Dout <= 0 || K1 <= 0 || K2 <= 0) return 0;
+    return ((int64_t)gradw_slabs(N) + FOLD_GROUPS) * (Dout * (K1 + K2) + Dout);
+}
+
+int gnnmp_dense_grad_w2_f32(const float *dz, const float *x1, int64_t K1, const float *x2, int64_t K2, int64_t N, int64_t Dout,
+                            float *out, float *workspace, int64_t workspace_floats, gnnmp_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (N < 0 || Dout <= 0 || K1 <= 0 || K2 <= 0 || Dout > (1 << 16) || K1 > (1 << 16) || K2 > (1 << 16))
+        return fail(GNNMP_EINVAL, "dense_grad_w2: bad size");
+    if (!out) return fail(GNNMP_EINVAL, "dense_grad_w2: null output");
+    const int64_t L = Dout * (K1 + K2) + Dout;
+    if (N == 0) {
+        GNNMP_HIP(hipMemsetAsync(out, 0, sizeof(float) * L, stream));
+        return GNNMP_OK;
+    }
+    if (!dz || !x1 || !x2 || !workspace) return fail(GNNMP_EINVAL, "dense_grad_w2: null pointer");
+    // a wave's column tiles must lie in ONE operand: K1 a multiple of 16 tiles_per_wave
+    if (K1 % 16 != 0) return fail(GNNMP_EUNSUPPORTED, "dense_grad_w2: K1 = %lld is not a multiple of 16 (use gnnmp_dense_grad_w_f32 twice)", (long long)K1);
+    if (workspace_floats < gnnmp_dense_grad_w2_workspace(N, Dout, K1, K2))
+        return fail(GNNMP_EINVAL, "dense_grad_w2: workspace too small (%lld < %lld floats)", (long long)workspace_floats,
+                    (long long)gnnmp_dense_grad_w2_workspace(N, Dout, K1, K2));
+    const int slabs = gradw_slabs(N);
+    int64_t rps = (N + slabs - 1) / slabs;
+    rps = (rps + 3) & ~(int64_t)3;
+    if ((rps & 63) == 0) rps += 4;          // (the channel-interleave de-tuning of gnnmp_dense_grad_w_f32: same slabs, same bits)
+    GradW16Args a;
+    a.dz = dz;
+    a.x = x1;
+    a.x2 = x2;
+    a.K = (int)K1;
+    a.K2 = (int)K2;
+    a.part = workspace;
+    a.part_db = workspace + Dout * (K1 + K2);
+    a.part_stride = a.db_stride = L;
+    a.N = N;
+    a.rows_per_slab = rps;
+    a.Dout = (int)Dout;
+    const int kt1 = (int)(K1 / 16), kt2 = (int)((K2 + 15) / 16);
+    int tpw = 4;
+    while (tpw > 1 && kt1 % tpw != 0) tpw >>= 1;
+    a.tiles_per_wave = tpw;
+    const int kwaves_all = kt1 / tpw + (kt2 + tpw - 1) / tpw;
+    const int waves = std::min(4, kwaves_all);
+    const int kblocks = (kwaves_all + waves - 1) / waves;
+    dim3 grid((unsigned)slabs, (unsigned)((Dout + 127) / 128), (unsigned)kblocks);
+    if ((Dout + 15) / 16 <= 7)
+        dense_gradw16_kernel<7, 4, 6, 2><<<grid, 64 * waves, 0, stream>>>(a);
+    else
+        dense_gradw16_kernel<8, 4, 4, 2><<<grid, 64 * waves, 0, stream>>>(a);
+    GNNMP_LAUNCH_CHECK("dense_gradw16_kernel (two operands)");
+    return fold_partials(workspace, slabs, L, out, workspace + (int64_t)slabs * L, stream);
+}
+
+/* Δx of GlobalPool(+ | mean) followed by the activation's derivative of the layer that FED the pool, in one pass (gnnmp.h) */
+int gnnmp_pool_grad_act_f32(const float *dpool, const void *graph_indicator, int idx_bytes, int index_base, const float *inv_count,
+                            const float *y, int act, float *dz, int64_t N, int64_t G, int64_t D, gnnmp_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (idx_bytes != 4 && idx_bytes != 8) return fail(GNNMP_EINVAL, "pool_grad_act: idx_bytes must be 4 or 8");
+    if (act != GNNMP_ACT_IDENTITY && act != GNNMP_ACT_RELU) return fail(GNNMP_EINVAL, "pool_grad_act: bad act %d", act);
+    if (N < 0 || G < 0 || D <= 0) return fail(GNNMP_EINVAL, "pool_grad_act: bad size");
+    if (N == 0) return GNNMP_OK;
+    if (!dpool || !graph_indicator || !dz || (act == GNNMP_ACT_RELU && !y)) return fail(GNNMP_EINVAL, "pool_grad_act: null pointer");
+    const int64_t n4 = (D % 4 == 0 && ((reinterpret_cast<uintptr_t>(dpool) | reinterpret_cast<uintptr_t>(dz) | reinterpret_cast<uintptr_t>(y)) & 15) == 0)
+                           ? D / 4 : 0;
+    const int64_t items = n4 ? N * n4 : N * D;
+    if (n4)
+        pool_grad_act_kernel<4><<<(unsigned)((items + 255) / 256), 256, 0, stream>>>(dpool, graph_indicator, idx_bytes, index_base, inv_count, y, act,
+                                                                                   dz, N, G, (int)D);
+    else
+        pool_grad_act_kernel<1><<<(unsigned)((items + 255) / 256), 256, 0, stream>>>(dpool, graph_indicator, idx_bytes, index_base, inv_count, y, act,
+                                                                                   dz, N, G, (int)D);
+    GNNMP_LAUNCH_CHECK("pool_grad_act_kernel");
     return GNNMP_OK;
 }
 

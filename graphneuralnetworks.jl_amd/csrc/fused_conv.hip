@@ -208,7 +208,7 @@ static int dispatch_fused(FusedArgs &a, int op, bool scaled, size_t img_bytes, h
 int run_reduce(gnnmp_graph_t *p, const int32_t *idx, int aggr, const float *x, const float *w, const float *ss,
                const float *w_slot, const float *ss_slot, const float *sd, float *out, int64_t D, hipStream_t stream,
                const float *emat, const float *rowsub, const float *gate_i, int gated, int act, int long_only, const float *bias,
-               int bias_relu);   // propagate.hip
+               int bias_relu, const float *addend, const float *mask_y);   // propagate.hip
 
 }  // namespace gnnmp
 
@@ -254,7 +254,7 @@ extern "C" int gnnmp_fused_conv_f32(gnnmp_graph_t *p, int aggr, const float *xj,
     float *agg_long = p->ws + ((pc + 3) & ~(size_t)3);
     if (p->n_long > 0) {
         if (int rc = run_reduce(p, p->col, aggr, xj, w, scale_src, w_slot, ss_slot, scale_dst, agg_long, D, stream, nullptr,
-                                nullptr, nullptr, 1, 0, 1, nullptr, 0))
+                                nullptr, nullptr, 1, 0, 1, nullptr, 0, nullptr, nullptr))
             return rc;
     }
     FusedArgs a = {};

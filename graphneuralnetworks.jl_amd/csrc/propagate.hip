@@ -355,7 +355,7 @@ int run_reduce(gnnmp_graph_t *p, const int32_t *idx, int aggr, const float *x, c
                const float *ss, const float *w_slot, const float *ss_slot, const float *sd, float *out,
                int64_t D, hipStream_t stream, const float *emat = nullptr, const float *rowsub = nullptr,
                const float *gate_i = nullptr, int gated = 1, int act = 0, int long_only = 0, const float *bias = nullptr,
-               int bias_relu = 0) {
+               int bias_relu = 0, const float *addend = nullptr, const float *mask_y = nullptr) {
     // long_only: reduce ONLY the split rows (their chunk virtual rows + the combine) and write row long_rows[r], finalised, to
     // out[r] — a compact [n_long][D] buffer the fused kernel reads instead of walking those rows (the caller sized the
     // workspace and passes out inside it)
@@ -386,6 +386,8 @@ int run_reduce(gnnmp_graph_t *p, const int32_t *idx, int aggr, const float *x, c
     a.out = out;
     a.bias = bias;
     a.bias_relu = bias_relu;
+    a.addend = addend;
+    a.mask_y = mask_y;
     a.partial = p->ws;
     a.chunk_row = p->chunk_row;
     a.chunk_beg = p->chunk_beg;
@@ -406,6 +408,8 @@ int run_reduce(gnnmp_graph_t *p, const int32_t *idx, int aggr, const float *x, c
     a.chunk_lrow = p->chunk_lrow;
     a.arrive = nullptr;
     int vec = pick_vec(D, x, out);
+    if (addend && (reinterpret_cast<uintptr_t>(addend) & (4 * vec - 1)) != 0) vec = 1;
+    if (mask_y && (reinterpret_cast<uintptr_t>(mask_y) & (4 * vec - 1)) != 0) vec = 1;
     if (emat && (reinterpret_cast<uintptr_t>(emat) & (4 * vec - 1)) != 0) vec = 1;
     if (gate_i && (reinterpret_cast<uintptr_t>(gate_i) & (4 * vec - 1)) != 0) vec = 1;
     a.log2g = pick_log2g((D + vec - 1) / vec);
@@ -713,6 +717,18 @@ int gnnmp_propagate_slots_act_f32(gnnmp_graph_t *plan, int aggr, const float *xj
         return fail(GNNMP_EINVAL, "propagate_slots_act: null xj/out");
     return run_reduce(plan, plan->col, aggr, xj, nullptr, nullptr, w_slot, ss_slot, scale_dst, out, D, (hipStream_t)stream, nullptr,
                       nullptr, nullptr, 1, 0, 0, bias, act == GNNMP_ACT_RELU ? 1 : 0);
+}
+
+/* out = act'( addend + aggregate ): the tail of graph_conv's / sage_conv's pullback w.r.t. x in the row kernel's epilogue (gnnmp.h) */
+int gnnmp_propagate_add_mask_f32(gnnmp_graph_t *plan, int aggr, const float *xj, const float *scale_dst, const float *addend,
+                                 const float *mask_y, float *out, int64_t D, gnnmp_stream_t stream) {
+    if (!plan) return fail(GNNMP_EINVAL, "propagate_add_mask: null plan");
+    if (aggr != GNNMP_SUM && aggr != GNNMP_MEAN) return fail(GNNMP_EINVAL, "propagate_add_mask: aggr must be + or mean (got %d)", aggr);
+    if (D < 0 || D > (1 << 20)) return fail(GNNMP_EINVAL, "propagate_add_mask: bad D %lld", (long long)D);
+    if (plan->n_dst > 0 && D > 0 && (!out || (!xj && plan->n_total > 0)))
+        return fail(GNNMP_EINVAL, "propagate_add_mask: null xj/out");
+    return run_reduce(plan, plan->col, aggr, xj, nullptr, nullptr, nullptr, nullptr, scale_dst, out, D, (hipStream_t)stream, nullptr,
+                      nullptr, nullptr, 1, 0, 0, nullptr, 0, addend, mask_y);
 }
 
 int gnnmp_scatter_f32(gnnmp_graph_t *plan, int aggr, const float *m, float *out, int64_t D,

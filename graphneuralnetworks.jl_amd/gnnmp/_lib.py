@@ -42,6 +42,7 @@ SYMBOLS = (
     "gnnmp_edge_dot_f32", "gnnmp_edge_dot_plan_f32", "gnnmp_propagate_maxmin_grad_f32",
     "gnnmp_head_mean_f32", "gnnmp_head_mean_grad_f32", "gnnmp_add_f32", "gnnmp_axpy_f32", "gnnmp_mul_rows_f32", "gnnmp_is_sorted",
     "gnnmp_act_grad_f32", "gnnmp_dense_grad_workspace", "gnnmp_dense_grad_w_f32",
+    "gnnmp_dense_grad_w2_workspace", "gnnmp_dense_grad_w2_f32", "gnnmp_pool_grad_act_f32", "gnnmp_propagate_add_mask_f32",
     "gnnmp_row_normalize_f32", "gnnmp_row_normalize_grad_f32", "gnnmp_propagate_cg_f32", "gnnmp_gru_pointwise_f32", "gnnmp_propagate_nn_f32", "gnnmp_gmm_weights_f32", "gnnmp_row_sqnorm_normalize_f32", "gnnmp_lstm_pointwise_f32", "gnnmp_rowdot_f32",
 )
 
@@ -153,6 +154,9 @@ def load():
         "gnnmp_propagate_maxmin_grad_f32": [vp, vp, vp, vp, vp, i64, vp],
         "gnnmp_act_grad_f32": [vp, vp, i, vp, i64, vp],
         "gnnmp_dense_grad_w_f32": [vp, vp, i64, i64, i64, vp, vp, vp, i64, vp],
+        "gnnmp_dense_grad_w2_f32": [vp, vp, i64, vp, i64, i64, i64, vp, vp, i64, vp],
+        "gnnmp_pool_grad_act_f32": [vp, vp, i, i, vp, vp, i, vp, i64, i64, i64, vp],
+        "gnnmp_propagate_add_mask_f32": [vp, i, vp, vp, vp, vp, vp, i64, vp],
         "gnnmp_shard_by_size": [ctypes.POINTER(i64), i64, i, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(i64), ctypes.POINTER(i64)],
         "gnnmp_allgather_f32": [vp, vp, vp, i64, vp],
         "gnnmp_chain_jobs_create": [ctypes.POINTER(vp), vp, i64, vp],
@@ -175,6 +179,12 @@ def load():
         fn.restype = i
     L.gnnmp_dense_grad_workspace.argtypes = [i64, i64, i64]
     L.gnnmp_dense_grad_workspace.restype = i64
+    try:
+        L.gnnmp_dense_grad_w2_workspace.argtypes = [i64, i64, i64, i64]
+        L.gnnmp_dense_grad_w2_workspace.restype = i64
+    except AttributeError:
+        if not os.environ.get("GNNMP_LIB"):
+            raise
     try:
         L.gnnmp_graphconv_chain_scratch_floats.argtypes = [i64, i, ctypes.POINTER(i64), i64]
         L.gnnmp_graphconv_chain_scratch_floats.restype = i64

@@ -347,6 +347,135 @@ class _GlobalPoolFn(torch.autograd.Function):
         return dx, None, None
 
 
+# ---------------------------------------------------------------------------------------------------------
+# The graph-classification chain as ONE differentiable function (round 5)
+# ---------------------------------------------------------------------------------------------------------
+def dense_grad_w2(dz, x1, x2):
+    """(ΔW1, ΔW2, Δb) = (Δz' x1, Δz' x2, colsum(Δz)) from one read of Δz (gnnmp_dense_grad_w2_f32); views of one buffer, each contiguous.
+    None when the shape is outside that entry point's envelope (K1 not a multiple of 16)."""
+    lib = L.load()
+    N, Dout = dz.shape
+    K1, K2 = x1.shape[1], x2.shape[1]
+    if K1 % 16 != 0:
+        return None
+    out = torch.empty(Dout * (K1 + K2) + Dout, dtype=torch.float32, device=dz.device)
+    ws = torch.empty(max(1, lib.gnnmp_dense_grad_w2_workspace(N, Dout, K1, K2)), dtype=torch.float32, device=dz.device)
+    L.check(lib.gnnmp_dense_grad_w2_f32(L.ptr(dz), L.ptr(x1), K1, L.ptr(x2), K2, N, Dout, L.ptr(out), L.ptr(ws), ws.numel(), L.stream_ptr()))
+    return out[: Dout * K1].view(Dout, K1), out[Dout * K1: Dout * (K1 + K2)].view(Dout, K2), out[Dout * (K1 + K2):]
+
+
+class _GraphChainFn(torch.autograd.Function):
+    """GNNChain(GraphConv(σ), ..., GraphConv(σ), GlobalPool(+ | mean), Dense) — examples/graph_classification_tudataset.jl:79-82 — forward
+    layer by layer with the activations stored, and a pullback that touches every (N, D) array as few times as the arithmetic allows:
+      * Δz_L = relu'(h_L) .* gather(Δpool) ./ count        one pass (gnnmp_pool_grad_act_f32; was mul_rows + gather + act_grad)
+      * ΔW_root, ΔW_agg, Δb of a layer                      one read of Δz (gnnmp_dense_grad_w2_f32; was two calls, six fold launches)
+      * Δz_{l-1} = relu'(h_{l-1}) .* (Δz_l W_root + Aᵀ(Δz_l W_agg))   the sum and the relu' in the row kernel's epilogue
+                                                            (gnnmp_propagate_add_mask_f32; was add + act_grad passes)
+    Every value is the one the layer-by-layer composition (graph_conv_ad / global_pool_ad / dense_ad) computes, bit for bit (tested).
+    Arguments: x, then (w1, w2, b) per GraphConv, then the head's (W, b)."""
+
+    @staticmethod
+    def forward(ctx, x, g, convs, pool_aggr, head_sigma, *params):
+        from .layers import dense
+        from .msgpass import _fused
+        from .utils import reduce_nodes
+        x = x.contiguous()
+        hs, ms = [x], []
+        k = 0
+        for (sigma, aggr) in convs:
+            w1, w2, b = params[k], params[k + 1], params[k + 2]
+            k += 3
+            m = _fused(g, L.COPY_XJ, aggr, hs[-1], None)
+            hs.append(dense(hs[-1], w1, b, sigma, x2=m, W2=w2))
+            ms.append(m)
+        pooled = reduce_nodes(pool_aggr, g, hs[-1])
+        wh, bh = params[k], params[k + 1]
+        y = dense(pooled, wh, bh, head_sigma)
+        ctx.save_for_backward(*hs, *ms, pooled, y, *params)
+        ctx.g, ctx.convs, ctx.pool_aggr, ctx.head_sigma = g, convs, pool_aggr, head_sigma
+        ctx.has_bias = [p is not None for p in params]
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .graph import graph_indicator
+        g, convs = ctx.g, ctx.convs
+        nl = len(convs)
+        saved = ctx.saved_tensors
+        hs, ms = saved[: nl + 1], saved[nl + 1: 2 * nl + 1]
+        pooled, y = saved[2 * nl + 1], saved[2 * nl + 2]
+        params = saved[2 * nl + 3:]
+        lib = L.load()
+        grads = [None] * len(params)
+        # head: Dense
+        wh, bh = params[3 * nl], params[3 * nl + 1]
+        dzh = act_grad(dy.contiguous(), y, ctx.head_sigma)
+        grads[3 * nl], grads[3 * nl + 1] = dense_grad_w(dzh, pooled, need_w=True, need_b=bh is not None)
+        dpool = dense_grad_x(dzh, wh)
+        # pool + relu' of the last GraphConv, one pass
+        gi = graph_indicator(g)
+        N, G = g.num_nodes, g.num_graphs
+        inv = None
+        if ctx.pool_aggr == "mean":
+            inv = g._cache.get("pool_inv_count")
+            if inv is None:
+                from .utils import reduce_nodes
+                cnt = reduce_nodes("+", g, torch.ones((N, 1), dtype=torch.float32, device=dy.device)).reshape(G)
+                inv = g._cache["pool_inv_count"] = torch.reciprocal(cnt).reshape(G, 1).contiguous()
+        D = hs[-1].shape[1]
+        dz = torch.empty((N, D), dtype=torch.float32, device=dy.device)
+        L.check(lib.gnnmp_pool_grad_act_f32(L.ptr(dpool), L.ptr(gi), 8 if gi.dtype == torch.int64 else 4, g.index_base, L.ptr(inv),
+                                            L.ptr(hs[-1]), _act_code(convs[-1][0]), L.ptr(dz), N, G, D, L.stream_ptr()))
+        for l in range(nl - 1, -1, -1):
+            sigma, aggr = convs[l]
+            w1, w2, b = params[3 * l], params[3 * l + 1], params[3 * l + 2]
+            both = dense_grad_w2(dz, hs[l], ms[l]) if (ctx.needs_input_grad[5 + 3 * l] and ctx.needs_input_grad[6 + 3 * l]) else None
+            if both is not None:
+                grads[3 * l], grads[3 * l + 1] = both[0], both[1]
+                grads[3 * l + 2] = both[2] if b is not None else None
+            else:
+                grads[3 * l], grads[3 * l + 2] = dense_grad_w(dz, hs[l], need_w=True, need_b=b is not None)
+                grads[3 * l + 1] = dense_grad_w(dz, ms[l], need_b=False)[0]
+            need_dx = l > 0 or ctx.needs_input_grad[0]
+            if not need_dx:
+                break
+            # Δh_{l} = Δz W_root + Aᵀ(Δz W_agg); for l > 0 times relu'(h_l) of the layer below — all in the row kernel's epilogue
+            r = dense_grad_x(dz, w1)
+            u = dense_grad_x(dz, w2)
+            code = aggr_code(aggr)
+            assert code in (L.SUM, L.MEAN), "the chain's pullback covers + and mean aggregation"
+            sd = None
+            if code == L.MEAN:
+                u_scaled = torch.empty_like(u)      # mean: Δm ./ count BEFORE the transposed sum (propagate_grad_xj's order)
+                invc = torch.reciprocal(torch.clamp(_in_count(g, False), min=1.0)).reshape(N, 1).contiguous()
+                L.check(lib.gnnmp_mul_rows_f32(L.ptr(invc), 1, L.ptr(u), L.ptr(u_scaled), N, u.shape[1], L.stream_ptr()))
+                u = u_scaled
+            out = torch.empty_like(r)
+            mask = hs[l] if l > 0 else None
+            mcode = _act_code(convs[l - 1][0]) if l > 0 else L.ACT_IDENTITY
+            L.check(lib.gnnmp_propagate_add_mask_f32(plan_transposed(g, False).handle, L.SUM, L.ptr(u), L.ptr(sd), L.ptr(r),
+                                                     L.ptr(mask) if mcode == L.ACT_RELU else None, L.ptr(out), r.shape[1], L.stream_ptr()))
+            dz = out
+        dx = dz if ctx.needs_input_grad[0] else None
+        return (dx, None, None, None, None, *grads)
+
+
+def graph_chain_ad(model, g: GNNGraph, x):
+    """differentiable GNNChain(GraphConv..., GlobalPool, Dense) — the model of BASELINE config 5 — as one autograd function whose
+    pullback is scheduled over the whole chain (see _GraphChainFn); gradients w.r.t. x and every layer's parameters"""
+    from .layers import Dense, GlobalPool, GraphConv
+    layers = model.layers if hasattr(model, "layers") else list(model)
+    convs, pool, head = layers[:-2], layers[-2], layers[-1]
+    assert all(isinstance(c, GraphConv) for c in convs) and isinstance(pool, GlobalPool) and isinstance(head, Dense)
+    assert pool.aggr in ("+", "sum", "mean"), "the pullback covers + and mean pooling"
+    check_num_nodes(g, x)
+    params = []
+    for c in convs:
+        params += [c.weight1, c.weight2, c.bias]
+    params += [head.weight, head.bias]
+    return _GraphChainFn.apply(x, g, tuple((c.sigma, c.aggr) for c in convs), "+" if pool.aggr == "sum" else pool.aggr, head.sigma, *params)
+
+
 def global_pool_ad(l, g: GNNGraph, x):
     """differentiable GlobalPool(+ | mean) over a batched graph"""
     assert l.aggr in ("+", "sum", "mean"), "the pullback covers + and mean pooling"

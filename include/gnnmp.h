@@ -767,6 +767,27 @@ int gnnmp_propagate_maxmin_grad_f32(gnnmp_graph_t *plan_transposed, const float 
  *                           `workspace` (gnnmp_dense_grad_workspace(N, Dout, K) floats) folded in slab order: no atomics.
  *   Δx = W' * Δz is the forward kernel: gnnmp_dense_f32(Δz, W, D1 = Dout, ldw1 = K, ..., w_layout = 1, ..., Dout = K). */
 int gnnmp_act_grad_f32(const float *dy, const float *y, int act, float *dz, int64_t n, gnnmp_stream_t stream);
+/* The training step of the graph-classification chain (examples/graph_classification_tudataset.jl:79-82,97-104) with fewer passes over
+ * the (N, D) arrays — the same arithmetic as the entry points above, fused where two of them touched one array (round 5):
+ *   gnnmp_dense_grad_w2_f32   ΔW1 = Δz' x1, ΔW2 = Δz' x2 and Δb = colsum(Δz) from ONE read of Δz — graph_conv's / sage_conv's two weight
+ *                             gradients (conv.jl:102-108: x1 = x_i, x2 = the aggregate).  out = [ΔW1 (Dout x K1) | ΔW2 (Dout x K2) | Δb
+ *                             (Dout)], contiguous; K1 a multiple of 16 (else GNNMP_EUNSUPPORTED: call gnnmp_dense_grad_w_f32 twice);
+ *                             workspace: gnnmp_dense_grad_w2_workspace floats.  Same slabs, same fold order: the three results are
+ *                             bit-identical to the separate calls.
+ *   gnnmp_pool_grad_act_f32   dz[i][:] = act'(y[i][:]) .* dpool[g(i)][:] (.* inv_count[g(i)] if given): the pullback of
+ *                             reduce_nodes(+ | mean) (utils.jl:12-16, NNlib's ∇scatter = gather) and of the activation of the layer
+ *                             that fed the pool, one pass instead of mul_rows + gather + act_grad.
+ *   gnnmp_propagate_add_mask_f32   out[i][:] = act'(mask_y[i][:]) .* (addend[i][:] + Σ_{j -> i} xj[j][:]) — the x-pullback of graph_conv,
+ *                             Δx = Δz W_root + Aᵀ(Δz W_agg), with the sum and the relu' of the layer below in the row kernel's
+ *                             epilogue (plan = the plan of the REVERSED edges; aggr + or mean with scale_dst = 1 / count as in
+ *                             gnnmp_propagate_f32; addend / mask_y optional). */
+int64_t gnnmp_dense_grad_w2_workspace(int64_t N, int64_t Dout, int64_t K1, int64_t K2);
+int gnnmp_dense_grad_w2_f32(const float *dz, const float *x1, int64_t K1, const float *x2, int64_t K2, int64_t N, int64_t Dout,
+                            float *out, float *workspace, int64_t workspace_floats, gnnmp_stream_t stream);
+int gnnmp_pool_grad_act_f32(const float *dpool, const void *graph_indicator, int idx_bytes, int index_base, const float *inv_count,
+                            const float *y, int act, float *dz, int64_t N, int64_t G, int64_t D, gnnmp_stream_t stream);
+int gnnmp_propagate_add_mask_f32(gnnmp_graph_t *plan, int aggr, const float *xj, const float *scale_dst, const float *addend,
+                                 const float *mask_y, float *out, int64_t D, gnnmp_stream_t stream);
 int64_t gnnmp_dense_grad_workspace(int64_t N, int64_t Dout, int64_t K);
 int gnnmp_dense_grad_w_f32(const float *dz, const float *x, int64_t N, int64_t Dout, int64_t K, float *dW,
                            float *db, float *workspace, int64_t workspace_floats, gnnmp_stream_t stream);

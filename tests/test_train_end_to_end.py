@@ -113,7 +113,11 @@ def test_graph_classification_training_learns(pool):
     params = [c1.weight1, c1.weight2, c1.bias, c2.weight1, c2.weight2, c2.bias, head.weight, head.bias]
     for p in params:
         p.requires_grad_(True)
-    fwd = lambda: dense_ad(head, global_pool_ad(poolL, g, graph_conv_ad(c2, g, graph_conv_ad(c1, g, g.x))))   # noqa: E731
+    # the chain as one scheduled pullback (gnnmp.backward.graph_chain_ad: bit-identical to the layer-by-layer composition,
+    # tests/test_graph_chain_train.py) — the path bench.py times as extras.batched.training_step
+    from gnnmp.backward import graph_chain_ad
+    model = gnnmp.GNNChain(c1, c2, poolL, head)
+    fwd = lambda: graph_chain_ad(model, g, g.x)   # noqa: E731
     opt = torch.optim.Adam(params, lr=3e-3 if pool == "mean" else 3e-4)
     losses = []
     for epoch in range(80):

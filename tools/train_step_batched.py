@@ -12,7 +12,7 @@ import torch
 import torch.nn.functional as F
 import gnnmp
 from gnnmp import synth
-from gnnmp.backward import dense_ad, global_pool_ad, graph_conv_ad
+from gnnmp.backward import dense_ad, global_pool_ad, graph_chain_ad, graph_conv_ad
 
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 50
@@ -26,13 +26,16 @@ params = [c1.weight1, c1.weight2, c1.bias, c2.weight1, c2.weight2, c2.bias, head
 for p in params:
     p.requires_grad_(True)
 Y = torch.from_numpy(rng.integers(0, 2, G)).cuda()
+model = gnnmp.GNNChain(c1, c2, pool, head)
+LAYERS = "--layers" in sys.argv        # the round-4 path: layer-by-layer adjoints
+fwd = (lambda: dense_ad(head, global_pool_ad(pool, g, graph_conv_ad(c2, g, graph_conv_ad(c1, g, g.x))))) if LAYERS else (lambda: graph_chain_ad(model, g, g.x))
 
 
 def run(opt, n):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n):
         opt.zero_grad(set_to_none=True)
-        lg = dense_ad(head, global_pool_ad(pool, g, graph_conv_ad(c2, g, graph_conv_ad(c1, g, g.x))))
+        lg = fwd()
         F.cross_entropy(lg, Y).backward()
         opt.step()
     torch.cuda.synchronize()
@@ -41,7 +44,7 @@ def run(opt, n):
 
 opt = torch.optim.Adam(params, lr=1e-3)
 run(opt, 5)
-print(f"eager: {run(opt, steps):.3f} ms/step", flush=True)
+print(f"{'layer-by-layer adjoints' if LAYERS else 'chain pullback'} eager: {run(opt, steps):.3f} ms/step", flush=True)
 
 if "--graph" in sys.argv:
     # the whole step as ONE captured HIP graph (static batch: same pointers every replay); Adam in its capturable form
@@ -51,14 +54,14 @@ if "--graph" in sys.argv:
     with torch.cuda.stream(side):
         for _ in range(3):
             opt.zero_grad(set_to_none=True)
-            lg = dense_ad(head, global_pool_ad(pool, g, graph_conv_ad(c2, g, graph_conv_ad(c1, g, g.x))))
+            lg = fwd()
             F.cross_entropy(lg, Y).backward()
             opt.step()
     torch.cuda.current_stream().wait_stream(side)
     cg = torch.cuda.CUDAGraph()
     opt.zero_grad(set_to_none=True)
     with torch.cuda.graph(cg):
-        lg = dense_ad(head, global_pool_ad(pool, g, graph_conv_ad(c2, g, graph_conv_ad(c1, g, g.x))))
+        lg = fwd()
         loss = F.cross_entropy(lg, Y)
         loss.backward()
         opt.step()
