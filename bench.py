@@ -282,7 +282,7 @@ def batched_setup(rank, world, dist, G=8192, forward_factory=None, device=None):
             saved = [p.detach().clone() for p in tparams]
             for p in tparams:
                 p.requires_grad_(True)
-            opt = torch.optim.Adam(tparams, lr=1e-3)
+            opt = torch.optim.Adam(tparams, lr=1e-3, fused=True)
             Yb = torch.from_numpy(np.random.default_rng(8).integers(0, 2, g.num_graphs)).cuda()
 
             def train_steps(n, chain=True):

@@ -93,7 +93,8 @@ enum Knob {
                                // a block (default 12); 16: dense_split runs its column tiles one after the other; 32: dense_split stores
                                // straight from the accumulator layout (default: through the per-wave LDS stage); 64: never dense_wreg;
                                // 128: split rows folded by a second kernel (csr_combine / gat_fused_combine) as in rounds 1-4 instead of
-                               // by the last chunk to arrive inside the row kernel (round 5, use_fold)
+                               // by the last chunk to arrive inside the row kernel (round 5, use_fold); 512: dense_wreg from 4 096 rows
+                               // on (default 32 768: below that its eight-wave blocks are too few) — so that small tests reach it
     KNOB_COUNT = 20
 };
 int knob(int k);

@@ -147,10 +147,13 @@ __global__ void __launch_bounds__(WR_THREADS) dense_wreg_kernel(const WregArgs a
             av.w0 = wr[kb][0]; av.w1 = wr[kb][1]; av.w2 = wr[kb][2];
             acc[0] = split_mac(acc[0], av, b);
             // the wave's rows of image j + 1, one unit (two float4 of x) per lane at a time through the same eight registers
-            static_assert(RND == 2 && NKB >= 8, "two rounds");
+            // (one round of units when the concatenated K is at most 128 — 8 k-blocks, 64 units a wave — else two)
+            static_assert((RND == 2 && NKB >= 9) || (RND == 1 && NKB >= 4), "one or two rounds of units per wave and tile");
             if (kb == 0) write_unit(nbuf, 0);
-            if (kb == 1) load_unit(tile_of(j + 1), 1);
-            if (kb == NKB - 4) write_unit(nbuf, 1);
+            if constexpr (RND == 2) {
+                if (kb == 1) load_unit(tile_of(j + 1), 1);
+                if (kb == NKB - 4) write_unit(nbuf, 1);
+            }
             if (kb == NKB - 2) load_unit(tile_of(j + 2), 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);              // 3 ds_read, then 6 x (1 MFMA, 3 VALU), ...
 #pragma unroll
@@ -208,7 +211,7 @@ static int launch_wreg(const WregArgs &a, hipStream_t stream) {
 int dense_wreg_try(const float *x1, const float *W1, int64_t D1, int64_t ldw1, const float *x2, const float *W2, int64_t D2, int64_t ldw2,
                    int w_layout, const float *bias, int act, float *out, int64_t N, int64_t Dout, hipStream_t stream) {
     if (knob(KNOB_VARIANT) & 64) return 1;                    // knob 19 bit 6: never (A/B runs)
-    if (Dout != WR_DP || N < 4096 || N > (int64_t)INT32_MAX - 64) return 1;      // (row numbers of a tile are 32-bit)
+    if (Dout != WR_DP || N < ((knob(KNOB_VARIANT) & 512) ? 4096 : 32768) || N > (int64_t)INT32_MAX - 64) return 1;      // (knob 19 bit 9: tests)      // (row numbers of a tile are 32-bit)
     const bool two = D2 > 0;
     if ((reinterpret_cast<uintptr_t>(x1) & 15) || (reinterpret_cast<uintptr_t>(out) & 127)) return 1;
     if (two && (reinterpret_cast<uintptr_t>(x2) & 15)) return 1;
@@ -223,7 +226,22 @@ int dense_wreg_try(const float *x1, const float *W1, int64_t D1, int64_t ldw1, c
     a.out = out;
     a.N = N;
     a.Dout = (int)Dout;
-    if (D1 == 100 && D2 == 100) return launch_wreg<100, 100>(a, stream);      // SAGEConv(100 => 256), GraphConv(100 => 256)
+    // Instantiated for the layer widths of the reference's examples and benchmarks (64, 100, 128 per segment; one segment up to 256): the
+    // W planes of a wave's 32 columns take 12 VGPRs per 16 positions of the concatenated K — 96 (K = 128) to 192 (K = 256) of the 256 a
+    // wave has at two waves a SIMD.  K = 228 and 256 (100 + 128, 128 + 128, 256) were compiled too and spill 22-34 registers: left to
+    // dense_split's LDS-resident W, like every other shape (return 1).  Measured at N = 2.4 M, => 256 (tools/dense_wreg_ab.py, one box,
+    // microseconds, this kernel / dense_split): 100+100 1439 / 1578, 64+64 1006 / 1200, 64+100 1326 / 1626, 128+64 1514 / 1701, 200 1572 /
+    // 1670 — and one segment of K <= 128 the other way round (64: 699 / 679, 100: 922 / 871, 128: 988 / 969: not instantiated); at
+    // N = 5 000 the eight-wave blocks are too few (31 / 18): from 32 768 rows on.  Bit-identical to dense_split on every shape.
+#define GNNMP_WREG_CASE(K0, K1) if (D1 == K0 && D2 == K1) return launch_wreg<K0, K1>(a, stream)
+    GNNMP_WREG_CASE(100, 100);      // SAGEConv(100 => 256), GraphConv(100 => 256): BASELINE config 4
+    GNNMP_WREG_CASE(64, 64);
+    GNNMP_WREG_CASE(64, 100);
+    GNNMP_WREG_CASE(100, 64);
+    GNNMP_WREG_CASE(64, 128);
+    GNNMP_WREG_CASE(128, 64);
+    GNNMP_WREG_CASE(200, 0);        // one segment: only where x is split twice by dense_split's two column passes AND K is large
+#undef GNNMP_WREG_CASE
     return 1;
 }
 

@@ -135,43 +135,57 @@ def test_non_finite_operands_take_the_exact_path(gm):
     assert torch.equal(torch.isnan(y), torch.isnan(y32)) and torch.equal(torch.isinf(y), torch.isinf(y32))
 
 
-# ---- dense_wreg_kernel (csrc/dense_wreg.hip): W * vcat(xi, m) at 100 + 100 => 256 from N = 4096 rows on -------------------------------
-def _wreg_case(gm, N, act, has_bias, w_layout, seed):
+# ---- dense_wreg_kernel (csrc/dense_wreg.hip): W * vcat(xi, m) => 256 with W in registers, two segments of 64 / 100 / 128 (K <= 200) ------
+WREG_SHAPES = [(100, 100), (64, 64), (64, 100), (100, 64), (64, 128), (128, 64), (200, 0)]
+
+
+@pytest.fixture
+def wreg_small(gm):
+    """knob 19 bit 9: the register-resident kernel from 4 096 rows on (default 32 768), so that these sizes reach it"""
+    before = gm.knob(19)
+    gm.tune(19, before | 512)
+    yield before | 512
+    gm.tune(19, before)
+
+
+def _wreg_case(gm, N, act, has_bias, w_layout, seed, K1=100, K2=100):
     import torch
     g = torch.Generator(device="cuda")
     g.manual_seed(seed)
-    x = torch.randn((N, 100), device="cuda", generator=g)
-    m = torch.randn((N, 100), device="cuda", generator=g)
-    Wfull = torch.randn((256, 200), device="cuda", generator=g) * 0.3
+    x = torch.randn((N, K1), device="cuda", generator=g)
+    m = torch.randn((N, K2), device="cuda", generator=g) if K2 else None
+    Wfull = torch.randn((256, K1 + K2), device="cuda", generator=g) * 0.3
     b = torch.randn(256, device="cuda", generator=g) * 0.2 if has_bias else None
     if w_layout == 0:
-        W1, W2 = Wfull[:, :100], Wfull[:, 100:]              # views of one matrix, row stride 200 (sage_conv's W * vcat(xi, m))
+        W1, W2 = Wfull[:, :K1], (Wfull[:, K1:] if K2 else None)      # views of one matrix, row stride K1 + K2 (sage_conv's W * vcat(xi, m))
     else:
         Wt = Wfull.t().contiguous()
-        W1, W2 = Wt[:100], Wt[100:]
+        W1, W2 = Wt[:K1], (Wt[K1:] if K2 else None)
     return x, m, W1, W2, b, Wfull
 
 
 @pytest.mark.parametrize("N", [4096, 4099, 8192 + 31, 70001])      # fewer tiles than CUs (blocks with no tile), ragged ends, several tiles a block
 @pytest.mark.parametrize("w_layout", [0, 1])
-def test_register_resident_kernel_is_bit_identical_to_the_lds_kernel(gm, N, w_layout):
+@pytest.mark.parametrize("K", WREG_SHAPES, ids=lambda k: f"{k[0]}+{k[1]}")
+def test_register_resident_kernel_is_bit_identical_to_the_lds_kernel(gm, wreg_small, N, w_layout, K):
     import torch
-    x, m, W1, W2, b, Wfull = _wreg_case(gm, N, 1, True, w_layout, N + w_layout)
-    before = gm.knob(19)
+    K1, K2 = K
+    x, m, W1, W2, b, Wfull = _wreg_case(gm, N, 1, True, w_layout, N + w_layout, K1, K2)
     y = run_dense(gm, x, W1, b, 1, m, W2, w_layout)
-    gm.tune(19, before | 64)                                     # bit 6: never dense_wreg_kernel
+    gm.tune(19, wreg_small | 64)                                 # bit 6: never dense_wreg_kernel
     try:
         y_lds = run_dense(gm, x, W1, b, 1, m, W2, w_layout)
     finally:
-        gm.tune(19, before)
+        gm.tune(19, wreg_small)
     assert torch.equal(y, y_lds)
-    ref = torch.relu(torch.cat([x, m], 1).double() @ Wfull.double().t() + b.double())
-    mag = torch.cat([x, m], 1).double().abs() @ Wfull.double().abs().t() + b.double().abs()
+    xc = torch.cat([x, m], 1) if K2 else x
+    ref = torch.relu(xc.double() @ Wfull.double().t() + b.double())
+    mag = xc.double().abs() @ Wfull.double().abs().t() + b.double().abs()
     assert float(((y.double() - ref).abs() / mag).max()) <= SPLIT_BOUND
     assert torch.equal(run_dense(gm, x, W1, b, 1, m, W2, w_layout), y)
 
 
-def test_register_resident_kernel_non_finite_operands(gm):
+def test_register_resident_kernel_non_finite_operands(gm, wreg_small):
     import torch
     N = 5000
     x, m, W1, W2, _, Wfull = _wreg_case(gm, N, 0, False, 0, 99)
@@ -186,10 +200,9 @@ def test_register_resident_kernel_non_finite_operands(gm):
     assert float((y[good].double() - ref[good]).abs().max()) <= 1e-5 * float(ref[good].abs().max())
     assert torch.isnan(y[37]).all()
     assert torch.equal(torch.isinf(y[4100]), torch.isinf(ref[4100])) and torch.equal(torch.sign(y[4100]), torch.sign(ref[4100]).float())
-    before = gm.knob(19)
-    gm.tune(19, before | 64)
+    gm.tune(19, wreg_small | 64)
     try:
         y_lds = run_dense(gm, x, W1, None, 0, m, W2, 0)
     finally:
-        gm.tune(19, before)
+        gm.tune(19, wreg_small)
     assert torch.equal(torch.isnan(y), torch.isnan(y_lds)) and torch.equal(y[good], y_lds[good])

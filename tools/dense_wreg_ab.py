@@ -19,11 +19,16 @@ def t(fn, it=10):
     return ts[len(ts) // 2]
 
 
-for (N, K, two) in [(2449029, 100, True), (2449029, 100, False), (2449029, 128, False), (169343, 128, False), (5000, 100, True)]:
-    x = torch.randn((N, K), device="cuda"); m = torch.randn((N, K), device="cuda")
-    W = torch.randn((256, 2 * K if two else K), device="cuda") * 0.1
+SHAPES = [(2449029, 100, 100), (2449029, 64, 64), (2449029, 64, 100), (2449029, 128, 64), (2449029, 64, 0), (2449029, 100, 0),
+          (2449029, 128, 0), (2449029, 200, 0), (169343, 128, 0), (169343, 64, 64), (5000, 100, 100)]
+if len(sys.argv) > 1:
+    SHAPES = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]]
+for (N, K1, K2) in SHAPES:
+    two = K2 > 0
+    x = torch.randn((N, K1), device="cuda"); m = torch.randn((N, max(K2, 4)), device="cuda")
+    W = torch.randn((256, K1 + K2), device="cuda") * 0.1
     b = torch.randn(256, device="cuda")
-    f = (lambda: gnnmp.dense(x, W[:, :K].contiguous(), b, "relu", x2=m, W2=W[:, K:].contiguous())) if two else (lambda: gnnmp.dense(x, W, b, "relu"))
+    f = (lambda: gnnmp.dense(x, W[:, :K1], b, "relu", x2=m, W2=W[:, K1:])) if two else (lambda: gnnmp.dense(x, W, b, "relu"))
     res = {0: [], 64: []}
     ys = {}
     for rep in range(4):
@@ -35,5 +40,6 @@ for (N, K, two) in [(2449029, 100, True), (2449029, 100, False), (2449029, 128, 
     ref = (torch.cat([x, m], 1) if two else x).double() @ W.double().T + b.double()
     ref = torch.relu(ref)
     e0 = (ys[0].double() - ref).abs().max().item(); e64 = (ys[64].double() - ref).abs().max().item()
-    print(f"N={N} K={K}{'+' + str(K) if two else ''}: wreg {sorted(res[0])[1]*1e3:8.1f} us   split {sorted(res[64])[1]*1e3:8.1f} us   "
+    print(f"N={N} K={K1}{'+' + str(K2) if two else ''} => 256: wreg {sorted(res[0])[1]*1e3:8.1f} us   split {sorted(res[64])[1]*1e3:8.1f} us   "
           f"|wreg-f64| {e0:.2e} |split-f64| {e64:.2e}  wreg==split {bool(torch.equal(ys[0], ys[64]))}", flush=True)
+    del x, m, W, ref, ys
