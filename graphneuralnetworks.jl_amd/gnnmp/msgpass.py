@@ -146,6 +146,16 @@ def apply_edges(f, g: GNNGraph, xi=None, xj=None, e=None):
         # the two-row message functions in one pass over the edges (no gathered (D, E) temporaries)
         if f is xi_dot_xj and xi.dim() == 2:
             out = torch.empty((g.num_edges, 1), dtype=torch.float32, device=xi.device)
+            if g.num_edges > 0 and g.num_nodes > 0:
+                # walked in the plan's destination-sorted order: the row of xi stays in registers for all of a destination's edges — half
+                # the gathered bytes of the COO-order kernel (products shape: 6.6 against 10.3 ms); results land in original edge order.
+                # Rows wider than a wave of 16-byte lanes (D > 256): GNNMP_EUNSUPPORTED, the COO-order kernel below.
+                rc = L.load().gnnmp_edge_dot_plan_f32(g.plan(False).handle, L.ptr(xi.contiguous()), L.ptr(xj.contiguous()), L.ptr(out),
+                                                      xi.shape[1], L.stream_ptr())
+                if rc == L.OK:
+                    return out
+                if rc != L.EUNSUPPORTED:
+                    L.check(rc)
             L.check(L.load().gnnmp_edge_dot_f32(L.ptr(xi.contiguous()), L.ptr(xj.contiguous()), L.ptr(s), L.ptr(t),
                                                 g.idx_bytes, g.index_base, g.num_edges, xi.shape[1], L.ptr(out),
                                                 L.stream_ptr()))
