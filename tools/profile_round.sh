@@ -38,6 +38,20 @@ run pmc_rd --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_EA0
 run pmc_wr --kernel-trace --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_HIT_sum TCC_MISS_sum
 run pmc_fs --kernel-trace --pmc FETCH_SIZE
 run pmc_ws --kernel-trace --pmc WRITE_SIZE
+# the other configs' dominant kernels through the same three counter passes (round 5: csr_rows_kernel's mean aggregation of config 4,
+# the arxiv pair of configs 2 / 3, the chain kernel of config 5) -> profiles/pmc_traffic.json via tools/pmc_traffic.py
+for W in sage arxiv batched; do
+  if [ "$W" = "sage" ]; then CMD="python $REPO/tools/small_configs.py sage noplace"; else CMD="python $REPO/tools/small_configs.py $W"; fi
+  run pmc_${W}_rd --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_32B_sum
+  run pmc_${W}_fs --kernel-trace --pmc FETCH_SIZE
+  run pmc_${W}_ws --kernel-trace --pmc WRITE_SIZE
+done
+CMD="python $REPO/tools/small_configs.py sage noplace"
+run sage_mfma --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE
+CMD="python $REPO/tools/small_configs.py batched"
+run batched_sq1 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE
+CMD="python $REPO/tools/train_step_batched.py 8192 30"
+run train_kernel_stats --kernel-trace --stats
 CMD="python $REPO/tools/dense_small.py shape=2449029,100,100"
 run dense_mfma --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE
 CMD="python $REPO/tools/dense_small.py shape=2449029,100,128"
