@@ -805,6 +805,45 @@ function register_concat_plan!(gb::GNNGraph{<:COO_T}, gs::Vector{<:GNNGraph}; se
     return p
 end
 
+# ---- the fused steps of the graph-classification chain's pullback (INTEGRATION.md §2f; examples/graph_classification_tudataset.jl:79-82) ----
+# Thin wrappers over the three round-5 entry points; a chain-level rrule strings them together exactly like the tested Python mirror
+# (gnnmp/backward.py: _GraphChainFn.backward) — same calls, same order, bit-identical gradients to the layer-by-layer rules above.
+# Δz = relu'(y) .* gather(Δpool, graph_indicator) (.* inv_count[graph] for mean pooling): reduce_nodes' pullback + the activation's, one pass
+function pool_grad_act(Δpool::ROCMatrix{Float32}, gi::ROCVector{I}, inv_count::Union{Nothing, ROCVector{Float32}},
+                       y::ROCMatrix{Float32}, σ) where {I <: Union{Int32, Int64}}
+    D, N = size(y)
+    Δz = similar(y)
+    check(@ccall libgnnmp.gnnmp_pool_grad_act_f32(devptr(Δpool)::Ptr{Cvoid}, devptr(gi)::Ptr{Cvoid}, sizeof(I)::Cint, 1::Cint,
+              devptr(inv_count)::Ptr{Cvoid}, devptr(y)::Ptr{Cvoid}, something(act_code(σ), Cint(0))::Cint, devptr(Δz)::Ptr{Cvoid},
+              N::Int64, size(Δpool, 2)::Int64, D::Int64, stream_ptr()::Ptr{Cvoid})::Cint)
+    return Δz
+end
+# (ΔW1, ΔW2, Δb) = (Δz * x1', Δz * x2', sum(Δz, dims = 2)) from ONE read of Δz; nothing if the shape is outside the entry point's envelope
+function dense_grad_w2(Δz::ROCMatrix{Float32}, x1::AnyROCMatrix{Float32}, x2::AnyROCMatrix{Float32})
+    Dout, N = size(Δz)
+    K1, K2 = size(x1, 1), size(x2, 1)
+    K1 % 16 == 0 || return nothing
+    nws = @ccall libgnnmp.gnnmp_dense_grad_w2_workspace(N::Int64, Dout::Int64, K1::Int64, K2::Int64)::Int64
+    ws = AMDGPU.zeros(Float32, max(nws, 1))
+    out = ROCVector{Float32}(undef, Dout * (K1 + K2) + Dout)
+    check(@ccall libgnnmp.gnnmp_dense_grad_w2_f32(devptr(Δz)::Ptr{Cvoid}, devptr(x1)::Ptr{Cvoid}, K1::Int64, devptr(x2)::Ptr{Cvoid},
+              K2::Int64, N::Int64, Dout::Int64, devptr(out)::Ptr{Cvoid}, devptr(ws)::Ptr{Cvoid}, length(ws)::Int64,
+              stream_ptr()::Ptr{Cvoid})::Cint)
+    # C row-major [Dout][K] = Julia (K, Dout): transpose like dense's pullback does
+    ΔW1 = permutedims(reshape(view(out, 1:(Dout * K1)), K1, Dout))
+    ΔW2 = permutedims(reshape(view(out, (Dout * K1 + 1):(Dout * (K1 + K2))), K2, Dout))
+    return ΔW1, ΔW2, out[(Dout * (K1 + K2) + 1):end]
+end
+# out = relu'(mask_y) .* (addend .+ Aᵀ xj): graph_conv's x-pullback with its sum and the relu' of the layer below in the row kernel's epilogue
+function propagate_add_mask(g::DeviceGraph, xj::ROCMatrix{Float32}, addend::Union{Nothing, ROCMatrix{Float32}},
+                            mask_y::Union{Nothing, ROCMatrix{Float32}})
+    out = similar(xj)
+    check(@ccall libgnnmp.gnnmp_propagate_add_mask_f32(plan(g; transposed = true).handle::Ptr{Cvoid}, 0::Cint, devptr(xj)::Ptr{Cvoid},
+              C_NULL::Ptr{Cvoid}, devptr(addend)::Ptr{Cvoid}, devptr(mask_y)::Ptr{Cvoid}, devptr(out)::Ptr{Cvoid}, size(xj, 1)::Int64,
+              stream_ptr()::Ptr{Cvoid})::Cint)
+    return out
+end
+
 # ---- the placement arena (csrc/arena.hip): outputs of the gather kernels in a placement class other than their gathered matrix's ---------
 # MI355X: device memory falls into three placement classes; propagate / the fused layers / the one-pass attention run 6 % slower when the
 # matrix they gather from and their output share a class.  `arena_similar(x, dims...)` = similar(x, dims...) from an arena range whose

@@ -5,7 +5,8 @@
  *   plan_create(validate) -> plan_info / plan_export -> degree -> propagate(copy_xj | w_mul_xj; +, mean, max) ->
  *   dense -> fused_conv -> gat_conv -> plan_destroy, the EBOUNDS error path, and (round 4) a batch taken from a resident dataset:
  *   plan_select == plan_create on the concatenated COO, plan_edge_index, the node map, chain_jobs_pack / export, plan_release;
- *   plan_from_csc == plan_create on findnz(A) for a sparse-matrix graph.
+ *   plan_from_csc == plan_create on findnz(A) for a sparse-matrix graph; (round 5) the fused steps of the chain's pullback:
+ *   dense_grad_w2 == two dense_grad_w calls, pool_grad_act and propagate_add_mask against host loops.
  * Expected values come from plain host loops in this file (edge order, separately rounded products: bit-exact where the
  * library promises bits).  Prints C_HARNESS_OK and exits 0 on success.   Built by __graft_entry__.build() / tests. */
 #include <hip/hip_runtime_api.h>
@@ -377,6 +378,72 @@ int main(void) {
         CHECK_G(gnnmp_plan_destroy(pc));
         CHECK_G(gnnmp_plan_destroy(pf));
         (void)h1; (void)h2;
+    }
+
+    /* ---- the fused steps of the graph-classification chain's pullback (round 5; examples/graph_classification_tudataset.jl:79-82,97-104):
+     * each must give the bits of the separate calls / of a host loop.  Shapes: Δz (n x 64), x1 = 64 columns, x2 = 100 columns. ---- */
+    {
+        const int Do = 64, K1 = 64, K2 = D, G = 4;
+        float *dzh = malloc(4 * n * Do), *x1h = malloc(4 * n * K1);
+        for (int64_t i = 0; i < n * Do; ++i) dzh[i] = rndf();
+        for (int64_t i = 0; i < n * K1; ++i) x1h[i] = rndf();
+        float *ddz = dev_copy(dzh, 4 * n * Do), *dx1 = dev_copy(x1h, 4 * n * K1);
+        /* (a) ΔW1, ΔW2, Δb from one read of Δz == two gnnmp_dense_grad_w_f32 calls, bit for bit */
+        const int64_t L = (int64_t)Do * (K1 + K2) + Do;
+        const int64_t nws2 = gnnmp_dense_grad_w2_workspace(n, Do, K1, K2), nws1 = gnnmp_dense_grad_workspace(n, Do, K2 > K1 ? K2 : K1);
+        float *dws2 = dev_alloc(4 * nws2), *dws1 = dev_alloc(4 * nws1), *dout2 = dev_alloc(4 * L);
+        float *dW1 = dev_alloc(4 * Do * K1), *dW2 = dev_alloc(4 * Do * K2), *dbb = dev_alloc(4 * Do);
+        CHECK_G(gnnmp_dense_grad_w2_f32(ddz, dx1, K1, dx, K2, n, Do, dout2, dws2, nws2, stream));
+        CHECK_G(gnnmp_dense_grad_w_f32(ddz, dx1, n, Do, K1, dW1, dbb, dws1, nws1, stream));
+        CHECK_G(gnnmp_dense_grad_w_f32(ddz, dx, n, Do, K2, dW2, NULL, dws1, nws1, stream));
+        CHECK_HIP(hipStreamSynchronize(stream));
+        float *o2 = malloc(4 * L), *o1 = malloc(4 * L);
+        to_host(o2, dout2, 4 * L);
+        to_host(o1, dW1, 4 * Do * K1); to_host(o1 + Do * K1, dW2, 4 * Do * K2); to_host(o1 + Do * (K1 + K2), dbb, 4 * Do);
+        REQUIRE(memcmp(o1, o2, 4 * L) == 0, "dense_grad_w2 differs from two dense_grad_w calls");
+        double ref00 = 0.0;                                   /* and one element against a host sum: ΔW1[0][0] = Σ_n Δz[n][0] x1[n][0] */
+        for (int64_t i = 0; i < n; ++i) ref00 += (double)dzh[i * Do] * (double)x1h[i * K1];
+        REQUIRE(fabs(o2[0] - ref00) <= 1e-5 * (fabs(ref00) + 1.0), "dense_grad_w2: dW1[0][0] = %g, host %g", o2[0], ref00);
+        int st2 = gnnmp_dense_grad_w2_f32(ddz, dx, K2, dx1, K1, n, Do, dout2, dws2, nws2, stream);      /* K1 = 100: not a multiple of 16 */
+        REQUIRE(st2 == GNNMP_EUNSUPPORTED, "dense_grad_w2 with K1 = 100 gave status %d", st2);
+        /* (b) Δz = relu'(y) .* Δpool[g(i)] .* inv[g(i)] — bits of the host loop */
+        int64_t *gi = malloc(8 * n);
+        float *dp = malloc(4 * G * Do), *inv = malloc(4 * G), *yy = malloc(4 * n * Do), *want = malloc(4 * n * Do), *have = malloc(4 * n * Do);
+        for (int64_t i = 0; i < n; ++i) gi[i] = 1 + i * G / n;
+        for (int i = 0; i < G * Do; ++i) dp[i] = rndf();
+        for (int g2 = 0; g2 < G; ++g2) inv[g2] = 1.0f / (float)(3 + g2);
+        for (int64_t i = 0; i < n * Do; ++i) yy[i] = rndf();
+        for (int64_t i = 0; i < n; ++i)
+            for (int d = 0; d < Do; ++d) {
+                volatile float r = inv[gi[i] - 1] * dp[(gi[i] - 1) * Do + d];
+                want[i * Do + d] = yy[i * Do + d] > 0.0f ? r : 0.0f;
+            }
+        void *dgi2 = dev_copy(gi, 8 * n);
+        float *ddp = dev_copy(dp, 4 * G * Do), *dinv = dev_copy(inv, 4 * G), *dyy = dev_copy(yy, 4 * n * Do), *dhave = dev_alloc(4 * n * Do);
+        CHECK_G(gnnmp_pool_grad_act_f32(ddp, dgi2, 8, 1, dinv, dyy, GNNMP_ACT_RELU, dhave, n, G, Do, stream));
+        CHECK_HIP(hipStreamSynchronize(stream));
+        to_host(have, dhave, 4 * n * Do);
+        REQUIRE(memcmp(have, want, 4 * n * Do) == 0, "pool_grad_act differs from the host loop");
+        /* (c) out = relu'(mask) .* (addend + Σ_{j -> i} xj) on the plan: bits of propagate + add + mask on the unsplit rows */
+        float *add = malloc(4 * n * D), *msk = malloc(4 * n * D);
+        for (int64_t i = 0; i < n * D; ++i) { add[i] = rndf(); msk[i] = rndf(); }
+        float *dadd = dev_copy(add, 4 * n * D), *dmsk = dev_copy(msk, 4 * n * D);
+        CHECK_G(gnnmp_propagate_add_mask_f32(plan, GNNMP_SUM, dx, NULL, dadd, dmsk, dout, D, stream));
+        CHECK_HIP(hipStreamSynchronize(stream));
+        to_host(got, dout, 4 * n * D);
+        for (int64_t i = 0; i < n; ++i)
+            for (int f = 0; f < D; ++f) ref[i * D + f] = 0.0f;
+        for (int64_t k = 0; k < E; ++k)
+            for (int f = 0; f < D; ++f) ref[(t[k] - 1) * D + f] = ref[(t[k] - 1) * D + f] + x[(s[k] - 1) * D + f];
+        for (int64_t i = 0; i < n; ++i) {
+            const int len = rowptr[i + 1] - rowptr[i];
+            for (int f = 0; f < D; ++f) {
+                volatile float v = add[i * D + f] + ref[i * D + f];
+                ref[i * D + f] = msk[i * D + f] > 0.0f ? v : 0.0f;
+            }
+            if (len <= thresh) REQUIRE(memcmp(got + i * D, ref + i * D, 4 * D) == 0, "propagate_add_mask row %lld not bit-exact", (long long)i);
+        }
+        REQUIRE(rel_err(got, ref, n * D) <= 1e-5, "propagate_add_mask");
     }
 
     /* ---- error contract: an index outside 1..n is refused with GNNMP_EBOUNDS and a message (convert.jl:47-54) ---- */
