@@ -157,7 +157,7 @@ def test_propagate_on_a_sparse_graph(gm, oracle, aggr):
             assert np.array_equal(ys.cpu().numpy(), ref, equal_nan=True), f.__name__
 
 
-def test_layers_on_a_sparse_graph(gm):
+def test_layers_on_a_sparse_graph(gm, oracle):
     import torch
     rng = np.random.default_rng(9)
     n = 1500
@@ -177,3 +177,22 @@ def test_layers_on_a_sparse_graph(gm):
     gcn = gm.GCNConv((24, 16), "relu", add_self_loops=True, use_edge_weight=True, seed=5)
     y = gcn(gs, x)
     assert torch.isfinite(y).all() and torch.equal(y, gcn(gc, x))
+    # ... and against the ORACLE on findnz(A)'s edge list (not only HIP against HIP): the four layer bodies of conv.jl on a sparse graph
+    xh = x.cpu().numpy()
+
+    def close(got, ref, what):
+        got = got.cpu().numpy()
+        assert np.linalg.norm(got - ref) <= 1e-5 * np.linalg.norm(ref), what
+        assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max(), what
+    l = gm.GCNConv((24, 16), "relu", add_self_loops=False, seed=1)
+    close(l(gs, x), oracle.gcn_conv(s, t, n, xh, l.weight.cpu().numpy(), l.bias.cpu().numpy(), "relu", add_self_loops_=False), "GCNConv")
+    close(y, oracle.gcn_conv(s, t, n, xh, gcn.weight.cpu().numpy(), gcn.bias.cpu().numpy(), "relu", add_self_loops_=True, use_edge_weight=True,
+                             graph_w=v), "GCNConv(use_edge_weight)")
+    l = gm.SAGEConv((24, 16), "relu", seed=2)
+    close(l(gs, x), oracle.sage_conv(s, t, n, xh, l.weight.cpu().numpy(), l.bias.cpu().numpy(), "relu", aggr="mean", blas=False), "SAGEConv")
+    l = gm.GraphConv((24, 16), "relu", seed=3)
+    close(l(gs, x), oracle.graph_conv(s, t, n, xh, l.weight1.cpu().numpy(), l.weight2.cpu().numpy(), l.bias.cpu().numpy(), "relu", aggr="+",
+                                      blas=False), "GraphConv")
+    l = gm.GATConv((24, 8), heads=2, add_self_loops=False, seed=4)
+    close(l(gs, x), oracle.gat_conv(s, t, n, xh, l.dense_x_weight.cpu().numpy(), l.a.cpu().numpy(), l.bias.cpu().numpy(), None, heads=2,
+                                    add_self_loops_=False), "GATConv")
