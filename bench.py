@@ -763,7 +763,7 @@ def main():
             t_ss = layer_time(lambda: sage(g, x), 5)
             extras["sage_products"] = {"E": E, "layer_ms_mean": t_sm, "layer_ms_sum": t_ss,
                                        "edges_per_s_mean": E / t_sm * 1e3, "edges_per_s_sum": E / t_ss * 1e3,
-                                       "placed_buffers": sorted(k[0] for k in getattr(sage, "_placed", {}))}
+                                       "placed_buffers": sorted(k[0] for k, v in getattr(sage, "_placed", {}).items() if v is not None and v is not False)}
             del out_p, out_g, Wx, sage
             # SURVEY §8f "next" rows on the same graph: the standalone neighbourhood softmax (a20) and the training step of the two
             # headline layers (f1: forward + backward through the HIP adjoints)

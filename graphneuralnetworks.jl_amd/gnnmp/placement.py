@@ -206,6 +206,8 @@ def choice_for(layer, tag, shape, avoid, prefer_not=()):
     avoid = list(avoid)
     key = (tag, tuple(shape), tuple(avoid))
     ch = cache.get(key)
+    if ch is False:                 # no class could serve this buffer before: not asked again on every call
+        return None
     if ch is None:
         free = [c for c in range(a.n_classes) if c not in avoid and c not in prefer_not]
         free += [c for c in range(a.n_classes) if c not in avoid and c in prefer_not]
@@ -213,6 +215,7 @@ def choice_for(layer, tag, shape, avoid, prefer_not=()):
             free = [c for c in range(a.n_classes) if c != avoid[0]] or [0]
         bufs = [b for b in (a.alloc(shape, c) for c in free) if b is not None]
         if not bufs:
+            cache[key] = False
             return None
         ch = cache[key] = Choice(bufs)
     return ch
@@ -228,11 +231,12 @@ def buffer_for(layer, tag, shape, avoid):
     free = [c for c in range(a.n_classes) if c not in avoid] or [c for c in range(a.n_classes) if c != avoid[0]] or [0]
     for cls in free:
         key = (tag, tuple(shape), cls)
-        buf = cache.get(key)
-        if buf is None:
-            buf = a.alloc(shape, cls)
-            if buf is None:
-                continue
-            cache[key] = buf
-        return buf, cls
+        if key in cache:
+            buf = cache[key]
+            if buf is None:         # this class could not serve the buffer before: not asked again (a buffer larger than a block costs the
+                continue            # arena three probed allocations to refuse — once, not on every call of the layer)
+            return buf, cls
+        buf = cache[key] = a.alloc(shape, cls)
+        if buf is not None:
+            return buf, cls
     return None, a.n_classes
