@@ -326,6 +326,8 @@ int gnnmp_arena_alloc(gnnmp_arena_t *a, int cls, int64_t bytes, void **ptr) {
         for (auto &b : a->big)
             if (!b.used && b.cls == cls && b.bytes >= bytes && b.bytes <= bytes + (bytes >> 2)) { b.used = true; *ptr = b.p; return GNNMP_OK; }
         if (a->thr <= 0.0f || !a->ref[0]) return fail(GNNMP_EALLOC, "arena_alloc: no class references to classify a %lld-byte buffer", (long long)bytes);
+        // (gnnmp_arena_class_of on foreign memory may have rebuilt the probe's graph for a smaller source range: the threshold belongs to this one)
+        if (int rcp = make_probe_plan(a, (CHUNK / 2) / (PROBE_D * 4), nullptr)) return rcp;
         const int64_t win = CHUNK / 4, nb = (bytes + win - 1) / win * win;
         std::vector<unsigned char *> rejects;
         int rc = GNNMP_EALLOC;
