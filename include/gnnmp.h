@@ -18,8 +18,10 @@
  *     1-based (index_base = 1, Julia) or 0-based (index_base = 0).
  *   - `stream` is a hipStream_t (NULL = the null stream).  Compute entry points launch on it and
  *     return; they never call hipDeviceSynchronize and never allocate (exception: the first use of a
- *     plan with a row longer than GNNMP_LONG_ROW at a larger D than before grows a plan-owned
- *     workspace with hipMalloc).  gnnmp_plan_create synchronises `stream` (it is graph prep, done
+ *     plan with a row longer than GNNMP_LONG_ROW at a larger D than before grows plan-owned scratch
+ *     with hipMalloc: the workspace of the split rows' partials and, since round 5, their slice
+ *     partials and arrival counters — the split rows are folded inside the row kernels by the last
+ *     chunk to arrive, not by a second launch).  gnnmp_plan_create synchronises `stream` (it is graph prep, done
  *     once per graph, outside the timed path).
  *   - a plan carries scratch of its own (the partials of split rows, the tile ticket of the fused layer kernel, cached
  *     orderings): calls that take the SAME plan must be ordered on ONE stream (or by events) — two streams may run
