@@ -760,7 +760,7 @@ def main():
         try:      # side lines only: whatever goes wrong here must not take the bench line (or, at N > 1, the other ranks) with it
             # BASELINE.json config 4: SAGEConv(100 => 256) on the same graph (no self loops), aggr = mean and aggr = +
             sage = gnnmp.SAGEConv((D, 256), "relu", aggr="mean", seed=13)
-            sage.place_outputs = not args.no_placement
+            sage.place_outputs = sage.persistent_out = not args.no_placement   # (aggregate AND output placed: the second is its own opt-in)
             t_sm = layer_time(lambda: sage(g, x), 5)
             sage.aggr = "+"
             t_ss = layer_time(lambda: sage(g, x), 5)

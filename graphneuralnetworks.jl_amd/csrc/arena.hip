@@ -321,8 +321,10 @@ int gnnmp_arena_alloc(gnnmp_arena_t *a, int cls, int64_t bytes, void **ptr) {
         // Larger than a block (SAGEConv's 2.5 GB output on the products shape).  Separate hipMallocs are never adjacent in the address space
         // (measured: 2 GiB + 2 MiB apart), so such a buffer is an allocation of its own, classified where it lies — every 512 MiB window
         // probed against the class references, all windows must agree — and kept if it came out in class `cls`; up to three tries, the
-        // rejects held until the end (freed earlier they would come straight back).  Synchronises (this is set-up: the buffers are
-        // persistent); GNNMP_EALLOC = not today, the caller allocates as usual.
+        // rejects held until the end (freed earlier they would come straight back).  SYNCHRONISES THE DEVICE and holds the arena's lock
+        // for the whole of it (multi-GB hipMallocs + probes: tens of milliseconds) — this is set-up, the buffers are persistent, but a
+        // layer that asks for a placed output (gnnmp.placement / sage_conv's buffer_for) pays it on its FIRST call: gnnmp.h says so.
+        // GNNMP_EALLOC = not today, the caller allocates as usual.
         for (auto &b : a->big)
             if (!b.used && b.cls == cls && b.bytes >= bytes && b.bytes <= bytes + (bytes >> 2)) { b.used = true; *ptr = b.p; return GNNMP_OK; }
         if (a->thr <= 0.0f || !a->ref[0]) return fail(GNNMP_EALLOC, "arena_alloc: no class references to classify a %lld-byte buffer", (long long)bytes);
@@ -330,6 +332,7 @@ int gnnmp_arena_alloc(gnnmp_arena_t *a, int cls, int64_t bytes, void **ptr) {
         if (int rcp = make_probe_plan(a, (CHUNK / 2) / (PROBE_D * 4), nullptr)) return rcp;
         const int64_t win = CHUNK / 4, nb = (bytes + win - 1) / win * win;
         std::vector<unsigned char *> rejects;
+        bool spare_kept = false;
         int rc = GNNMP_EALLOC;
         for (int attempt = 0; attempt < 3 && rc == GNNMP_EALLOC; ++attempt) {
             unsigned char *p = nullptr;
@@ -352,13 +355,18 @@ int gnnmp_arena_alloc(gnnmp_arena_t *a, int cls, int64_t bytes, void **ptr) {
                 a->big.push_back({p, nb, cls, true});
                 *ptr = p;
                 rc = GNNMP_OK;
-            } else if (got >= 0 && got < a->n_classes) {
-                a->big.push_back({p, nb, got, false});       // a pure buffer of another class: somebody may ask for it
+            } else if (got >= 0 && got < a->n_classes && !spare_kept) {
+                // a pure buffer of another class: somebody may ask for it — but at most ONE unused spare is ever retained per arena (the
+                // first version kept every miss until gnnmp_arena_destroy: one 2.5 GB request could pin 7.5 GB)
+                bool have_spare = false;
+                for (const auto &b : a->big) have_spare |= !b.used;
+                if (have_spare) rejects.push_back(p);
+                else { a->big.push_back({p, nb, got, false}); spare_kept = true; }
             } else {
                 rejects.push_back(p);
             }
         }
-        (void)hipDeviceSynchronize();
+        (void)hipDeviceSynchronize();                        // (the probes ran on the null stream; rejects are freed behind them)
         for (unsigned char *p : rejects) (void)hipFree(p);
         if (rc == GNNMP_OK) return GNNMP_OK;
         if (rc != GNNMP_EALLOC) return rc;

@@ -217,6 +217,16 @@ struct Vec<1> {
 // through to the coherence point themselves and leave every other line of the cache alone.  Ordering is then the program's job:
 // coh_publish() waits until this lane's stores have been acknowledged before the arrival counter is bumped, and the consumer reads only
 // through coh_load after it saw the count (a control dependency: no load is issued before the counter's value is back).
+//
+// ARCHITECTURE CONTRACT.  This is outside the HIP memory model (relaxed atomics + a hand-written wait give no release / acquire): it is
+// correct on the ISA of gfx942 / gfx950 ONLY, where (i) s_waitcnt vmcnt(0) also counts STORES (gfx10+ track them in vscnt: the last
+// arriver could fold stale partials there) and (ii) an sc1 access goes through to the device coherence point.  The library therefore
+// refuses to compile its device code for anything else (the Makefile's ARCH is overridable); tests/test_fold_isa.py greps the built
+// code object: the FOLD kernels must contain sc1 loads / stores and no buffer_wbl2 / buffer_inv.  Escape hatches: knob 19 bit 7 or the
+// environment variable GNNMP_NO_FOLD=1 send split rows through the two-kernel path of rounds 1-4 (csr_combine / gat_fused_combine).
+#if defined(__HIP_DEVICE_COMPILE__) && !(defined(__gfx942__) || defined(__gfx950__))
+#error "libgnnmp's cross-workgroup fold (coh_store / coh_load / coh_publish) relies on gfx942 / gfx950 semantics of s_waitcnt vmcnt and sc1; build with ARCH=gfx950"
+#endif
 template <int VEC>
 __device__ __forceinline__ void coh_store(float *p, const float v[VEC]) {
     if (VEC == 1) {
@@ -352,10 +362,18 @@ struct gnnmp_graph {
 namespace gnnmp {
 // make sure plan->ws holds at least `floats` floats (hipMalloc on growth; hipFree waits for in-flight work)
 int ensure_workspace(gnnmp_graph *p, size_t floats);
-// make sure plan->arrive holds at least n zeroed counters and plan->spart at least `floats` floats
+// make sure plan->arrive holds at least n zeroed counters and plan->spart at least `floats` floats.
+// INVARIANT: every arrival counter of a plan is ZERO whenever no compute call on that plan is in flight — the last arriver of a slice /
+// row resets its counter inside the launch that raised it.  It holds as long as (i) a plan is used by one stream at a time (gnnmp.h:
+// the plan's workspace rule — two concurrent launches on one plan would also share `ws` / `spart`) and (ii) every FOLD launch runs to
+// completion.  A launch that is REFUSED (hipGetLastError at the launch site) never touched the counters; a launch that faults on the
+// device poisons the HIP context and with it every later call.  The one remaining way to leave them dirty — a caller breaking (i) — is
+// what gnnmp_plan_reset_counters (gnnmp.h) repairs: a stream-ordered memset of the counters, a few KB.
 int ensure_arrive(gnnmp_graph *p, size_t n, size_t floats, hipStream_t stream);
-// split rows folded inside the row kernels (default) or by the combine kernels of rounds 1-4 (knob 19 bit 7)?
-inline bool use_fold() { return (knob(KNOB_VARIANT) & 128) == 0; }
+// split rows folded inside the row kernels (default) or by the combine kernels of rounds 1-4 (knob 19 bit 7, or GNNMP_NO_FOLD=1 in the
+// environment of the process, read once)?
+bool fold_disabled_by_env();
+inline bool use_fold() { return (knob(KNOB_VARIANT) & 128) == 0 && !fold_disabled_by_env(); }
 // allocate + zero plan->ticket on first use
 int ensure_ticket(gnnmp_graph *p, hipStream_t stream);
 // build plan->row_order on first use

@@ -539,6 +539,7 @@ int gnnmp_pool_grad_act_f32(const float *dpool, const void *graph_indicator, int
     if (idx_bytes != 4 && idx_bytes != 8) return fail(GNNMP_EINVAL, "pool_grad_act: idx_bytes must be 4 or 8");
     if (act != GNNMP_ACT_IDENTITY && act != GNNMP_ACT_RELU) return fail(GNNMP_EINVAL, "pool_grad_act: bad act %d", act);
     if (N < 0 || G < 0 || D <= 0) return fail(GNNMP_EINVAL, "pool_grad_act: bad size");
+    if (G == 0 && N > 0) return fail(GNNMP_EINVAL, "pool_grad_act: %lld rows but no graphs (the kernel reads dpool[0] for a row whose indicator is out of range)", (long long)N);
     if (N == 0) return GNNMP_OK;
     if (!dpool || !graph_indicator || !dz || (act == GNNMP_ACT_RELU && !y)) return fail(GNNMP_EINVAL, "pool_grad_act: null pointer");
     const int64_t n4 = (D % 4 == 0 && ((reinterpret_cast<uintptr_t>(dpool) | reinterpret_cast<uintptr_t>(dz) | reinterpret_cast<uintptr_t>(y)) & 15) == 0)

@@ -63,6 +63,14 @@ int ensure_workspace(gnnmp_graph *p, size_t floats) {
     return GNNMP_OK;
 }
 
+bool fold_disabled_by_env() {
+    static const bool off = [] {
+        const char *e = getenv("GNNMP_NO_FOLD");
+        return e && *e && *e != '0';
+    }();
+    return off;
+}
+
 int ensure_arrive(gnnmp_graph *p, size_t n, size_t floats, hipStream_t stream) {
     if (floats > p->spart_floats) {
         if (p->spart) (void)hipFree(p->spart);   // (waits for in-flight work)
@@ -436,6 +444,15 @@ int gnnmp_debug_pool_pick(const uint64_t *caps, int n, uint64_t bytes) {
 }
 
 int gnnmp_plan_destroy(gnnmp_graph_t *p) { return plan_dispose(p, nullptr, false); }
+
+/* the arrival counters of the in-kernel fold and the fused layer kernel's ticket back to zero, stream-ordered (gnnmp.h: repair hook) */
+int gnnmp_plan_reset_counters(gnnmp_graph_t *p, gnnmp_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!p) return fail(GNNMP_EINVAL, "plan_reset_counters: null plan");
+    if (p->arrive && p->arrive_n) GNNMP_HIP(hipMemsetAsync(p->arrive, 0, sizeof(uint32_t) * p->arrive_n, stream));
+    if (p->ticket) GNNMP_HIP(hipMemsetAsync(p->ticket, 0, 2 * sizeof(uint32_t), stream));
+    return GNNMP_OK;
+}
 
 /* stream-ordered destroy of a pooled plan (gnnmp_plan_concat / gnnmp_plan_select): see gnnmp.h */
 int gnnmp_plan_release(gnnmp_graph_t *p, gnnmp_stream_t stream) { return plan_dispose(p, (hipStream_t)stream, true); }

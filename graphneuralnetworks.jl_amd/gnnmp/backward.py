@@ -124,9 +124,12 @@ def propagate_ad(g: GNNGraph, aggr, xj, w=None):
 # dense part and the whole GCNConv layer
 # ---------------------------------------------------------------------------------------------------------
 def _act_code(sigma):
+    """fused activation code of an adjoint; ValueError (never an `assert`: those vanish under `python -O`) for anything the HIP
+    pullbacks do not cover — treating an unknown σ as identity would hand back silently wrong gradients"""
     from .layers import _act_code as ac
     code, post = ac(sigma)
-    assert post is None, "the HIP adjoint covers identity and relu"
+    if post is not None or code not in (L.ACT_IDENTITY, L.ACT_RELU):
+        raise ValueError(f"the HIP adjoints cover σ = identity and relu, not {sigma!r}")
     return code
 
 
@@ -443,7 +446,8 @@ class _GraphChainFn(torch.autograd.Function):
             r = dense_grad_x(dz, w1)
             u = dense_grad_x(dz, w2)
             code = aggr_code(aggr)
-            assert code in (L.SUM, L.MEAN), "the chain's pullback covers + and mean aggregation"
+            if code not in (L.SUM, L.MEAN):       # (checked before the forward too: graph_chain_ad)
+                raise ValueError("the chain's pullback covers + and mean aggregation")
             sd = None
             if code == L.MEAN:
                 u_scaled = torch.empty_like(u)      # mean: Δm ./ count BEFORE the transposed sum (propagate_grad_xj's order)
@@ -466,8 +470,18 @@ def graph_chain_ad(model, g: GNNGraph, x):
     from .layers import Dense, GlobalPool, GraphConv
     layers = model.layers if hasattr(model, "layers") else list(model)
     convs, pool, head = layers[:-2], layers[-2], layers[-1]
-    assert all(isinstance(c, GraphConv) for c in convs) and isinstance(pool, GlobalPool) and isinstance(head, Dense)
-    assert pool.aggr in ("+", "sum", "mean"), "the pullback covers + and mean pooling"
+    if not (all(isinstance(c, GraphConv) for c in convs) and isinstance(pool, GlobalPool) and isinstance(head, Dense)):
+        raise TypeError("graph_chain_ad takes GNNChain(GraphConv..., GlobalPool, Dense)")
+    # everything the scheduled pullback cannot differentiate is refused BEFORE the forward runs, with a real exception: a late `assert` in
+    # backward (gone under `python -O`) or a dropped relu' mask would mean silently wrong gradients.  Such models train through the
+    # layer-by-layer adjoints (graph_conv_ad / global_pool_ad).
+    if pool.aggr not in ("+", "sum", "mean"):
+        raise ValueError(f"graph_chain_ad: pooling {pool.aggr!r} is outside the chain pullback (+ and mean); use global_pool_ad / the layer adjoints")
+    for c in convs:
+        if aggr_code(c.aggr) not in (L.SUM, L.MEAN):
+            raise ValueError(f"graph_chain_ad: GraphConv aggr {c.aggr!r} is outside the chain pullback (+ and mean); use graph_conv_ad per layer")
+        _act_code(c.sigma)                 # ValueError unless identity / relu
+    _act_code(head.sigma)
     check_num_nodes(g, x)
     params = []
     for c in convs:
@@ -478,7 +492,8 @@ def graph_chain_ad(model, g: GNNGraph, x):
 
 def global_pool_ad(l, g: GNNGraph, x):
     """differentiable GlobalPool(+ | mean) over a batched graph"""
-    assert l.aggr in ("+", "sum", "mean"), "the pullback covers + and mean pooling"
+    if l.aggr not in ("+", "sum", "mean"):
+        raise ValueError(f"global_pool_ad: the pullback covers + and mean pooling, not {l.aggr!r}")
     return _GlobalPoolFn.apply(x, g, "+" if l.aggr == "sum" else l.aggr)
 
 

@@ -316,10 +316,12 @@ def sage_conv(l, g: GNNGraph, x):
     m = _fused(g, L.COPY_XJ, l.aggr, xj, None, out=mb)
     if ch is not None:
         ch.end(tok)
-    # opt-in, end to end: the layer's output too is a persistent arena buffer (a buffer larger than one 2 GiB block — (N, 256) on the
-    # products shape — takes adjacent blocks of one class, gnnmp_arena_alloc), in a class other than the aggregate's
+    # A second, explicit opt-in (`l.persistent_out = True`): the layer's output too is a persistent arena buffer (a buffer larger than one
+    # 2 GiB block — (N, 256) on the products shape — is an allocation of its own, gnnmp_arena_alloc), in a class other than the
+    # aggregate's.  Without it only the INTERNAL aggregate is persistent and the returned tensor is an ordinary allocation: a layer
+    # applied twice, or outputs collected across iterations, must not alias because placement was switched on globally.
     ob = None
-    if mb is not None:
+    if mb is not None and getattr(l, "persistent_out", False):
         ar = placement.arena()
         ob, _ = placement.buffer_for(l, "out", (m.shape[0], W.shape[0]), [ar.class_of(m)])
     return dense(xi, W[:, :Din], l.bias, l.sigma, x2=m, W2=W[:, Din:], out=ob)

@@ -15,7 +15,8 @@ gather from (the output's dirty lines are still being written back while that ke
 The returned tensor is a PERSISTENT buffer of the layer, overwritten by its next call (like the static outputs of a captured graph): that
 is the opt-in.  Results are bit-identical wherever buffers lie.
 
-    gcn = gnnmp.GCNConv(...); gcn.place_outputs = True        # per layer
+    gcn = gnnmp.GCNConv(...); gcn.place_outputs = True        # per layer (the returned tensor aliases the layer's next result!)
+    sage = gnnmp.SAGEConv(...); sage.place_outputs = True     # the internal aggregate only; + sage.persistent_out = True: the output too
     gnnmp.placement.enable(True)                              # or for every GCNConv / GATConv call
     GNNMP_ARENA_GIB=8                                         # bytes per class (default 4 GiB), rounded up to 2 GiB chunks
 """
@@ -33,6 +34,13 @@ MIN_BYTES = 256 << 20          # smaller outputs: the effect is not worth a pers
 
 
 def enable(on=True):
+    """Opt every GCNConv / GATConv / SAGEConv call of the process into placed buffers.
+
+    ALIASING — read before enabling: a placed layer RETURNS a persistent arena buffer of that layer and shape, overwritten by the layer's
+    next call (GCNConv / GATConv: the output IS what placement places).  A layer applied twice in one model, or outputs collected across
+    iterations (`outs.append(layer(g, x))` in an eval loop), alias and are silently overwritten — `.clone()` what must survive the next
+    call, or do not enable placement for that layer.  SAGEConv keeps only its INTERNAL aggregate persistent under this switch; its returned
+    tensor is an ordinary allocation unless the layer sets `persistent_out = True`."""
     _ENABLED[0] = bool(on)
 
 

@@ -812,9 +812,12 @@ end
 function pool_grad_act(Δpool::ROCMatrix{Float32}, gi::ROCVector{I}, inv_count::Union{Nothing, ROCVector{Float32}},
                        y::ROCMatrix{Float32}, σ) where {I <: Union{Int32, Int64}}
     D, N = size(y)
+    code = act_code(σ)
+    # an activation the kernel cannot differentiate is an error, never "identity": that would be a silently wrong gradient
+    code === nothing && throw(ArgumentError("pool_grad_act: σ must be identity or relu (got $(σ)); use the layer-by-layer rules"))
     Δz = similar(y)
     check(@ccall libgnnmp.gnnmp_pool_grad_act_f32(devptr(Δpool)::Ptr{Cvoid}, devptr(gi)::Ptr{Cvoid}, sizeof(I)::Cint, 1::Cint,
-              devptr(inv_count)::Ptr{Cvoid}, devptr(y)::Ptr{Cvoid}, something(act_code(σ), Cint(0))::Cint, devptr(Δz)::Ptr{Cvoid},
+              devptr(inv_count)::Ptr{Cvoid}, devptr(y)::Ptr{Cvoid}, code::Cint, devptr(Δz)::Ptr{Cvoid},
               N::Int64, size(Δpool, 2)::Int64, D::Int64, stream_ptr()::Ptr{Cvoid})::Cint)
     return Δz
 end

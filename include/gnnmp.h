@@ -215,8 +215,12 @@ int gnnmp_plan_edge_index(const gnnmp_graph_t *plan, int idx_bytes, int index_ba
  *                        classes = none of them / mixed / too small to tell / no room left for the probe's output; synchronises
  *   gnnmp_arena_alloc(a, cls, bytes, &ptr)   bump allocation (4 KiB aligned) inside one block of class cls; a buffer LARGER than a block
  *                        (SAGEConv's 2.5 GB output on the products shape) is an allocation of its own, classified where it lies when it
- *                        is asked for (every 512 MiB window probed, all must agree; up to three tries; synchronises — set-up work for a
- *                        persistent buffer); GNNMP_EALLOC when the class cannot serve it (the caller then allocates as usual)
+ *                        is asked for (every 512 MiB window probed, all must agree; up to three tries; SYNCHRONISES THE DEVICE and holds the
+ *                        arena's lock meanwhile — set-up work for a persistent buffer, tens of milliseconds: the arena is NOT a compute
+ *                        entry point and the "never synchronise" rule above does not cover it; a layer that asks for a placed output pays
+ *                        this on its first call only.  At most one unused buffer of another class is retained as a spare, the other
+ *                        misses are freed before the call returns); GNNMP_EALLOC when the class cannot serve it (the caller then
+ *                        allocates as usual)
  *   gnnmp_arena_reset(a)  forget every allocation (the caller knows nothing uses them any more)
  *   gnnmp_arena_info      info[14]: [0] bytes per class asked for [1], [2], [8] bytes used in range 0 / 1 / 2 [3] blocks created while classifying
  *                         [4] released again [5], [6] the probe's microseconds with source and output in one class / in two [7] classes held
@@ -793,6 +797,31 @@ int gnnmp_propagate_add_mask_f32(gnnmp_graph_t *plan, int aggr, const float *xj,
 int64_t gnnmp_dense_grad_workspace(int64_t N, int64_t Dout, int64_t K);
 int gnnmp_dense_grad_w_f32(const float *dz, const float *x, int64_t N, int64_t Dout, int64_t K, float *dW,
                            float *db, float *workspace, int64_t workspace_floats, gnnmp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Repair hook.  The split rows of a plan are folded inside the row kernels through per-plan arrival counters that every launch leaves at
+ * zero (csrc/common.h: ensure_arrive states the invariant and when it holds).  A caller that broke the one-stream-per-plan rule above
+ * — two compute calls on one plan in flight at once — may leave them dirty, and every later result on that plan's split rows would be
+ * wrong.  gnnmp_plan_reset_counters enqueues a memset of the counters (and of the fused layer kernel's tile ticket) on `stream`; a few
+ * KB, no synchronisation, a no-op for a plan without split rows.  Never needed by a caller that keeps the rule.
+ * ---------------------------------------------------------------------------------------------- */
+int gnnmp_plan_reset_counters(gnnmp_graph_t *plan, gnnmp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * GNNMP_INTERNAL — exported, NOT part of the drop-in surface: experiment and test hooks.  Declared here so that C callers (tests/c_harness)
+ * do not declare them by hand; a Julia / C host has no reason to call them, and their meaning may change between builds.
+ *   gnnmp_tune(knob, value)        process-global tuning knobs of the perf experiments (csrc/common.h: enum Knob; every value selects
+ *                                  correct code).  Not thread-safe against concurrent compute calls.
+ *   gnnmp_debug_mock_device(d)     d >= 0: the calling thread's "current device" for the library's per-device tables; d < 0: hipGetDevice
+ *   gnnmp_debug_device_once(...)   runs the once-per-device machinery with a counting stand-in (tests/test_multi_device_cpu.py)
+ *   gnnmp_debug_plan_block(plan)   the pooled block of a gnnmp_plan_concat / gnnmp_plan_select plan (NULL otherwise)
+ *   gnnmp_debug_pool_pick(...)     the block pool's slot choice on host arrays
+ * ---------------------------------------------------------------------------------------------- */
+int gnnmp_tune(int knob, int value);
+int gnnmp_debug_mock_device(int dev);
+int gnnmp_debug_device_once(const int *devs, int n, int fail_on, int *n_failed);
+void *gnnmp_debug_plan_block(const gnnmp_graph_t *plan);
+int gnnmp_debug_pool_pick(const uint64_t *caps, int n, uint64_t bytes);
 
 #ifdef __cplusplus
 }

@@ -18,7 +18,6 @@
 
 #include "gnnmp.h"
 
-int gnnmp_tune(int knob, int value);   /* experiment hook of the library (not part of the drop-in surface, hence not in gnnmp.h) */
 
 #define CHECK_HIP(e)                                                                  \
     do {                                                                              \

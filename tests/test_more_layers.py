@@ -22,6 +22,11 @@ def graph(rng, n, E, hubs=False):
     return s, t
 
 
+# Every layer of this file is held to north_star's 1e-5 (norm-wise, against the oracle's fp32 restatement taken to float64).  Round 5 had
+# 2e-5 at seven sites — GatedGraphConv, DConv, EGNNConv (two outputs), ChebConv, Set2Set; round 6 runs them at 1e-5 as well.
+TOL_DEEP = 1e-5
+
+
 def rel(a, b):
     return np.linalg.norm(np.asarray(a, np.float64) - b) / max(np.linalg.norm(b), 1e-30)
 
@@ -231,7 +236,7 @@ def test_hip_gated_graph_conv_vs_oracle(gm, ML, Din, dims, layers, aggr):
     y = l(g, dev(x)).cpu().numpy()
     ref = ML.gated_graph_conv(s, t, n, x, w, Wi, Wh, b, aggr)
     assert y.shape == ref.shape == (n, dims)
-    assert rel(y, ref.astype(np.float64)) < 2e-5
+    assert rel(y, ref.astype(np.float64)) < TOL_DEEP
 
 
 @pytest.mark.gpu
@@ -249,7 +254,7 @@ def test_hip_d_conv_vs_oracle(gm, ML, Din, Dout, k, weighted):
     l.weights, l.bias = dev(W), dev(b)
     y = l(g, dev(x)).cpu().numpy()
     ref = ML.d_conv(s, t, n, x, W, b, k, ew)
-    assert rel(y, ref.astype(np.float64)) < 2e-5
+    assert rel(y, ref.astype(np.float64)) < TOL_DEEP
 
 
 def test_oracle_nn_conv_vs_float64_edge_loop(oracle, ML):
@@ -383,8 +388,8 @@ def test_hip_egnn_conv_vs_oracle(gm, ML, nin, ein, out, hid, residual):
     c = lambda ch: [(W.cpu().numpy(), None if b is None else b.cpu().numpy(), a_) for W, b, a_ in ch]
     rh, rx = ML.egnn_conv(s, t, n, h, x, e, c(l.phi_e), c(l.phi_x), c(l.phi_h), residual)
     assert hn.shape == rh.shape == (n, out) and xn.shape == rx.shape == (n, 3)
-    assert rel(hn.cpu().numpy(), rh.astype(np.float64)) < 2e-5
-    assert rel(xn.cpu().numpy(), rx.astype(np.float64)) < 2e-5
+    assert rel(hn.cpu().numpy(), rh.astype(np.float64)) < TOL_DEEP
+    assert rel(xn.cpu().numpy(), rx.astype(np.float64)) < TOL_DEEP
 
 
 def test_oracle_egnn_conv_vs_float64_edge_loop(oracle, ML):
@@ -463,7 +468,7 @@ def test_hip_cheb_conv_vs_oracle(gm, ML, Din, Dout, k, weighted):
     from gnnmp.layers_more import scaled_laplacian_op
     lam = scaled_laplacian_op(g)[3]
     assert lam == pytest.approx(ML.scaled_laplacian_dense(s, t, n, ew)[1], rel=2e-6)      # Lanczos vs LAPACK
-    assert rel(y, ref.astype(np.float64)) < 2e-5
+    assert rel(y, ref.astype(np.float64)) < TOL_DEEP
     with pytest.raises(AssertionError):
         gm.ChebConv((Din, Dout), 2)(gm.GNNGraph(dev(s[:50]), dev(t[:50]), num_nodes=n), dev(x))     # directed / isolated
 
@@ -489,4 +494,4 @@ def test_hip_set2set_pool_vs_oracle(gm, ML, n_in, iters, G):
     gi = np.repeat(np.arange(1, G + 1), sizes)
     ref = ML.set2set_pool(gi, G, x, l.Wi.cpu().numpy(), l.Wh.cpu().numpy(), l.b.cpu().numpy(), iters)
     assert y.shape == ref.shape == (G, 2 * n_in)
-    assert rel(y, ref.astype(np.float64)) < 2e-5
+    assert rel(y, ref.astype(np.float64)) < TOL_DEEP
