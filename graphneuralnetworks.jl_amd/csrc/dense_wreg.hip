@@ -11,7 +11,7 @@
 // stage as whole 128-byte lines.  Non-finite operands: NaN accumulators, the tile is redone by fp32 fma loops afterwards (msplit.h).
 // Same products in the same order as dense_split_kernel: the results are bit-identical to it (tests/test_dense_split.py).
 //
-// Measured on MI355X at 2.4 M x (100 + 100) => 256 (tools/dense_wreg_ab.py, both kernels interleaved on one box): 1.43-1.50 ms against
+// Measured on MI355X at 2.4 M x (100 + 100) => 256 (tools/experiments/dense_wreg_ab.py, both kernels interleaved on one box): 1.43-1.50 ms against
 // 1.55-1.63 ms.  What the time is made of (s_memtime stamps per wave and phase, round 4):
 //   * a tile costs ~7900 shader cycles a SIMD where its 156 MFMAs need 5000: the ~440 other instructions a wave issues per tile (39 LDS
 //     reads + waits, the split of its two units of the next tile, the epilogue, addresses) only partly fit in the gaps between MFMAs;
@@ -229,7 +229,7 @@ int dense_wreg_try(const float *x1, const float *W1, int64_t D1, int64_t ldw1, c
     // Instantiated for the layer widths of the reference's examples and benchmarks (64, 100, 128 per segment; one segment up to 256): the
     // W planes of a wave's 32 columns take 12 VGPRs per 16 positions of the concatenated K — 96 (K = 128) to 192 (K = 256) of the 256 a
     // wave has at two waves a SIMD.  K = 228 and 256 (100 + 128, 128 + 128, 256) were compiled too and spill 22-34 registers: left to
-    // dense_split's LDS-resident W, like every other shape (return 1).  Measured at N = 2.4 M, => 256 (tools/dense_wreg_ab.py, one box,
+    // dense_split's LDS-resident W, like every other shape (return 1).  Measured at N = 2.4 M, => 256 (tools/experiments/dense_wreg_ab.py, one box,
     // microseconds, this kernel / dense_split): 100+100 1439 / 1578, 64+64 1006 / 1200, 64+100 1326 / 1626, 128+64 1514 / 1701, 200 1572 /
     // 1670 — and one segment of K <= 128 the other way round (64: 699 / 679, 100: 922 / 871, 128: 988 / 969: not instantiated); at
     // N = 5 000 the eight-wave blocks are too few (31 / 18): from 32 768 rows on.  Bit-identical to dense_split on every shape.

@@ -578,7 +578,7 @@ __global__ void __launch_bounds__(PK_THREADS) chain_pack_kernel(const PackArgs a
     __shared__ int32_t wcnt[PK_WAVES][PACK_ROWS + 1];       // per wave: graphs of each size in its range, then the running output position
     __shared__ int32_t flags[2];                             // largest size seen, graphs without a node
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // phase stamps (100 MHz wall clock) in hdr[16..]: tools/pack_phases.py
+    // phase stamps (100 MHz wall clock) in hdr[16..]: tools/experiments/pack_phases.py
     long long *stamp = reinterpret_cast<long long *>(a.hdr + 16);
 #define PK_STAMP(i) do { if (tid == 0) stamp[i] = (long long)wall_clock64(); } while (0)
     PK_STAMP(0);
@@ -812,7 +812,7 @@ extern "C" int gnnmp_chain_jobs_create(gnnmp_chain_jobs_t **out, const int64_t *
     if (njobs > 0) {
         // one device block for the job table, the set-aside list and the z rows; a training loop builds a handle per batch, so freed
         // blocks are parked and handed out again (jobs_block_take) instead of three hipMalloc + three hipFree (each a device-wide
-        // synchronisation) per batch.  (tools/batched_prep.py: the create is ~0.37 ms at G = 8192 — the copy of seg_ptr to the host,
+        // synchronisation) per batch.  (tools/experiments/batched_prep.py: the create is ~0.37 ms at G = 8192 — the copy of seg_ptr to the host,
         // the packing, the upload of the table; 0.8 ms while the packing sorted and kept a vector per job.)
         const size_t bytes = tab.size() * sizeof(int32_t);
         const size_t off_bad = (bytes + 255) & ~(size_t)255;

@@ -1,6 +1,6 @@
 """Placement-aware output buffers for the gather kernels of the hot path (opt-in) — the host side of csrc/arena.hip.
 
-Measured on MI355X (tools/placement_probe.py, placement_map*.py, vmm_probe.py; profiles/README.md, round 4): the 288 GB of HBM3E fall into three
+Measured on MI355X (tools/experiments/placement_probe.py, placement_map*.py, vmm_probe.py; profiles/README.md, round 4): the 288 GB of HBM3E fall into three
 placement classes of 96 GiB of physical memory each.  The one-pass attention kernel and the fused GCN layer kernel (~27 random row reads
 per row written) run 6 % slower when the gathered matrix and the output lie in the SAME class than when they lie in two — 5.15 vs 4.84 ms
 and 4.94 vs 4.66 ms on the products shape; same binary, same data, same predecessors on the stream.  hipMalloc (and so torch's allocator)

@@ -26,7 +26,7 @@ CMD="python $REPO/tools/small_configs.py batched"
 run batched_kernel_stats --kernel-trace --stats
 CMD="python $REPO/tools/small_configs.py sage noplace"
 run sage_kernel_stats --kernel-trace --stats
-CMD="python $REPO/tools/batched_newbatch.py 8192 100"
+CMD="python $REPO/tools/experiments/batched_newbatch.py 8192 100"
 run newbatch_kernel_stats --kernel-trace --stats
 CMD="python $REPO/tools/backward_bench.py"
 run backward_kernel_stats --kernel-trace --stats
