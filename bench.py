@@ -59,7 +59,18 @@ def compulsory_bytes(N, Ep, D_in, D_out):
     return 4 * N * D_in + 4 * N * D_out + 4 * Ep + 4 * (N + 1)
 
 
-def cpu_baseline(products_graph=None):
+def mem_available_gib():
+    try:
+        with open("/proc/meminfo") as f:
+            for line in f:
+                if line.startswith("MemAvailable:"):
+                    return int(line.split()[1]) / (1 << 20)
+    except OSError:
+        pass
+    return 0.0
+
+
+def cpu_baseline(products_graph=None, full_gat=False):
     """The reference's algorithm (oracle port), single thread, on the paths the reference takes with CPU arrays: GCNConv through
     the SpMM fast path (COO -> CSC rebuild + CSC sweep per call, msgpass.jl:215-238), GATConv through gather -> message ->
     scatter with materialised (D, E') temporaries.  Sample: both layers of the bench step once on a 1/32-scale products-shaped
@@ -95,19 +106,25 @@ def cpu_baseline(products_graph=None):
         t2 = time.perf_counter()
         orc.gcn_conv(s, t, N, x, W, b, "relu", fast_path=False)     # the generic path for GCN too (what its GPU ext does)
         t3 = time.perf_counter()
-        full = None
+        full = full_a = None
         if products_graph is not None:
             sf, tf, xf = products_graph
             t4 = time.perf_counter()
             orc.gcn_conv(sf, tf, xf.shape[0], xf, W, b, "relu", fast_path=True)
             full = time.perf_counter() - t4
-        return t1 - t0, t2 - t1, t3 - t2, full
+            # --cpu-baseline-full: the GAT leg at full size too.  The reference's path materialises Wxi, Wxj and β
+            # as (C, H, E') arrays — 3 x 33 GB here, plus the softmax temporaries — so it runs only on a host with the memory for it.
+            if full_gat and mem_available_gib() >= 256.0:
+                t5 = time.perf_counter()
+                orc.gat_conv(sf, tf, xf.shape[0], xf, Wd, a, ba, "relu", heads=H)
+                full_a = time.perf_counter() - t5
+        return t1 - t0, t2 - t1, t3 - t2, full, full_a
 
     if threadpool_limits is not None:
         with threadpool_limits(limits=1):
-            tg, ta, tgg, tfull = run()
+            tg, ta, tgg, tfull, tfull_a = run()
     else:
-        tg, ta, tgg, tfull = run()
+        tg, ta, tgg, tfull, tfull_a = run()
     out = {
         "value": 2 * Ep / (tg + ta), "unit": "edges/s", "cores": 1, "kind": "port", "cpu_model": host_cpu_model(),
         "host_cores": os.cpu_count(),
@@ -121,6 +138,12 @@ def cpu_baseline(products_graph=None):
     if tfull:
         Epf = len(products_graph[0]) + products_graph[2].shape[0]
         out["gcn_full_products"] = {"E_prime": Epf, "seconds": tfull, "edges_per_s": Epf / tfull}
+        if tfull_a:
+            out["gat_full_products"] = {"E_prime": Epf, "seconds": tfull_a, "edges_per_s": Epf / tfull_a}
+            out["full_products_value"] = {"edges_per_s": 2 * Epf / (tfull + tfull_a),
+                                          "what": "both layers of the step once at FULL size on one core: the identical workload to `value`"}
+        elif full_gat:
+            out["gat_full_products"] = {"skipped": f"MemAvailable {mem_available_gib():.0f} GiB < 256 GiB (the path materialises ~110 GB of (C,H,E') temporaries)"}
     try:
         # a fair "best CPU" line — OpenMP CSR aggregation on every host core, CSR built once (NOT the
         # reference's algorithm: its CPU propagate is single-threaded)
@@ -460,6 +483,9 @@ def main():
                     help="products (default, the BASELINE.json metric) | arxiv | batched (config 5: 8192 graphs sharded "
                          "by graph across the ranks, one RCCL all-gather of logits per step; strong scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-full", action="store_true",
+                    help="also time the GATConv leg of the CPU baseline once at FULL products size (~40 s of one core and ~110 GB of host "
+                         "memory for the reference path's (C,H,E') temporaries; skipped below 256 GiB available)")
     ap.add_argument("--no-extras", action="store_true", help="skip the side measurements (other configs, 8d protocol)")
     ap.add_argument("--no-placement", action="store_true", help="fresh output allocations per layer call instead of gnnmp.placement's persistent, placement-tuned buffers")
     args = ap.parse_args()
@@ -540,6 +566,8 @@ def main():
     # output buffer whose placement they found fastest by timing themselves on three candidates.  --no-placement: fresh allocations per
     # call, the mode is then whatever the allocator hands out (the r3 behaviour).
     gcn.place_outputs = gat.place_outputs = not args.no_placement
+
+    x_plain = x                # the features as torch's allocator placed them (extras.value_without_arena)
 
     def step():
         y1 = gcn(g, x)
@@ -658,7 +686,48 @@ def main():
         if traffic:   # L2->fabric bytes actually requested per second (Infinity-Cache hits included): what the memory system serves
             r["traffic_GBs"] = traffic / k["ms"] / 1e6
             r["traffic_frac"] = r["traffic_GBs"] / HBM_PEAK_GBS
+        # WHAT THESE NUMBERS ARE.  `achieved` = ALGORITHMIC bytes / time priced against the 8 TB/s HBM
+        # spec.  `traffic` = L2->fabric request bytes (TCC_EA0_RDREQ x 128 B + WRITE_SIZE): requests the 256 MiB Infinity Cache serves
+        # are IN it — no counter of this rocprofv3 sees behind the Infinity Cache (rocprofv3 -L on gfx950: TCC_EA0_* only; there is no
+        # MALL / DF / UMC counter) — so neither figure is "HBM bytes", and frac_of_achievable can exceed 1 (a streaming copy has no
+        # Infinity-Cache hits, a gather of power-law sources has).  `hbm_bytes_est` is the model estimate of what DRAM serves.
+        r["semantics"] = {"achieved": "algorithmic bytes per second (SURVEY.md 8d), not a measured HBM rate",
+                          "traffic": "L2->fabric request bytes per launch, Infinity-Cache hits INCLUDED (not HBM bytes)",
+                          "frac_of_achievable": "algorithmic GB/s over the 6.29 TB/s a streaming copy reaches; > 1 only because Infinity-Cache hits never reach HBM"}
+        if traffic and name in mall:
+            m = mall[name]
+            rd = src_rw[name][0] if name in src_rw else traffic
+            wr = traffic - rd
+            est = rd * (1.0 - m["hit_share_upper_bound"]) + wr
+            r["hbm_bytes_est"] = int(est)
+            r["hbm_bytes_est_method"] = {
+                "what": "read traffic x (1 - h) + write traffic, h = share of the row gathers that go to the hottest source rows that fit "
+                        "the 256 MiB Infinity Cache (perfect-LFU bound from this graph's out-degree histogram): an UPPER bound on the hit "
+                        "rate, hence a LOWER estimate of HBM bytes; the truth lies between hbm_bytes_est and traffic",
+                "rows_resident": m["rows_resident"], "row_bytes": m["row_bytes"], "hit_share_upper_bound": m["hit_share_upper_bound"],
+                "evidence": "profiles/r06_mall_sweep.txt: the bare row gather by working set (64 MB .. 2 GB)"}
+            r["hbm_GBs_est"] = est / k["ms"] / 1e6
+            r["hbm_frac_est"] = r["hbm_GBs_est"] / HBM_PEAK_GBS
         return r
+
+    # Infinity-Cache residency model for the two gathered matrices: sources by decreasing out-degree (+1 for the self loop), as many rows
+    # as fit 256 MiB, the share of all gathers they serve
+    mall, src_rw = {}, {}
+    try:
+        outdeg = torch.bincount(sd - 1, minlength=N).to(torch.float64) + 1.0
+        srt, _ = torch.sort(outdeg, descending=True)
+        cum = torch.cumsum(srt, 0)
+        for name, row_bytes in (("gcn_fused_layer", 4 * D), ("gat_aggregate", 4 * H * C)):
+            rows = min(N, (256 << 20) // row_bytes)
+            mall[name] = {"rows_resident": int(rows), "row_bytes": row_bytes, "hit_share_upper_bound": float(cum[rows - 1] / cum[-1])}
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            _doc = json.load(f).get(args.workload, {})
+        for name, kn in (("gcn_fused_layer", "fused_conv_kernel"), ("gat_aggregate", "gat_fused_rows_kernel")):
+            if kn in _doc:
+                src_rw[name] = (_doc[kn]["hbm_read_bytes"], _doc[kn]["hbm_write_bytes"])
+        del outdeg, srt, cum
+    except Exception as e:   # the model is a side figure: never at the price of the line
+        log(f"[bench] Infinity-Cache model skipped: {e!r}")
 
     step_kernels = [k for k in kern if k != "gcn_propagate"]
     dom = max(step_kernels, key=lambda k: kern[k]["ms"])
@@ -705,7 +774,20 @@ def main():
         gcn.place_outputs = gat.place_outputs = False
         extras["placement"]["gcn_layer_ms_fresh_allocations"] = layer_time(lambda: gcn(g, x), 5)
         extras["placement"]["gat_layer_ms_fresh_allocations"] = layer_time(lambda: gat(g, x), 5)
+        # the SAME timed region with nothing placed: features where torch's allocator put them, fresh output allocations per layer call —
+        # what a caller gets who does not opt into gnnmp.placement / gnnmp_arena_* (the headline depends on the arena)
+        def step_plain():
+            return gcn(g, x_plain), gat(g, x_plain)
+        for _ in range(args.warmup):
+            step_plain()
+        dt_plain, _ = timed_region(step_plain, args.steps, 0, barrier, dist)
+        extras["value_without_arena"] = {"value": world * 2 * Ep / (dt_plain / args.steps), "unit": "edges/s",
+                                         "ms_per_step": dt_plain / args.steps * 1e3, "steps": args.steps,
+                                         "what": "the step of `value` with placement off: x in an ordinary allocation, fresh outputs per call"}
         gcn.place_outputs = gat.place_outputs = True
+    else:
+        extras["value_without_arena"] = {"value": value, "unit": "edges/s", "ms_per_step": ms_per_step, "steps": args.steps,
+                                         "what": "--no-placement: `value` itself is the un-placed figure"}
     extras["gcn_layer_edges_per_s"] = Ep / extras["gcn_layer_ms"] * 1e3
     extras["gat_layer_edges_per_s"] = Ep / extras["gat_layer_ms"] * 1e3
     if not args.no_extras:
@@ -866,7 +948,7 @@ def main():
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            result["cpu_baseline"] = cpu_baseline((s, t, x_host) if keep_host else None)
+            result["cpu_baseline"] = cpu_baseline((s, t, x_host) if keep_host else None, full_gat=args.cpu_baseline_full)
             ref = julia_reference_baseline()
             if ref is not None and "value" in ref:      # the reference itself ran here: it is the baseline, the port stays next to it
                 ref["port"] = {k: result["cpu_baseline"][k] for k in ("value", "unit", "cores", "sample")}
