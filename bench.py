@@ -561,7 +561,7 @@ def main():
     torch.cuda.synchronize()
     norm_cache_ms = (time.perf_counter() - t0) * 1e3
 
-    # Output placement (gnnmp/placement.py): both gather kernels run 6 % faster or slower depending on where the
+    # Output placement (gnnmp/placement.py, LABNOTES.md §5 round 4): both gather kernels run 6 % faster or slower depending on where the
     # gathered matrix and the output lie relative to each other in device memory (same binary, same data); the layers keep a persistent
     # output buffer whose placement they found fastest by timing themselves on three candidates.  --no-placement: fresh allocations per
     # call, the mode is then whatever the allocator hands out (the r3 behaviour).

@@ -46,7 +46,7 @@ __global__ void __launch_bounds__(256) edge_dot_kernel(const float *a, const flo
 
 // The same dot products in the plan's destination-sorted order: the destination row a[i] is loaded once per row (per
 // chunk for split rows) and stays in registers, only b[col_p] is gathered per edge — half the traffic of the COO-order
-// kernel above (measured 12.0 -> see DESIGN.md).  Results are written back in ORIGINAL edge order through eid.
+// kernel above (measured 12.0 -> 6.6 ms, LABNOTES.md §7).  Results are written back in ORIGINAL edge order through eid.
 struct EdgeDotRowsArgs {
     const uint32_t *rowptr;
     const int32_t *col, *eid;

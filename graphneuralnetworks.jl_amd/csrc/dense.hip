@@ -288,7 +288,7 @@ __global__ void __launch_bounds__(512) dense_wlds_kernel(const DenseWArgs w) {
             const float *__restrict__ x = a.x[seg] + m0 * K;
             const bool vec = rows == 32 && (K & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
             // The 32 x K tile goes through the wave's region in k-chunks of w.ks columns (w.ks = K when the whole image
-            // fits; smaller chunks buy the LDS for two waves per SIMD — measured 148 -> see DESIGN.md on the arxiv shape).
+            // fits; smaller chunks buy the LDS for two waves per SIMD — measured 148 -> see LABNOTES.md on the arxiv shape).
             for (int kc0 = 0; kc0 < Kp; kc0 += w.ks) {
                 const int kcn = min(w.ks, K - kc0);          // real columns in this chunk (may be odd at the tail)
                 const int kcp = min(w.ks, Kp - kc0);         // even number of k-steps' worth
@@ -597,7 +597,7 @@ extern "C" int gnnmp_dense_f32(const float *x1, const float *W1, int64_t D1, int
     a.Dout = (int)Dout;
     // W-resident kernel when W^T (for one column tile) plus the wave regions fit the 160 KB LDS.  The column tile is 128
     // wide unless that leaves room for only 4 waves (K1 + K2 around 256): then 64-wide tiles — x is staged twice, but 8
-    // waves (two per SIMD) overlap one wave's staging with the other's MFMAs (GraphConv 128 => 128: see DESIGN.md).
+    // waves (two per SIMD) overlap one wave's staging with the other's MFMAs (GraphConv 128 => 128: see LABNOTES.md).
     {
         const int k0p = ((int)D1 + 1) & ~1, k1p = ((int)D2 + 1) & ~1;
         const int ktot = k0p + (D2 > 0 ? k1p : 0);

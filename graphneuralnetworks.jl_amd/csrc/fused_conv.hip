@@ -16,13 +16,14 @@
 //      W1 * x_i, by 16-byte loads of x_i straight from HBM), A operands from the W image; bias + activation on the
 //      accumulators; one 16-byte store per accumulator to the output row.
 // No workgroup barrier after the image is built; the only cross-lane hand-off is inside a wave (LDS tile).  The kernel stays
-// bound by the row gather (cache-line requests: DESIGN.md section 5): the MFMA phase of a tile (175 MFMAs = 5 600 cycles at
+// bound by the row gather (cache-line requests: DESIGN.md §5, LABNOTES.md §5): the MFMA phase of a tile (175 MFMAs = 5 600 cycles at
 // 100 => 100) is ~5 % of the tile's gather time and overlaps with the other waves' gathers.  Used by default only where it
 // removes an HBM round trip (aggregate >= 128 MiB) and there is no root term: see gnnmp_fused_conv_f32 below.
 #include <algorithm>
 
 #include "csr_reduce.h"
 #include "mfma16.h"
+#include "msplit.h"
 
 namespace gnnmp {
 
@@ -205,6 +206,380 @@ static int dispatch_fused(FusedArgs &a, int op, bool scaled, size_t img_bytes, h
     }
 }
 
+
+// =====================================================================================================================================
+// fused_cat_kernel (round 6) — sage_conv / graph_conv with a ROOT term and 256 outputs in one kernel (BASELINE.json config 4:
+// SAGEConv(100 => 256) on the products shape):   σ.(W * vcat(x_i, aggr_j x_j) .+ b)   GNNlib/src/layers/conv.jl:277-283,102-108
+// The two-kernel path writes the (N, 100) aggregate (0.98 GB) and reads it back in the contraction; here it never leaves the CU.
+// fused_conv_kernel above cannot take this layer: 200 x 256 weights are 205 KB in fp32 and 307 KB as three bf16 planes — more than LDS.
+//   * persistent block per CU, 12 waves; each WAVE takes 32-row tiles (7/8 static, 1/8 by ticket, as above) and
+//     1. walks the 32 destination rows exactly like csr_rows_kernel (reduce_range: the aggregate is BIT-IDENTICAL to gnnmp_propagate_f32)
+//        into a wave-private 32 x K1 fp32 LDS tile (stride K1 = 100 floats: 100 = 36 mod 64 banks, the later ds_read_b128 of 16 rows are
+//        conflict-free without padding — 12.8 KB a wave, 12 waves = 154 KB);
+//     2. contracts [x_i | m_i] (x_i straight from HBM, 16 bytes per lane and k-piece; m_i from the tile) with W on the bf16 matrix core in
+//        the exact three-plane split of msplit.h — six v_mfma_f32_32x32x16_bf16 per product — in two passes of 128 output columns
+//        (64 accumulator registers).  W is NOT resident anywhere near the wave: its three planes, pre-split once per call into MFMA operand
+//        order (fused_cat_wimg_kernel: 312 KB), are streamed from L2 — one coalesced 1 KB load per (k-block, 32 columns, plane), a ring
+//        of three units in flight ahead of the MFMAs.  Every wave of the chip re-reads the same 312 KB per tile: L2 hits (the image is
+//        touched every few hundred ns, the gather stream turns an L2 over every ~4 us), ~5 TB/s of L2 -> L1 traffic beside the gather.
+//        The node rows are the MFMA's A operand and W its B operand, so a lane ends up with ONE output column of 16 nodes: a store
+//        instruction writes two whole 128-byte lines of the output, no LDS staging.
+//   * non-finite operands (the -Inf of an empty max aggregation, Inf / NaN features) turn a tile's accumulators NaN (msplit.h): that
+//     half-tile is recomputed by plain fp32 fma loops (cold, out of line).
+// The m-part of the contraction (k-blocks from the LDS tile) runs first: the x_i pieces of the first three k-blocks are requested at the
+// start of the phase and arrive behind it.
+//
+// MEASURED (MI355X, products shape, SAGEConv(100 => 256, relu; mean), one box, tools/experiments/sage_fused_ab.py): the kernel is CORRECT
+// (tests/test_fused_conv.py: aggregate bit-identical, output 8e-7 of the two-kernel path) and LOSES — 6.85 ms (12 waves) / 7.42 ms (8 waves)
+// against 5.77-5.82 ms for csr_rows_kernel + dense_wreg_kernel — so it is off by default (knob 14 > 0 runs it).  Ablations (knob 13), ms:
+//                                    12 waves    8 waves
+//     whole kernel                     6.85        7.42
+//     no contraction (gather + tile)   4.55        4.42      <- the gather phase alone is AT the fetch ceiling (csr_rows_kernel: 4.50),
+//     no gather (contraction + store)  2.69        3.08         with a third of csr_rows_kernel's waves: eight 8-lane groups per wave, each
+//     neither                          0.30        0.26         pulling the tile's next row when done (the first version walked two rows at a
+//     no stores                        6.43        6.98         time like csr_rows_kernel: 6.8 / 7.9 ms, gather-bound)
+// The phases ADD UP.  A wave-tile streams the whole 312 KB image through its CU's vector-memory path: 2 496 line requests per 32 rows next
+// to the gather's ~3 400 (840 edges x 4 lines) — L2 hits, but they queue where the gather's misses queue, and the gather is bound by exactly
+// that per-CU request capacity (LABNOTES.md: the line-request wall; profiles/r06_mall_sweep.txt: the rate follows the latency, 58 G
+// lines/s from the Infinity Cache, 50 from HBM).  A fused SAGE layer therefore needs W resident on the CU — 307 KB of planes do not fit
+// 160 KB of LDS, and in registers (dense_wreg's 156 per wave, eight waves) they leave the same eight waves no room to gather.  What fusing
+// could save at best is the aggregate's round trip: ~200 of ~4 000 line requests per 32 rows (5 %), 0.25 ms.
+constexpr int FC2_ROWS = 32;
+
+struct FusedCatArgs {
+    ReduceArgs r;
+    const float *agg_long;
+    float *agg_out;
+    const float *xi;          // [n_rows][K0]
+    const u32x4 *wimg;        // [NH][NKB][4][3][64] operand units (fused_cat_wimg_kernel)
+    WCat w;                   // the raw weights (exact path only)
+    const float *bias;
+    int act;
+    float *out;               // [n_rows][Dout]
+    int Dout, NH;
+    uint32_t *ticket;
+    int dbg;                  // knob 13 (experiments only): 1 = skip the contraction, 2 = skip the gather, 4 = skip the stores
+};
+
+// W (Dout x (K0 + K1), two blocks) -> the three bf16 planes of every (128-column half, k-block, 32-column block) in MFMA operand order:
+// lane (f, h) of a unit holds W(128 half + 32 cb + f, 16 kb + 8 (e >> 2) + 4 h + (e & 3)), e = 0..7 (msplit.h's element order)
+template <int K0, int K1>
+__global__ void __launch_bounds__(64) fused_cat_wimg_kernel(const WCat w, int Dout, u32x4 *img) {
+    constexpr int NKB = (K0 + K1 + 15) / 16, KCAT = K0 + K1;
+    const int t = blockIdx.x, lane = threadIdx.x;
+    const int cb = t & 3, kb = (t >> 2) % NKB, half = (t >> 2) / NKB;
+    const int f = lane & 31, h = lane >> 5;
+    const int j = 128 * half + 32 * cb + f;
+    float4 q[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int c = 16 * kb + 4 * h + 8 * u;
+        q[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (c < KCAT && j < Dout) q[u] = make_float4(wcat_at(w, j, c), wcat_at(w, j, c + 1), wcat_at(w, j, c + 2), wcat_at(w, j, c + 3));
+    }
+    const Split8 s8 = split8(q[0], q[1]);
+    img[((size_t)t * 3 + 0) * 64 + lane] = s8.p0;
+    img[((size_t)t * 3 + 1) * 64 + lane] = s8.p1;
+    img[((size_t)t * 3 + 2) * 64 + lane] = s8.p2;
+}
+
+// the exact path of one half-tile (cold): lane (j, h) recomputes its 4 x 16 outputs with fp32 fma chains in c order and stores them
+__device__ __forceinline__ void fused_cat_exact(const WCat w, const float *xi, const float *tile, int K0, int K1, int col0, int row0,
+                                             int n_rows, const float *bias, int act, float *out, int Dout, int lane) {
+    const int j = lane & 31, h = lane >> 5;
+#pragma unroll 1
+    for (int i = 0; i < 64; ++i) {
+        const int cb = i >> 4, r = i & 15;
+        const int col = col0 + 32 * cb + j;
+        const int node = 8 * (r >> 2) + 4 * h + (r & 3);
+        const int row = row0 + node;
+        if (row >= n_rows || col >= Dout) continue;
+        float s = 0.0f;
+#pragma unroll 1
+        for (int c = 0; c < K0; ++c) s = fmaf(wcat_at(w, col, c), xi[(int64_t)row * K0 + c], s);
+#pragma unroll 1
+        for (int c = 0; c < K1; ++c) s = fmaf(wcat_at(w, col, K0 + c), tile[node * K1 + c], s);
+        float v = s + (bias ? bias[col] : 0.0f);
+        if (act == GNNMP_ACT_RELU) v = v < 0.0f ? 0.0f : v;
+        out[(int64_t)row * Dout + col] = v;
+    }
+}
+
+// NW waves a block (12 = what LDS holds tiles for: 3 a SIMD, 168 registers; 8 = 2 a SIMD, 256 registers), RD = W units / x_i k-blocks in
+// flight, U = row loads in flight per lane group in the gather phase
+template <int K0, int K1, int OP, bool SCALED, int NW, int RD, int U>
+__global__ void __launch_bounds__(64 * NW) fused_cat_kernel(const FusedCatArgs a) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    constexpr int FC2_WAVES = NW;
+    constexpr int NKB = (K0 + K1 + 15) / 16;
+    constexpr int KBX = K0 / 16;                      // k-blocks that lie entirely in x_i
+    static_assert((K0 & 3) == 0 && (K1 & 3) == 0 && K1 <= 128, "segments are multiples of 4; the aggregate row fits one lane group");
+    const ReduceArgs &r = a.r;
+    float *tiles = reinterpret_cast<float *>(lds_raw);                       // [FC2_WAVES][32][K1]
+    float *biasl = tiles + FC2_WAVES * FC2_ROWS * K1;                        // [Dout]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < a.Dout; i += 64 * FC2_WAVES) biasl[i] = a.bias ? a.bias[i] : 0.0f;
+    __syncthreads();
+
+    const int lane = tid & 63, wave = tid >> 6;
+    float *tile = tiles + wave * FC2_ROWS * K1;
+    const int n = lane & 31, h = lane >> 5;
+    const int ntiles = (r.n_rows + FC2_ROWS - 1) / FC2_ROWS;
+
+    const int total_waves = (int)gridDim.x * FC2_WAVES;
+    const int wave_global = (int)blockIdx.x * FC2_WAVES + wave;
+    const int n_static = (int)(((int64_t)ntiles * 7 / 8) / total_waves) * total_waves;
+    int next_static = wave_global;
+    for (;;) {
+        int t;
+        if (next_static < n_static) {
+            t = next_static;
+            next_static += total_waves;
+        } else {
+            t = 0;
+            if (lane == 0) t = n_static + (int)atomicAdd(a.ticket, 1u);
+            t = __builtin_amdgcn_readfirstlane(t);
+        }
+        if (t >= ntiles) break;
+        const int row0 = t * FC2_ROWS;
+        const uint32_t rp = lane <= FC2_ROWS ? r.rowptr[min(row0 + lane, r.n_rows)] : 0u;
+        // ---- 1. the 32 rows of the tile: EIGHT lane groups of 8 lanes, each on its own row, pulling the tile's next row when done ----
+        // (first version: csr_rows_kernel's walk, a group of 32 lanes per row, two rows at a time — 6.8 ms at 12 waves, 7.9 at 8: a
+        // persistent wave has only its own rows in flight, and most rows are short.  Here a lane owns the 16-byte pieces at columns
+        // 4 lig + 32 k, k = 0 .. 3, of its group's row; up to U edges of each of the 8 rows are in flight, and no group waits for a
+        // longer neighbour.  Adds are still in ORIGINAL edge order per row from the identity: the same bits as csr_rows_kernel.)
+        {
+            constexpr int GL = 8, NT = (K1 + 31) / 32;          // lanes per group, 16-byte pieces per lane
+            const int gl = lane & (GL - 1), gb8 = lane - gl, g8 = lane >> 3;
+            bool pact[NT];
+#pragma unroll
+            for (int k = 0; k < NT; ++k) pact[k] = 4 * gl + 32 * k < K1;
+            float acc[NT][4];
+            int cur = g8;                                       // tile-relative row of this group (FC2_ROWS = none left)
+            int next_rr = 8;                                    // wave-uniform: next row of the tile nobody has taken
+            uint32_t p = 0, pend = 0, pbeg = 0;
+            bool is_long = false;
+            // start row rr in the lanes with `mine` set (a whole group at a time); EVERY lane of the wave executes the two exchanges — a
+            // ds_bpermute under a divergent branch would read the row pointers from lanes that are switched off
+            auto take = [&](int rr, bool mine) {
+                const uint32_t rb = (uint32_t)__shfl((int)rp, min(rr, FC2_ROWS), 64), re = (uint32_t)__shfl((int)rp, min(rr + 1, FC2_ROWS), 64);
+                if (!mine) return;
+                cur = rr;
+                is_long = false;
+                p = pend = pbeg = 0;
+#pragma unroll
+                for (int k = 0; k < NT; ++k)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[k][q] = op_identity<OP>();
+                if (rr >= FC2_ROWS) return;
+                const int row = row0 + rr;
+                if (row >= r.n_rows) {                           // past the last row: a zero row (never stored)
+#pragma unroll
+                    for (int k = 0; k < NT; ++k)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc[k][q] = 0.0f;
+                    is_long = true;                              // (= "finished as it stands")
+                } else if (re - rb > (uint32_t)r.long_thresh) {  // split row: reduced beforehand by the chunk pass, copied in
+                    const float *src = a.agg_long + (int64_t)long_slot(r.long_rows, r.n_long, row) * K1;
+#pragma unroll
+                    for (int k = 0; k < NT; ++k)
+                        if (pact[k]) Vec<4>::load(src + 4 * gl + 32 * k, acc[k]);
+                    is_long = true;
+                } else {
+                    p = pbeg = rb; pend = re;
+                }
+            };
+            take(cur, true);
+            for (;;) {
+                if (a.dbg & 2) break;
+                if (__builtin_amdgcn_ballot_w64(cur < FC2_ROWS) == 0) break;
+                // up to 8 slots of this group's row: their source ids in one coalesced load, then two batches of U4 = 4 row fetches
+                const uint32_t left = pend - p;
+                const int nb = (int)min(left, (uint32_t)GL);
+                const uint32_t cidx = (uint32_t)gl < left ? (uint32_t)r.idx[p + gl] : 0u;
+#pragma unroll
+                for (int j0 = 0; j0 < GL; j0 += 4) {
+                    if (__builtin_amdgcn_ballot_w64(j0 < nb) == 0) break;
+                    uint32_t cj[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) cj[u] = (uint32_t)__shfl((int)cidx, gb8 + j0 + u, 64);
+                    float v[4][NT][4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int k = 0; k < NT; ++k) {
+                            if (pact[k] && j0 + u < nb) Vec<4>::load(r.x + (int64_t)cj[u] * K1 + 4 * gl + 32 * k, v[u][k]);
+                            else v[u][k][0] = v[u][k][1] = v[u][k][2] = v[u][k][3] = 0.0f;
+                        }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (j0 + u < nb) {
+#pragma unroll
+                            for (int k = 0; k < NT; ++k)
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) acc[k][q] = op_apply<OP>(acc[k][q], v[u][k][q]);
+                        }
+                }
+                p += (uint32_t)nb;
+                const bool fin = cur < FC2_ROWS && p >= pend;
+                if (fin) {
+                    const int row = row0 + cur;
+                    if (!is_long) {
+#pragma unroll
+                        for (int k = 0; k < NT; ++k) finalize_row<4, OP>(r, row, pend - pbeg, acc[k]);
+                    }
+#pragma unroll
+                    for (int k = 0; k < NT; ++k)
+                        if (pact[k]) {
+                            if (a.agg_out && row < r.n_rows) Vec<4>::store(a.agg_out + (int64_t)row * K1 + 4 * gl + 32 * k, acc[k]);
+                            *reinterpret_cast<float4 *>(tile + cur * K1 + 4 * gl + 32 * k) = make_float4(acc[k][0], acc[k][1], acc[k][2], acc[k][3]);
+                        }
+                }
+                // the groups that finished take the next rows of the tile, in group order
+                const unsigned long long done = __builtin_amdgcn_ballot_w64(fin && gl == 0);
+                if (done) {
+                    const int rank = __builtin_popcountll(done & ((1ull << gb8) - 1ull));
+                    const int nr = min(next_rr + rank, FC2_ROWS);
+                    next_rr += __builtin_popcountll(done);
+                    take(fin ? nr : cur, fin);
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        // ---- 2. [x_i | m_i] * W^T, 128 columns at a time ----
+        const int rowc = min(row0 + n, r.n_rows - 1);
+        const float *xr = a.xi + (int64_t)rowc * K0;
+        const float *tr = tile + n * K1;
+        // piece p of k-block kb (p = 0, 1: positions 16 kb + 4 h + 8 p .. + 3 of the concatenated row): from x_i or from the tile
+        auto piece_x = [&](int kb, int p) -> float4 {          // (only called where the piece can lie in x_i; clamped: W holds zeros past KCAT)
+            const int c = min(16 * kb + 4 * h + 8 * p, K0 - 4);
+            return *reinterpret_cast<const float4 *>(xr + c);
+        };
+        auto piece_m = [&](int kb, int p) -> float4 {
+            const int c = min(max(16 * kb + 4 * h + 8 * p - K0, 0), K1 - 4);
+            return *reinterpret_cast<const float4 *>(tr + c);
+        };
+        const bool full_tile = row0 + FC2_ROWS <= r.n_rows;
+#pragma unroll 1
+        for (int half = 0; half < ((a.dbg & 1) ? 0 : a.NH); ++half) {
+            f32x16 acc2[4];
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc2[cb][q] = 0.0f;
+            const u32x4 *wp = a.wimg + (size_t)half * NKB * 4 * 3 * 64 + lane;
+            // k-blocks in the order: those that touch the tile first (kb = NKB - 1 .. KBX), then the pure x_i blocks (KBX - 1 .. 0)
+            float4 xq[RD][2];                                  // x_i pieces of up to RD k-blocks in flight
+#pragma unroll
+            for (int i = 0; i < RD; ++i)
+                if (KBX - 1 - i >= 0) { xq[i][0] = piece_x(KBX - 1 - i, 0); xq[i][1] = piece_x(KBX - 1 - i, 1); }
+            SplitA ring[RD];
+            auto load_unit = [&](int step) -> SplitA {          // step = position in the visiting order * 4 + cb
+                const int ord = step >> 2, cb = step & 3;
+                const int kb = NKB - 1 - ord;
+                const u32x4 *u = wp + (size_t)((kb * 4 + cb) * 3) * 64;
+                SplitA s;
+                s.w0 = u[0]; s.w1 = u[64]; s.w2 = u[128];
+                return s;
+            };
+#pragma unroll
+            for (int i = 0; i + 1 < RD; ++i) ring[i] = load_unit(i);
+#pragma unroll
+            for (int ord = 0; ord < NKB; ++ord) {
+                const int kb = NKB - 1 - ord;
+                float4 q0, q1;
+                if (kb < KBX) {                                 // pure x_i block: from the in-flight ring, then refill the slot three blocks on
+                    const int slot = (KBX - 1 - kb) % RD;
+                    q0 = xq[slot][0]; q1 = xq[slot][1];
+                    if (kb - RD >= 0) { xq[slot][0] = piece_x(kb - RD, 0); xq[slot][1] = piece_x(kb - RD, 1); }
+                } else if (16 * kb >= K0) {                     // pure tile block
+                    q0 = piece_m(kb, 0); q1 = piece_m(kb, 1);
+                } else {                                        // the block that straddles K0: each 4-piece lies wholly on one side
+                    const float4 x0 = piece_x(kb, 0), x1 = piece_x(kb, 1), m0 = piece_m(kb, 0), m1 = piece_m(kb, 1);
+                    const bool in0 = 16 * kb + 4 * h < K0, in1 = 16 * kb + 4 * h + 8 < K0;
+                    q0 = in0 ? x0 : m0; q1 = in1 ? x1 : m1;
+                }
+                const Split8 b = split8(q0, q1);
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) {
+                    const int step = ord * 4 + cb;
+                    if (step + RD - 1 < NKB * 4) ring[(step + RD - 1) % RD] = load_unit(step + RD - 1);
+                    const SplitA &wv = ring[step % RD];
+                    // the six plane products (smallest first), node rows as A, weights as B: lane (j, h) gets column j of nodes 8 a + 4 h + b
+                    f32x16 c = acc2[cb];
+                    c = mfma32(b.p0, wv.w2, c);
+                    c = mfma32(b.p2, wv.w0, c);
+                    c = mfma32(b.p1, wv.w1, c);
+                    c = mfma32(b.p0, wv.w1, c);
+                    c = mfma32(b.p1, wv.w0, c);
+                    c = mfma32(b.p0, wv.w0, c);
+                    acc2[cb] = c;
+                }
+            }
+            const int col0 = 128 * half;
+            if (split_any_nan<4>(acc2)) {
+                fused_cat_exact(a.w, a.xi, tile, K0, K1, col0, row0, r.n_rows, a.bias, a.act, a.out, a.Dout, lane);
+                continue;
+            }
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                const int col = col0 + 32 * cb + n;
+                const float bv = biasl[col];
+                float *op = a.out + ((int64_t)row0 + 4 * h) * a.Dout + col;      // lane (j, h): column j, nodes 4 h + (8 a + b)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int nu = 8 * (q >> 2) + (q & 3);                         // wave-uniform part of the node number
+                    float v = acc2[cb][q] + bv;
+                    if (a.act == GNNMP_ACT_RELU) v = fmaxf(v, 0.0f);      // (finite here: NaN tiles took the exact path)
+                    if ((full_tile || row0 + nu + 4 * h < r.n_rows) && !(a.dbg & 4)) op[(int64_t)nu * a.Dout] = v;
+                }
+            }
+        }
+        // the tile is rewritten by the next gather: program order within the wave keeps the reads above before those writes
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+template <int K0, int K1, int OP, bool SCALED, int NW, int RD, int U>
+static int launch_fused_cat_v(FusedCatArgs &a, u32x4 *wimg, hipStream_t stream) {
+    constexpr int NKB = (K0 + K1 + 15) / 16, FC2_WAVES = NW;
+    const size_t lds = (size_t)FC2_WAVES * FC2_ROWS * K1 * sizeof(float) + (size_t)a.Dout * sizeof(float);
+    if (lds > 160 * 1024) return 1;
+    fused_cat_wimg_kernel<K0, K1><<<a.NH * NKB * 4, 64, 0, stream>>>(a.w, a.Dout, wimg);
+    GNNMP_LAUNCH_CHECK("fused_cat_wimg_kernel");
+    a.wimg = wimg;
+    GNNMP_LDS_OPTIN("fused_cat_kernel", &fused_cat_kernel<K0, K1, OP, SCALED, NW, RD, U>);
+    const int ntiles = (a.r.n_rows + FC2_ROWS - 1) / FC2_ROWS;
+    const int gx = std::min(device_cus(), (ntiles + FC2_WAVES - 1) / FC2_WAVES);
+    GNNMP_HIP(hipMemsetAsync(a.ticket, 0, 2 * sizeof(uint32_t), stream));
+    fused_cat_kernel<K0, K1, OP, SCALED, NW, RD, U><<<gx, 64 * FC2_WAVES, lds, stream>>>(a);
+    GNNMP_LAUNCH_CHECK("fused_cat_kernel");
+    return GNNMP_OK;
+}
+// knob 14 picks the variant (A/B runs): 8 = 8 waves, 9 = 8 waves with 16 row loads in flight, anything else = 12 waves
+template <int K0, int K1, int OP, bool SCALED>
+static int launch_fused_cat(FusedCatArgs &a, u32x4 *wimg, hipStream_t stream) {
+    const int k = knob(KNOB_FUSED_WAVES);
+    if (k == 8) return launch_fused_cat_v<K0, K1, OP, SCALED, 8, 3, 8>(a, wimg, stream);
+    if (k == 9) return launch_fused_cat_v<K0, K1, OP, SCALED, 8, 3, 16>(a, wimg, stream);
+    return launch_fused_cat_v<K0, K1, OP, SCALED, 12, 2, 8>(a, wimg, stream);
+}
+
+template <int K0, int K1>
+static int dispatch_fused_cat(FusedCatArgs &a, int op, bool scaled, u32x4 *wimg, hipStream_t stream) {
+    switch (op) {
+        case OP_SUM:
+            return scaled ? launch_fused_cat<K0, K1, OP_SUM, true>(a, wimg, stream) : launch_fused_cat<K0, K1, OP_SUM, false>(a, wimg, stream);
+        case OP_MAX: return launch_fused_cat<K0, K1, OP_MAX, false>(a, wimg, stream);
+        default: return launch_fused_cat<K0, K1, OP_MIN, false>(a, wimg, stream);
+    }
+}
+
 int run_reduce(gnnmp_graph_t *p, const int32_t *idx, int aggr, const float *x, const float *w, const float *ss,
                const float *w_slot, const float *ss_slot, const float *sd, float *out, int64_t D, hipStream_t stream,
                const float *emat, const float *rowsub, const float *gate_i, int gated, int act, int long_only, const float *bias,
@@ -231,6 +606,46 @@ extern "C" int gnnmp_fused_conv_f32(gnnmp_graph_t *p, int aggr, const float *xj,
     // shapes this kernel takes; anything else: GNNMP_EUNSUPPORTED, the caller runs propagate + dense
     const bool scaled = w || scale_src || w_slot || ss_slot;
     const int op = (aggr == GNNMP_MAX) ? OP_MAX : (aggr == GNNMP_MIN ? OP_MIN : OP_SUM);
+    // sage_conv / graph_conv with a root term and a multiple of 128 outputs: fused_cat_kernel (W streamed from L2 as pre-split bf16 planes)
+    if (D1 > 0 && Dout > 128) {
+        const bool shape_ok = D == 100 && D1 == 100 && (Dout & 127) == 0 && Dout <= 512 && w_layout == 0 && p->n_dst >= FC2_ROWS &&
+                              !(scaled && op != OP_SUM) && !(reinterpret_cast<uintptr_t>(xj) & 15) && !(reinterpret_cast<uintptr_t>(xi) & 15) &&
+                              !(reinterpret_cast<uintptr_t>(out) & 3) && !(agg_out && (reinterpret_cast<uintptr_t>(agg_out) & 15)) &&
+                              (ldw_root & 3) == 0 && (ldw_agg & 3) == 0 && knob(KNOB_FUSED_WAVES) >= 0;
+        if (!shape_ok)
+            return fail(GNNMP_EUNSUPPORTED, "fused_conv: shape not fused (D=%lld D1=%lld Dout=%lld)", (long long)D, (long long)D1, (long long)Dout);
+        // NOT the default (knob 14 > 0 runs it): measured on the products shape it LOSES to csr_rows_kernel + dense_wreg_kernel, 6.85 ms
+        // against 5.77-5.82 (tools/experiments/sage_fused_ab.py, profiles/r06_sage_fused_ab.txt; see the kernel's header for why)
+        if (knob(KNOB_FUSED_WAVES) == 0)
+            return fail(GNNMP_EUNSUPPORTED, "fused_conv: root term with > 128 outputs, the two-kernel path is faster (knob 14 > 0 forces fused_cat_kernel)");
+        const int NH = (int)(Dout / 128);
+        const size_t pc = (size_t)p->n_chunks * (size_t)D, pl = (size_t)p->n_long * (size_t)D;
+        const size_t wimg_at = (((pc + 3) & ~(size_t)3) + pl + 255) & ~(size_t)255;        // 1 KB aligned
+        const size_t wimg_floats = (size_t)NH * 13 * 4 * 3 * 64 * 4;
+        if (int rc = ensure_workspace(p, wimg_at + wimg_floats + 4)) return rc;
+        if (int rc = ensure_ticket(p, stream)) return rc;
+        float *agg_long = p->ws + ((pc + 3) & ~(size_t)3);
+        if (p->n_long > 0) {
+            if (int rc = run_reduce(p, p->col, aggr, xj, w, scale_src, w_slot, ss_slot, scale_dst, agg_long, D, stream, nullptr,
+                                    nullptr, nullptr, 1, 0, 1, nullptr, 0, nullptr, nullptr))
+                return rc;
+        }
+        FusedCatArgs a = {};
+        ReduceArgs &r = a.r;
+        r.rowptr = p->rowptr; r.idx = p->col; r.eid = p->eid; r.x = xj; r.w = w; r.ss = scale_src; r.w_slot = w_slot; r.ss_slot = ss_slot;
+        r.sd = scale_dst; r.long_rows = p->long_rows; r.n_long = p->n_long; r.D = (int)D; r.n_rows = (int)p->n_dst; r.n_src = (int)p->n_src;
+        r.n_edges = (uint32_t)p->n_edges; r.mean = (aggr == GNNMP_MEAN); r.long_thresh = p->long_thresh;
+        r.log2g = pick_log2g((D + 3) / 4);
+        if (r.log2g != 5) return fail(GNNMP_EUNSUPPORTED, "fused_conv: lane-group width forced by a knob");
+        a.agg_long = agg_long; a.agg_out = agg_out; a.xi = xi;
+        a.w.W[0] = W_root; a.w.W[1] = W_agg; a.w.K[0] = (int)D1; a.w.K[1] = (int)D;
+        a.w.sj[0] = ldw_root; a.w.sk[0] = 1; a.w.sj[1] = ldw_agg; a.w.sk[1] = 1;
+        a.bias = bias; a.act = act; a.out = out; a.Dout = (int)Dout; a.NH = NH; a.ticket = p->ticket;
+        a.dbg = knob(KNOB_T16_DEBUG);
+        const int rc = dispatch_fused_cat<100, 100>(a, op, scaled, reinterpret_cast<u32x4 *>(p->ws + wimg_at), stream);
+        if (rc == 1) return fail(GNNMP_EUNSUPPORTED, "fused_conv: no LDS for the row tiles");
+        return rc;
+    }
     if ((D & 3) || D > 128 || (D1 & 3) || D1 > 128 || (Dout & 3) || Dout > 128 || p->n_dst < 16 || (scaled && op != OP_SUM) ||
         (reinterpret_cast<uintptr_t>(xj) & 15) || (reinterpret_cast<uintptr_t>(out) & 15) ||
         (xi && (reinterpret_cast<uintptr_t>(xi) & 15)) || (agg_out && (reinterpret_cast<uintptr_t>(agg_out) & 15)) ||

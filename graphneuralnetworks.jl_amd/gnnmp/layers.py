@@ -96,6 +96,8 @@ def fused_conv(plan, aggr, xj, W_agg, bias=None, sigma=None, xi=None, W_root=Non
     # failed call with a formatted error string: with knob 14 at its default the kernel fuses only a layer without a root term
     # whose aggregate exceeds 128 MiB (csrc/fused_conv.hip); knob 14 > 0 forces it, < 0 disables it
     k14 = _knob14()
+    # (round 6: sage_conv / graph_conv 100 + 100 => a multiple of 128 outputs has a fused kernel too — fused_cat_kernel — but it loses to
+    # the two-kernel path on the products shape, 6.85 against 5.77 ms, and runs only when knob 14 > 0 forces it)
     if k14 < 0 or (k14 == 0 and (D1 > 0 or plan.n_dst * D * 4 < (128 << 20))):
         return None
     if out is None:

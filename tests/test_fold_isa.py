@@ -4,7 +4,7 @@ agent-scope atomics + `s_waitcnt vmcnt(0)` — outside the HIP memory model, cor
 This test disassembles the device code of the built objects and pins exactly that:
   * every FOLD instance of csr_rows_kernel / gat_fused_rows_kernel contains loads AND stores with the `sc1` bit and an agent-scope atomic add;
   * none of them contains a whole-L2 write-back / invalidate (`buffer_wbl2`, `buffer_inv`): a __threadfence() creeping back in would be
-    correct but cost 170 us on the arxiv shape (DESIGN.md), and its absence is what the hand-written ordering has to make up for;
+    correct but cost 170 us on the arxiv shape (LABNOTES.md §3), and its absence is what the hand-written ordering has to make up for;
   * the device code was built for gfx950 (common.h refuses to compile for anything but gfx942 / gfx950).
 No GPU needed: hipcc cross-compiles, llvm-objdump reads the code object.  (VERDICT r5 item 7 / ADVICE r5.)"""
 import os

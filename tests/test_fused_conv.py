@@ -114,6 +114,70 @@ def test_root_segment(gm, oracle, D1, D, Dout):
         close(y.cpu().numpy(), ref)
 
 
+@pytest.mark.parametrize("variant", [16, 8, 9])
+@pytest.mark.parametrize("Dout", [256, 384])
+def test_sage_fused_cat_kernel(gm, oracle, variant, Dout):
+    """fused_cat_kernel (round 6, BASELINE config 4): sage_conv / graph_conv 100 + 100 => 256 in ONE kernel, W streamed from L2 as
+    pre-split bf16 planes (conv.jl:277-283,102-108).  The pre-GEMM aggregate is BIT-IDENTICAL to gnnmp_propagate_f32 for every aggr
+    (split hubs included), the output within 1e-5 of the oracle and of the two-kernel path, non-finite rows (empty max / min rows, NaN
+    and Inf features) come out exactly like the two-kernel path's.  variant = knob 14: 12 waves a block (default), 8, 8 with 16 loads."""
+    import torch
+    from gnnmp import _lib as L
+    from gnnmp.graph import Plan
+    rng = np.random.default_rng(Dout + variant)
+    s, t, n = hub_graph(rng, n=2500, E=30000)
+    D = 100
+    xj = rng.standard_normal((n, D)).astype(np.float32)
+    W1 = (rng.standard_normal((Dout, D)) * 0.2).astype(np.float32)
+    W2 = (rng.standard_normal((Dout, D)) * 0.2).astype(np.float32)
+    b = (rng.standard_normal(Dout) * 0.1).astype(np.float32)
+    g = gm.GNNGraph(dev(s), dev(t), num_nodes=n)
+    plan = g.plan(False)
+    assert plan.n_long >= 2
+    xd, W1d, W2d, bd = dev(xj), dev(W1), dev(W2), dev(b)
+    gm.tune(14, variant)
+    try:
+        for aggr, name in ((L.SUM, "+"), (L.MEAN, "mean"), (L.MAX, "max"), (L.MIN, "min")):
+            res = gm.fused_conv(plan, aggr, xd, W2d, bd, "relu", xi=xd, W_root=W1d, return_aggregate=True)
+            assert res is not None, "100 + 100 => a multiple of 128 is inside fused_cat_kernel's envelope"
+            y, agg = res
+            ref_agg = torch.empty_like(agg)
+            L.check(L.load().gnnmp_propagate_f32(plan.handle, L.COPY_XJ, aggr, L.ptr(xd), None, None, None, L.ptr(ref_agg), D, L.stream_ptr()))
+            assert torch.equal(agg, ref_agg), f"aggregate differs from the unfused kernel (aggr {name})"
+            y_ref = gm.dense(xd, W1d, bd, "relu", x2=ref_agg, W2=W2d)
+            fin = torch.isfinite(ref_agg).all(1)
+            close(y[fin].cpu().numpy(), y_ref[fin].cpu().numpy())
+            # rows whose aggregate is -Inf / +Inf (no incoming edge under max / min): the exact path, same non-finite pattern
+            assert torch.equal(torch.isnan(y), torch.isnan(y_ref)) and torch.equal(torch.isinf(y), torch.isinf(y_ref))
+            assert torch.equal(gm.fused_conv(plan, aggr, xd, W2d, bd, "relu", xi=xd, W_root=W1d).view(torch.int32), y.view(torch.int32))
+            if name in ("+", "mean"):
+                m = oracle.propagate(name, s, t, n, xj)
+                ref = oracle._act("relu", oracle.matmul(W1, xj) + oracle.matmul(W2, m) + b[None, :])
+                close(y.cpu().numpy(), ref)
+        # Inf / NaN features: the tiles that see them are redone in exact fp32; every other row is untouched
+        xbad = xj.copy()
+        xbad[17, 3] = np.inf
+        xbad[900, 50] = np.nan
+        xbad[1500, 99] = -np.inf
+        xb = dev(xbad)
+        y = gm.fused_conv(plan, L.SUM, xb, W2d, bd, None, xi=xb, W_root=W1d)
+        aggb = torch.empty_like(xb)
+        L.check(L.load().gnnmp_propagate_f32(plan.handle, L.COPY_XJ, L.SUM, L.ptr(xb), None, None, None, L.ptr(aggb), D, L.stream_ptr()))
+        y_ref = gm.dense(xb, W1d, bd, None, x2=aggb, W2=W2d)
+        assert torch.equal(torch.isnan(y), torch.isnan(y_ref)) and torch.equal(torch.isinf(y), torch.isinf(y_ref))
+        fin = torch.isfinite(y_ref)
+        assert fin.any() and not fin.all()
+        d = (y[fin] - y_ref[fin]).abs().max().item()
+        assert d <= 1e-5 * y_ref[fin].abs().max().item()
+        # the layer itself takes the kernel (sage_conv: W * vcat(x_i, m))
+        l = gm.SAGEConv((D, Dout), "relu", aggr="mean", seed=5)
+        yl = l(g, xd).cpu().numpy()
+        ref = oracle.sage_conv(s, t, n, xj, l.weight.cpu().numpy(), l.bias.cpu().numpy(), "relu", "mean")
+        close(yl, ref)
+    finally:
+        gm.tune(14, 16)
+
+
 def test_layers_take_the_fused_kernel_and_fall_back_outside_it(gm, oracle):
     import torch
     rng = np.random.default_rng(77)
