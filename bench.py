@@ -575,6 +575,13 @@ def main():
         return y1, y2
 
     if not args.no_placement:          # builds the arena (set-up, like the plan) and moves the input features into it
+        # The probing budget is the CALLER's choice (gnnmp_arena_create's max_probe_bytes / GNNMP_ARENA_BUDGET_MS).  hipMalloc hands out
+        # physical memory in runs of one placement class that can be tens of GiB long: with the library's default (32 GiB held, 0.3 s) two of
+        # this round's four boxes found only two classes — and the step is 4-5 % slower there.  The bench owns the whole 288 GB device, so
+        # it lets the search hold up to 112 GiB for up to 2 s (still set-up, reported as arena_create_and_first_step_ms); the environment
+        # overrides both.
+        os.environ.setdefault("GNNMP_ARENA_PROBE_GIB", "112")
+        os.environ.setdefault("GNNMP_ARENA_BUDGET_MS", "2000")
         t0 = time.perf_counter()
         ar0 = gnnmp.placement.arena()
         if ar0 is not None:
@@ -764,6 +771,8 @@ def main():
     extras["placement"] = {"enabled": ar is not None, "arena": (ar.info() if ar is not None else None),
                            "arena_create_and_first_step_ms": (arena_ms if not args.no_placement else None),
                            "class_of_x": (ar.class_of(x) if ar is not None else None),
+                           "probe_budget": {"max_probe_gib": float(os.environ.get("GNNMP_ARENA_PROBE_GIB", "0")) or 32.0,
+                                            "budget_ms": float(os.environ.get("GNNMP_ARENA_BUDGET_MS", "300"))},
                            "trials_ms": {name: {k[0]: ch.times_ms for k, ch in getattr(layer, "_placed", {}).items() if hasattr(ch, "times_ms")}
                                          for name, layer in (("gcn", gcn), ("gat", gat))},
                            "note": "outputs of the two gather kernels live in a placement class other than their gathered matrix's "

@@ -54,6 +54,143 @@ __device__ __forceinline__ int long_slot(const int32_t *__restrict__ long_rows, 
     return lo;
 }
 
+
+// The gather phase of a persistent wave (rounds 6): ROWS consecutive destination rows starting at row0 into an LDS tile, by EIGHT lane
+// groups of 8 lanes, each on its own row and pulling the tile's next row when its own is done.  A lane owns the 16-byte pieces at columns
+// 4 gl + 32 k, k = 0 .. ceil(D / 32) - 1, of its group's row; up to four edges of each of the 8 rows are in flight, and no group waits for
+// a longer neighbour.  (The walk the row kernels use — a group of 32 lanes per row, two rows a wave — leaves a persistent wave with only
+// two rows' loads in flight, and most rows are short: fused_cat_kernel's first version ran 6.8 ms gather-bound with it; with this one its
+// gather phase alone takes 4.4-4.5 ms on the products shape at 8-12 waves a CU — the fetch ceiling csr_rows_kernel reaches with 24.)
+// Adds are in ORIGINAL edge order per row from the identity, products rounded separately: the same bits as reduce_range / csr_rows_kernel.
+// rp: lane l <= ROWS holds rowptr[row0 + l].  Rows the plan splits are copied from agg_long; rows past n_rows become zero rows.
+template <int D, int ROWS, int OP, bool SCALED>
+__device__ __forceinline__ void gather_rows8(const ReduceArgs &r, const float *__restrict__ agg_long, float *__restrict__ agg_out, int row0,
+                                             uint32_t rp, float *tile, int stride, int lane) {
+    constexpr int GL = 8, NT = (D + 31) / 32;           // lanes per group, 16-byte pieces per lane
+    const int gl = lane & (GL - 1), gb8 = lane - gl, g8 = lane >> 3;
+    bool pact[NT];
+#pragma unroll
+    for (int k = 0; k < NT; ++k) pact[k] = 4 * gl + 32 * k < D;
+    float acc[NT][4];
+    int cur = g8;                                       // tile-relative row of this group (>= ROWS = none left)
+    int next_rr = 8;                                    // wave-uniform: next row of the tile nobody has taken
+    uint32_t p = 0, pend = 0, pbeg = 0;
+    bool is_long = false;
+    // start row rr in the lanes with `mine` set (a whole group at a time); EVERY lane of the wave executes the two exchanges — a
+    // ds_bpermute under a divergent branch would read the row pointers from lanes that are switched off
+    auto take = [&](int rr, bool mine) {
+        const uint32_t rb = (uint32_t)__shfl((int)rp, min(rr, ROWS), 64), re = (uint32_t)__shfl((int)rp, min(rr + 1, ROWS), 64);
+        if (!mine) return;
+        cur = rr;
+        is_long = false;
+        p = pend = pbeg = 0;
+#pragma unroll
+        for (int k = 0; k < NT; ++k)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[k][q] = op_identity<OP>();
+        if (rr >= ROWS) return;
+        const int row = row0 + rr;
+        if (row >= r.n_rows) {                           // past the last row: a zero row (never stored)
+#pragma unroll
+            for (int k = 0; k < NT; ++k)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[k][q] = 0.0f;
+            is_long = true;                              // (= "finished as it stands")
+        } else if (re - rb > (uint32_t)r.long_thresh) {  // split row: reduced beforehand by the chunk pass, copied in
+            const float *src = agg_long + (int64_t)long_slot(r.long_rows, r.n_long, row) * D;
+#pragma unroll
+            for (int k = 0; k < NT; ++k)
+                if (pact[k]) Vec<4>::load(src + 4 * gl + 32 * k, acc[k]);
+            is_long = true;
+        } else {
+            p = pbeg = rb; pend = re;
+        }
+    };
+    take(cur, cur < ROWS);
+    for (;;) {
+        if (__builtin_amdgcn_ballot_w64(cur < ROWS) == 0) break;
+        // up to 8 slots of this group's row: their source ids (and factors) in one coalesced load, then two batches of four row fetches
+        const uint32_t left = pend - p;
+        const int nb = (int)min(left, (uint32_t)GL);
+        const bool have = (uint32_t)gl < left;
+        const uint32_t cidx = have ? (uint32_t)r.idx[p + gl] : 0u;
+        float wv = 1.0f, sv = 1.0f;
+        if (SCALED && have) {
+            if (r.w_slot) {
+                wv = r.w_slot[p + gl];
+            } else if (r.w) {
+                const uint32_t e = (uint32_t)r.eid[p + gl];
+                if (e < r.n_edges) wv = r.w[e];
+            }
+            if (r.ss_slot) sv = r.ss_slot[p + gl];
+            else if (r.ss) sv = r.ss[cidx];
+        }
+#pragma unroll
+        for (int j0 = 0; j0 < GL; j0 += 4) {
+            if (__builtin_amdgcn_ballot_w64(j0 < nb) == 0) break;
+            uint32_t cj[4];
+            float wj[4], sj[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                cj[u] = (uint32_t)__shfl((int)cidx, gb8 + j0 + u, 64);
+                if (SCALED) {
+                    wj[u] = __shfl(wv, gb8 + j0 + u, 64);
+                    sj[u] = __shfl(sv, gb8 + j0 + u, 64);
+                }
+            }
+            float v[4][NT][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int k = 0; k < NT; ++k) {
+                    if (pact[k] && j0 + u < nb) Vec<4>::load(r.x + (int64_t)cj[u] * D + 4 * gl + 32 * k, v[u][k]);
+                    else v[u][k][0] = v[u][k][1] = v[u][k][2] = v[u][k][3] = 0.0f;
+                }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (j0 + u < nb) {
+#pragma unroll
+                    for (int k = 0; k < NT; ++k)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            float t = v[u][k][q];
+                            if (SCALED) {
+                                t = t * sj[u];          // xj .* cout'   (conv.jl:59), rounded
+                                t = wj[u] * t;          // w .* xj       (msgpass.jl:203-208), rounded
+                            }
+                            acc[k][q] = op_apply<OP>(acc[k][q], t);
+                        }
+                }
+        }
+        p += (uint32_t)nb;
+        const bool fin = cur < ROWS && p >= pend;
+        if (fin) {
+            const int row = row0 + cur;
+            if (!is_long) {
+#pragma unroll
+                for (int k = 0; k < NT; ++k) finalize_row<4, OP>(r, row, pend - pbeg, acc[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < NT; ++k)
+                if (pact[k]) {
+                    if (agg_out && row < r.n_rows) Vec<4>::store(agg_out + (int64_t)row * D + 4 * gl + 32 * k, acc[k]);
+                    *reinterpret_cast<float4 *>(tile + cur * stride + 4 * gl + 32 * k) = make_float4(acc[k][0], acc[k][1], acc[k][2], acc[k][3]);
+                }
+        }
+        // the groups that finished take the next rows of the tile, in group order
+        const unsigned long long done = __builtin_amdgcn_ballot_w64(fin && gl == 0);
+        if (done) {
+            const int rank = __builtin_popcountll(done & ((1ull << gb8) - 1ull));
+            const int nr = min(next_rr + rank, ROWS);
+            next_rr += __builtin_popcountll(done);
+            take(fin ? nr : cur, fin);
+        }
+    }
+}
+
+// (Round 6 also tried gather_rows8 as THIS kernel's gather phase — 16-row tiles, 12 waves: products GCN layer 5.42 ms against 4.96 with the
+// walk below on the same box, arxiv 179 against 186 us and 150 us unfused (profiles/r06_fused_gather_ab.txt).  With only 16 rows a tile
+// eight groups get two rows each and idle at every tile's end; 32-row tiles do not fit beside the W image at more than 8 waves.  Removed.)
 template <int NCB, int KQA, int OP, bool SCALED>
 __global__ void __launch_bounds__(1024) fused_conv_kernel(const FusedArgs a) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -343,108 +480,8 @@ __global__ void __launch_bounds__(64 * NW) fused_cat_kernel(const FusedCatArgs a
         if (t >= ntiles) break;
         const int row0 = t * FC2_ROWS;
         const uint32_t rp = lane <= FC2_ROWS ? r.rowptr[min(row0 + lane, r.n_rows)] : 0u;
-        // ---- 1. the 32 rows of the tile: EIGHT lane groups of 8 lanes, each on its own row, pulling the tile's next row when done ----
-        // (first version: csr_rows_kernel's walk, a group of 32 lanes per row, two rows at a time — 6.8 ms at 12 waves, 7.9 at 8: a
-        // persistent wave has only its own rows in flight, and most rows are short.  Here a lane owns the 16-byte pieces at columns
-        // 4 lig + 32 k, k = 0 .. 3, of its group's row; up to U edges of each of the 8 rows are in flight, and no group waits for a
-        // longer neighbour.  Adds are still in ORIGINAL edge order per row from the identity: the same bits as csr_rows_kernel.)
-        {
-            constexpr int GL = 8, NT = (K1 + 31) / 32;          // lanes per group, 16-byte pieces per lane
-            const int gl = lane & (GL - 1), gb8 = lane - gl, g8 = lane >> 3;
-            bool pact[NT];
-#pragma unroll
-            for (int k = 0; k < NT; ++k) pact[k] = 4 * gl + 32 * k < K1;
-            float acc[NT][4];
-            int cur = g8;                                       // tile-relative row of this group (FC2_ROWS = none left)
-            int next_rr = 8;                                    // wave-uniform: next row of the tile nobody has taken
-            uint32_t p = 0, pend = 0, pbeg = 0;
-            bool is_long = false;
-            // start row rr in the lanes with `mine` set (a whole group at a time); EVERY lane of the wave executes the two exchanges — a
-            // ds_bpermute under a divergent branch would read the row pointers from lanes that are switched off
-            auto take = [&](int rr, bool mine) {
-                const uint32_t rb = (uint32_t)__shfl((int)rp, min(rr, FC2_ROWS), 64), re = (uint32_t)__shfl((int)rp, min(rr + 1, FC2_ROWS), 64);
-                if (!mine) return;
-                cur = rr;
-                is_long = false;
-                p = pend = pbeg = 0;
-#pragma unroll
-                for (int k = 0; k < NT; ++k)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) acc[k][q] = op_identity<OP>();
-                if (rr >= FC2_ROWS) return;
-                const int row = row0 + rr;
-                if (row >= r.n_rows) {                           // past the last row: a zero row (never stored)
-#pragma unroll
-                    for (int k = 0; k < NT; ++k)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) acc[k][q] = 0.0f;
-                    is_long = true;                              // (= "finished as it stands")
-                } else if (re - rb > (uint32_t)r.long_thresh) {  // split row: reduced beforehand by the chunk pass, copied in
-                    const float *src = a.agg_long + (int64_t)long_slot(r.long_rows, r.n_long, row) * K1;
-#pragma unroll
-                    for (int k = 0; k < NT; ++k)
-                        if (pact[k]) Vec<4>::load(src + 4 * gl + 32 * k, acc[k]);
-                    is_long = true;
-                } else {
-                    p = pbeg = rb; pend = re;
-                }
-            };
-            take(cur, true);
-            for (;;) {
-                if (a.dbg & 2) break;
-                if (__builtin_amdgcn_ballot_w64(cur < FC2_ROWS) == 0) break;
-                // up to 8 slots of this group's row: their source ids in one coalesced load, then two batches of U4 = 4 row fetches
-                const uint32_t left = pend - p;
-                const int nb = (int)min(left, (uint32_t)GL);
-                const uint32_t cidx = (uint32_t)gl < left ? (uint32_t)r.idx[p + gl] : 0u;
-#pragma unroll
-                for (int j0 = 0; j0 < GL; j0 += 4) {
-                    if (__builtin_amdgcn_ballot_w64(j0 < nb) == 0) break;
-                    uint32_t cj[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) cj[u] = (uint32_t)__shfl((int)cidx, gb8 + j0 + u, 64);
-                    float v[4][NT][4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-#pragma unroll
-                        for (int k = 0; k < NT; ++k) {
-                            if (pact[k] && j0 + u < nb) Vec<4>::load(r.x + (int64_t)cj[u] * K1 + 4 * gl + 32 * k, v[u][k]);
-                            else v[u][k][0] = v[u][k][1] = v[u][k][2] = v[u][k][3] = 0.0f;
-                        }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (j0 + u < nb) {
-#pragma unroll
-                            for (int k = 0; k < NT; ++k)
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) acc[k][q] = op_apply<OP>(acc[k][q], v[u][k][q]);
-                        }
-                }
-                p += (uint32_t)nb;
-                const bool fin = cur < FC2_ROWS && p >= pend;
-                if (fin) {
-                    const int row = row0 + cur;
-                    if (!is_long) {
-#pragma unroll
-                        for (int k = 0; k < NT; ++k) finalize_row<4, OP>(r, row, pend - pbeg, acc[k]);
-                    }
-#pragma unroll
-                    for (int k = 0; k < NT; ++k)
-                        if (pact[k]) {
-                            if (a.agg_out && row < r.n_rows) Vec<4>::store(a.agg_out + (int64_t)row * K1 + 4 * gl + 32 * k, acc[k]);
-                            *reinterpret_cast<float4 *>(tile + cur * K1 + 4 * gl + 32 * k) = make_float4(acc[k][0], acc[k][1], acc[k][2], acc[k][3]);
-                        }
-                }
-                // the groups that finished take the next rows of the tile, in group order
-                const unsigned long long done = __builtin_amdgcn_ballot_w64(fin && gl == 0);
-                if (done) {
-                    const int rank = __builtin_popcountll(done & ((1ull << gb8) - 1ull));
-                    const int nr = min(next_rr + rank, FC2_ROWS);
-                    next_rr += __builtin_popcountll(done);
-                    take(fin ? nr : cur, fin);
-                }
-            }
-        }
+        // ---- 1. the 32 rows of the tile: eight lane groups of 8 lanes, each pulling the tile's next row when done (gather_rows8) ----
+        if (!(a.dbg & 2)) gather_rows8<K1, FC2_ROWS, OP, SCALED>(r, a.agg_long, a.agg_out, row0, rp, tile, K1, lane);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
