@@ -25,8 +25,13 @@ fwd = t(lambda: gnnmp.propagate(gnnmp.copy_xj, g, "+", xj=x))
 dx = t(lambda: bw.propagate_grad_xj(g, "+", dy))
 dxw = t(lambda: bw.propagate_grad_xj(g, "+", dy, w=w))
 dw = t(lambda: bw.propagate_grad_w(g, dy, x))
-dwc = t(lambda: bw.propagate_grad_w(g, dy, x, coo_order=True))
-print(f"edge_dot: plan order {dw:.3f} ms, COO order {dwc:.3f} ms")
+# the COO-order comparator (gnnmp_edge_dot_f32 without a plan: what a caller gets who has no plan of the graph) only on request: it is not
+# on any default path, and its 10-12 ms only cluttered the profile of the adjoints
+if "--coo" in sys.argv:
+    dwc = t(lambda: bw.propagate_grad_w(g, dy, x, coo_order=True))
+    print(f"edge_dot: plan order {dw:.3f} ms, COO order {dwc:.3f} ms")
+else:
+    print(f"edge_dot: plan order {dw:.3f} ms")
 dmax = t(lambda: bw.propagate_grad_xj(g, "max", dy, xj=x, y=y))
 b1 = E * (4 * D + 4) + N * (4 * D + 8)
 print(f"products D={D}: fwd(+) {fwd:.3f} ms | dxj(+) {dx:.3f} ms {b1/dx/1e6:.0f} GB/s | dxj(w) {dxw:.3f} ms | "

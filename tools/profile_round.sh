@@ -56,5 +56,12 @@ CMD="python $REPO/tools/dense_small.py shape=2449029,100,100"
 run dense_mfma --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE
 CMD="python $REPO/tools/dense_small.py shape=2449029,100,128"
 run dense128_mfma --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE
+# round 6: fused_cat_kernel (knob 14 forces it) next to the two-kernel path of the same layer — durations, then the requests that reach
+# the L2 (TCC_REQ: L2 hits included — the W image it streams) and those that leave it (TCC_EA0_RDREQ)
+CMD="python $REPO/tools/small_configs.py sage noplace 14=16"
+run sage_fused_kernel_stats --kernel-trace --stats
+run pmc_sage_fused_l2 --kernel-trace --pmc TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum
+CMD="python $REPO/tools/small_configs.py sage noplace"
+run pmc_sage_l2 --kernel-trace --pmc TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum
 fi
 ls -la "$OUT" | grep "$TAG"
