@@ -304,6 +304,15 @@ int plan_long_thresh(int64_t Etot) {
     return th;
 }
 
+// slots per chunk of a split row (<= the plan's long_thresh); GNNMP_CHUNK_SLOTS in the environment overrides it per plan build (A/B runs)
+static int plan_chunk_slots() {
+    if (const char *e = getenv("GNNMP_CHUNK_SLOTS")) {
+        const int v = atoi(e);
+        if (v >= 16) return v;
+    }
+    return 128;
+}
+
 int plan_build_long_rows(gnnmp_graph *p, hipStream_t stream) {
     const int64_t n_dst = p->n_dst, Etot = p->n_total;
     const int BS = 256;
@@ -347,10 +356,15 @@ int plan_build_long_rows(gnnmp_graph *p, hipStream_t stream) {
             std::vector<int32_t> rows, cptr, crow, clrow;
             std::vector<uint32_t> cbeg, cend;
             cptr.push_back(0);
+            // Chunk length (round 6): rows are split ABOVE long_thresh (that is what bounds bit-exactness and keeps a sequential row from
+            // being the kernel's tail), but the chunks of a row that is split anyway are at most plan_chunk_slots() = 128 slots long: a chunk
+            // is a latency-bound chain of len / 8 row-load batches, and the fused layer kernel's pre-pass over the split rows — nothing
+            // else runs beside it — took 110 us of a 4.8 ms GCN layer with 512-slot chunks on the products shape.
+            const int64_t clen = std::min<int64_t>(p->long_thresh, plan_chunk_slots());
             for (const Tri &t : h) {
                 const int64_t len = t.end - t.beg;
-                const int64_t nch = (len + p->long_thresh - 1) / p->long_thresh;
-                const int64_t csz = (len + nch - 1) / nch;  // balanced chunks, each <= long_thresh slots
+                const int64_t nch = (len + clen - 1) / clen;
+                const int64_t csz = (len + nch - 1) / nch;  // balanced chunks, each <= clen <= long_thresh slots
                 for (int64_t c = 0; c < nch; ++c) {
                     crow.push_back((int32_t)t.row);
                     clrow.push_back((int32_t)rows.size());
