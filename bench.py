@@ -279,6 +279,13 @@ def batched_setup(rank, world, dist, G=8192, forward_factory=None, device=None):
         epochs(5, True)
         t_new = epochs(50, True)
         t_prep = epochs(50, False)
+        # the same loop with the loader's prefetch (round 6): batch k + 1 — plan, features, wave jobs — prepared on a side stream beside
+        # batch k's step; same batches, same logits (tests/test_plan_batch.py)
+        loader_single = loader
+        loader = gnnmp.DataLoader(ds, batchsize=len(mine), shuffle=True, seed=7, prefetch=True, prepare=gnnmp.layers.chain_prepare)
+        epochs(5, True)
+        t_new_prefetch = epochs(50, True)
+        loader = loader_single
 
         def prep_sync(n):          # one batch at a time, synchronised: the latency of one preparation (nothing to overlap with)
             tot = 0.0
@@ -290,11 +297,13 @@ def batched_setup(rank, world, dist, G=8192, forward_factory=None, device=None):
                 del gb, jb
             return tot / n * 1e3
         batched_setup.new_batch = {
-            "batched_new_batch_every_step_ms": t_new, "prep_only_ms_pipelined": t_prep, "prep_only_ms_synchronised": prep_sync(20),
+            "batched_new_batch_every_step_ms": t_new_prefetch, "batched_new_batch_every_step_ms_single_stream": t_new,
+            "prep_only_ms_pipelined": t_prep, "prep_only_ms_synchronised": prep_sync(20),
             "what": "per step: shuffle on the host, ONE upload of the permutation (64 KB), gnnmp_plan_select (2 launches), gnnmp_gather_f32 "
                     "of the features, gnnmp_chain_jobs_pack (1 launch), then the fused chain (2 launches); no host synchronisation in "
-                    "the loop (the host prepares step k + 1 while the device runs step k)"}
-        del loader, ds
+                    "the loop (the host prepares step k + 1 while the device runs step k); the first figure with the preparation of "
+                    "step k + 1 on a side stream beside step k's kernels (DataLoader(prefetch = True)), the second with everything on one stream"}
+        del loader, loader_single, ds
         # The TRAINING step of the same model on the same batch (the reference example is a training script,
         # graph_classification_tudataset.jl:97-104): forward layer by layer with stored activations, every pullback a libgnnmp adjoint
         # kernel (gnnmp/backward.py), torch for the loss and Adam.  There is no fused backward chain: reported, not claimed.

@@ -117,31 +117,90 @@ class GraphDataset:
 class DataLoader:
     """MLUtils.DataLoader(data; batchsize, shuffle, collate = true) over a GraphDataset: yields the batched GNNGraph of every step (and
     the targets when the dataset has them).  The permutation of an epoch is drawn on the host (numpy, seeded) and uploaded ONCE; a batch's
-    device ids are a slice of it."""
+    device ids are a slice of it.
 
-    def __init__(self, data: GraphDataset, batchsize=1, shuffle=False, partial=True, seed=None):
+    prefetch = True (round 6): batch k + 1 is PREPARED ON A SIDE STREAM while the consumer's stream runs batch k — its plan
+    (gnnmp_plan_select), its features (one gather) and whatever `prepare(g)` adds (gnnmp.layers.chain_prepare: the fused chain's wave jobs)
+    are a handful of small latency-bound kernels that fit beside the step's own kernels; the consumer's stream waits for the batch's event
+    before it touches it (no host synchronisation), and the first batch of the NEXT epoch is prepared behind the last batch of this one.
+    The sequence of batches is the same with and without prefetch (same seeded permutations in the same order).  Blocks of the library's
+    pool cross streams by construction (csrc/pool.h: a block is parked with an event on its last stream); torch tensors made under the
+    side stream are handed to the consumer's stream with record_stream."""
+
+    def __init__(self, data: GraphDataset, batchsize=1, shuffle=False, partial=True, seed=None, prefetch=False, prepare=None):
         self.data = data
         self.batchsize = int(batchsize)
         self.shuffle = bool(shuffle)
         self.partial = bool(partial)
+        self.prefetch = bool(prefetch)
+        self.prepare = prepare
         self._rng = np.random.default_rng(seed)
+        self._side = None
+        self._pending = None          # (perm, perm_dev, first prepared batch) of the next epoch, made while this one's last batch runs
 
     def __len__(self):
         n = len(self.data)
         return (n + self.batchsize - 1) // self.batchsize if self.partial else n // self.batchsize
 
-    def __iter__(self):
+    def _draw(self):
         n = len(self.data)
         perm = self._rng.permutation(n) if self.shuffle else np.arange(n)
         perm_dev = torch.from_numpy(perm + self.data.gall.index_base).to(self.data.device)      # one upload per epoch
-        for b in range(len(self)):
-            lo, hi = b * self.batchsize, min(n, (b + 1) * self.batchsize)
-            ids_dev = perm_dev[lo:hi]
-            g = self.data.batch(perm[lo:hi], ids_dev)
-            if self.data.targets is not None:
-                yield g, self.data.targets_of(ids_dev)
-            else:
-                yield g
+        return perm, perm_dev
+
+    def _make(self, perm, perm_dev, b):
+        n = len(self.data)
+        lo, hi = b * self.batchsize, min(n, (b + 1) * self.batchsize)
+        ids_dev = perm_dev[lo:hi]
+        g = self.data.batch(perm[lo:hi], ids_dev)
+        if self.prepare is not None:
+            self.prepare(g)
+        tgt = self.data.targets_of(ids_dev) if self.data.targets is not None else None
+        return g, tgt
+
+    def __iter__(self):
+        if not self.prefetch:
+            perm, perm_dev = self._draw()
+            for b in range(len(self)):
+                g, tgt = self._make(perm, perm_dev, b)
+                yield (g, tgt) if tgt is not None else g
+            return
+        dev = self.data.device
+        main = torch.cuda.current_stream(dev)
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=dev)
+        side = self._side
+
+        def on_side(fn):
+            with torch.cuda.stream(side):
+                out = fn()
+                ev = torch.cuda.Event()
+                ev.record(side)
+            return out, ev
+
+        def first_of_new_epoch():
+            def go():
+                perm, perm_dev = self._draw()
+                return perm, perm_dev, self._make(perm, perm_dev, 0)
+            (perm, perm_dev, first), ev = on_side(go)
+            return perm, perm_dev, first, ev
+
+        if self._pending is None:
+            self._pending = first_of_new_epoch()
+        perm, perm_dev, nxt, ev = self._pending
+        self._pending = None
+        nb = len(self)
+        for b in range(nb):
+            (g, tgt), ev_b = nxt, ev
+            if b + 1 < nb:          # enqueue the NEXT batch's preparation before this one is handed out
+                nxt, ev = on_side(lambda: self._make(perm, perm_dev, b + 1))
+            else:                   # ... or the next epoch's first batch
+                self._pending = first_of_new_epoch()
+            main.wait_event(ev_b)
+            for t in (g.x, g.graph_indicator, g._cache.get("node_ptr"), g._cache.get("node_map"), tgt):
+                if isinstance(t, torch.Tensor):
+                    t.record_stream(main)
+            yield (g, tgt) if tgt is not None else g
 
 
 def concat_plans(plans, want_indicator=False, idx_dtype=torch.int64, index_base=1):

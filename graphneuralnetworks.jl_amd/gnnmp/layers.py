@@ -642,6 +642,14 @@ class ChainJobs:
             pass
 
 
+def chain_prepare(g):
+    """the fused chain's wave jobs of a batched graph, made ahead of the model call (DataLoader(prepare = chain_prepare): on the loader's
+    side stream, beside the previous step's kernels); the model call finds them in the batch's cache"""
+    if g._cache.get("chain_jobs") is None and g._cache.get("node_ptr") is not None:
+        g._cache["chain_jobs"] = ChainJobs(g._cache["node_ptr"], g.num_graphs, g._cache.get("member_stats"))
+    return g
+
+
 def _chain_pattern(layers):
     """(convs, pool, head) if `layers` is GraphConv, ..., GraphConv, GlobalPool(+ | mean), Dense(identity) — the graph-classification
     chain of examples/graph_classification_tudataset.jl:79-82 — inside the fused kernel's envelope; else None."""

@@ -334,3 +334,33 @@ def test_dataloader_epoch_equals_collated_batches(gm):
         assert torch.equal(model(g, g.x), model(ref, ref.x)), b
         seen += len(ids)
     assert seen == len(members) and len(loader) == 3
+
+
+def test_prefetching_dataloader_yields_the_same_batches(gm):
+    """DataLoader(prefetch = True, prepare = chain_prepare): batch k + 1 (plan, features, wave jobs) is prepared on a side stream beside
+    batch k's step, the next epoch's first batch behind this epoch's last — the sequence of batches, their targets and the model's logits
+    are those of the plain loader, epoch after epoch, also when the consumer is slow or fast (the hand-over is an event, not luck)"""
+    import torch
+    from gnnmp import synth
+    from gnnmp.layers import chain_prepare
+    members = synth.batched_graphs(G=700, seed=9)
+    rng = np.random.default_rng(7)
+    xs = [rng.standard_normal((n, 16), dtype=np.float32) for _, _, n in members]
+    y_all = torch.arange(len(members), device="cuda", dtype=torch.float32)
+    ds = gm.GraphDataset.from_members(members, xs, targets=y_all)
+    model = build_model(gm)
+    plain = gm.DataLoader(ds, batchsize=256, shuffle=True, seed=321)
+    pre = gm.DataLoader(ds, batchsize=256, shuffle=True, seed=321, prefetch=True, prepare=chain_prepare)
+    big = torch.empty(64 << 20, device="cuda")
+    for epoch in range(4):
+        want = [(model(g, g.x).clone(), yb.clone(), g.num_nodes) for g, yb in plain]
+        got = []
+        for b, (g, yb) in enumerate(pre):
+            assert g._cache.get("chain_jobs") is not None, "prepare ran on the batch"
+            if (epoch + b) % 2:          # a consumer that keeps its stream busy before it gets to the batch
+                big.fill_(float(b))
+            got.append((model(g, g.x).clone(), yb.clone(), g.num_nodes))
+        assert len(got) == len(want) == 3
+        for (ya, ta, na), (yb_, tb, nb_) in zip(got, want):
+            assert na == nb_ and torch.equal(ta, tb) and torch.equal(ya, yb_), epoch
+    torch.cuda.synchronize()
