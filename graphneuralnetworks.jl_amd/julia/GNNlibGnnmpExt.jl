@@ -87,6 +87,10 @@ mutable struct Plan
     end
 end
 
+# Repair hook (gnnmp.h): a plan's split rows are folded through per-plan arrival counters that every launch leaves at zero — as long as the
+# plan is used from one task / stream at a time.  A caller that may have broken that rule (two tasks on one GNNGraph) resets them here.
+reset_counters!(p::Plan) = (check(@ccall libgnnmp.gnnmp_plan_reset_counters(p.handle::Ptr{Cvoid}, stream_ptr()::Ptr{Cvoid})::Cint); p)
+
 # The cache is keyed on the IDENTITY of the two index vectors plus everything else a plan depends on.  (Round 1 keyed a
 # WeakKeyDict on `s` alone: two graphs sharing s but not t, or num_nodes, got the first graph's plan — and WeakKeyDict hashes
 # array CONTENTS, a scalar-indexing O(E) walk of a ROCVector per call.)  GNNGraph is immutable and shares s, t across copies
