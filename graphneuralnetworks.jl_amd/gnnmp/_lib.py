@@ -45,6 +45,7 @@ SYMBOLS = (
     "gnnmp_dense_grad_w2_workspace", "gnnmp_dense_grad_w2_f32", "gnnmp_pool_grad_act_f32", "gnnmp_propagate_add_mask_f32",
     "gnnmp_row_normalize_f32", "gnnmp_row_normalize_grad_f32", "gnnmp_propagate_cg_f32", "gnnmp_gru_pointwise_f32", "gnnmp_propagate_nn_f32", "gnnmp_gmm_weights_f32", "gnnmp_row_sqnorm_normalize_f32", "gnnmp_lstm_pointwise_f32", "gnnmp_rowdot_f32",
     "gnnmp_plan_reset_counters",
+    "gnnmp_propagate_f64", "gnnmp_gather_f64", "gnnmp_scatter_f64",
     # the GNNMP_INTERNAL section of the header: experiment / test hooks, exported but not part of the drop-in surface
     "gnnmp_tune", "gnnmp_debug_mock_device", "gnnmp_debug_device_once", "gnnmp_debug_plan_block", "gnnmp_debug_pool_pick",
 )
@@ -169,6 +170,9 @@ def load():
                                       ctypes.POINTER(vp), ctypes.POINTER(i), i, i, i, vp, vp, i64, vp, vp, vp],
         "gnnmp_tune": [i, i],
         "gnnmp_plan_reset_counters": [vp, vp],
+        "gnnmp_propagate_f64": [vp, i, i, vp, vp, vp, vp, vp, i64, vp],
+        "gnnmp_gather_f64": [vp, vp, i, i, i64, vp, i64, vp],
+        "gnnmp_scatter_f64": [vp, i, vp, vp, i64, vp],
     }
     for name, args in sig.items():
         try:

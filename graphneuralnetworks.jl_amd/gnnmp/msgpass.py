@@ -39,9 +39,20 @@ def aggr_code(aggr) -> int:
 
 def _flat(x: torch.Tensor):
     """[N, ...] -> contiguous float32 [N, D]"""
-    assert x.dtype == torch.float32, "gnnmp supports Float32 features"
+    assert x.dtype == torch.float32, "gnnmp supports Float32 features (Float64: propagate / _gather / _scatter only)"
     x = x.contiguous()
     return x.view(x.shape[0], -1) if x.dim() != 2 else x
+
+
+def _flat_any(x: torch.Tensor):
+    """[N, ...] -> contiguous [N, D] of x's own eltype — Float32 or Float64 (the *_f64 entry points: gnnmp.h, round 6)"""
+    assert x.dtype in (torch.float32, torch.float64), "gnnmp supports Float32 and (for propagate / _gather / _scatter) Float64 features"
+    x = x.contiguous()
+    return x.view(x.shape[0], -1) if x.dim() != 2 else x
+
+
+def _sfx(t: torch.Tensor):
+    return "f64" if t.dtype == torch.float64 else "f32"
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -57,11 +68,11 @@ def _gather(x, i, index_base=1):
         return tuple(_gather(v, i, index_base) for v in x)
     if isinstance(x, list):
         return [_gather(v, i, index_base) for v in x]
-    xf = _flat(x)
+    xf = _flat_any(x)
     K, D = i.numel(), xf.shape[1]
-    out = torch.empty((K,) + tuple(x.shape[1:]), dtype=torch.float32, device=x.device)
-    L.check(L.load().gnnmp_gather_f32(L.ptr(xf), L.ptr(i), 8 if i.dtype == torch.int64 else 4, index_base, K,
-                                      L.ptr(out), D, L.stream_ptr()))
+    out = torch.empty((K,) + tuple(x.shape[1:]), dtype=xf.dtype, device=x.device)
+    L.check(getattr(L.load(), "gnnmp_gather_" + _sfx(xf))(L.ptr(xf), L.ptr(i), 8 if i.dtype == torch.int64 else 4, index_base, K,
+                                                          L.ptr(out), D, L.stream_ptr()))
     return out
 
 
@@ -75,11 +86,11 @@ def _scatter_plan(aggr, src, plan: Plan):
         return tuple(_scatter_plan(aggr, v, plan) for v in src)
     if isinstance(src, list):
         return [_scatter_plan(aggr, v, plan) for v in src]
-    sf = _flat(src)
+    sf = _flat_any(src)
     assert sf.shape[0] == plan.n_total
-    out = torch.empty((plan.n_dst,) + tuple(src.shape[1:]), dtype=torch.float32, device=src.device)
-    L.check(L.load().gnnmp_scatter_f32(plan.handle, aggr_code(aggr), L.ptr(sf), L.ptr(out), sf.shape[1],
-                                       L.stream_ptr()))
+    out = torch.empty((plan.n_dst,) + tuple(src.shape[1:]), dtype=sf.dtype, device=src.device)
+    L.check(getattr(L.load(), "gnnmp_scatter_" + _sfx(sf))(plan.handle, aggr_code(aggr), L.ptr(sf), L.ptr(out), sf.shape[1],
+                                                           L.stream_ptr()))
     return out
 
 
@@ -142,7 +153,8 @@ def apply_edges(f, g: GNNGraph, xi=None, xj=None, e=None):
     check_num_nodes(g, (xj, xi))
     check_num_edges(g, e)
     s, t = edge_index(g)
-    if isinstance(xi, torch.Tensor) and isinstance(xj, torch.Tensor) and xi.shape[1:] == xj.shape[1:]:
+    if isinstance(xi, torch.Tensor) and isinstance(xj, torch.Tensor) and xi.shape[1:] == xj.shape[1:] \
+            and xi.dtype == torch.float32 and xj.dtype == torch.float32:      # (Float64: the generic gather -> f -> scatter path below)
         # the two-row message functions in one pass over the edges (no gathered (D, E) temporaries)
         if f is xi_dot_xj and xi.dim() == 2:
             out = torch.empty((g.num_edges, 1), dtype=torch.float32, device=xi.device)
@@ -180,13 +192,16 @@ def aggregate_neighbors(g: GNNGraph, aggr, m):
 
 def _fused(g: GNNGraph, msg: int, aggr, xj, w, scale_src=None, scale_dst=None, add_self_loops=False, out=None):
     plan = g.plan(add_self_loops)
-    xf = _flat(xj)
+    xf = _flat_any(xj)
     if out is None:
-        out = torch.empty((plan.n_dst,) + tuple(xj.shape[1:]), dtype=torch.float32, device=xj.device)
+        out = torch.empty((plan.n_dst,) + tuple(xj.shape[1:]), dtype=xf.dtype, device=xj.device)
     else:
-        assert out.shape == (plan.n_dst,) + tuple(xj.shape[1:]) and out.dtype == torch.float32 and out.is_contiguous()
-    L.check(L.load().gnnmp_propagate_f32(plan.handle, msg, aggr_code(aggr), L.ptr(xf), L.ptr(w), L.ptr(scale_src),
-                                         L.ptr(scale_dst), L.ptr(out), xf.shape[1], L.stream_ptr()))
+        assert out.shape == (plan.n_dst,) + tuple(xj.shape[1:]) and out.dtype == xf.dtype and out.is_contiguous()
+    # Float64 features (the reference's own micro-benchmark, perf/bench_gnn.jl:9-10): weights and factors in the features' eltype
+    conv = (lambda t: None if t is None else t.to(xf.dtype).contiguous())
+    w, scale_src, scale_dst = conv(w), conv(scale_src), conv(scale_dst)
+    L.check(getattr(L.load(), "gnnmp_propagate_" + _sfx(xf))(plan.handle, msg, aggr_code(aggr), L.ptr(xf), L.ptr(w), L.ptr(scale_src),
+                                                             L.ptr(scale_dst), L.ptr(out), xf.shape[1], L.stream_ptr()))
     return out
 
 
@@ -206,7 +221,9 @@ def propagate(f, g: GNNGraph, aggr, xi=None, xj=None, e=None):
         if f is e_mul_xj and isinstance(e, torch.Tensor) and e.dim() == 1:
             check_num_nodes(g, (xj, xi))
             check_num_edges(g, e)
-            return _fused(g, L.W_MUL_XJ, aggr, xj, e.to(torch.float32).contiguous())
+            if e.dtype == torch.float64 and xj.dtype == torch.float32:      # Julia's `e .* xj` promotes: Float64 result
+                xj = xj.to(torch.float64)
+            return _fused(g, L.W_MUL_XJ, aggr, xj, e)      # (e converted to xj's eltype in _fused)
         if f is e_mul_xj and isinstance(e, torch.Tensor) and e.dim() == xj.dim() and e.shape[1:] == xj.shape[1:] \
                 and e.dtype == torch.float32:
             # matrix e (D, E): one row of factors per edge, fetched by edge id inside the fused kernel

@@ -164,6 +164,54 @@ function GNNlib.propagate(::typeof(w_mul_xj), g::GNNGraph{<:COO_T}, aggr::FusedA
     fused_propagate(g, aggr, xj, get_edge_weight(g))              # the CPU fast path's weighted adjacency (msgpass.jl:234-238)
 end
 
+# ---- Float64 features (round 6; the reference's own micro-benchmark, perf/bench_gnn.jl:9-40, runs propagate on rand(100, n)) ---------------
+# The three methods of the seam for ROCMatrix{Float64}: same plan, same order of operations, the *_f64 entry points.  Forward only — no
+# rrule: differentiating through them falls back to Zygote's generic path (the Float32 methods above carry the adjoint kernels).  Weights of
+# another float eltype are promoted like `w .* xj` would.
+function fused_propagate64(g::GNNGraph, aggr, xj::AnyROCMatrix{Float64}, w)
+    check_num_nodes(g, xj)
+    p = plan(g; self_loops = false)
+    D = size(xj, 1)
+    out = similar(xj, D, g.num_nodes)
+    w64 = w === nothing ? nothing : (eltype(w) === Float64 ? w : Float64.(w))
+    msg = w64 === nothing ? Cint(0) : Cint(1)
+    check(@ccall libgnnmp.gnnmp_propagate_f64(p.handle::Ptr{Cvoid}, msg::Cint, aggr_code(aggr)::Cint, devptr(xj)::Ptr{Cvoid},
+                                              devptr(w64)::Ptr{Cvoid}, C_NULL::Ptr{Cvoid}, C_NULL::Ptr{Cvoid}, devptr(out)::Ptr{Cvoid},
+                                              D::Int64, stream_ptr()::Ptr{Cvoid})::Cint)
+    return out
+end
+function GNNlib.propagate(::typeof(copy_xj), g::GNNGraph{<:COO_T}, aggr::FusedAggr, xi, xj::AnyROCMatrix{Float64}, e)
+    fused_propagate64(g, aggr, xj, nothing)
+end
+function GNNlib.propagate(::typeof(e_mul_xj), g::GNNGraph{<:COO_T}, aggr::FusedAggr, xi, xj::AnyROCMatrix{Float64},
+                          e::ROCVector{<:Union{Float32, Float64}})
+    check_num_edges(g, e)
+    fused_propagate64(g, aggr, xj, e)
+end
+function GNNlib.propagate(::typeof(w_mul_xj), g::GNNGraph{<:COO_T}, aggr::FusedAggr, xi, xj::AnyROCMatrix{Float64}, e::Nothing)
+    fused_propagate64(g, aggr, xj, get_edge_weight(g))
+end
+# the leaves for generic closures (GNNGraphs/src/gatherscatter.jl:4,12-18)
+function GNNGraphs._gather(x::AnyROCMatrix{Float64}, i::ROCVector{I}) where {I <: Union{Int32, Int64}}
+    D = size(x, 1)
+    out = similar(x, D, length(i))
+    check(@ccall libgnnmp.gnnmp_gather_f64(devptr(x)::Ptr{Cvoid}, devptr(i)::Ptr{Cvoid}, sizeof(I)::Cint, 1::Cint, length(i)::Int64,
+                                           devptr(out)::Ptr{Cvoid}, D::Int64, stream_ptr()::Ptr{Cvoid})::Cint)
+    return out
+end
+# _scatter(aggr, m, t, n) with t === the graph's own target vector: the graph's plan is the plan of that scatter (m in edge order)
+function scatter_edges64(g::GNNGraph{<:COO_T}, aggr, m::AnyROCMatrix{Float64})
+    check_num_edges(g, m)
+    D = size(m, 1)
+    out = similar(m, D, g.num_nodes)
+    check(@ccall libgnnmp.gnnmp_scatter_f64(plan(g; self_loops = false).handle::Ptr{Cvoid}, aggr_code(aggr)::Cint, devptr(m)::Ptr{Cvoid},
+                                            devptr(out)::Ptr{Cvoid}, D::Int64, stream_ptr()::Ptr{Cvoid})::Cint)
+    return out
+end
+function GNNlib.aggregate_neighbors(g::GNNGraph{<:COO_T}, aggr::FusedAggr, m::AnyROCMatrix{Float64})
+    scatter_edges64(g, aggr, m)
+end
+
 # ---- GNNGraph{SPARSE_T}: the other half of the reference seam's Union{COO_T, SPARSE_T} (GNNlibAMDGPUExt.jl:13-32) ----------------------
 # The reference's methods gather / scatter over edge_index(g), which for a device sparse matrix is findnz on a ROCSparseMatrixCSC — the
 # cases GNNlib/test/msgpass.jl:171-196 mark `broken` on AMDGPU.  Here the adjacency's CSC arrays are the plan (gnnmp_plan_from_csc):

@@ -13,7 +13,7 @@
  *   - every pointer is a DEVICE pointer, borrowed for the duration of the call only;
  *     the caller allocates inputs AND outputs.  The only long-lived object is the opaque plan.
  *   - feature arrays are Julia column-major (D, N)  ==  C row-major [N][D]: one node's / edge's
- *     feature vector is contiguous.  fp32 only.
+ *     feature vector is contiguous.  fp32 (every entry point) or fp64 (the *_f64 entry points: propagate, _gather, _scatter).
  *   - index arrays are passed exactly as the reference holds them: Int64 or Int32 (idx_bytes = 8 | 4),
  *     1-based (index_base = 1, Julia) or 0-based (index_base = 0).
  *   - `stream` is a hipStream_t (NULL = the null stream).  Compute entry points launch on it and
@@ -797,6 +797,25 @@ int gnnmp_propagate_add_mask_f32(gnnmp_graph_t *plan, int aggr, const float *xj,
 int64_t gnnmp_dense_grad_workspace(int64_t N, int64_t Dout, int64_t K);
 int gnnmp_dense_grad_w_f32(const float *dz, const float *x, int64_t N, int64_t Dout, int64_t K, float *dW,
                            float *db, float *workspace, int64_t workspace_floats, gnnmp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Float64 features (round 6).  The reference's message passing is eltype-generic, and its own micro-benchmark runs in Float64
+ * (GraphNeuralNetworks/perf/bench_gnn.jl:9-10: `B = rand(100, n)`; it asserts isequal(propagate(e_mul_xj, g, +; xj = B, e), B * A)).  The
+ * seam's methods and their leaves exist for `double` too — the same plan, the same walk, the same order of operations as the `_f32` entry
+ * points (adds in ORIGINAL edge order, products rounded separately: bit-identical to NNlib's CPU loop on every row the plan does not split;
+ * split rows: chunk partials folded in chunk order, deterministic):
+ *   gnnmp_propagate_f64   propagate(copy_xj | w_mul_xj | e_mul_xj with a vector e, g, + | mean | max | min)   msgpass.jl:71-79, 215-238;
+ *                         arguments as gnnmp_propagate_f32 (w: n_edges doubles in original edge order; scale_src / scale_dst nullable)
+ *   gnnmp_gather_f64      _gather   (gatherscatter.jl:4)
+ *   gnnmp_scatter_f64     _scatter  (gatherscatter.jl:12-18) with idx = the plan's targets, m in original edge order
+ * The layer bodies' dense products stay with the caller in Float64 (`l.weight * x` is rocBLAS in Julia): the fused layer kernels, the
+ * attention kernels and the adjoints are Float32 only, and so is everything `bench.py` measures.
+ * ---------------------------------------------------------------------------------------------- */
+int gnnmp_propagate_f64(gnnmp_graph_t *plan, int msg, int aggr, const double *xj, const double *w, const double *scale_src,
+                        const double *scale_dst, double *out, int64_t D, gnnmp_stream_t stream);
+int gnnmp_gather_f64(const double *x, const void *idx, int idx_bytes, int index_base, int64_t K, double *out, int64_t D,
+                     gnnmp_stream_t stream);
+int gnnmp_scatter_f64(gnnmp_graph_t *plan, int aggr, const double *m, double *out, int64_t D, gnnmp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Repair hook.  The split rows of a plan are folded inside the row kernels through per-plan arrival counters that every launch leaves at

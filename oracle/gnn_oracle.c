@@ -152,6 +152,79 @@ int orc_propagate(int aggr, const int64_t *s, const int64_t *t, int64_t E, int64
     return rc;
 }
 
+/* ---- the same three loops for Float64 features (round 6: the reference's message passing is eltype-generic; its micro-benchmark
+ * GraphNeuralNetworks/perf/bench_gnn.jl:9-27 runs propagate(e_mul_xj, g, +) on `rand(100, n)` — Float64 — and asserts isequal with B * A) */
+static double jl_max64(double x, double y) {
+    if (x != x) return x;
+    if (y != y) return y;
+    if (y > x) return y;
+    if (x > y) return x;
+    return signbit(x) ? y : x;
+}
+static double jl_min64(double x, double y) {
+    if (x != x) return x;
+    if (y != y) return y;
+    if (y < x) return y;
+    if (x < y) return x;
+    return signbit(x) ? x : y;
+}
+int orc_gather64(const double *x, int64_t n, int64_t D, const int64_t *idx, int64_t K, double *out) {
+    for (int64_t k = 0; k < K; ++k) {
+        int64_t r = idx[k] - 1;
+        if (r < 0 || r >= n) return -1;
+        memcpy(out + k * D, x + r * D, sizeof(double) * (size_t)D);
+    }
+    return 0;
+}
+int orc_scatter64(int aggr, const double *src, int64_t D, const int64_t *idx, int64_t K, int64_t n, double *out) {
+    const double init = aggr == ORC_MAX ? -INFINITY : (aggr == ORC_MIN ? INFINITY : 0.0);
+    for (int64_t i = 0; i < n * D; ++i) out[i] = init;
+    int64_t *cnt = NULL;
+    if (aggr == ORC_MEAN) {
+        cnt = (int64_t *)calloc((size_t)(n > 0 ? n : 1), sizeof(int64_t));
+        if (!cnt) return -2;
+    }
+    for (int64_t k = 0; k < K; ++k) {
+        int64_t r = idx[k] - 1;
+        if (r < 0 || r >= n) {
+            free(cnt);
+            return -1;
+        }
+        double *d = out + r * D;
+        const double *s = src + k * D;
+        if (aggr == ORC_SUM || aggr == ORC_MEAN) {
+            for (int64_t f = 0; f < D; ++f) d[f] = d[f] + s[f];
+        } else if (aggr == ORC_MAX) {
+            for (int64_t f = 0; f < D; ++f) d[f] = jl_max64(d[f], s[f]);
+        } else {
+            for (int64_t f = 0; f < D; ++f) d[f] = jl_min64(d[f], s[f]);
+        }
+        if (cnt) cnt[r] += 1;
+    }
+    if (cnt) {
+        for (int64_t r = 0; r < n; ++r) {
+            double c = (double)cnt[r];
+            double *d = out + r * D;
+            for (int64_t f = 0; f < D; ++f) d[f] = 0.0 + (cnt[r] == 0 ? d[f] : d[f] / c);
+        }
+        free(cnt);
+    }
+    return 0;
+}
+int orc_propagate64(int aggr, const int64_t *s, const int64_t *t, int64_t E, int64_t n_src, int64_t n_dst, const double *xj, int64_t D,
+                    const double *w, double *out) {
+    double *m = (double *)malloc(sizeof(double) * (size_t)(E > 0 ? E : 1) * (size_t)(D > 0 ? D : 1));
+    if (!m) return -2;
+    int rc = orc_gather64(xj, n_src, D, s, E, m);
+    if (rc == 0 && w) {
+        for (int64_t k = 0; k < E; ++k)
+            for (int64_t f = 0; f < D; ++f) m[k * D + f] = w[k] * m[k * D + f];
+    }
+    if (rc == 0) rc = orc_scatter64(aggr, m, D, t, E, n_dst, out);
+    free(m);
+    return rc;
+}
+
 /* The CPU fast path: propagate(copy_xj | w_mul_xj | e_mul_xj, g, +) = xj * adjacency_matrix(g)
  *   — GNNlib/src/msgpass.jl:215-238 -> GNNGraphs/src/query.jl:220-231 -> convert.jl:221-237
  * A = sparse(s, t, val, n, n): CSC (column = destination), row indices ascending inside a column, duplicate (s,t)

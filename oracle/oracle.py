@@ -45,6 +45,8 @@ def lib():
         _lib.orc_scatter.restype = ctypes.c_int
         _lib.orc_degree.restype = ctypes.c_int
         _lib.orc_propagate.restype = ctypes.c_int
+        for name in ("orc_gather64", "orc_scatter64", "orc_propagate64"):
+            getattr(_lib, name).restype = ctypes.c_int
         _lib.orc_spmm_csc.restype = ctypes.c_int
         _lib.orc_softmax_edge_neighbors.restype = ctypes.c_int
         for name in ("orc_add_self_loops", "orc_batch", "orc_gat_logits", "orc_gat_weight_messages",
@@ -79,8 +81,23 @@ def _check(rc, what):
 # ---------------------------------------------------------------------------------------------------------
 # primitives
 # ---------------------------------------------------------------------------------------------------------
+def _is64(a):
+    return getattr(a, "dtype", None) == np.float64
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
 def gather(x, idx):
-    """NNlib.gather — GNNGraphs/src/gatherscatter.jl:4.  x [N, ...] -> [K, ...]"""
+    """NNlib.gather — GNNGraphs/src/gatherscatter.jl:4.  x [N, ...] -> [K, ...]  (Float64 input: the Float64 loop)"""
+    if _is64(x):
+        x = _f64(x)
+        idx = _i64(idx)
+        D = int(np.prod(x.shape[1:], dtype=np.int64))
+        out = np.empty((idx.shape[0],) + x.shape[1:], np.float64)
+        _check(lib().orc_gather64(_p(x), _i(x.shape[0]), _i(D), _p(idx), _i(idx.shape[0]), _p(out)), "gather")
+        return out
     x = _f32(x)
     idx = _i64(idx)
     n = x.shape[0]
@@ -92,7 +109,17 @@ def gather(x, idx):
 
 def scatter(aggr, src, idx, n=None):
     """NNlib.scatter(aggr, src, idx; dstsize) — GNNGraphs/src/gatherscatter.jl:12-18.
-    n omitted => maximum(idx), like NNlib (GNNlib/src/utils.jl:15)."""
+    n omitted => maximum(idx), like NNlib (GNNlib/src/utils.jl:15).  Float64 input: the Float64 loop."""
+    if _is64(src):
+        src = _f64(src)
+        idx = _i64(idx)
+        assert src.shape[0] == idx.shape[0]
+        if n is None:
+            n = int(idx.max()) if idx.size else 0
+        D = int(np.prod(src.shape[1:], dtype=np.int64))
+        out = np.empty((n,) + src.shape[1:], np.float64)
+        _check(lib().orc_scatter64(_AGGR[aggr], _p(src), _i(D), _p(idx), _i(idx.shape[0]), _i(n), _p(out)), "scatter")
+        return out
     src = _f32(src)
     idx = _i64(idx)
     assert src.shape[0] == idx.shape[0]
@@ -143,9 +170,18 @@ def batch(graphs):
 def propagate(aggr, s, t, n, xj, w=None, n_dst=None):
     """Generic propagate (gather -> message -> scatter) with copy_xj (w None) or w_mul_xj / e_mul_xj (vector w)
     — GNNlib/src/msgpass.jl:71-79,121-129,145-149,162,191-208.  This is what the reference runs for any aggr and,
-    on GPU arrays, also for `+` (GNNlib/ext/GNNlibAMDGPUExt.jl:13-32)."""
+    on GPU arrays, also for `+` (GNNlib/ext/GNNlibAMDGPUExt.jl:13-32).  Float64 xj: the Float64 loops (w promoted like `w .* xj`)."""
     s = _i64(s)
     t = _i64(t)
+    if _is64(xj):
+        xj = _f64(xj)
+        w = None if w is None else _f64(w)
+        n_dst = n if n_dst is None else n_dst
+        D = int(np.prod(xj.shape[1:], dtype=np.int64))
+        out = np.empty((n_dst,) + xj.shape[1:], np.float64)
+        _check(lib().orc_propagate64(_AGGR[aggr], _p(s), _p(t), _i(s.shape[0]), _i(xj.shape[0]), _i(n_dst), _p(xj), _i(D), _p(w), _p(out)),
+               "propagate")
+        return out
     xj = _f32(xj)
     w = None if w is None else _f32(w)
     n_dst = n if n_dst is None else n_dst

@@ -158,6 +158,35 @@ int main(void) {
         REQUIRE(pass == 2 || rel_err(got, ref, n * D) <= 1e-5, "propagate pass %d", pass);
     }
 
+    /* ---- the same propagate for Float64 features (gnnmp_propagate_f64: round 6), w_mul_xj + against the host loop in edge order ---- */
+    {
+        double *x64 = malloc(8 * n * D), *w64 = malloc(8 * E), *ref64 = calloc(n * D, 8), *got64 = malloc(8 * n * D);
+        for (int64_t i = 0; i < n * D; ++i) x64[i] = (double)x[i] + 1e-9 * (double)rndf();      /* values that are NOT representable in fp32 */
+        for (int64_t k = 0; k < E; ++k) w64[k] = (double)w[k];
+        for (int64_t k = 0; k < E; ++k)
+            for (int f = 0; f < D; ++f) {
+                volatile double m = w64[k] * x64[(s[k] - 1) * D + f];
+                ref64[(t[k] - 1) * D + f] = ref64[(t[k] - 1) * D + f] + m;
+            }
+        double *dx64 = dev_copy(x64, 8 * n * D), *dw64 = dev_copy(w64, 8 * E), *do64 = dev_alloc(8 * n * D);
+        CHECK_G(gnnmp_propagate_f64(plan, GNNMP_W_MUL_XJ, GNNMP_SUM, dx64, dw64, NULL, NULL, do64, D, stream));
+        CHECK_HIP(hipStreamSynchronize(stream));
+        to_host(got64, do64, 8 * n * D);
+        double worst = 0.0, scale = 0.0;
+        for (int64_t i = 0; i < n; ++i) {
+            const int len = rowptr[i + 1] - rowptr[i];
+            if (len <= thresh) REQUIRE(memcmp(got64 + i * D, ref64 + i * D, 8 * D) == 0, "propagate_f64 row %lld (len %d) not bit-exact", (long long)i, len);
+            for (int f = 0; f < D; ++f) {
+                const double d = fabs(got64[i * D + f] - ref64[i * D + f]), a = fabs(ref64[i * D + f]);
+                if (d > worst) worst = d;
+                if (a > scale) scale = a;
+            }
+        }
+        REQUIRE(worst <= 1e-12 * scale, "propagate_f64 split rows: %g of %g", worst, scale);
+        CHECK_HIP(hipFree(dx64)); CHECK_HIP(hipFree(dw64)); CHECK_HIP(hipFree(do64));
+        free(x64); free(w64); free(ref64); free(got64);
+    }
+
     /* ---- dense: Julia (Dout, Din) column-major weight = C [Din][Dout], w_layout = 1, ldw = Dout ---- */
     float *Wjl = malloc(4 * Dout * D), *b = malloc(4 * Dout);
     for (int i = 0; i < Dout * D; ++i) Wjl[i] = 0.2f * rndf();         /* Wjl[k * Dout + j] = W(j, k) */
