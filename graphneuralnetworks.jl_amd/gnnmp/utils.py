@@ -38,6 +38,9 @@ def reduce_nodes(aggr, g, x, num_graphs=None, sorted_indicator=None):
             L.check(L.load().gnnmp_is_sorted(L.ptr(gi), 8 if gi.dtype == torch.int64 else 4, gi.numel(), ctypes.byref(res),
                                              L.stream_ptr()))
             is_sorted = bool(res.value)
+    if x.dtype == torch.float64:      # Float64 readout (round 6): the Float64 scatter over a plan of the indicator, rows in node order
+        plan = _segment_plan(g, gi, "nodes") if (isinstance(g, GNNGraph) and is_sorted) else _idx_plan(gi, G, base)
+        return _scatter_plan(aggr, x, plan)
     xf = _flat(x)
     if not is_sorted:
         return _scatter_plan(aggr, x, _idx_plan(gi, G, base))

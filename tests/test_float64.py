@@ -137,3 +137,23 @@ def test_leaves_f64(oracle):
     g2 = gm.GNNGraph(torch.tensor([1, 2]).cuda(), torch.tensor([2, 1]).cuda(), num_nodes=5)
     with pytest.raises(AssertionError):
         gcn(g2, torch.from_numpy(rng.standard_normal((5, 4))).cuda())
+
+
+@pytest.mark.gpu
+def test_reduce_nodes_f64(oracle):
+    """reduce_nodes(aggr, g, x) = scatter(aggr, x, graph_indicator) (GNNlib/src/utils.jl:12-16) for Float64 node features: the Float64
+    scatter over a plan of the indicator, rows in node order — bit-identical to the CPU loop (segments of a batch are short rows)"""
+    import torch
+    import gnnmp as gm
+    from gnnmp import synth
+    gm.load()
+    members = synth.batched_graphs(G=40, seed=2)
+    rng = np.random.default_rng(5)
+    xs = [rng.standard_normal((n, 5)).astype(np.float32) for _, _, n in members]
+    g = gm.batch_arrays(members, xs)
+    x64 = torch.from_numpy(rng.standard_normal((g.num_nodes, 5))).cuda()
+    gi = g.graph_indicator.cpu().numpy()
+    for aggr in ("+", "mean", "max", "min"):
+        got = gm.reduce_nodes(aggr, g, x64)
+        assert got.dtype == torch.float64
+        assert np.array_equal(got.cpu().numpy(), oracle.scatter(aggr, x64.cpu().numpy(), gi, g.num_graphs)), aggr
