@@ -5,7 +5,7 @@
 // `B = rand(100, n)`, and asserts isequal(propagate(e_mul_xj, g, +; xj = B, e), B * A)); rounds 1-5 took Float32 only, so such calls
 // fell through to the reference's three-pass path ("missing" 6).  This file is the Float64 spelling of the same plan walk:
 // one lane group of G = 2^k lanes per destination row, a lane owns TWO doubles (16 bytes) of every feature tile of 2 G columns, source ids
-// loaded coalesced and broadcast inside the group, U = 4 row loads in flight, adds in ORIGINAL edge order with separately rounded
+// loaded coalesced and broadcast inside the group, U = 8 row loads (16 bytes each when D is even) in flight, adds in ORIGINAL edge order with separately rounded
 // products — bit-identical to NNlib's sequential CPU loop on every row the plan does not split.  Split rows: chunk partials (virtual rows)
 // folded in chunk order by a second small kernel (the two-kernel scheme of rounds 1-4: deterministic, no cross-workgroup hand-off inside
 // a launch).  Bound: HBM / the fabric's line-request rate like the fp32 kernels — a row of D doubles is 8 D bytes; no effort was spent
@@ -55,9 +55,10 @@ struct R64Args {
     uint32_t n_edges;
 };
 
-template <int OP, bool SCALED>
+// PAIR: D is even and x is 16-byte aligned — a lane's two doubles are ONE 16-byte load (otherwise two 8-byte loads)
+template <int OP, bool SCALED, bool PAIR>
 __global__ void __launch_bounds__(256) csr_rows_f64_kernel(const R64Args a) {
-    constexpr int U = 4;
+    constexpr int U = 8;
     const int lane = threadIdx.x & 63;
     const int G = 1 << a.log2g;
     const int lig = lane & (G - 1), gbase = lane - lig;
@@ -109,8 +110,14 @@ __global__ void __launch_bounds__(256) csr_rows_f64_kernel(const R64Args a) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const double *px = a.x + (int64_t)cj[u] * D + f0;
-                    v0[u] = one ? px[0] : 0.0;
-                    v1[u] = two ? px[1] : 0.0;
+                    if (PAIR) {
+                        double2 q = make_double2(0.0, 0.0);
+                        if (one) q = *reinterpret_cast<const double2 *>(px);
+                        v0[u] = q.x; v1[u] = q.y;
+                    } else {
+                        v0[u] = one ? px[0] : 0.0;
+                        v1[u] = two ? px[1] : 0.0;
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
@@ -171,7 +178,11 @@ template <int OP, bool SCALED>
 static int launch_rows64(const R64Args &a, hipStream_t stream) {
     const int64_t groups = (int64_t)a.n_rows + a.n_chunks;
     const int64_t threads = groups << a.log2g;
-    csr_rows_f64_kernel<OP, SCALED><<<(unsigned)((threads + 255) / 256), 256, 0, stream>>>(a);
+    const unsigned nb = (unsigned)((threads + 255) / 256);
+    if ((a.D & 1) == 0 && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0)
+        csr_rows_f64_kernel<OP, SCALED, true><<<nb, 256, 0, stream>>>(a);
+    else
+        csr_rows_f64_kernel<OP, SCALED, false><<<nb, 256, 0, stream>>>(a);
     GNNMP_LAUNCH_CHECK("csr_rows_f64_kernel");
     if (a.n_long > 0) {
         const int64_t tc = (int64_t)a.n_long * a.D;
