@@ -14,19 +14,18 @@
 
 namespace gnnmp {
 
+// (v_max_f64 / v_min_f64 order -0 < +0 and return the other operand for a NaN, like their f32 twins: common.h jl_max)
 __device__ __forceinline__ double jl_max64(double x, double y) {
-    if (x != x) return x;
-    if (y != y) return y;
-    if (y > x) return y;
-    if (x > y) return x;
-    return __builtin_signbit(x) ? y : x;
+    double m;
+    asm("v_max_f64 %0, %1, %2" : "=v"(m) : "v"(x), "v"(y));
+    const double nan_pick = (x != x) ? x : y;
+    return __builtin_isunordered(x, y) ? nan_pick : m;
 }
 __device__ __forceinline__ double jl_min64(double x, double y) {
-    if (x != x) return x;
-    if (y != y) return y;
-    if (y < x) return y;
-    if (x < y) return x;
-    return __builtin_signbit(x) ? x : y;
+    double m;
+    asm("v_min_f64 %0, %1, %2" : "=v"(m) : "v"(x), "v"(y));
+    const double nan_pick = (x != x) ? x : y;
+    return __builtin_isunordered(x, y) ? nan_pick : m;
 }
 template <int OP>
 __device__ __forceinline__ double op_identity64() {

@@ -157,3 +157,28 @@ def test_reduce_nodes_f64(oracle):
         got = gm.reduce_nodes(aggr, g, x64)
         assert got.dtype == torch.float64
         assert np.array_equal(got.cpu().numpy(), oracle.scatter(aggr, x64.cpu().numpy(), gi, g.num_graphs)), aggr
+
+
+@pytest.mark.gpu
+def test_max_min_special_values_f64(oracle):
+    """Base.max / Base.min in Float64: first NaN met wins (payload included), -0.0 < +0.0, +-Inf ordinary — every bit against the oracle"""
+    import torch
+    import gnnmp as gm
+    gm.load()
+    rng = np.random.default_rng(11)
+    n, E, D = 300, 5000, 6
+    s = rng.integers(1, n + 1, E).astype(np.int64)
+    t = rng.integers(1, n - 10 + 1, E).astype(np.int64)
+    x = rng.standard_normal((n, D))
+    x[rng.random((n, D)) < 0.3] = 0.0
+    x[rng.random((n, D)) < 0.15] = -0.0
+    specials = np.array([np.inf, -np.inf, np.nan, 0.0, -0.0])
+    pick = rng.random((n, D)) < 0.1
+    x[pick] = specials[rng.integers(0, len(specials), int(pick.sum()))]
+    bits = x.view(np.uint64)
+    isn = np.isnan(x)
+    bits[isn] = np.where(rng.random(int(isn.sum())) < 0.5, 0x7FF8000000000001, 0xFFF8000000000123).astype(np.uint64)
+    g = gm.GNNGraph(torch.from_numpy(s).cuda(), torch.from_numpy(t).cuda(), num_nodes=n)
+    for aggr in ("max", "min"):
+        got = gm.propagate(gm.copy_xj, g, aggr, xj=torch.from_numpy(x).cuda()).cpu().numpy()
+        assert np.array_equal(got.view(np.uint64), oracle.propagate(aggr, s, t, n, x).view(np.uint64)), aggr

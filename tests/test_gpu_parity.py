@@ -606,3 +606,41 @@ def test_dense_julia_weight_layout(gm):
                                               L.ptr(out), N, Dout, L.stream_ptr()))
             assert_close(host(out), ref)
         gm.tune(6, 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D", [4, 100])
+def test_max_min_special_values_bit_for_bit(gm, oracle, D):
+    """Base.max / Base.min on floats as NNlib.scatter!(max | min, ...) applies them element by element (GNNGraphs/src/gatherscatter.jl:12-18):
+    NaN-propagating (the FIRST NaN met in edge order stays, payload included), max(-0.0, +0.0) = +0.0, min(+0.0, -0.0) = -0.0, +-Inf ordinary
+    values.  The kernels use v_max_f32 / v_min_f32 + a NaN select (csrc/common.h: jl_max): every bit of every output against the oracle's
+    comparison chain, on rows that mix the special values in every order, for propagate, the scatter leaf and segment pooling."""
+    import torch
+    rng = np.random.default_rng(D)
+    n, E = 400, 6000
+    s = rng.integers(1, n + 1, E).astype(np.int64)
+    t = rng.integers(1, n - 20 + 1, E).astype(np.int64)          # the last 20 nodes receive nothing: identities -Inf / +Inf
+    x = rng.standard_normal((n, D)).astype(np.float32)
+    specials = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1.0, -1.0], np.float32)
+    x[rng.random((n, D)) < 0.35] = 0.0
+    x[rng.random((n, D)) < 0.15] = -0.0
+    pick = rng.random((n, D)) < 0.1
+    x[pick] = specials[rng.integers(0, len(specials), int(pick.sum()))]
+    # two distinguishable NaN payloads: the first one met in edge order must be the one that comes out
+    nanbits = x.view(np.uint32)
+    isn = np.isnan(x)
+    nanbits[isn] = np.where(rng.random(int(isn.sum())) < 0.5, 0x7FC00001, 0xFFC00123).astype(np.uint32)
+    g = gm.GNNGraph(dev(s), dev(t), num_nodes=n)
+    xd = dev(x)
+    for aggr in ("max", "min"):
+        got = host(gm.propagate(gm.copy_xj, g, aggr, xj=xd))
+        ref = oracle.propagate(aggr, s, t, n, x)
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), f"propagate(copy_xj, {aggr}) differs from Base.{aggr} in some bit"
+        m = x[s - 1]
+        got = host(gm.aggregate_neighbors(g, aggr, dev(m)))
+        assert np.array_equal(got.view(np.uint32), oracle.scatter(aggr, m, t, n).view(np.uint32)), aggr
+    # segment pooling (reduce_nodes) takes the same functions
+    gi = np.sort(rng.integers(1, 31, n)).astype(np.int64)
+    for aggr in ("max", "min"):
+        got = host(gm.reduce_nodes(aggr, dev(gi), xd, num_graphs=30))
+        assert np.array_equal(got.view(np.uint32), oracle.scatter(aggr, x, gi, 30).view(np.uint32)), aggr
