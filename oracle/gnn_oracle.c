@@ -14,8 +14,10 @@
  * (GNNGraphs/test/query.jl:49-87), add_self_loops adjacency (GNNGraphs/test/transform.jl:1-17), batch
  * (GNNGraphs/test/transform.jl:29-39), conv_weight zeros (conv.jl:55-65), softmax_edge_neighbors
  * (GNNlib/test/utils.jl:58-67), propagate == X*Adj (GNNlib/test/msgpass.jl:69-116), reduce_nodes mean
- * (GNNlib/test/utils.jl:13-20).  PARITY UNPINNED for: the fp32 summation ORDER (restated as NNlib's CPU loop:
- * sequential in edge order), the value of empty destinations under max/min (-Inf/+Inf = NNlib's identity fill) and
+ * (GNNlib/test/utils.jl:13-20), and the EXACT assertion of the reference's micro-benchmark, isequal(propagate(e_mul_xj, g, +; xj = B,
+ * e), B * A) in Float64 (GraphNeuralNetworks/perf/bench_gnn.jl:38-40) — the one place where the reference itself fixes the summation order
+ * of scatter(+): edge order from zero, product rounded first.  PARITY UNPINNED for: the summation ORDER beyond that assertion (restated as
+ * NNlib's CPU loop: sequential in edge order), the value of empty destinations under max/min (-Inf/+Inf = NNlib's identity fill) and
  * under mean (0) — no reference test asserts these (risk R1).
  *
  * Layout: Julia column-major (D, N) == C row-major [N][D].  Index arrays are int64, 1-based, exactly as Julia holds

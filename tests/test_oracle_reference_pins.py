@@ -282,3 +282,32 @@ def test_softmax_twin(oracle, oracle_np):
 def test_index_out_of_range_is_reported(oracle):
     with pytest.raises(IndexError):
         oracle.propagate("+", np.array([1, 9]), np.array([1, 2]), 3, np.ones((3, 2), np.float32))
+
+
+def test_reference_microbenchmark_isequal_pins_the_summation_order(oracle):
+    """GraphNeuralNetworks/perf/bench_gnn.jl:7-40 holds an EXACT assertion, not an approximate one:
+        A = sprand(n, n, 0.01); B = rand(100, n); g = GNNGraph(A; graph_type = :coo)
+        @assert isequal(propagate((xi, xj, e) -> e .* xj, g, +; xj = B, e = A.nzval'), B * A)      # and the same for e_mul_xj
+    i.e. the reference's generic gather -> message -> scatter(+) result is BIT-EQUAL to the dense x CSC product, whose loop order is
+    fixed by SparseArrays (for col, for k in nzrange(col): C[:, col] += B[:, row_k] * val_k).  Both sides agree only if scatter(+) adds
+    the messages of a destination in edge order (= findnz order = ascending row inside a column) starting from zero, with the product
+    rounded before the add — which is how the oracle restates NNlib's CPU scatter.  One of the few places where the reference itself
+    pins the summation ORDER (otherwise 'parity unpinned'); checked in Float64 (the benchmark's eltype) and Float32."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(0)
+    n = 256
+    A = sp.random(n, n, density=0.03, format="csc", random_state=rng, dtype=np.float64)
+    A.sort_indices()
+    t = np.repeat(np.arange(1, n + 1), np.diff(A.indptr)).astype(np.int64)      # findnz(A): column by column, rows ascending
+    s = (A.indices + 1).astype(np.int64)
+    for dt in (np.float64, np.float32):
+        B = rng.random((n, 20)).astype(dt)
+        e = A.data.astype(dt)
+        ref = np.zeros((n, 20), dt)
+        for col in range(n):
+            for k in range(A.indptr[col], A.indptr[col + 1]):
+                ref[col] = ref[col] + B[A.indices[k]] * e[k]
+        got = oracle.propagate("+", s, t, n, B, e)
+        assert got.dtype == dt and np.array_equal(got, ref), dt
+        if dt == np.float32:
+            assert np.array_equal(oracle.spmm_csc(s, t, n, B, e), ref)          # the fast path's restatement is that loop too
