@@ -598,20 +598,19 @@ static int launch_fused_cat_v(FusedCatArgs &a, u32x4 *wimg, hipStream_t stream) 
     GNNMP_LAUNCH_CHECK("fused_cat_kernel");
     return GNNMP_OK;
 }
-// knob 14 picks the variant (A/B runs): 8 = 8 waves, 9 = 8 waves with 16 row loads in flight, anything else = 12 waves
+// knob 14 picks the variant (A/B runs): 8 = 8 waves a block (256 registers, three W units in flight), anything else = 12 waves (168
+// registers, two units in flight)
 template <int K0, int K1, int OP, bool SCALED>
 static int launch_fused_cat(FusedCatArgs &a, u32x4 *wimg, hipStream_t stream) {
-    const int k = knob(KNOB_FUSED_WAVES);
-    if (k == 8) return launch_fused_cat_v<K0, K1, OP, SCALED, 8, 3, 8>(a, wimg, stream);
-    if (k == 9) return launch_fused_cat_v<K0, K1, OP, SCALED, 8, 3, 16>(a, wimg, stream);
+    if (knob(KNOB_FUSED_WAVES) == 8) return launch_fused_cat_v<K0, K1, OP, SCALED, 8, 3, 8>(a, wimg, stream);
     return launch_fused_cat_v<K0, K1, OP, SCALED, 12, 2, 8>(a, wimg, stream);
 }
 
 template <int K0, int K1>
 static int dispatch_fused_cat(FusedCatArgs &a, int op, bool scaled, u32x4 *wimg, hipStream_t stream) {
+    if (scaled) return 1;      // (sage_conv / graph_conv never scale: not instantiated)
     switch (op) {
-        case OP_SUM:
-            return scaled ? launch_fused_cat<K0, K1, OP_SUM, true>(a, wimg, stream) : launch_fused_cat<K0, K1, OP_SUM, false>(a, wimg, stream);
+        case OP_SUM: return launch_fused_cat<K0, K1, OP_SUM, false>(a, wimg, stream);
         case OP_MAX: return launch_fused_cat<K0, K1, OP_MAX, false>(a, wimg, stream);
         default: return launch_fused_cat<K0, K1, OP_MIN, false>(a, wimg, stream);
     }
@@ -645,8 +644,7 @@ extern "C" int gnnmp_fused_conv_f32(gnnmp_graph_t *p, int aggr, const float *xj,
     const int op = (aggr == GNNMP_MAX) ? OP_MAX : (aggr == GNNMP_MIN ? OP_MIN : OP_SUM);
     // sage_conv / graph_conv with a root term and a multiple of 128 outputs: fused_cat_kernel (W streamed from L2 as pre-split bf16 planes)
     if (D1 > 0 && Dout > 128) {
-        const bool shape_ok = D == 100 && D1 == 100 && (Dout & 127) == 0 && Dout <= 512 && w_layout == 0 && p->n_dst >= FC2_ROWS &&
-                              !(scaled && op != OP_SUM) && !(reinterpret_cast<uintptr_t>(xj) & 15) && !(reinterpret_cast<uintptr_t>(xi) & 15) &&
+        const bool shape_ok = D == 100 && D1 == 100 && (Dout & 127) == 0 && Dout <= 512 && w_layout == 0 && p->n_dst >= FC2_ROWS && !scaled && !(reinterpret_cast<uintptr_t>(xj) & 15) && !(reinterpret_cast<uintptr_t>(xi) & 15) &&
                               !(reinterpret_cast<uintptr_t>(out) & 3) && !(agg_out && (reinterpret_cast<uintptr_t>(agg_out) & 15)) &&
                               (ldw_root & 3) == 0 && (ldw_agg & 3) == 0 && knob(KNOB_FUSED_WAVES) >= 0;
         if (!shape_ok)

@@ -114,13 +114,13 @@ def test_root_segment(gm, oracle, D1, D, Dout):
         close(y.cpu().numpy(), ref)
 
 
-@pytest.mark.parametrize("variant", [16, 8, 9])
+@pytest.mark.parametrize("variant", [16, 8])
 @pytest.mark.parametrize("Dout", [256, 384])
 def test_sage_fused_cat_kernel(gm, oracle, variant, Dout):
     """fused_cat_kernel (round 6, BASELINE config 4): sage_conv / graph_conv 100 + 100 => 256 in ONE kernel, W streamed from L2 as
     pre-split bf16 planes (conv.jl:277-283,102-108).  The pre-GEMM aggregate is BIT-IDENTICAL to gnnmp_propagate_f32 for every aggr
     (split hubs included), the output within 1e-5 of the oracle and of the two-kernel path, non-finite rows (empty max / min rows, NaN
-    and Inf features) come out exactly like the two-kernel path's.  variant = knob 14: 12 waves a block (default), 8, 8 with 16 loads."""
+    and Inf features) come out exactly like the two-kernel path's.  variant = knob 14: 12 waves a block, or 8."""
     import torch
     from gnnmp import _lib as L
     from gnnmp.graph import Plan

@@ -1,7 +1,6 @@
 #!/usr/bin/env python
 """BASELINE config 4, SAGEConv(100 => 256, relu; mean) on the products shape: the two-kernel path (csr_rows_kernel + dense_wreg_kernel, with
-and without placed buffers) against fused_cat_kernel's variants (knob 14: 0 / 16 = 12 waves a block, 8 = 8 waves, 9 = 8 waves with 16 row
-loads in flight), interleaved on ONE box.  python tools/experiments/sage_fused_ab.py [rounds]"""
+and without placed buffers) against fused_cat_kernel's variants (knob 14: 16 = 12 waves a block, 8 = 8 waves), interleaved on ONE box.  python tools/experiments/sage_fused_ab.py [rounds]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, os.path.join(ROOT, "graphneuralnetworks.jl_amd")):
@@ -32,7 +31,7 @@ def measure(it=20):
 
 ref = None
 variants = [("two kernels, fresh buffers", -1, False), ("two kernels, placed m + out", -1, True), ("fused_cat 12 waves", 16, False),
-            ("fused_cat 8 waves", 8, False), ("fused_cat 8 waves U=16", 9, False)]
+            ("fused_cat 8 waves", 8, False)]
 for r in range(rounds):
     for name, k14, placed in variants:
         gnnmp.tune(14, k14)
