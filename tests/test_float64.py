@@ -172,7 +172,7 @@ def test_max_min_special_values_f64(oracle):
     x = rng.standard_normal((n, D))
     x[rng.random((n, D)) < 0.3] = 0.0
     x[rng.random((n, D)) < 0.15] = -0.0
-    specials = np.array([np.inf, -np.inf, np.nan, 0.0, -0.0])
+    specials = np.array([np.inf, -np.inf, np.nan, 0.0, -0.0, 1e-310, -1e-310, 5e-324])      # (with subnormals)
     pick = rng.random((n, D)) < 0.1
     x[pick] = specials[rng.integers(0, len(specials), int(pick.sum()))]
     bits = x.view(np.uint64)

@@ -621,7 +621,8 @@ def test_max_min_special_values_bit_for_bit(gm, oracle, D):
     s = rng.integers(1, n + 1, E).astype(np.int64)
     t = rng.integers(1, n - 20 + 1, E).astype(np.int64)          # the last 20 nodes receive nothing: identities -Inf / +Inf
     x = rng.standard_normal((n, D)).astype(np.float32)
-    specials = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1.0, -1.0], np.float32)
+    specials = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1.0, -1.0, 1e-40, -1e-40, 3e-45, -3e-45], np.float32)      # (with subnormals:
+    # v_max_f32 must return them unflushed)
     x[rng.random((n, D)) < 0.35] = 0.0
     x[rng.random((n, D)) < 0.15] = -0.0
     pick = rng.random((n, D)) < 0.1
